@@ -1,0 +1,370 @@
+"""Torch-CPU oracle for the reflectance / VQ path (decomp half).  TEST INFRASTRUCTURE.
+
+PARITY UNPINNED: the reference for this half is TensorFlow 2.4.1 + dm-sonnet 2.0.0 +
+tensorflow-probability 0.12.1, none of which exist in the build image (no network),
+and the reference ships no fixtures or tests.  This file restates, from the source
+text, the arithmetic of
+    decomp/nerfvq_nfr3/nerfactor/networks/embedder.py:23-47   -> posenc
+    .../networks/mlp.py:24-50, seq.py:24-38                    -> mlp_forward (Keras Dense: y = x @ W[in,out] + b)
+    .../networks/vq_layers.py:257-349                          -> vq_ema_call
+    sonnet.src.moving_averages.ExponentialMovingAverage (dm-sonnet 2.0.0, third party,
+        not under /root/reference; published algorithm: hidden -= (hidden - v)*(1-decay);
+        counter += 1; average = hidden / (1 - decay**counter))  -> EMA
+    .../util/math.py:63-64                                     -> safe_l2_normalize (tf.linalg.l2_normalize:
+        x * rsqrt(max(sum(x^2), eps)))
+    .../util/microfacet.py:9-89                                -> get_brdf
+    .../util/img.py:142-186                                    -> linear2srgb / srgb2linear
+    .../models/shape.py:103-119                                -> calc_ldir / calc_vdir
+    .../models/vq_nfr.py:534-692                               -> model_call
+    .../models/vq_nfr.py:694-733                               -> render_integrate
+    .../models/vq_nfr.py:761-769                               -> get_codebook
+    .../models/vq_nfr.py:771-833                               -> pred_enc / pred_diff / pred_spec / pred_rough / normal_correct
+    .../models/vq_nfr.py:876-986                               -> compute_loss
+    decomp/nerfvq_nfr3/brdf/renderer.py:184-219                -> gen_light_xyz (twin at geo/NeuS-ours2/models/util.py:84-119,
+        which IS importable: tests/golden/light_xyz_16x32.npz pins it)
+It is pinned by analytic known-answer tests only (tests/test_oracle_decomp.py).
+"""
+import math
+import numpy as np
+import torch
+
+PI = math.pi
+
+# shipped network shapes (nfr_unit.py:110-129, vq_nfr.py:135-164; vq_nfr.ini: mlp_width=128, conv_width=256)
+def net_specs(mlp_width=128, z_dim=256, n_freqs_xyz=10):
+    d_in = 3 + 3 * 2 * n_freqs_xyz
+    head = lambda out: dict(widths=[z_dim, z_dim // 2, out], act=['relu', 'relu', 'sigmoid'], skip_at=[1], d_in=z_dim)
+    return {
+        'fine_enc': dict(widths=[mlp_width] * 4, act=['relu'] * 4, skip_at=[2], d_in=d_in),
+        'bottleneck': dict(widths=[mlp_width, z_dim, z_dim], act=[None, 'relu', 'sigmoid'], skip_at=None, d_in=mlp_width),
+        'diff_main': head(3), 'spec_main': head(1), 'rough_main': head(1),
+        'diff_vq': head(3), 'spec_vq': head(3), 'rough_vq': head(1),
+    }
+
+
+def layer_in_dims(spec):
+    """Input width of every Dense layer given mlp.py:41-50 (concat AFTER layer i in skip_at)."""
+    dims, d = [], spec['d_in']
+    for i, w in enumerate(spec['widths']):
+        dims.append(d)
+        d = w + (spec['d_in'] if spec['skip_at'] and i in spec['skip_at'] else 0)
+    return dims
+
+
+def make_mlp_params(spec, rng):
+    """Keras Dense default init: glorot-uniform kernel [in,out], zero bias (bias jittered so it is exercised)."""
+    ps = []
+    for d_in, w in zip(layer_in_dims(spec), spec['widths']):
+        lim = math.sqrt(6.0 / (d_in + w))
+        ps.append((rng.uniform(-lim, lim, (d_in, w)).astype(np.float32),
+                   rng.uniform(-0.05, 0.05, (w,)).astype(np.float32)))
+    return ps
+
+
+def make_model_params(seed=0, K=15, **kw):
+    rng = np.random.default_rng(seed)
+    specs = net_specs(**kw)
+    p = {name: make_mlp_params(s, rng) for name, s in specs.items()}
+    z_dim = specs['diff_main']['d_in']
+    p['codebook_raw'] = rng.uniform(-0.1, 1.1, (z_dim, K)).astype(np.float32)   # exercises the [0,1] clip
+    p['light'] = rng.uniform(0.0, 1.0, (16, 32, 3)).astype(np.float32)
+    return p, specs
+
+
+def make_points(n, seed=1, lvis=True):
+    """SURVEY 8(d) synthetic surface points."""
+    rng = np.random.default_rng(seed)
+    xyz = rng.uniform(-1, 1, (n, 3))
+    xyz = xyz / np.linalg.norm(xyz, axis=1, keepdims=True) * rng.uniform(0.5, 1.0, (n, 1))
+    normal = xyz / np.linalg.norm(xyz, axis=1, keepdims=True) + 0.1 * rng.normal(size=(n, 3))
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    rayo = np.tile(np.array([[0.0, 0.0, 4.0]]), (n, 1))
+    rgb = rng.uniform(0, 1, (n, 3))
+    out = dict(xyz=xyz.astype(np.float32), normal=normal.astype(np.float32), rayo=rayo.astype(np.float32),
+               rgb=rgb.astype(np.float32))
+    if lvis:
+        out['lvis'] = (rng.uniform(size=(n, 512)) < 0.7).astype(np.float32)
+    return out
+
+
+def T(x, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(x), dtype=dtype)
+
+
+# ----------------------------------------------------------------------------
+def gen_light_xyz(h, w, radius=1e2):
+    lat_step, lng_step = PI / (h + 2), 2 * PI / (w + 2)
+    lats = np.linspace(PI / 2 - lat_step, -PI / 2 + lat_step, h)
+    lngs = np.linspace(PI - lng_step, -PI + lng_step, w)
+    lngs, lats = np.meshgrid(lngs, lats)
+    xyz = np.stack([radius * np.cos(lats) * np.cos(lngs), radius * np.cos(lats) * np.sin(lngs),
+                    radius * np.sin(lats)], -1)
+    sin_colat = np.sin(PI / 2 - lats)
+    areas = 4 * PI * sin_colat / np.sum(sin_colat)
+    return xyz, areas
+
+
+def posenc(x, n_freqs):
+    outs = [x]
+    for k in range(n_freqs):
+        f = float(2.0 ** k)
+        outs += [torch.sin(x * f), torch.cos(x * f)]
+    return torch.cat(outs, -1)
+
+
+def _act(y, a):
+    if a is None:
+        return y
+    if a == 'relu':
+        return torch.relu(y)
+    if a == 'sigmoid':
+        return torch.sigmoid(y)
+    raise ValueError(a)
+
+
+def mlp_forward(params, spec, x):
+    x0, h = x, x
+    for i, ((W, b), a) in enumerate(zip(params, spec['act'])):
+        y = _act(h @ W + b, a)
+        if spec['skip_at'] and i in spec['skip_at']:
+            y = torch.cat([y, x0], -1)
+        h = y
+    return h
+
+
+def safe_l2_normalize(x, dim, eps=1e-6):
+    return x * torch.rsqrt(torch.clamp((x * x).sum(dim, keepdim=True), min=eps))
+
+
+def get_codebook(raw):
+    return safe_l2_normalize(raw.clamp(0.0, 1.0), 0)
+
+
+class EMA:
+    """dm-sonnet 2.0.0 ExponentialMovingAverage (zero-debiased)."""
+
+    def __init__(self, decay, shape, dtype=torch.float32):
+        self.decay = decay
+        self.counter = 0
+        self.hidden = torch.zeros(shape, dtype=dtype)
+        self.average = torch.zeros(shape, dtype=dtype)
+
+    def __call__(self, v):
+        self.counter += 1
+        self.hidden = self.hidden - (self.hidden - v) * (1.0 - self.decay)
+        self.average = self.hidden / (1.0 - self.decay ** self.counter)
+        return self.average
+
+
+def vq_distances(x, C):
+    return (x * x).sum(1, keepdim=True) - 2.0 * (x @ C) + (C * C).sum(0, keepdim=True)
+
+
+def vq_ema_call(x, C, ema_cs, ema_dw, is_training, thres=None, roll=None, commitment_cost=0.1, eps=1e-5):
+    """vq_layers.py:257-349.  `roll` is the explicit stand-in for tf.random.uniform((1,K)) (:287)."""
+    K = C.shape[1]
+    dist = vq_distances(x, C)
+    if thres is not None:
+        mask_value = dist.max()
+        sel = (roll >= thres).to(dist.dtype).reshape(1, K)
+        dist = dist * sel + mask_value * (1.0 - sel)
+    idx = torch.argmax(-dist, 1)
+    enc = torch.nn.functional.one_hot(idx, K).to(x.dtype)
+    q = C.t()[idx]
+    e_latent = ((q.detach() - x) ** 2).mean()
+    ret = {}
+    if is_training:
+        counts = enc.sum(0)
+        cs = ema_cs(counts)
+        dw = ema_dw(x.detach().t() @ enc)
+        n = cs.sum()
+        cs = (cs + eps) / (n + K * eps) * n
+        w = dw / cs.reshape(1, -1)
+        used = (counts > 0).to(x.dtype)
+        ret['update'] = w * used[None, :] + C.detach() * (1.0 - used[None, :])
+    loss = commitment_cost * e_latent
+    q_ste = x + (q - x).detach()
+    avg = enc.mean(0)
+    ret.update(quantize=q_ste, loss=loss, perplexity=torch.exp(-(avg * torch.log(avg + 1e-10)).sum()),
+               encodings=enc, encoding_indices=idx, distances=dist)
+    return ret
+
+
+# ----------------------------------------------------------------------------
+def _clip01_pg(x):
+    """tfp.math.clip_by_value_preserve_gradient(x, 0, 1): clipped value, identity gradient."""
+    return x + (x.clamp(0.0, 1.0) - x).detach()
+
+
+def _div_no_nan(a, b):
+    return torch.where(b == 0, torch.zeros_like(a * b), a / torch.where(b == 0, torch.ones_like(b), b))
+
+
+def get_brdf(pts2l, pts2c, normal, albedo, rough, f0):
+    """microfacet.py:9-89.  pts2l [N,L,3], pts2c/normal/albedo/f0 [N,3], rough [N,1] -> 3 x [N,L,3].
+    NB alpha = rough**2 is squared AGAIN inside D and G (effective width rough**4), as the reference does."""
+    l = safe_l2_normalize(pts2l, 2)
+    v = safe_l2_normalize(pts2c, 1)
+    n = safe_l2_normalize(normal, 1)
+    h = safe_l2_normalize(l + v[:, None, :], 2)
+    # F
+    cos_vh = _clip01_pg(torch.einsum('ijk,ik->ij', h, v)[:, :, None])
+    f = f0[:, None, :] + (1 - f0[:, None, :]) * (1 - cos_vh) ** 5
+    alpha = (rough ** 2)[:, None, :]                                     # Nx1x1
+    # D
+    cos_m = _clip01_pg(torch.einsum('ijk,ik->ij', h, n))
+    denom = PI * ((cos_m ** 2)[:, :, None] * (alpha ** 2 - 1) + 1) ** 2
+    d = _div_no_nan(alpha ** 2 * torch.ones_like(denom), denom)
+    # G
+    def g1(c):
+        c = _clip01_pg(c)
+        den = c + torch.sqrt(torch.abs(alpha ** 2 + (1 - alpha ** 2) * c ** 2))
+        return _div_no_nan(2 * c * torch.ones_like(den), den)
+    l_dot_n = torch.einsum('ijk,ik->ij', l, n)[:, :, None]
+    v_dot_n = torch.einsum('ij,ij->i', v, n)[:, None, None]
+    g = g1(l_dot_n) * g1(v_dot_n)
+    den = 4 * l_dot_n.abs() * v_dot_n.abs()
+    glossy = _div_no_nan(f * g * d, den * torch.ones_like(f))
+    diffuse = (albedo / PI)[:, None, :].expand_as(glossy)
+    return glossy + diffuse, glossy, diffuse
+
+
+def calc_ldir(lxyz, xyz):
+    return safe_l2_normalize(lxyz.reshape(1, -1, 3) - xyz[:, None, :], 2)
+
+
+def calc_vdir(rayo, xyz):
+    return safe_l2_normalize(rayo - xyz, 1)
+
+
+def normal_correct(normal, surf2c):
+    cos = (normal * surf2c).sum(-1, keepdim=True)
+    return torch.where(cos >= 0, normal, -normal)
+
+
+def render_integrate(brdf, l, n, lareas, light, lvis=None, gamma=None):
+    """vq_nfr.py:694-723.  light [16,32,3] (already clipped >= 0).  gamma=(bias, index) for non-nerf data."""
+    cos = torch.einsum('ijk,ik->ij', l, n)
+    front = (cos > 0).to(cos.dtype)
+    vis = front if lvis is None else front * lvis
+    L = light.reshape(-1, 3)
+    contrib = brdf * (vis[:, :, None] * L[None]) * cos[:, :, None] * lareas.reshape(1, -1, 1)
+    rgb = contrib.sum(1)
+    if gamma is not None:
+        rgb = (rgb * gamma[0]) ** gamma[1]
+    return _clip01_pg(rgb)
+
+
+def linear2srgb(x):
+    x = x.clamp(0.0, 1.0)
+    return torch.where(x <= 0.0031308, x * 12.92, 1.055 * torch.pow(x, 1 / 2.4) - 0.055)
+
+
+def srgb2linear(x):
+    return torch.where(x <= 0.04045, x / 12.92, torch.pow((x + 0.055) / 1.055, 2.4))
+
+
+def rgb2chromaticity(rgb):
+    den = torch.sqrt((rgb ** 2).sum(-1, keepdim=True))
+    return _div_no_nan(rgb, den * torch.ones_like(rgb))
+
+
+# ----------------------------------------------------------------------------
+def pred_enc(p, specs, xyz, n_freqs=10):
+    e = posenc(xyz, n_freqs)
+    return mlp_forward(p['bottleneck'], specs['bottleneck'], mlp_forward(p['fine_enc'], specs['fine_enc'], e))
+
+
+def heads(p, specs, z, vq):
+    s = 'vq' if vq else 'main'
+    return (mlp_forward(p['diff_' + s], specs['diff_' + s], z),
+            mlp_forward(p['spec_' + s], specs['spec_' + s], z),
+            mlp_forward(p['rough_' + s], specs['rough_' + s], z))
+
+
+def model_call(p, specs, batch, lxyz, lareas, ema_cs, ema_dw, mode='train', thres=None, roll=None,
+               data_type='nerf', gamma=None, commitment_cost=0.1):
+    """vq_nfr.Model.call (vq_nfr.py:534-692) on already-masked foreground points.
+    p holds torch tensors (possibly requiring grad).  Returns the loss_kwargs-level quantities."""
+    xyz, normal, rayo = batch['xyz'], batch['normal'], batch['rayo']
+    lvis = batch.get('lvis') if data_type == 'nerf' else None
+    surf2l = calc_ldir(lxyz, xyz)
+    surf2c = calc_vdir(rayo, xyz)
+    n_pred = normal_correct(normal, surf2c)
+    z_enc = pred_enc(p, specs, xyz)
+    z_norm = safe_l2_normalize(z_enc, 1)
+    C = get_codebook(p['codebook_raw'])
+    vq = vq_ema_call(z_norm, C, ema_cs, ema_dw, is_training=(mode == 'train'), thres=thres, roll=roll,
+                     commitment_cost=commitment_cost)
+    z_vq = vq['quantize']
+    basecolor, ks, rough = heads(p, specs, z_enc, vq=False)
+    spec = ks * basecolor
+    albedo = (1 - ks) * basecolor
+    light = p['light'] + (p['light'].clamp(min=0.0) - p['light']).detach()   # clip_by_value_preserve_gradient(., 0, inf)
+    brdf, brdf_s, brdf_d = get_brdf(surf2l, surf2c, n_pred, albedo, rough, spec)
+    rgb = render_integrate(brdf, surf2l, n_pred, lareas, light, lvis, gamma)
+    vq_albedo, vq_spec, vq_rough = heads(p, specs, z_vq, vq=True)
+    vq_brdf, _, _ = get_brdf(surf2l, surf2c, n_pred, vq_albedo, vq_rough, vq_spec)
+    vq_rgb = render_integrate(vq_brdf, surf2l, n_pred, lareas, light, lvis, gamma)
+    out = dict(z_enc=z_enc, z_norm=z_norm, codebook=C, vq=vq, z_vq=z_vq, rgb=rgb, vq_rgb=vq_rgb,
+               albedo=albedo, spec=spec, rough=rough, ks=ks, basecolor=basecolor,
+               vq_albedo=vq_albedo, vq_spec=vq_spec, vq_rough=vq_rough, normal=n_pred,
+               embed=vq['encoding_indices'] + 1)
+    if mode != 'train':
+        out['rgb_diff'] = render_integrate(brdf_d, surf2l, n_pred, lareas, light, lvis, gamma)
+        out['rgb_spec'] = render_integrate(brdf_s, surf2l, n_pred, lareas, light, lvis, gamma)
+    return out
+
+
+def _mse(a, b):
+    return ((a - b) ** 2).mean(-1)
+
+
+def compute_loss(out, rgb_gt, codebook_raw, mode='train', data_type='nerf', chr_alpha=60.0, chr_thres=0.1,
+                 vq_loss_weight=1.0, chromaticity_weight=1.0, mat_sloss_weight=0.05, combine_weight=0.2,
+                 sim_loss_weight=1e-4, lambert_weight=1e-3):
+    """vq_nfr.Model.compute_loss (vq_nfr.py:876-986) -> (per_example_loss [N], dict)."""
+    rgb_pred, vq_rgb = out['rgb'], out['vq_rgb']
+    if data_type == 'nerf':
+        linear_gt, srgb_pred = srgb2linear(rgb_gt), linear2srgb(rgb_pred)
+    else:
+        linear_gt, srgb_pred = rgb_gt, rgb_pred
+    ld = {}
+    if mode != 'train':
+        ld['rgb'] = _mse(rgb_gt, srgb_pred)
+        ld['vqrgb'] = _mse(rgb_gt, linear2srgb(vq_rgb))
+        ld['chromaticity'] = _mse(rgb2chromaticity(linear_gt), rgb2chromaticity(vq_rgb))
+        return ld['rgb'] + ld['vqrgb'] + ld['chromaticity'], ld
+    ld['rgb'] = combine_weight * _mse(linear_gt, rgb_pred)
+    ld['vqrgb'] = _mse(linear_gt, vq_rgb)
+    ld['vqloss'] = vq_loss_weight * out['vq']['loss']
+    loss = ld['rgb'] + ld['vqrgb'] + ld['vqloss']
+    schr_gt = rgb2chromaticity(rgb_gt)
+    if chromaticity_weight > 0:
+        ld['chromaticity'] = chromaticity_weight * _mse(rgb2chromaticity(linear_gt), rgb2chromaticity(vq_rgb))
+        loss = loss + ld['chromaticity']
+    if mat_sloss_weight > 0:
+        z_vq = out['z_vq']
+        e = torch.sqrt(((schr_gt[::2] - schr_gt[1::2]) ** 2).sum(-1))
+        e = torch.where(e > chr_thres, e, torch.zeros_like(e))
+        w_chr = torch.exp(-chr_alpha * e)
+        sl = w_chr * (1.0 - (z_vq[::2] * z_vq[1::2]).sum(-1))
+        ld['chr_smooth'] = mat_sloss_weight * torch.stack([sl, sl], -1).reshape(-1)
+        loss = loss + ld['chr_smooth']
+    if sim_loss_weight > 0:
+        cb = get_codebook(codebook_raw).t()
+        K = cb.shape[0]
+        eye = torch.eye(K, dtype=cb.dtype)
+        # the diagonal is exactly 0 and is masked out below; "+ eye" only keeps d sqrt/dx finite there
+        # (TF's SqrtGrad returns 0 where the incoming gradient is 0; torch would give 0*inf = NaN)
+        dist = torch.sqrt(((cb[:, None, :] - cb[None, :, :]) ** 2).sum(-1) + eye) * (1 - eye)
+        masked = dist * (1 - eye) + eye * dist.max()
+        ld['sim_smooth'] = sim_loss_weight * (-torch.log(masked.min()))
+        loss = loss + ld['sim_smooth']
+    if lambert_weight > 0:
+        r = out['rough'].detach()
+        r = torch.where(r < 0.5, torch.zeros_like(r), 2 * r - 1.0)
+        ld['lambert'] = lambert_weight * out['spec'].max(-1)[0] * r[:, 0]
+        loss = loss + ld['lambert']
+    ld['loss'] = loss
+    return loss, ld

@@ -1,0 +1,171 @@
+"""CPU: analytic known-answer tests for the decomp oracle (oracle/decomp.py, oracle/vq_strict.c).
+
+The decomp reference (TensorFlow/Sonnet) cannot run in the build image and ships no fixtures, so
+these closed-form cases are all that pins this half of the oracle ("parity unpinned")."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decomp as od
+from oracle import vq_strict as vs
+
+
+def test_vq_known_nearest_and_ties():
+    C = torch.eye(4)[:, :3].contiguous()                    # D=4, K=3 : unit codes e0,e1,e2
+    x = torch.tensor([[0.9, 0.1, 0.0, 0.0], [0.0, 0.2, 0.7, 0.1], [0.5, 0.5, 0.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+    r = od.vq_ema_call(x, C, None, None, is_training=False)
+    assert r['encoding_indices'].tolist() == [0, 2, 0, 0]   # row 2: tie 0/1 -> lowest; row 3: 3-way tie -> 0
+    np.testing.assert_allclose(r['quantize'].numpy(), C.t()[[0, 2, 0, 0]].numpy())
+    # commitment loss is ONE scalar over all N*D entries (vq_layers.py:302)
+    want = 0.1 * ((C.t()[[0, 2, 0, 0]] - x) ** 2).mean()
+    assert abs(r['loss'].item() - want.item()) < 1e-8
+    # perplexity: p = [3/4, 0, 1/4]
+    p = np.array([0.75, 0.0, 0.25])
+    assert abs(r['perplexity'].item() - math.exp(-(p * np.log(p + 1e-10)).sum())) < 1e-6
+
+
+def test_vq_code_dropout_mask():
+    rng = np.random.default_rng(0)
+    x = torch.tensor(rng.uniform(0, 1, (50, 8)).astype(np.float32))
+    C = torch.tensor(rng.uniform(0, 1, (8, 5)).astype(np.float32))
+    roll = torch.tensor([[0.9, 0.05, 0.9, 0.05, 0.05]])
+    r = od.vq_ema_call(x, C, None, None, False, thres=torch.tensor(0.5), roll=roll)
+    assert set(r['encoding_indices'].tolist()) <= {0, 2}     # only codes with roll >= thres survive
+    full = od.vq_distances(x, C)
+    assert torch.all(r['distances'][:, [1, 3, 4]] == full.max())
+    # all codes dropped -> every distance equals the max -> index 0
+    r = od.vq_ema_call(x, C, None, None, False, thres=torch.tensor(0.5), roll=torch.zeros(1, 5))
+    assert r['encoding_indices'].tolist() == [0] * 50
+
+
+def test_ema_zero_debias_first_two_updates():
+    e = od.EMA(0.999, (3,))
+    v1 = torch.tensor([1.0, 2.0, 3.0])
+    a1 = e(v1)
+    np.testing.assert_allclose(a1.numpy(), v1.numpy(), rtol=1e-4)       # average == v after the first update
+    v2 = torch.tensor([3.0, 2.0, 1.0])
+    a2 = e(v2)
+    h2 = 0.999 * 0.001 * v1 + 0.001 * v2
+    np.testing.assert_allclose(a2.numpy(), (h2 / (1 - 0.999 ** 2)).numpy(), rtol=1e-4)
+    assert e.counter == 2
+
+
+def test_vq_ema_update_laplace_and_unused_fallback():
+    x = torch.tensor([[1.0, 0.0], [0.8, 0.2], [0.0, 1.0]])
+    C = torch.tensor([[1.0, 0.0, 0.6], [0.0, 1.0, -0.8]])              # K=3, code 2 never wins
+    K = 3
+    r = od.vq_ema_call(x, C, od.EMA(0.999, (K,)), od.EMA(0.999, (2, K)), True)
+    assert r['encoding_indices'].tolist() == [0, 0, 1]
+    cs = torch.tensor([2.0, 1.0, 0.0]); n = 3.0
+    cs_s = (cs + 1e-5) / (n + K * 1e-5) * n
+    assert abs(cs_s.sum().item() - n) < 1e-5                            # Laplace smoothing keeps the total
+    dw = torch.tensor([[1.8, 0.0, 0.0], [0.2, 1.0, 0.0]])
+    want = dw / cs_s[None]
+    want[:, 2] = C[:, 2]                                                 # unused -> the (normalised) codebook column
+    np.testing.assert_allclose(r['update'].numpy(), want.numpy(), rtol=2e-4, atol=1e-6)
+
+
+def test_strict_c_agrees_with_fp64_where_gap_is_clear():
+    rng = np.random.default_rng(1)
+    for K in (8, 15, 16, 64):
+        x = rng.uniform(0, 1, (4000, 256)).astype(np.float32)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        C = rng.uniform(0, 1, (256, K)).astype(np.float32)
+        C /= np.linalg.norm(C, axis=0, keepdims=True)
+        idx, dist, quant = vs.assign(x, C)
+        d64 = od.vq_distances(torch.tensor(x, dtype=torch.float64), torch.tensor(C, dtype=torch.float64)).numpy()
+        assert np.abs(dist - d64).max() < 1e-5
+        top2 = np.sort(d64, 1)[:, :2]
+        clear = (top2[:, 1] - top2[:, 0]) > 1e-5
+        assert clear.mean() > 0.98
+        assert np.array_equal(idx[clear], d64.argmin(1)[clear])
+        np.testing.assert_array_equal(quant, C.T[idx])
+
+
+def test_strict_c_masked_and_ragged():
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=(33, 20)).astype(np.float32)                    # D not a multiple of 16
+    C = rng.normal(size=(20, 7)).astype(np.float32)
+    sel = np.array([1, 0, 1, 1, 0, 0, 1], np.float32)
+    idx, dist, _ = vs.assign(x, C, sel)
+    full = od.vq_distances(torch.tensor(x, dtype=torch.float64), torch.tensor(C, dtype=torch.float64)).numpy()
+    ref = np.where(sel[None] > 0, full, full.max())
+    assert np.array_equal(idx, ref.argmin(1))
+    idx0, _, _ = vs.assign(x, C, np.zeros(7, np.float32))
+    assert (idx0 == 0).all()
+    # empty input
+    idx_e, _, _ = vs.assign(np.zeros((0, 20), np.float32), C)
+    assert idx_e.shape == (0,)
+
+
+def test_brdf_closed_forms():
+    N, L = 5, 7
+    rng = np.random.default_rng(3)
+    n = torch.tensor([[0.0, 0.0, 1.0]]).repeat(N, 1)
+    v = od.safe_l2_normalize(torch.tensor(rng.uniform(0.1, 1, (N, 3)).astype(np.float32)), 1)
+    l = od.safe_l2_normalize(torch.tensor(rng.uniform(0.1, 1, (N, L, 3)).astype(np.float32)), 2)
+    albedo = torch.tensor(rng.uniform(0, 1, (N, 3)).astype(np.float32))
+    # rough = 1, f0 = 0 -> alpha = 1: D = 1/pi, G1(c) = 2c/(c+1), F = (1 - h.v)^5
+    brdf, glossy, diffuse = od.get_brdf(l, v, n, albedo, torch.ones(N, 1), torch.zeros(N, 3))
+    h = od.safe_l2_normalize(l + v[:, None], 2)
+    hv = (h * v[:, None]).sum(-1)
+    ln, vn = l[..., 2], v[:, 2][:, None]
+    want = (1 - hv) ** 5 * (2 * ln / (ln + 1)) * (2 * vn / (vn + 1)) / math.pi / (4 * ln * vn)
+    np.testing.assert_allclose(glossy[..., 0].numpy(), want.numpy(), rtol=2e-3, atol=1e-12)  # (1-h.v)^5 cancels in fp32
+    np.testing.assert_allclose(diffuse.numpy(), (albedo / math.pi)[:, None].expand(N, L, 3).numpy(), rtol=1e-6)
+    # grazing view exactly in the tangent plane: n.v = 0 -> divide_no_nan -> glossy = 0
+    v0 = torch.tensor([[1.0, 0.0, 0.0]]).repeat(N, 1)
+    _, g0, _ = od.get_brdf(l, v0, n, albedo, torch.full((N, 1), 0.5), torch.full((N, 3), 0.04))
+    assert torch.all(g0 == 0)
+
+
+def test_shading_white_light_lambertian():
+    lxyz, lareas = od.gen_light_xyz(16, 32)
+    lxyz, lareas = od.T(lxyz.reshape(-1, 3)), od.T(lareas.reshape(-1))
+    xyz = torch.zeros(3, 3)
+    n = torch.tensor([[0.0, 0.0, 1.0], [0.0, 1.0, 0.0], [0.6, 0.0, 0.8]])
+    albedo = torch.tensor([[0.2, 0.4, 0.6]]).repeat(3, 1)
+    l = od.calc_ldir(lxyz, xyz)
+    brdf = (albedo / math.pi)[:, None].expand(3, 512, 3)
+    rgb = od.render_integrate(brdf, l, n, lareas, torch.ones(16, 32, 3))
+    # int_{hemisphere} cos dw = pi  -> rgb ~= albedo (quadrature of a 16x32 lat-long grid)
+    np.testing.assert_allclose(rgb.numpy(), albedo.numpy(), rtol=0.04)
+    # a light behind the surface contributes nothing; lvis = 0 kills everything
+    rgb0 = od.render_integrate(brdf, l, n, lareas, torch.ones(16, 32, 3), lvis=torch.zeros(3, 512))
+    assert torch.all(rgb0 == 0)
+
+
+def test_srgb_roundtrip_and_thresholds():
+    x = torch.linspace(0, 1, 1001)
+    np.testing.assert_allclose(od.srgb2linear(od.linear2srgb(x)).numpy(), x.numpy(), atol=2e-6)
+    assert abs(od.linear2srgb(torch.tensor(0.0031308)).item() - 0.0031308 * 12.92) < 1e-7
+    assert od.linear2srgb(torch.tensor(1.7)).item() == pytest.approx(1.0)   # clips first (img.py:155)
+
+
+def test_mlp_skip_concat_order():
+    # mlp.py:45-49: output of the skip layer is concat(y, x_input): hidden first, input last
+    spec = dict(widths=[2, 1], act=[None, None], skip_at=[0], d_in=3)
+    W0 = torch.tensor([[1.0, 0.0], [0.0, 1.0], [0.0, 0.0]]); b0 = torch.zeros(2)
+    W1 = torch.tensor([[1.0], [10.0], [100.0], [1000.0], [10000.0]]); b1 = torch.zeros(1)
+    y = od.mlp_forward([(W0, b0), (W1, b1)], spec, torch.tensor([[1.0, 2.0, 3.0]]))
+    assert y.item() == 1 + 20 + 100 + 2000 + 30000
+    assert od.layer_in_dims(od.net_specs()['fine_enc']) == [63, 128, 128, 191]
+    assert od.layer_in_dims(od.net_specs()['diff_vq']) == [256, 256, 384]
+
+
+def test_model_call_and_loss_shapes_and_grads():
+    p, specs = od.make_model_params(0, K=15)
+    pt = {k: ([(od.T(W).requires_grad_(), od.T(b).requires_grad_()) for W, b in v] if isinstance(v, list)
+              else od.T(v).requires_grad_()) for k, v in p.items()}
+    b = {k: od.T(v) for k, v in od.make_points(64).items()}
+    lxyz, la = od.gen_light_xyz(16, 32)
+    out = od.model_call(pt, specs, b, od.T(lxyz.reshape(-1, 3)), od.T(la.reshape(-1)),
+                        od.EMA(0.999, (15,)), od.EMA(0.999, (256, 15)))
+    loss, ld = od.compute_loss(out, b['rgb'], pt['codebook_raw'])
+    assert loss.shape == (64,)
+    (loss.sum() / 1024).backward()
+    assert all(torch.isfinite(W.grad).all() for W, _ in pt['fine_enc'])
+    assert torch.isfinite(pt['codebook_raw'].grad).all() and pt['codebook_raw'].grad.abs().sum() > 0
+    assert out['vq']['update'].shape == (256, 15)

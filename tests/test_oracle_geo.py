@@ -1,0 +1,135 @@
+"""CPU: the geo oracle (oracle/geo.py) against fixtures produced by the real reference
+(oracle/gen_golden_geo.py -> tests/golden/geo_*.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import geo as og
+
+torch.set_num_threads(8)
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def _close(a, b, rtol=1e-5, atol=1e-6):
+    np.testing.assert_allclose(np.asarray(a), np.asarray(b), rtol=rtol, atol=atol)
+
+
+def test_sample_pdf_matches_reference(golden_dir):
+    g = _load(golden_dir, 'geo_sample_pdf.npz')
+    rng = np.random.default_rng(10)
+    for n in (64, 80, 96, 112):
+        bins = np.sort(rng.uniform(2.0, 6.0, (8, n)).astype(np.float32), -1)
+        w = rng.uniform(0, 1, (8, n - 1)).astype(np.float32) ** 4
+        w[0] = 0.0
+        w[1, : n // 2] = 0.0
+        w[2] = 0.0; w[2, 5] = 1.0
+        s = og.sample_pdf_det(torch.tensor(bins), torch.tensor(w), 16)
+        np.testing.assert_array_equal(s.numpy(), g[f'samples_{n}'])
+
+
+CASES = [('full', og.FULL_CFG, 16), ('small', og.SMALL_CFG, 64)]
+
+
+@pytest.fixture(scope='module', params=CASES, ids=[c[0] for c in CASES])
+def case(request, golden_dir):
+    tag, cfg, B = request.param
+    g = _load(golden_dir, f'geo_{tag}.npz')
+    p_sdf = og.to_torch(og.make_sdf_params(cfg, 0))
+    p_col = og.to_torch(og.make_color_params(cfg, 1))
+    o, d, near, far = map(torch.tensor, og.make_rays(B, 2))
+    return dict(tag=tag, cfg=cfg, B=B, g=g, p_sdf=p_sdf, p_col=p_col, o=o, d=d, near=near, far=far)
+
+
+def test_networks(case):
+    g, cfg = case['g'], case['cfg']
+    rng = np.random.default_rng(3)
+    pts = torch.tensor(rng.uniform(-1.2, 1.2, (96, 3)).astype(np.float32))
+    dirs = rng.normal(size=(96, 3)).astype(np.float32)
+    dirs = torch.tensor(dirs / np.linalg.norm(dirs, axis=1, keepdims=True))
+    with torch.no_grad():
+        y = og.sdf_forward(case['p_sdf'], cfg, pts)
+    _close(y, g['net_sdf_out'])
+    gr = og.sdf_gradient(case['p_sdf'], cfg, pts)
+    _close(gr, g['net_sdf_grad'], rtol=1e-4, atol=1e-5)
+    with torch.no_grad():
+        rgb = og.color_forward(case['p_col'], cfg, pts, gr, dirs, y[:, 1:])
+    _close(rgb, g['net_color'], rtol=1e-4, atol=1e-5)
+
+
+def test_upsample_chain(case):
+    g, cfg, B = case['g'], case['cfg'], case['B']
+    o, d = case['o'], case['d']
+    n0 = cfg['renderer']['n_samples']
+    z = torch.linspace(0.0, 1.0, n0)
+    zz = case['near'] + (case['far'] - case['near']) * z[None, :]
+    with torch.no_grad():
+        pts = o[:, None, :] + d[:, None, :] * zz[..., None]
+        ss = og.sdf_only(case['p_sdf'], cfg, pts.reshape(-1, 3)).reshape(B, n0)
+        _close(ss, g['coarse_sdf'])
+        for i in range(4):
+            # feed the reference's own state so that each stage is checked in isolation
+            zz_ref = torch.tensor(g[f'up_z_{i - 1}']) if i else zz
+            ss_ref = torch.tensor(g[f'up_sdf_{i - 1}']) if i else torch.tensor(g['coarse_sdf'])
+            new_z = og.up_sample(o, d, zz_ref, ss_ref, 2.0, 16, 64 * 2 ** i)
+            _close(new_z, g[f'up_new_z_{i}'], rtol=0, atol=2e-6)
+            z2, s2, ties = og.cat_z_vals(case['p_sdf'], cfg, o, d, zz_ref, torch.tensor(g[f'up_new_z_{i}']), ss_ref, last=(i == 3))
+            assert not ties and not bool(g[f'up_ties_{i}'])
+            np.testing.assert_array_equal(z2.numpy(), g[f'up_z_{i}'])
+            _close(s2, g[f'up_sdf_{i}'])
+
+
+@pytest.mark.parametrize('car', [0.0, 0.5, 1.0])
+def test_render_core(case, car):
+    g, cfg = case['g'], case['cfg']
+    z_in = torch.tensor(g['core_z_in'])
+    n0 = cfg['renderer']['n_samples']
+    rc = og.render_core(case['p_sdf'], case['p_col'], 0.3, cfg, case['o'], case['d'], z_in, 2 * 2.0 / n0, 2.0,
+                        background_rgb=torch.ones(1, 3), cos_anneal_ratio=car)
+    for k in ('color', 'sdf', 'dists', 'gradients', 's_val', 'mid_z_vals', 'weights', 'cdf',
+              'gradient_error', 'inside_sphere', 'surf', 'depth'):
+        _close(rc[k].detach(), g[f'core{car}_{k}'], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize('bg', ['white', 'none'])
+@pytest.mark.parametrize('car', [0.0, 1.0])
+def test_render_end_to_end(case, bg, car):
+    g, cfg = case['g'], case['cfg']
+    rr = og.render(case['p_sdf'], case['p_col'], 0.3, cfg, case['o'], case['d'], case['near'], case['far'], 2.0,
+                   jitter=None, background_rgb=torch.ones(1, 3) if bg == 'white' else None, cos_anneal_ratio=car)
+    assert not rr['had_ties']
+    for k in ('color_fine', 's_val', 'cdf_fine', 'weight_sum', 'weight_max', 'gradients', 'weights',
+              'gradient_error', 'inside_sphere', 'surf', 'depth'):
+        _close(rr[k].detach(), g[f'render_{bg}_{car}_{k}'], rtol=5e-4, atol=5e-5)
+
+
+def test_backward_matches_reference(case):
+    """Grads of L1(color) + 0.1*eikonal wrt every weight_g / weight_v / bias / variance."""
+    g, cfg, B = case['g'], case['cfg'], case['B']
+    p_sdf = {k: v.clone().requires_grad_(True) for k, v in case['p_sdf'].items()}
+    p_col = {k: v.clone().requires_grad_(True) for k, v in case['p_col'].items()}
+    var = torch.tensor(0.3, requires_grad=True)
+    rr = og.render(p_sdf, p_col, var, cfg, case['o'], case['d'], case['near'], case['far'], 2.0, jitter=None,
+                   background_rgb=torch.ones(1, 3), cos_anneal_ratio=1.0, create_graph=True)
+    tgt = torch.tensor(np.random.default_rng(4).uniform(0, 1, (B, 3)).astype(np.float32))
+    loss = (rr['color_fine'] - tgt).abs().sum() / B + 0.1 * rr['gradient_error']
+    loss.backward()
+    _close(loss.detach(), g['bwd_loss'], rtol=1e-4)
+    for name, p in (('sdf', p_sdf), ('col', p_col)):
+        for k, v in p.items():
+            ref = g[f'bwd_{name}.{k}']
+            scale = max(np.abs(ref).max(), 1e-6)
+            assert np.abs(v.grad.numpy() - ref).max() <= 2e-3 * scale + 1e-6, (name, k)
+    assert abs(var.grad.item() - float(g['bwd_var.variance'])) <= 2e-3 * abs(float(g['bwd_var.variance'])) + 1e-6
+
+
+def test_gen_light_xyz(golden_dir):
+    from oracle import decomp as od
+    g = _load(golden_dir, 'light_xyz_16x32.npz')
+    xyz, areas = od.gen_light_xyz(16, 32)
+    np.testing.assert_allclose(xyz, g['xyz'], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(areas, g['areas'], rtol=0, atol=1e-15)
