@@ -1,0 +1,94 @@
+"""ctypes binding of libvqnerf_hip.so (include/vqnerf_hip.h).
+
+There is NO fallback: if the library is missing or a call fails this raises.  Tensors are passed as
+raw device pointers (tensor.data_ptr()) plus sizes; work is enqueued on torch's current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libvqnerf_hip.so')
+_lib = None
+
+
+class VqnError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    cmd = ['make', '-C', os.path.join(_HERE, 'csrc'), '-j8']
+    if not verbose:
+        cmd.append('-s')
+    subprocess.check_call(cmd)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VqnError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                           '(or `make -C vqnerf_release_amd/csrc`). There is no non-HIP fallback.')
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.vqn_last_error.restype = ctypes.c_char_p
+        _lib.vqn_version.restype = ctypes.c_int
+    return _lib
+
+
+def _check(rc, name):
+    if rc != 0:
+        raise VqnError(f'{name} failed (rc={rc}): {lib().vqn_last_error().decode()}')
+
+
+def _ptr(t):
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+        raise VqnError(f'{name}: expected a contiguous float32 device tensor, got {t.dtype} '
+                       f'contiguous={t.is_contiguous()} device={t.device}')
+    return t
+
+
+# --------------------------------------------------------------------------------------
+def vq_assign(x, codebook, sel_mask=None, want_quant=True, want_dist=False):
+    """x [N,D], codebook [D,K] -> (idx int64 [N], quant [N,D] | None, dist [N,K] | None)."""
+    _f32c(x, 'x'); _f32c(codebook, 'codebook')
+    N, D = x.shape
+    K = codebook.shape[1]
+    assert codebook.shape[0] == D
+    idx = torch.empty((N,), dtype=torch.int64, device=x.device)
+    quant = torch.empty((N, D), dtype=torch.float32, device=x.device) if want_quant else None
+    dist = torch.empty((N, K), dtype=torch.float32, device=x.device) if want_dist else None
+    ws = None
+    if sel_mask is not None:
+        sel_mask = _f32c(sel_mask.reshape(-1).to(torch.float32).contiguous(), 'sel_mask')
+        assert sel_mask.numel() == K
+        ws = torch.empty((4,), dtype=torch.float32, device=x.device)
+    rc = lib().vqn_vq_assign(_ptr(x), ctypes.c_int64(N), ctypes.c_int(D), _ptr(codebook), ctypes.c_int(K),
+                             _ptr(sel_mask), _ptr(ws), _ptr(idx), _ptr(quant), _ptr(dist), _stream())
+    _check(rc, 'vqn_vq_assign')
+    return idx, quant, dist
+
+
+def vq_ema_stats(x, idx, K):
+    """x [N,D], idx [N] int64 -> (counts [K], dw [D,K])."""
+    _f32c(x, 'x')
+    N, D = x.shape
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() == N
+    counts = torch.empty((K,), dtype=torch.float32, device=x.device)
+    dw = torch.empty((D, K), dtype=torch.float32, device=x.device)
+    rc = lib().vqn_vq_ema_stats(_ptr(x), _ptr(idx), ctypes.c_int64(N), ctypes.c_int(D), ctypes.c_int(K),
+                                _ptr(counts), _ptr(dw), _stream())
+    _check(rc, 'vqn_vq_ema_stats')
+    return counts, dw

@@ -1,0 +1,254 @@
+// VQ codebook nearest-neighbour assignment + EMA statistics for gfx950 (MI355X).
+//
+// Replaces the framework-op sequences at
+//   decomp/nerfvq_nfr3/nerfactor/networks/vq_layers.py:277-301,346-349  (distances, dropout mask, argmax(-d), lookup)
+//   decomp/nerfvq_nfr3/nerfactor/networks/vq_layers.py:304-309          (sum(enc,0), x^T @ enc)
+//
+// vq_assign: HBM-bound (1 KB/row in at D=256).  One wave owns 16 rows; the dot products run on the
+// f32 matrix pipe (v_mfma_f32_16x16x4_f32), whose result is bit-for-bit a k-ordered fmaf chain, so
+// the summation order is *defined* (oracle/vq_strict.c states the same order in plain C):
+//     dot[n][k] : fmaf chain over d = 16t + 4q + e, (t outer, e, q inner)
+//     x2[n]     : four chains p_q, then (p0+p1)+(p2+p3)      (two xor-shuffles)
+//     c2[k]     : fmaf chain over d = 0..D-1
+//     dist      : (x2 - 2 dot) + c2 ; argmin, lowest index wins ties.
+// The codebook lives in LDS already laid out as MFMA B-fragments (one ds_read_b128 per 4 MFMAs).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ int f2key(float f) {
+  int b = __float_as_int(f);
+  return b >= 0 ? b : (b ^ 0x7fffffff);
+}
+__device__ __forceinline__ float key2f(int k) { return __int_as_float(k >= 0 ? k : (k ^ 0x7fffffff)); }
+
+template <int KT, bool MAXONLY>
+__global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict__ x, long N, int D,
+                                                        const float* __restrict__ C, int K,
+                                                        const float* __restrict__ sel, int* __restrict__ gmax_key,
+                                                        long long* __restrict__ idx, float* __restrict__ quant,
+                                                        float* __restrict__ dist) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int D16 = (D + 15) >> 4;
+  f32x4* Bf = reinterpret_cast<f32x4*>(smem);             // [KT][D16][64] float4
+  float* c2 = smem + (size_t)KT * D16 * 256;              // [KT*16]
+  float* selm = c2 + KT * 16;                             // [KT*16]  1 = keep, 0 = dropped
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, q = lane >> 4;
+
+  // ---- stage the codebook as B fragments: Bf[kt][t][l][e] = C[16t + 4(l>>4) + e][16kt + (l&15)] ----
+  for (int i = tid; i < KT * D16 * 64; i += 256) {
+    int l = i & 63, t = (i >> 6) % D16, kt = (i >> 6) / D16;
+    int code = 16 * kt + (l & 15);
+    f32x4 v;
+    for (int e = 0; e < 4; ++e) {
+      int d = 16 * t + 4 * (l >> 4) + e;
+      v[e] = (d < D && code < K) ? C[(size_t)d * K + code] : 0.0f;
+    }
+    Bf[i] = v;
+  }
+  for (int k = tid; k < KT * 16; k += 256) {
+    float acc = 0.f;
+    if (k < K)
+      for (int d = 0; d < D; ++d) { float c = C[(size_t)d * K + k]; acc = fmaf(c, c, acc); }
+    c2[k] = acc;
+    selm[k] = (k < K) ? ((sel != nullptr && !MAXONLY) ? sel[k] : 1.0f) : 0.0f;
+  }
+  __syncthreads();
+
+  const float gmax = (!MAXONLY && sel != nullptr) ? key2f(*gmax_key) : 0.f;
+  float wmax = -INFINITY;
+  const long n_groups = (N + 15) >> 4;
+  for (long rg = (long)blockIdx.x * 4 + wave; rg < n_groups; rg += (long)gridDim.x * 4) {
+    const long row0 = rg << 4;
+    const bool rvalid = (row0 + col) < N;
+    const float* xr = x + (size_t)(row0 + col) * D + 4 * q;
+    f32x4 acc[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) acc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float p = 0.f;
+#pragma unroll 4
+    for (int t = 0; t < D16; ++t) {
+      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (rvalid && (16 * t + 4 * q) < D) a = *reinterpret_cast<const f32x4*>(xr + 16 * t);
+      p = fmaf(a[0], a[0], p); p = fmaf(a[1], a[1], p); p = fmaf(a[2], a[2], p); p = fmaf(a[3], a[3], p);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        f32x4 b = Bf[((size_t)kt * D16 + t) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc[kt], 0, 0, 0);
+      }
+    }
+    // x2 for row (lane&15): (p0+p1)+(p2+p3)
+    p = p + __shfl_xor(p, 16);
+    p = p + __shfl_xor(p, 32);
+    float best_v[4];
+    int best_i[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x2 = __shfl(p, 4 * q + j);          // acc reg j of this lane is row 4q+j
+      const bool row_ok = (row0 + 4 * q + j) < N;
+      best_v[j] = INFINITY;
+      best_i[j] = 0x7fffffff;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const int code = 16 * kt + col;
+        float t1 = x2 - 2.0f * acc[kt][j];
+        float dv = t1 + c2[code];
+        if (MAXONLY) {
+          if (row_ok && code < K) wmax = fmaxf(wmax, dv);
+        } else {
+          if (selm[code] == 0.0f) dv = gmax;
+          if (code < K) {
+            if (dist != nullptr && row_ok) dist[(size_t)(row0 + 4 * q + j) * K + code] = dv;
+            if (dv < best_v[j] || best_i[j] == 0x7fffffff) { best_v[j] = dv; best_i[j] = code; }
+          }
+        }
+      }
+    }
+    if (!MAXONLY) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+          float ov = __shfl_xor(best_v[j], m);
+          int oi = __shfl_xor(best_i[j], m);
+          bool take = (oi != 0x7fffffff) && (best_i[j] == 0x7fffffff || ov < best_v[j] || (ov == best_v[j] && oi < best_i[j]));
+          if (take) { best_v[j] = ov; best_i[j] = oi; }
+        }
+        if (col == 0 && (row0 + 4 * q + j) < N) idx[row0 + 4 * q + j] = (long long)best_i[j];
+      }
+      if (quant != nullptr) {
+        const int nchunk = (D + 255) >> 8;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (row0 + r >= N) continue;                                // wave-uniform
+          const int k = __shfl(best_i[r & 3], (r >> 2) * 16);
+          const int kt = k >> 4, kc = k & 15;
+          for (int c = 0; c < nchunk; ++c) {
+            const int d4 = lane + 64 * c;                            // float4 index along D
+            if (4 * d4 < D) {
+              f32x4 v = Bf[((size_t)kt * D16 + (d4 >> 2)) * 64 + (d4 & 3) * 16 + kc];
+              *reinterpret_cast<f32x4*>(quant + (size_t)(row0 + r) * D + 4 * d4) = v;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (MAXONLY) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, m));
+    if (lane == 0 && wmax > -INFINITY) atomicMax(gmax_key, f2key(wmax));
+  }
+}
+
+__global__ void vq_ema_stats_kernel(const float* __restrict__ x, const long long* __restrict__ idx, long N, int D,
+                                    int K, float* __restrict__ counts, float* __restrict__ dw) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* acc = smem;                                  // [K][D]
+  int* cnt = reinterpret_cast<int*>(smem + (size_t)K * D);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < K * D; i += blockDim.x) acc[i] = 0.f;
+  for (int i = tid; i < K; i += blockDim.x) cnt[i] = 0;
+  __syncthreads();
+  const int D4 = D >> 2;
+  for (long row = (long)blockIdx.x * 4 + wave; row < N; row += (long)gridDim.x * 4) {
+    const int k = (int)idx[row];
+    if (k < 0 || k >= K) continue;                    // wave-uniform
+    if (lane == 0) atomicAdd(&cnt[k], 1);
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
+    float* a = acc + (size_t)k * D;
+    for (int c = lane; c < D4; c += 64) {
+      f32x4 v = xr[c];
+      atomicAdd(&a[4 * c + 0], v[0]);
+      atomicAdd(&a[4 * c + 1], v[1]);
+      atomicAdd(&a[4 * c + 2], v[2]);
+      atomicAdd(&a[4 * c + 3], v[3]);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < K * D; i += blockDim.x) {
+    const int k = i / D, d = i - k * D;
+    const float v = acc[i];
+    if (v != 0.f) atomicAdd(&dw[(size_t)d * K + k], v);
+  }
+  for (int i = tid; i < K; i += blockDim.x)
+    if (cnt[i]) atomicAdd(&counts[i], (float)cnt[i]);
+}
+
+template <int KT>
+int launch_assign(const float* x, long N, int D, const float* C, int K, const float* sel, float* ws, long long* idx,
+                  float* quant, float* dist, hipStream_t s) {
+  const int D16 = (D + 15) >> 4;
+  const size_t lds = ((size_t)KT * D16 * 256 + 2 * KT * 16) * sizeof(float);
+  const long n_groups = (N + 15) >> 4;
+  long blocks = (n_groups + 3) / 4;
+  const long cap = (long)vqn_num_cus() * 8;
+  if (blocks > cap) blocks = cap;
+  if (lds > 64 * 1024) {
+    VQN_HIP(hipFuncSetAttribute((const void*)vq_assign_kernel<KT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VQN_HIP(hipFuncSetAttribute((const void*)vq_assign_kernel<KT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  if (sel != nullptr) {
+    // distances.max() is taken over the UNMASKED distances (vq_layers.py:285) -> extra pass
+    VQN_HIP(hipMemsetD32Async((hipDeviceptr_t)ws, (int)0x807fffff /* key(-inf) */, 1, s));
+    hipLaunchKernelGGL((vq_assign_kernel<KT, true>), dim3((unsigned)blocks), dim3(256), lds, s, x, N, D, C, K, sel,
+                       reinterpret_cast<int*>(ws), idx, quant, dist);
+    VQN_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL((vq_assign_kernel<KT, false>), dim3((unsigned)blocks), dim3(256), lds, s, x, N, D, C, K, sel,
+                     reinterpret_cast<int*>(ws), idx, quant, dist);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
+
+}  // namespace
+
+extern "C" int vqn_vq_assign(const float* x, int64_t N, int D, const float* codebook, int K, const float* sel_mask,
+                             float* ws, int64_t* idx, float* quant, float* dist, void* stream) {
+  VQN_CHECK_ARG(N >= 0 && D > 0 && K > 0, "N >= 0, D > 0, K > 0 required");
+  if (N == 0) return VQN_OK;
+  VQN_CHECK_ARG(x && codebook && idx, "x, codebook and idx must be non-null");
+  VQN_CHECK_ARG(sel_mask == nullptr || ws != nullptr, "sel_mask needs a 4-byte device workspace `ws`");
+  VQN_CHECK_SHAPE(D % 4 == 0, "D must be a multiple of 4 (16-byte rows)");
+  VQN_CHECK_SHAPE(((uintptr_t)x % 16) == 0 && (quant == nullptr || ((uintptr_t)quant % 16) == 0), "x/quant must be 16-byte aligned");
+  const int KT = (K + 15) / 16;
+  const int D16 = (D + 15) / 16;
+  VQN_CHECK_SHAPE(KT <= 8, "K <= 128");
+  int KTp = KT <= 1 ? 1 : KT <= 2 ? 2 : KT <= 4 ? 4 : 8;
+  VQN_CHECK_SHAPE(((size_t)KTp * D16 * 256 + 2 * KTp * 16) * 4 <= 160 * 1024, "codebook does not fit in 160 KB of LDS");
+  hipStream_t s = (hipStream_t)stream;
+  long long* idx_ll = reinterpret_cast<long long*>(idx);
+  switch (KTp) {
+    case 1: return launch_assign<1>(x, N, D, codebook, K, sel_mask, ws, idx_ll, quant, dist, s);
+    case 2: return launch_assign<2>(x, N, D, codebook, K, sel_mask, ws, idx_ll, quant, dist, s);
+    case 4: return launch_assign<4>(x, N, D, codebook, K, sel_mask, ws, idx_ll, quant, dist, s);
+    default: return launch_assign<8>(x, N, D, codebook, K, sel_mask, ws, idx_ll, quant, dist, s);
+  }
+}
+
+extern "C" int vqn_vq_ema_stats(const float* x, const int64_t* idx, int64_t N, int D, int K, float* counts, float* dw,
+                                void* stream) {
+  VQN_CHECK_ARG(N >= 0 && D > 0 && K > 0, "N >= 0, D > 0, K > 0 required");
+  VQN_CHECK_ARG(counts && dw, "counts and dw must be non-null");
+  hipStream_t s = (hipStream_t)stream;
+  VQN_HIP(hipMemsetAsync(counts, 0, sizeof(float) * K, s));
+  VQN_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)D * K, s));
+  if (N == 0) return VQN_OK;
+  VQN_CHECK_ARG(x && idx, "x and idx must be non-null");
+  VQN_CHECK_SHAPE(D % 4 == 0 && ((uintptr_t)x % 16) == 0, "D multiple of 4 and x 16-byte aligned");
+  const size_t lds = ((size_t)K * D + K) * sizeof(float);
+  VQN_CHECK_SHAPE(lds <= 160 * 1024, "K*D accumulators do not fit in 160 KB of LDS");
+  if (lds > 64 * 1024)
+    VQN_HIP(hipFuncSetAttribute((const void*)vq_ema_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  long blocks = (N + 63) / 64;                        // >= 16 rows per wave
+  const long cap = (long)vqn_num_cus() * 4;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(vq_ema_stats_kernel, dim3((unsigned)blocks), dim3(256), lds, s, x,
+                     reinterpret_cast<const long long*>(idx), (long)N, D, K, counts, dw);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}

@@ -1,0 +1,112 @@
+"""VectorQuantizerEMA on MI355X: mirror of
+decomp/nerfvq_nfr3/nerfactor/networks/vq_layers.py:174-349 (same constructor arguments, same call
+signature and result keys), with the nearest-code search and the EMA statistics running in the HIP
+kernels `vqn_vq_assign` / `vqn_vq_ema_stats` (csrc/vq.hip).
+
+Differences that are deliberate and documented:
+  * the code-dropout draw ``tf.random.uniform((1, K))`` (vq_layers.py:287) is an explicit optional
+    argument ``roll`` so that runs are reproducible and data-parallel ranks can share it;
+  * no host synchronisation: the reference's ``.numpy()`` at vq_layers.py:318 is gone;
+  * ``ExponentialMovingAverage`` restates dm-sonnet 2.0.0's ``sonnet.src.moving_averages`` (third
+    party, not in the reference tree): hidden -= (hidden - v) * (1 - decay); counter += 1;
+    average = hidden / (1 - decay ** counter).
+"""
+import torch
+
+from vqnerf_release_amd import _C
+
+
+class ExponentialMovingAverage(torch.nn.Module):
+    def __init__(self, decay, shape, dtype=torch.float32):
+        super().__init__()
+        self.decay = float(decay)
+        self.register_buffer('hidden', torch.zeros(shape, dtype=dtype))
+        self.register_buffer('average', torch.zeros(shape, dtype=dtype))
+        self.register_buffer('counter', torch.zeros((), dtype=torch.int64))
+        self._steps = 0     # host copy of `counter`, avoids a device sync per update
+
+    def initialize(self, value):
+        self.hidden = torch.zeros_like(value)
+        self.average = torch.zeros_like(value)
+
+    @torch.no_grad()
+    def update(self, value):
+        if self._steps == 0 and int(self.counter) != 0:     # restored from a checkpoint
+            self._steps = int(self.counter)
+        self._steps += 1
+        self.counter += 1
+        self.hidden -= (self.hidden - value) * (1.0 - self.decay)
+        self.average = self.hidden / (1.0 - self.decay ** self._steps)
+
+    @property
+    def value(self):
+        return self.average
+
+    def forward(self, value):
+        self.update(value)
+        return self.average
+
+
+class VectorQuantizerEMA(torch.nn.Module):
+    def __init__(self, embedding_dim, num_embeddings, commitment_cost, seed, decay=0.999, epsilon=1e-5,
+                 dtype=torch.float32, name='vector_quantizer_ema'):
+        super().__init__()
+        self.embedding_dim = embedding_dim
+        self.num_embeddings = num_embeddings
+        if not 0 <= decay <= 1:
+            raise ValueError('decay must be in range [0, 1]')
+        self.decay = decay
+        self.commitment_cost = commitment_cost
+        self.epsilon = epsilon
+        self.name = name
+        self._gen = torch.Generator(device='cpu')
+        self._gen.manual_seed(int(seed))
+        self.ema_cluster_size = ExponentialMovingAverage(decay, (num_embeddings,), dtype)
+        self.ema_dw = ExponentialMovingAverage(decay, (embedding_dim, num_embeddings), dtype)
+        # hook for data-parallel training: called with the flat [K + D*K] statistics buffer
+        # (sum over ranks) before the EMAs are updated -- see parallel.py
+        self.stats_all_reduce = None
+
+    def draw_roll(self, individual=True, device=None):
+        n = self.num_embeddings if individual else 1
+        return torch.rand((1, n), generator=self._gen).to(device or 'cpu')
+
+    def forward(self, inputs, codebook, is_training, thres=None, individual=True, roll=None,
+                return_distances=True):
+        D, K = self.embedding_dim, self.num_embeddings
+        flat = inputs.reshape(-1, D)
+        x = flat.detach().contiguous()
+        cb = codebook.detach().contiguous()
+        sel = None
+        if thres is not None:
+            if roll is None:
+                roll = self.draw_roll(individual, x.device)
+            thres_t = torch.as_tensor(thres, dtype=torch.float32, device=x.device)
+            sel = (roll.to(x.device) >= thres_t).to(torch.float32).expand(1, K).reshape(K).contiguous()
+        idx, quant, dist = _C.vq_assign(x, cb, sel_mask=sel, want_quant=True, want_dist=return_distances)
+        encodings = torch.nn.functional.one_hot(idx, K).to(flat.dtype)
+        encoding_indices = idx.reshape(inputs.shape[:-1])
+        quantized = quant.reshape(inputs.shape)
+        e_latent_loss = torch.mean((quantized - inputs) ** 2)
+        ret = {}
+        if is_training:
+            counts, dw = _C.vq_ema_stats(x, idx, K)
+            if self.stats_all_reduce is not None:
+                counts, dw = self.stats_all_reduce(counts, dw)
+            cs = self.ema_cluster_size(counts)
+            ema_dw = self.ema_dw(dw)
+            n = cs.sum()
+            cs = (cs + self.epsilon) / (n + K * self.epsilon) * n
+            w = ema_dw / cs.reshape(1, -1)
+            used = (counts > 0).to(w.dtype)
+            ret['update'] = w * used[None, :] + cb * (1.0 - used[None, :])
+        loss = self.commitment_cost * e_latent_loss
+        quantized = inputs + (quantized - inputs).detach()          # straight-through estimator
+        avg_probs = encodings.mean(0)
+        perplexity = torch.exp(-torch.sum(avg_probs * torch.log(avg_probs + 1e-10)))
+        ret.update({'quantize': quantized, 'loss': loss, 'perplexity': perplexity, 'encodings': encodings,
+                    'encoding_indices': encoding_indices, 'distances': dist})
+        return ret
+
+    def quantize(self, codebook, encoding_indices):
+        return codebook.t()[encoding_indices]
