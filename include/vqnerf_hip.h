@@ -41,6 +41,32 @@ int vqn_vq_assign(const float* x, int64_t N, int D, const float* codebook, int K
 int vqn_vq_ema_stats(const float* x, const int64_t* idx, int64_t N, int D, int K, float* counts, float* dw,
                      void* stream);
 
+/* ---- fused NeuS networks (geo/NeuS-ours2/models/{fields,renderer}.py) ---------------------- */
+
+/* Network descriptors are flat int32 arrays in HOST memory (layout: csrc/neus_desc.h, built by
+ * vqnerf_release_amd/geo/packing.py together with the packed weight buffers `wbuf_*`, which are
+ * device memory).  Points are either explicit (`pts` [P,3], `dirs` [P,3]) or ray samples
+ * (rays_o, rays_d [B,3], z [B,S], P = B*S, point = o + d*z) -- pass NULL for the unused form. */
+
+/* Replaces SDFNetwork.sdf(pts) as called at renderer.py:337-338 (coarse samples) and :180-185
+ * (new samples of each up-sampling step): posenc (embedder.py:16-34) + the whole weight-normed
+ * softplus(beta=100) MLP with its skip connection (fields.py:72-91), sdf only.  out_sdf [P]. */
+int vqn_neus_sdf_points(const int32_t* sdf_desc, const float* wbuf_sdf, const float* rays_o, const float* rays_d,
+                        const float* z, const float* pts, int64_t P, int S, float* out_sdf, void* stream);
+
+/* Bytes of device scratch vqn_neus_fine_points wants for full occupancy (it runs, slower, with less). */
+int64_t vqn_neus_fine_scratch_bytes(const int32_t* sdf_desc);
+
+/* Replaces renderer.py:216-227: sdf_network(pts) (fields.py:72-91), sdf_network.gradient(pts)
+ * (fields.py:96-107, autograd wrt the input -> here an explicit reverse sweep) and
+ * color_network(pts, gradients, dirs, feature) (fields.py:147-172).
+ * out_sdf [P], out_grad [P,3], out_rgb [P,3].  col_desc with n_lin == 0 skips the colour net
+ * (out_rgb may then be NULL): that is SDFNetwork.gradient(). */
+int vqn_neus_fine_points(const int32_t* sdf_desc, const float* wbuf_sdf, const int32_t* col_desc,
+                         const float* wbuf_col, const float* rays_o, const float* rays_d, const float* z,
+                         const float* pts, const float* dirs, int64_t P, int S, void* scratch,
+                         int64_t scratch_bytes, float* out_sdf, float* out_grad, float* out_rgb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,3 +92,66 @@ def vq_ema_stats(x, idx, K):
                                 _ptr(counts), _ptr(dw), _stream())
     _check(rc, 'vqn_vq_ema_stats')
     return counts, dw
+
+
+# --------------------------------------------------------------------------------------
+# fused NeuS networks (csrc/neus_mlp.hip)
+_scratch = {}
+
+
+def _i32(desc):
+    import numpy as np
+    d = np.ascontiguousarray(desc, dtype=np.int32)
+    return d, d.ctypes.data_as(ctypes.c_void_p)
+
+
+def neus_sdf_points(sdf_desc, wbuf_sdf, rays_o=None, rays_d=None, z=None, pts=None):
+    """SDF value at ray samples (rays_o/rays_d [B,3], z [B,S]) or at explicit pts [P,3] -> [P]."""
+    _f32c(wbuf_sdf, 'wbuf_sdf')
+    d, dp = _i32(sdf_desc)
+    if pts is not None:
+        _f32c(pts, 'pts'); P, S = pts.shape[0], 1
+        dev = pts.device
+    else:
+        _f32c(rays_o, 'rays_o'); _f32c(rays_d, 'rays_d'); _f32c(z, 'z')
+        B, S = z.shape
+        P = B * S
+        dev = z.device
+    out = torch.empty((P,), dtype=torch.float32, device=dev)
+    rc = lib().vqn_neus_sdf_points(dp, _ptr(wbuf_sdf), _ptr(rays_o), _ptr(rays_d), _ptr(z), _ptr(pts),
+                                   ctypes.c_int64(P), ctypes.c_int(S), _ptr(out), _stream())
+    _check(rc, 'vqn_neus_sdf_points')
+    return out
+
+
+def neus_fine_points(sdf_desc, wbuf_sdf, col_desc, wbuf_col, rays_o=None, rays_d=None, z=None, pts=None, dirs=None):
+    """sdf [P], d sdf/d x [P,3], rgb [P,3] at ray samples or explicit (pts, dirs)."""
+    _f32c(wbuf_sdf, 'wbuf_sdf'); _f32c(wbuf_col, 'wbuf_col')
+    sd, sdp = _i32(sdf_desc)
+    cd, cdp = _i32(col_desc)
+    if pts is not None:
+        _f32c(pts, 'pts'); _f32c(dirs, 'dirs'); P, S = pts.shape[0], 1
+        dev = pts.device
+    else:
+        _f32c(rays_o, 'rays_o'); _f32c(rays_d, 'rays_d'); _f32c(z, 'z')
+        B, S = z.shape
+        P = B * S
+        dev = z.device
+    L = lib()
+    L.vqn_neus_fine_scratch_bytes.restype = ctypes.c_int64
+    need = int(L.vqn_neus_fine_scratch_bytes(sdp))
+    if need <= 0:
+        raise VqnError('vqn_neus_fine_scratch_bytes: invalid SDF descriptor')
+    key = (str(dev), torch.cuda.current_stream().cuda_stream)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty((need,), dtype=torch.uint8, device=dev)
+        _scratch[key] = buf
+    sdf = torch.empty((P,), dtype=torch.float32, device=dev)
+    grad = torch.empty((P, 3), dtype=torch.float32, device=dev)
+    rgb = torch.empty((P, 3), dtype=torch.float32, device=dev)
+    rc = L.vqn_neus_fine_points(sdp, _ptr(wbuf_sdf), cdp, _ptr(wbuf_col), _ptr(rays_o), _ptr(rays_d), _ptr(z),
+                                _ptr(pts), _ptr(dirs), ctypes.c_int64(P), ctypes.c_int(S), _ptr(buf),
+                                ctypes.c_int64(buf.numel()), _ptr(sdf), _ptr(grad), _ptr(rgb), _stream())
+    _check(rc, 'vqn_neus_fine_points')
+    return sdf, grad, rgb

@@ -1,0 +1,164 @@
+// Device primitives of the fused small-MLP engine (gfx950, wave64, fp32 MFMA).  Not a public header.
+//
+// Data layout ("activation image").  A workgroup (4 waves) owns a tile of 32 points.  Activations
+// live in LDS as rows of 64 float4 (1 KB):  row (t, rq), lane (p = lane & 31, h = lane >> 5),
+// component j  holds feature  32 t + 2 (4 rq + j) + h  of point p.  That is exactly
+//   * the B operand of v_mfma_f32_32x32x2_f32 for K-step r = 4 rq + j (lane (p,h) supplies
+//     B[k = h][n = p]), fetched for 4 consecutive K-steps by ONE conflict-free ds_read_b128, and
+//   * the accumulator layout of the same instruction when the 32 output rows of a tile are
+//     ordered by  phi(i) = 2 (i & 3) + 8 (i >> 3) + ((i >> 2) & 1)  (done by the host-side weight
+//     packer), so an output tile is written back with four ds_write_b128 and no shuffles.
+// Weights are packed on the host as A fragments: pack[out_tile][k_group][lane][j] =
+//   W[out = 32 ot + phi(lane & 31)][in = feature(k_group, j, lane >> 5)]   (zero where padded),
+// so each lane fetches its A operands for 4 MFMAs with one coalesced global_load_dwordx4 (the
+// wave reads 1 KB contiguous); the packs stay L2-resident (3 MB for the NeuS nets).
+#pragma once
+#include "common.h"
+
+namespace eng {
+
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SOFTPLUS100 = 2, ACT_SIGMOID = 3 };
+
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float x) {
+  if (ACT == ACT_RELU) return fmaxf(x, 0.f);
+  if (ACT == ACT_SOFTPLUS100) {           // nn.Softplus(beta=100, threshold=20)  (fields.py:70)
+    const float t = 100.f * x;
+    return t > 20.f ? x : 0.01f * fast_log(1.f + fast_exp(t));
+  }
+  if (ACT == ACT_SIGMOID) return fast_rcp(1.f + fast_exp(-x));
+  return x;
+}
+
+// derivative of the activation expressed through its OUTPUT h
+template <int ACT>
+__device__ __forceinline__ float act_bwd_from_out(float h) {
+  if (ACT == ACT_RELU) return h > 0.f ? 1.f : 0.f;
+  if (ACT == ACT_SOFTPLUS100) return 1.f - fast_exp(-100.f * h);   // sigmoid(100 x) = 1 - exp(-100 softplus(x))
+  if (ACT == ACT_SIGMOID) return h * (1.f - h);
+  return 1.f;
+}
+
+struct KSegs {   // the K dimension of a layer = up to two runs of consecutive LDS rows
+  int rowA, nA, rowB, nB;
+};
+
+// out[32 x 32-point tile `ot`] = sum over K rows;  wave w owns tiles w, w+4, ...
+template <class Init, class Epi>
+__device__ __forceinline__ void gemm_tiles(const f32x4* __restrict__ lds, const KSegs ks,
+                                           const f32x4* __restrict__ w, const int n_out_tiles, const int wave,
+                                           const int lane, Init init, Epi epi) {
+  const int ng = ks.nA + ks.nB;
+  for (int ot = wave; ot < n_out_tiles; ot += 4) {
+    f32x16 acc;
+    init(ot, acc);
+    const f32x4* __restrict__ wp = w + (size_t)ot * ng * 64 + lane;
+    auto brow = [&](int g) { return ((g < ks.nA) ? (ks.rowA + g) : (ks.rowB + (g - ks.nA))) * 64 + lane; };
+    f32x4 a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < ng) { a0[i] = wp[i * 64]; b0[i] = lds[brow(i)]; }
+    for (int g = 0; g < ng; g += 8) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (g + 4 + i < ng) { a1[i] = wp[(g + 4 + i) * 64]; b1[i] = lds[brow(g + 4 + i)]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (g + i < ng) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][j], b0[i][j], acc, 0, 0, 0);
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (g + 8 + i < ng) { a0[i] = wp[(g + 8 + i) * 64]; b0[i] = lds[brow(g + 8 + i)]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (g + 4 + i < ng) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], b1[i][j], acc, 0, 0, 0);
+        }
+    }
+    epi(ot, acc);
+  }
+}
+
+__device__ __forceinline__ f32x4 acc_quad(const f32x16& acc, int rq) {
+  // static rq only (callers unroll)
+  return (f32x4){acc[4 * rq + 0], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]};
+}
+
+// acc init from a packed bias: bpack[ot][h][16]
+__device__ __forceinline__ void init_bias(const f32x4* __restrict__ bpack, int ot, int lane, f32x16& acc) {
+  const f32x4* b = bpack + (ot * 2 + (lane >> 5)) * 4;
+#pragma unroll
+  for (int rq = 0; rq < 4; ++rq) {
+    f32x4 v = b[rq];
+    acc[4 * rq + 0] = v[0]; acc[4 * rq + 1] = v[1]; acc[4 * rq + 2] = v[2]; acc[4 * rq + 3] = v[3];
+  }
+}
+
+__device__ __forceinline__ void init_zero(f32x16& acc) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+}
+
+__device__ __forceinline__ void init_rows(const f32x4* __restrict__ rows /* tile base, 4 rows */, int lane, f32x16& acc) {
+#pragma unroll
+  for (int rq = 0; rq < 4; ++rq) {
+    f32x4 v = rows[rq * 64 + lane];
+    acc[4 * rq + 0] = v[0]; acc[4 * rq + 1] = v[1]; acc[4 * rq + 2] = v[2]; acc[4 * rq + 3] = v[3];
+  }
+}
+
+// positional encoding feature f of a 3-vector (embedder.py:16-34): [x, sin(2^k x), cos(2^k x)]_k
+__device__ __forceinline__ float posenc_feat(int f, float x0, float x1, float x2) {
+  if (f < 3) return f == 0 ? x0 : (f == 1 ? x1 : x2);
+  const int g = f - 3, k = g / 6, m = g - 6 * k, c = m >= 3 ? m - 3 : m;
+  const float xc = c == 0 ? x0 : (c == 1 ? x1 : x2);
+  const float arg = xc * (float)(1 << k);
+  return m < 3 ? sinf(arg) : cosf(arg);
+}
+// d posenc_feat(f) / d x_c(f); *comp receives c(f)
+__device__ __forceinline__ float posenc_jac(int f, float x0, float x1, float x2, int* comp) {
+  if (f < 3) { *comp = f; return 1.f; }
+  const int g = f - 3, k = g / 6, m = g - 6 * k, c = m >= 3 ? m - 3 : m;
+  const float xc = c == 0 ? x0 : (c == 1 ? x1 : x2);
+  const float fr = (float)(1 << k), arg = xc * fr;
+  *comp = c;
+  return m < 3 ? fr * cosf(arg) : -fr * sinf(arg);
+}
+
+// feature index held by (row r of a segment, lane half h, component j)
+__device__ __forceinline__ int row_feat(int r, int h, int j) { return 32 * (r >> 2) + 2 * (4 * (r & 3) + j) + h; }
+
+// part[(wave*32 + p)*NOUT + o] = this wave's share of sum_f wimg[o][f] * act[f][p] over rows
+// [row0, row0+n_rows); the caller adds the four partials in a fixed order (deterministic)
+template <int NOUT>
+__device__ __forceinline__ void rowdot(const f32x4* __restrict__ lds, int row0, int n_rows,
+                                       const f32x4* __restrict__ wimg /* [NOUT][n_rows][2] float4 */, float* out_s,
+                                       int wave, int lane) {
+  float s[NOUT];
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) s[o] = 0.f;
+  const int h = lane >> 5;
+  for (int r = wave; r < n_rows; r += 4) {
+    const f32x4 b = lds[(row0 + r) * 64 + lane];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      const f32x4 wv = wimg[(o * n_rows + r) * 2 + h];
+      s[o] = fmaf(b[0], wv[0], s[o]); s[o] = fmaf(b[1], wv[1], s[o]);
+      s[o] = fmaf(b[2], wv[2], s[o]); s[o] = fmaf(b[3], wv[3], s[o]);
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) {
+    s[o] += __shfl_xor(s[o], 32);
+    if (h == 0) out_s[(wave * 32 + (lane & 31)) * NOUT + o] = s[o];
+  }
+}
+
+}  // namespace eng

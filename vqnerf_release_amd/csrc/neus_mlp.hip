@@ -1,0 +1,345 @@
+// Fused NeuS network evaluation for gfx950: ray -> points -> posenc -> SDF MLP [-> analytic
+// d sdf / d x -> colour MLP], one launch, activations never leave the CU except for the per-tile
+// backward stash.  Replaces the framework-op sequences at
+//   geo/NeuS-ours2/models/renderer.py:337-338,180-185   (coarse / up-sampling SDF evaluations)   -> vqn_neus_sdf_points
+//   geo/NeuS-ours2/models/renderer.py:216-227 + fields.py:72-107,147-172
+//        (sdf_network(pts), sdf_network.gradient(pts) = autograd wrt the input, color_network)   -> vqn_neus_fine_points
+// The reference's gradient() re-runs the whole SDF forward (fields.py:98) and then calls autograd;
+// here the input gradient is an explicit reverse sweep over the same packed weights (transposed
+// packs), reusing the forward activations stashed per tile, so the forward runs once.
+//
+// Execution model: 256-thread workgroups (4 waves), persistent over tiles of 32 points, 2 workgroups
+// per CU.  See mlp_prims.h for the LDS "activation image" and the weight-pack layout.
+#include "mlp_prims.h"
+#include "neus_desc.h"
+
+using namespace eng;
+
+namespace {
+
+constexpr int E0 = 0;        // LDS rows [0,8): embedding / colour-net extras / d sdf / d embedding
+constexpr int E_ROWS = 8;
+
+struct Smalls {              // per-tile scalars, after the activation rows
+  float pts[96], dirs[96], part[512], grad[96];
+};
+
+template <bool FINE>
+__global__ __launch_bounds__(256, 2) void neus_points_kernel(
+    const SdfDesc sd, const ColDesc cd, const f32x4* __restrict__ wsdf, const f32x4* __restrict__ wcol,
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ zv,
+    const float* __restrict__ pts_direct, const float* __restrict__ dirs_direct, const long P, const int S,
+    f32x4* __restrict__ scratch, float* __restrict__ out_sdf, float* __restrict__ out_grad,
+    float* __restrict__ out_rgb) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+  const int MT = sd.max_tiles;
+  const int X0 = E_ROWS, Y0 = E_ROWS + 4 * MT;
+  Smalls* sm = reinterpret_cast<Smalls*>(lds + (size_t)(E_ROWS + 8 * MT) * 64);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+  const int n_lin = sd.n_lin;
+  const int emb_tiles = (sd.emb_feats + 31) >> 5;
+  const long n_tiles = (P + 31) >> 5;
+  f32x4* save = FINE ? scratch + (size_t)blockIdx.x * (size_t)(n_lin - 1) * 4 * MT * 64 : nullptr;
+  const int feat_slot = (n_lin - 2) * 4 * MT;
+
+  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long p0 = tile << 5;
+    // ---------------- points of this tile ----------------
+    if (tid < 32) {
+      long pt = p0 + tid;
+      if (pt >= P) pt = P - 1;
+      float x, y, z, dx = 0.f, dy = 0.f, dz = 0.f;
+      if (pts_direct != nullptr) {
+        x = pts_direct[pt * 3 + 0]; y = pts_direct[pt * 3 + 1]; z = pts_direct[pt * 3 + 2];
+        if (FINE) { dx = dirs_direct[pt * 3 + 0]; dy = dirs_direct[pt * 3 + 1]; dz = dirs_direct[pt * 3 + 2]; }
+      } else {
+        const long ray = pt / S;
+        const float t = zv[pt];
+        dx = rays_d[ray * 3 + 0]; dy = rays_d[ray * 3 + 1]; dz = rays_d[ray * 3 + 2];
+        // o + d * z with separate mul/add roundings, as the reference's broadcasted expression
+        x = rays_o[ray * 3 + 0] + __fmul_rn(dx, t);
+        y = rays_o[ray * 3 + 1] + __fmul_rn(dy, t);
+        z = rays_o[ray * 3 + 2] + __fmul_rn(dz, t);
+      }
+      sm->pts[tid * 3 + 0] = x; sm->pts[tid * 3 + 1] = y; sm->pts[tid * 3 + 2] = z;
+      sm->dirs[tid * 3 + 0] = dx; sm->dirs[tid * 3 + 1] = dy; sm->dirs[tid * 3 + 2] = dz;
+    }
+    __syncthreads();
+    const float xs = sm->pts[p * 3 + 0] * sd.scale, ys = sm->pts[p * 3 + 1] * sd.scale, zs = sm->pts[p * 3 + 2] * sd.scale;
+    // ---------------- positional encoding -> E rows ----------------
+    for (int r = wave; r < sd.emb_rows; r += 4) {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int f = row_feat(r, h, j);
+        v[j] = f < sd.emb_feats ? posenc_feat(f, xs, ys, zs) : 0.f;
+      }
+      lds[(E0 + r) * 64 + lane] = v;
+    }
+    __syncthreads();
+
+    // ---------------- SDF hidden layers ----------------
+    int cur = X0, oth = Y0;
+    for (int l = 0; l < n_lin - 1; ++l) {
+      const LayerDesc L = sd.layers[l];
+      const KSegs ks = (l == 0) ? KSegs{E0, sd.emb_rows, 0, 0}
+                                : KSegs{cur, 4 * sd.layers[l - 1].n_out_tiles, E0, (l == sd.skip) ? sd.emb_rows : 0};
+      const int dst = (l == 0) ? X0 : oth;
+      const bool do_save = FINE && (l < n_lin - 2);
+      const f32x4* bp = wsdf + L.b_off;
+      f32x4* sv = save + (size_t)l * 4 * MT * 64;
+      gemm_tiles(lds, ks, wsdf + L.w_off, L.n_out_tiles, wave, lane,
+                 [&](int ot, f32x16& acc) { init_bias(bp, ot, lane, acc); },
+                 [&](int ot, const f32x16& acc) {
+#pragma unroll
+                   for (int rq = 0; rq < 4; ++rq) {
+                     f32x4 v = acc_quad(acc, rq);
+#pragma unroll
+                     for (int j = 0; j < 4; ++j) v[j] = act_fwd<ACT_SOFTPLUS100>(v[j]);
+                     lds[(dst + ot * 4 + rq) * 64 + lane] = v;
+                     if (do_save) sv[(ot * 4 + rq) * 64 + lane] = v;
+                   }
+                 });
+      __syncthreads();
+      if (l == 0) { cur = X0; oth = Y0; } else { const int t = cur; cur = oth; oth = t; }
+    }
+    const int hid_rows = 4 * sd.layers[n_lin - 2].n_out_tiles;
+
+    // ---------------- last layer: sdf row (VALU dot) [+ feature rows -> stash] ----------------
+    rowdot<1>(lds, cur, hid_rows, wsdf + sd.last_w_off, sm->part, wave, lane);
+    if (FINE && sd.layers[n_lin - 1].n_out_tiles > 0) {
+      const LayerDesc L = sd.layers[n_lin - 1];
+      const f32x4* bp = wsdf + L.b_off;
+      f32x4* sv = save + (size_t)feat_slot * 64;
+      gemm_tiles(lds, KSegs{cur, hid_rows, 0, 0}, wsdf + L.w_off, L.n_out_tiles, wave, lane,
+                 [&](int ot, f32x16& acc) { init_bias(bp, ot, lane, acc); },
+                 [&](int ot, const f32x16& acc) {
+#pragma unroll
+                   for (int rq = 0; rq < 4; ++rq) sv[(ot * 4 + rq) * 64 + lane] = acc_quad(acc, rq);
+                 });
+    }
+    __syncthreads();
+    if (tid < 32 && p0 + tid < P) {
+      const float s = ((sm->part[tid] + sm->part[32 + tid]) + (sm->part[64 + tid] + sm->part[96 + tid])) + sd.last_bias;
+      out_sdf[p0 + tid] = s / sd.scale;
+    }
+    if (!FINE) { __syncthreads(); continue; }
+
+    // ---------------- reverse sweep: d sdf / d x ----------------
+    // G_pre(last hidden) = w_sdf_row (.) act'(h), in place
+    for (int r = wave; r < hid_rows; r += 4) {
+      f32x4 v = lds[(cur + r) * 64 + lane];
+      const f32x4 wv = wsdf[sd.last_w_off + r * 2 + h];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = wv[j] * act_bwd_from_out<ACT_SOFTPLUS100>(v[j]);
+      lds[(cur + r) * 64 + lane] = v;
+    }
+    __syncthreads();
+    for (int l = n_lin - 2; l >= 1; --l) {
+      const LayerDesc L = sd.layers[l];
+      const KSegs ks{cur, 4 * L.n_out_tiles, 0, 0};
+      const f32x4* sv = save + (size_t)(l - 1) * 4 * MT * 64;
+      const int dst = oth;
+      gemm_tiles(lds, ks, wsdf + L.wT_off, sd.layers[l - 1].n_out_tiles, wave, lane,
+                 [&](int, f32x16& acc) { init_zero(acc); },
+                 [&](int ot, const f32x16& acc) {
+#pragma unroll
+                   for (int rq = 0; rq < 4; ++rq) {
+                     const f32x4 hv = sv[(ot * 4 + rq) * 64 + lane];
+                     f32x4 v = acc_quad(acc, rq);
+#pragma unroll
+                     for (int j = 0; j < 4; ++j) v[j] *= act_bwd_from_out<ACT_SOFTPLUS100>(hv[j]);
+                     lds[(dst + ot * 4 + rq) * 64 + lane] = v;
+                   }
+                 });
+      if (l == sd.skip)
+        gemm_tiles(lds, ks, wsdf + L.wTE_off, emb_tiles, wave, lane,
+                   [&](int, f32x16& acc) { init_zero(acc); },
+                   [&](int ot, const f32x16& acc) {
+#pragma unroll
+                     for (int rq = 0; rq < 4; ++rq) lds[(E0 + ot * 4 + rq) * 64 + lane] = acc_quad(acc, rq);
+                   });
+      __syncthreads();
+      const int t = cur; cur = oth; oth = t;
+    }
+    {
+      const LayerDesc L = sd.layers[0];
+      const bool accumulate = sd.skip >= 1;
+      gemm_tiles(lds, KSegs{cur, 4 * L.n_out_tiles, 0, 0}, wsdf + L.wTE_off, emb_tiles, wave, lane,
+                 [&](int ot, f32x16& acc) {
+                   if (accumulate) init_rows(lds + (E0 + ot * 4) * 64, lane, acc); else init_zero(acc);
+                 },
+                 [&](int ot, const f32x16& acc) {
+#pragma unroll
+                   for (int rq = 0; rq < 4; ++rq) lds[(E0 + ot * 4 + rq) * 64 + lane] = acc_quad(acc, rq);
+                 });
+    }
+    __syncthreads();
+    // chain through the embedding: thread (point pp, component c) sums its features in a fixed order
+    if (tid < 96) {
+      const int pp = tid & 31, c = tid >> 5;
+      const float x0 = sm->pts[pp * 3 + 0] * sd.scale, x1 = sm->pts[pp * 3 + 1] * sd.scale, x2 = sm->pts[pp * 3 + 2] * sd.scale;
+      const float* ldsf = reinterpret_cast<const float*>(lds);
+      auto G = [&](int f) {
+        const int t = f >> 5, fi = f & 31, hh = fi & 1, rr = fi >> 1;
+        return ldsf[(((E0 + t * 4 + (rr >> 2)) * 64) + pp + 32 * hh) * 4 + (rr & 3)];
+      };
+      float g = G(c);
+      int cc;
+      for (int k = 0; k < sd.multires; ++k) {
+        const int fs = 3 + 6 * k + c, fc = fs + 3;
+        g = fmaf(G(fs), posenc_jac(fs, x0, x1, x2, &cc), g);
+        g = fmaf(G(fc), posenc_jac(fc, x0, x1, x2, &cc), g);
+      }
+      sm->grad[pp * 3 + c] = g;
+      if (p0 + pp < P) out_grad[(p0 + pp) * 3 + c] = g;
+    }
+    __syncthreads();
+    if (cd.n_lin == 0) continue;          // SDFNetwork.gradient(): no colour net
+
+    // ---------------- colour network ----------------
+    {
+      const float px = sm->pts[p * 3 + 0], py = sm->pts[p * 3 + 1], pz = sm->pts[p * 3 + 2];
+      const float dx = sm->dirs[p * 3 + 0], dy = sm->dirs[p * 3 + 1], dz = sm->dirs[p * 3 + 2];
+      for (int r = wave; r < cd.extra_rows; r += 4) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int f = row_feat(r, h, j);
+          float val = 0.f;
+          if (f < 3) val = f == 0 ? px : (f == 1 ? py : pz);
+          else if (f < 3 + cd.n_view_feats) val = posenc_feat(f - 3, dx, dy, dz);
+          else if (f < cd.extra_feats) val = sm->grad[p * 3 + (f - 3 - cd.n_view_feats)];
+          v[j] = val;
+        }
+        lds[(E0 + r) * 64 + lane] = v;
+      }
+      const f32x4* sv = save + (size_t)feat_slot * 64;
+      const int feat_rows = 4 * sd.layers[n_lin - 1].n_out_tiles;
+      for (int r = wave; r < feat_rows; r += 4) lds[(X0 + r) * 64 + lane] = sv[r * 64 + lane];
+      __syncthreads();
+      cur = X0; oth = Y0;
+      int in_rows = feat_rows;
+      for (int l = 0; l < cd.n_lin - 1; ++l) {
+        const LayerDesc L = cd.layers[l];
+        const KSegs ks{cur, in_rows, E0, l == 0 ? cd.extra_rows : 0};
+        const f32x4* bp = wcol + L.b_off;
+        const int dst = oth;
+        gemm_tiles(lds, ks, wcol + L.w_off, L.n_out_tiles, wave, lane,
+                   [&](int ot, f32x16& acc) { init_bias(bp, ot, lane, acc); },
+                   [&](int ot, const f32x16& acc) {
+#pragma unroll
+                     for (int rq = 0; rq < 4; ++rq) {
+                       f32x4 v = acc_quad(acc, rq);
+#pragma unroll
+                       for (int j = 0; j < 4; ++j) v[j] = act_fwd<ACT_RELU>(v[j]);
+                       lds[(dst + ot * 4 + rq) * 64 + lane] = v;
+                     }
+                   });
+        __syncthreads();
+        const int t = cur; cur = oth; oth = t;
+        in_rows = 4 * L.n_out_tiles;
+      }
+      rowdot<3>(lds, cur, in_rows, wcol + cd.last_w_off, sm->part, wave, lane);
+      __syncthreads();
+      if (tid < 96) {
+        const int pp = tid & 31, o = tid >> 5;
+        float v = ((sm->part[(0 * 32 + pp) * 3 + o] + sm->part[(1 * 32 + pp) * 3 + o]) +
+                   (sm->part[(2 * 32 + pp) * 3 + o] + sm->part[(3 * 32 + pp) * 3 + o])) + cd.last_bias[o];
+        if (cd.squeeze_out) v = 1.f / (1.f + expf(-v));
+        if (p0 + pp < P) out_rgb[(p0 + pp) * 3 + o] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int check_sdf_desc(const SdfDesc& d) {
+  if (d.n_lin < 2 || d.n_lin > VQN_MAX_SDF_LAYERS) return 1;
+  if (d.max_tiles < 1 || d.max_tiles > 16) return 2;
+  if (d.emb_feats < 3 || d.emb_feats > 64 || d.emb_rows < 1 || d.emb_rows > 8) return 3;
+  if (d.skip >= d.n_lin - 1 || d.skip == 0) return 4;
+  for (int l = 0; l < d.n_lin; ++l)
+    if (d.layers[l].n_out_tiles < 0 || d.layers[l].n_out_tiles > d.max_tiles) return 5;
+  if (!(d.scale > 0.f)) return 6;
+  return 0;
+}
+
+size_t lds_bytes(int MT) { return (size_t)(E_ROWS + 8 * MT) * 1024 + sizeof(Smalls); }
+
+}  // namespace
+
+extern "C" int vqn_neus_sdf_points(const int32_t* sdf_desc, const float* wbuf_sdf, const float* rays_o,
+                                   const float* rays_d, const float* z, const float* pts, int64_t P, int S,
+                                   float* out_sdf, void* stream) {
+  VQN_CHECK_ARG(sdf_desc && wbuf_sdf && out_sdf, "sdf_desc, wbuf_sdf, out_sdf must be non-null");
+  VQN_CHECK_ARG(P >= 0, "P >= 0");
+  if (P == 0) return VQN_OK;
+  VQN_CHECK_ARG(pts != nullptr || (rays_o && rays_d && z && S > 0), "either pts or (rays_o, rays_d, z, S) required");
+  SdfDesc sd;
+  memcpy(&sd, sdf_desc, sizeof(SdfDesc));
+  VQN_CHECK_SHAPE(check_sdf_desc(sd) == 0, "invalid SDF network descriptor");
+  ColDesc cd;
+  memset(&cd, 0, sizeof(cd));
+  const size_t lds = lds_bytes(sd.max_tiles);
+  VQN_CHECK_SHAPE(lds <= 160 * 1024, "network too wide for LDS");
+  if (lds > 64 * 1024)
+    VQN_HIP(hipFuncSetAttribute((const void*)neus_points_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const long n_tiles = (P + 31) / 32;
+  long grid = (long)vqn_num_cus() * 2;
+  if (grid > n_tiles) grid = n_tiles;
+  hipLaunchKernelGGL(neus_points_kernel<false>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, sd, cd,
+                     reinterpret_cast<const f32x4*>(wbuf_sdf), (const f32x4*)nullptr, rays_o, rays_d, z, pts,
+                     (const float*)nullptr, (long)P, S, (f32x4*)nullptr, out_sdf, (float*)nullptr, (float*)nullptr);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
+
+extern "C" int64_t vqn_neus_fine_scratch_bytes(const int32_t* sdf_desc) {
+  if (!sdf_desc) return -1;
+  SdfDesc sd;
+  memcpy(&sd, sdf_desc, sizeof(SdfDesc));
+  if (check_sdf_desc(sd) != 0) return -2;
+  return (int64_t)vqn_num_cus() * 2 * (int64_t)(sd.n_lin - 1) * 4 * sd.max_tiles * 1024;
+}
+
+extern "C" int vqn_neus_fine_points(const int32_t* sdf_desc, const float* wbuf_sdf, const int32_t* col_desc,
+                                    const float* wbuf_col, const float* rays_o, const float* rays_d, const float* z,
+                                    const float* pts, const float* dirs, int64_t P, int S, void* scratch,
+                                    int64_t scratch_bytes, float* out_sdf, float* out_grad, float* out_rgb,
+                                    void* stream) {
+  VQN_CHECK_ARG(sdf_desc && wbuf_sdf && col_desc && wbuf_col, "descriptors and weight packs must be non-null");
+  VQN_CHECK_ARG(out_sdf && out_grad && scratch, "out_sdf, out_grad and scratch must be non-null");
+  VQN_CHECK_ARG(P >= 0, "P >= 0");
+  if (P == 0) return VQN_OK;
+  VQN_CHECK_ARG((pts != nullptr && dirs != nullptr) || (rays_o && rays_d && z && S > 0),
+                "either (pts, dirs) or (rays_o, rays_d, z, S) required");
+  SdfDesc sd;
+  ColDesc cd;
+  memcpy(&sd, sdf_desc, sizeof(SdfDesc));
+  memcpy(&cd, col_desc, sizeof(ColDesc));
+  VQN_CHECK_SHAPE(check_sdf_desc(sd) == 0, "invalid SDF network descriptor");
+  if (cd.n_lin != 0) {
+    VQN_CHECK_ARG(out_rgb != nullptr, "out_rgb must be non-null when a colour net is given");
+    VQN_CHECK_SHAPE(sd.layers[sd.n_lin - 1].n_out_tiles >= 1, "SDF network has no feature outputs (d_out == 1)");
+    VQN_CHECK_SHAPE(cd.n_lin >= 2 && cd.n_lin <= VQN_MAX_COL_LAYERS && cd.d_out == 3, "colour net: 2..8 layers, d_out == 3");
+    VQN_CHECK_SHAPE(cd.extra_feats >= 3 && cd.extra_feats <= 64 && cd.extra_rows >= 1 && cd.extra_rows <= 8, "colour net extras");
+    for (int l = 0; l < cd.n_lin - 1; ++l)
+      VQN_CHECK_SHAPE(cd.layers[l].n_out_tiles >= 1 && cd.layers[l].n_out_tiles <= sd.max_tiles, "colour layer wider than max_tiles");
+  }
+  const size_t lds = lds_bytes(sd.max_tiles);
+  VQN_CHECK_SHAPE(lds <= 160 * 1024, "network too wide for LDS");
+  if (lds > 64 * 1024)
+    VQN_HIP(hipFuncSetAttribute((const void*)neus_points_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const long n_tiles = (P + 31) / 32;
+  const int64_t per_wg = (int64_t)(sd.n_lin - 1) * 4 * sd.max_tiles * 1024;
+  long grid = (long)vqn_num_cus() * 2;
+  if (grid > n_tiles) grid = n_tiles;
+  if ((int64_t)grid * per_wg > scratch_bytes) grid = (long)(scratch_bytes / per_wg);
+  VQN_CHECK_ARG(grid >= 1, "scratch too small (see vqn_neus_fine_scratch_bytes)");
+  hipLaunchKernelGGL(neus_points_kernel<true>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, sd, cd,
+                     reinterpret_cast<const f32x4*>(wbuf_sdf), reinterpret_cast<const f32x4*>(wbuf_col), rays_o, rays_d,
+                     z, pts, dirs, (long)P, S, reinterpret_cast<f32x4*>(scratch), out_sdf, out_grad, out_rgb);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}

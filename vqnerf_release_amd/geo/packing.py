@@ -1,0 +1,275 @@
+"""Host-side weight packing for the fused NeuS kernels (csrc/neus_mlp.hip, csrc/mlp_prims.h).
+
+A pack is a pure gather of the effective weight matrix (index tensors are built once per network
+shape with numpy; applying them is one `torch.take` per matrix on the device), so it is cheap to
+redo after every optimiser step.  Layout, as consumed by `eng::gemm_tiles`:
+
+    pack[out_tile][k_group][lane][j] = M[row = 32*ot + phi(lane & 31)][col = colmap(k_group, j, lane >> 5)]
+
+with  phi(i) = 2*(i & 3) + 8*(i >> 3) + ((i >> 2) & 1)  and, inside a K segment, the feature held by
+(row r, component j, half h) being  32*(r >> 2) + 2*(4*(r & 3) + j) + h.
+"""
+import math
+
+import numpy as np
+import torch
+
+MAX_SDF_LAYERS = 12
+MAX_COL_LAYERS = 8
+SDF_DESC_INTS = 12 + MAX_SDF_LAYERS * 8
+COL_DESC_INTS = 16 + MAX_COL_LAYERS * 8
+
+
+def _phi():
+    i = np.arange(32)
+    return 2 * (i & 3) + 8 * (i >> 3) + ((i >> 2) & 1)
+
+
+PHI = _phi()
+
+
+def seg_features(n_rows):
+    """[n_rows, 64, 4] -> local feature index held by (row, lane, j)."""
+    r = np.arange(n_rows)[:, None, None]
+    lane = np.arange(64)[None, :, None]
+    j = np.arange(4)[None, None, :]
+    return 32 * (r >> 2) + 2 * (4 * (r & 3) + j) + (lane >> 5)
+
+
+def gemm_index(n_rows_out, n_cols, segs):
+    """Gather index [n_out_tiles, n_groups, 64, 4] into M.flatten() ++ [0].
+
+    segs: list of (n_rows, col_fn) where col_fn maps the local feature index array to a column
+    index array (negative = padding)."""
+    n_tiles = (n_rows_out + 31) // 32
+    zero_slot = n_rows_out * n_cols
+    cols = []
+    for n_rows, col_fn in segs:
+        cols.append(col_fn(seg_features(n_rows)))
+    col = np.concatenate(cols, 0)                                    # [ng, 64, 4]
+    ot = np.arange(n_tiles)[:, None, None, None]
+    lane = np.arange(64)[None, None, :, None]
+    row = 32 * ot + PHI[lane & 31]                                   # [nt,1,64,1]
+    row = np.broadcast_to(row, (n_tiles, col.shape[0], 64, 4))
+    colb = np.broadcast_to(col[None], row.shape)
+    idx = np.where((row < n_rows_out) & (colb >= 0), row * n_cols + colb, zero_slot)
+    return idx.astype(np.int64)
+
+
+def bias_index(n_out):
+    """[n_tiles, 2, 16] -> bias[32*ot + 2*rho + h] (or the zero slot n_out)."""
+    n_tiles = (n_out + 31) // 32
+    ot = np.arange(n_tiles)[:, None, None]
+    h = np.arange(2)[None, :, None]
+    rho = np.arange(16)[None, None, :]
+    f = 32 * ot + 2 * rho + h
+    return np.where(f < n_out, f, n_out).astype(np.int64)
+
+
+def rowdot_index(n_out, n_rows, n_cols, col_fn=None):
+    """[n_out, n_rows, 2, 4] image of the rows of M [n_out, n_cols] in activation-image order."""
+    r = np.arange(n_rows)[:, None, None]
+    h = np.arange(2)[None, :, None]
+    j = np.arange(4)[None, None, :]
+    f = 32 * (r >> 2) + 2 * (4 * (r & 3) + j) + h
+    col = f if col_fn is None else col_fn(f)
+    o = np.arange(n_out)[:, None, None, None]
+    colb = np.broadcast_to(col[None], (n_out,) + col.shape)
+    valid = (colb >= 0) & (colb < n_cols)
+    return np.where(valid, o * n_cols + colb, n_out * n_cols).astype(np.int64)
+
+
+def _take(mat, idx_dev):
+    flat = torch.cat([mat.reshape(-1), mat.new_zeros(1)])
+    return torch.take(flat, idx_dev).reshape(-1)
+
+
+def emb_rows_for(n_feats):
+    return (((n_feats + 1) // 2) + 3) // 4
+
+
+def ident_cols(n_valid, base=0):
+    return lambda f: np.where(f < n_valid, f + base, -1)
+
+
+class SdfPackPlan:
+    """Index tensors + descriptor for an SDFNetwork-shaped MLP (fields.py:9-107)."""
+
+    def __init__(self, dims, skip_in, multires, scale, max_tiles=None, with_reverse=True):
+        # dims: [d0, hidden..., d_out] as in fields.py:24 (d0 = embedded input width)
+        self.dims = list(dims)
+        self.n_lin = len(dims) - 1
+        assert 2 <= self.n_lin <= MAX_SDF_LAYERS
+        skips = [l for l in skip_in if 0 < l < self.n_lin]
+        assert len(skips) <= 1, 'one skip connection supported'
+        self.skip = skips[0] if skips else -1
+        assert self.skip != self.n_lin - 1, 'skip into the last layer is not supported'
+        self.multires = multires
+        self.emb = dims[0]
+        assert self.emb == 3 + 6 * multires and self.emb <= 64
+        self.emb_rows = emb_rows_for(self.emb)
+        self.scale = float(scale)
+        # true output width of every linear layer (fields.py:38-41)
+        self.out_dims = []
+        for l in range(self.n_lin):
+            o = dims[l + 1] - dims[0] if (l + 1) == self.skip else dims[l + 1]
+            self.out_dims.append(o)
+        self.in_dims = [dims[l] for l in range(self.n_lin)]
+        self.tiles = [(o + 31) // 32 for o in self.out_dims]
+        self.feat_out = self.out_dims[-1] - 1
+        self.tiles[-1] = (self.feat_out + 31) // 32 if self.feat_out > 0 else 0
+        self.max_tiles = max(max(self.tiles), max_tiles or 1)
+        self.with_reverse = with_reverse
+        self._build()
+
+    def _build(self):
+        E, er = self.emb, self.emb_rows
+        plan = []          # (kind, layer, index array)
+        for l in range(self.n_lin):
+            rows_prev = 4 * self.tiles[l - 1] if l > 0 else 0
+            if l == 0:
+                segs = [(er, ident_cols(E))]
+            elif l == self.skip:
+                prev = self.out_dims[l - 1]
+                segs = [(rows_prev, ident_cols(prev)), (er, ident_cols(E, base=prev))]
+            else:
+                segs = [(rows_prev, ident_cols(self.in_dims[l]))]
+            if l < self.n_lin - 1:
+                plan.append(('w', l, gemm_index(self.out_dims[l], self.in_dims[l], segs)))
+                plan.append(('b', l, bias_index(self.out_dims[l])))
+            else:
+                if self.feat_out > 0:   # feature rows = rows 1.. of the last layer
+                    plan.append(('wfeat', l, gemm_index(self.feat_out, self.in_dims[l], segs)))
+                    plan.append(('bfeat', l, bias_index(self.feat_out)))
+                plan.append(('wrow', l, rowdot_index(1, rows_prev, self.in_dims[l])))
+            if self.with_reverse and l < self.n_lin - 1:
+                ksegs = [(4 * self.tiles[l], ident_cols(self.out_dims[l]))]
+                if l >= 1:
+                    prev = self.out_dims[l - 1]
+                    plan.append(('wT', l, gemm_index(prev, self.out_dims[l], ksegs)))
+                if l == 0 or l == self.skip:
+                    plan.append(('wTE', l, gemm_index(E, self.out_dims[l], ksegs)))
+        self.plan = plan
+        self._dev_idx = {}
+
+    def _indices(self, device):
+        key = str(device)
+        if key not in self._dev_idx:
+            self._dev_idx[key] = [torch.from_numpy(ix).to(device) for _, _, ix in self.plan]
+        return self._dev_idx[key]
+
+    def pack(self, weights, biases):
+        """weights[l]: effective [out_l, in_l] (weight-norm already applied), biases[l]: [out_l].
+        Returns (wbuf float32 [n], desc int32 numpy [SDF_DESC_INTS])."""
+        dev = weights[0].device
+        idxs = self._indices(dev)
+        chunks, off = [], 0
+        layer = [dict(n_out_tiles=self.tiles[l], kA=0, kB=0, w=-1, b=-1, wT=-1, wTE=-1) for l in range(self.n_lin)]
+        last_w_off = -1
+        for (kind, l, _), ix in zip(self.plan, idxs):
+            W = weights[l]
+            if l == self.skip:
+                W = W / math.sqrt(2.0)
+            if kind == 'w':
+                src = W
+            elif kind == 'b':
+                src = biases[l]
+            elif kind == 'wfeat':
+                src = W[1:]
+            elif kind == 'bfeat':
+                src = biases[l][1:]
+            elif kind == 'wrow':
+                src = W[:1]
+            elif kind == 'wT':
+                src = W[:, :self.out_dims[l - 1]].t()
+            elif kind == 'wTE':
+                src = W[:, self.out_dims[l - 1]:].t() if l == self.skip else W.t()
+            c = _take(src.contiguous(), ix)
+            assert c.numel() % 4 == 0
+            o4 = off // 4
+            if kind in ('w', 'wfeat'):
+                layer[l]['w'] = o4
+            elif kind in ('b', 'bfeat'):
+                layer[l]['b'] = o4
+            elif kind == 'wrow':
+                last_w_off = o4
+            elif kind == 'wT':
+                layer[l]['wT'] = o4
+            elif kind == 'wTE':
+                layer[l]['wTE'] = o4
+            chunks.append(c)
+            off += c.numel()
+        wbuf = torch.cat(chunks).contiguous()
+        desc = np.zeros(SDF_DESC_INTS, np.int32)
+        desc[0:6] = [self.n_lin, self.skip, self.multires, self.emb, self.emb_rows, self.max_tiles]
+        desc[6] = np.float32(self.scale).view(np.int32)
+        desc[7] = last_w_off
+        self._last_bias_src = biases[self.n_lin - 1][0]
+        desc[8] = np.float32(float(self._last_bias_src)).view(np.int32)      # one scalar D2H per re-pack
+        for l in range(self.n_lin):
+            d = layer[l]
+            desc[12 + 8 * l: 12 + 8 * l + 8] = [d['n_out_tiles'], d['kA'], d['kB'], d['w'], d['b'], d['wT'], d['wTE'], 0]
+        return wbuf, desc
+
+
+class ColPackPlan:
+    """RenderingNetwork-shaped MLP (fields.py:111-172); input order [pts, view_embed, normals, feat]."""
+
+    def __init__(self, d_feature, mode, d_hidden, n_layers, d_out, multires_view, squeeze_out, feat_tiles):
+        self.mode = mode
+        self.n_view = (3 + 6 * multires_view) if mode in ('idr', 'no_normal') else 0
+        self.has_normal = 1 if mode in ('idr', 'no_view_dir') else 0
+        self.extra = 3 + self.n_view + 3 * self.has_normal
+        self.extra_rows = emb_rows_for(self.extra)
+        self.d_feature = d_feature
+        self.dims = [self.extra + d_feature] + [d_hidden] * n_layers + [d_out]
+        self.n_lin = len(self.dims) - 1
+        assert 2 <= self.n_lin <= MAX_COL_LAYERS and d_out == 3
+        self.tiles = [(self.dims[l + 1] + 31) // 32 for l in range(self.n_lin)]
+        self.squeeze_out = 1 if squeeze_out else 0
+        self.feat_tiles = feat_tiles
+        plan = []
+        for l in range(self.n_lin - 1):
+            if l == 0:
+                segs = [(4 * feat_tiles, ident_cols(d_feature, base=self.extra)), (self.extra_rows, ident_cols(self.extra))]
+            else:
+                segs = [(4 * self.tiles[l - 1], ident_cols(self.dims[l]))]
+            plan.append(('w', l, gemm_index(self.dims[l + 1], self.dims[l], segs)))
+            plan.append(('b', l, bias_index(self.dims[l + 1])))
+        L = self.n_lin - 1
+        plan.append(('wrow', L, rowdot_index(d_out, 4 * self.tiles[L - 1], self.dims[L])))
+        self.plan = plan
+        self._dev_idx = {}
+
+    def _indices(self, device):
+        key = str(device)
+        if key not in self._dev_idx:
+            self._dev_idx[key] = [torch.from_numpy(ix).to(device) for _, _, ix in self.plan]
+        return self._dev_idx[key]
+
+    def pack(self, weights, biases):
+        dev = weights[0].device
+        chunks, off = [], 0
+        layer = [dict(n_out_tiles=self.tiles[l], w=-1, b=-1) for l in range(self.n_lin)]
+        last_w_off = -1
+        for (kind, l, _), ix in zip(self.plan, self._indices(dev)):
+            src = weights[l] if kind in ('w', 'wrow') else biases[l]
+            c = _take(src.contiguous(), ix)
+            o4 = off // 4
+            if kind == 'w':
+                layer[l]['w'] = o4
+            elif kind == 'b':
+                layer[l]['b'] = o4
+            else:
+                last_w_off = o4
+            chunks.append(c)
+            off += c.numel()
+        wbuf = torch.cat(chunks).contiguous()
+        desc = np.zeros(COL_DESC_INTS, np.int32)
+        desc[0:8] = [self.n_lin, self.n_view, self.has_normal, self.extra, self.extra_rows, 3, self.squeeze_out, last_w_off]
+        lb = biases[self.n_lin - 1].detach().float().cpu().numpy()
+        desc[8:11] = lb.astype(np.float32).view(np.int32)
+        for l in range(self.n_lin):
+            d = layer[l]
+            desc[16 + 8 * l: 16 + 8 * l + 8] = [d['n_out_tiles'], 0, 0, d['w'], d['b'], -1, -1, 0]
+        return wbuf, desc
