@@ -67,6 +67,38 @@ int vqn_neus_fine_points(const int32_t* sdf_desc, const float* wbuf_sdf, const i
                          const float* pts, const float* dirs, int64_t P, int S, void* scratch,
                          int64_t scratch_bytes, float* out_sdf, float* out_grad, float* out_rgb, void* stream);
 
+/* ---- per-ray NeuS kernels (geo/NeuS-ours2/models/renderer.py) ------------------------------ */
+
+/* Replaces NeuSRenderer.up_sample (renderer.py:131-175) incl. sample_pdf(det=True) (:39-69):
+ * importance weights at a fixed inv_s from (z, sdf) [B,n], then n_new inverse-CDF samples per ray.
+ * u [n_new] = the deterministic quantiles (torch.linspace(.5/n_new, 1-.5/n_new, n_new)).
+ * z_new [B,n_new].  2 <= n <= 256, n_new <= 64. */
+int vqn_neus_upsample(const float* rays_o, const float* rays_d, const float* z, const float* sdf, int64_t B, int n,
+                      float r_limit, float inv_s, const float* u, int n_new, float* z_new, void* stream);
+
+/* Replaces NeuSRenderer.cat_z_vals (renderer.py:177-191): cat + sort + index-gather, as a stable
+ * merge of the (sorted) old samples with the new ones, old first on equal keys; sdf follows z.
+ * z_out [B,n+n_new]; sdf/sdf_new/sdf_out may all be NULL (last up-sampling step). */
+int vqn_neus_merge(const float* z, const float* sdf, const float* z_new, const float* sdf_new, int64_t B, int n,
+                   int n_new, float* z_out, float* sdf_out, void* stream);
+
+/* Replaces renderer.py:209-213: dists = diff(z) ++ sample_dist, mid_z = z + dists/2.
+ * sample_dist_per_ray [B] (the to_light variant, :211) or NULL to use the scalar. dists may be NULL. */
+int vqn_neus_section_mids(const float* z, int64_t B, int n, float sample_dist, const float* sample_dist_per_ray,
+                          float* mid_z, float* dists, void* stream);
+
+/* Replaces renderer.py:229-282 (n_outside == 0): iter_cos, estimated prev/next sdf, sigmoids, alpha
+ * clip, inside/relax sphere tests, transmittance cumprod, colour / surf / depth / weight sums, and
+ * the per-ray eikonal partial sums.  Per-sample inputs are [B,n(,3)] at the section mid-points;
+ * inv_s is a DEVICE scalar (exp(10*variance), clipped here to [1e-6,1e6]); background_rgb [3] or NULL.
+ * Outputs: color [B,3], weights [B,n], cdf [B,n], inside [B,n], surf [B,3], depth [B],
+ * weight_sum [B], weight_max [B], gerr [B,2] = (sum relax*(|g|-1)^2, sum relax); alpha [B,n] or NULL. */
+int vqn_neus_composite_fwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists,
+                           const float* sdf, const float* grad, const float* rgb, const float* inv_s,
+                           const float* background_rgb, int64_t B, int n, float radius, float cos_anneal_ratio,
+                           float* color, float* weights, float* cdf, float* inside, float* surf, float* depth,
+                           float* weight_sum, float* weight_max, float* gerr, float* alpha, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -155,3 +155,72 @@ def neus_fine_points(sdf_desc, wbuf_sdf, col_desc, wbuf_col, rays_o=None, rays_d
                                 ctypes.c_int64(buf.numel()), _ptr(sdf), _ptr(grad), _ptr(rgb), _stream())
     _check(rc, 'vqn_neus_fine_points')
     return sdf, grad, rgb
+
+
+# --------------------------------------------------------------------------------------
+# per-ray NeuS kernels (csrc/neus_rays.hip)
+def neus_upsample(rays_o, rays_d, z, sdf, r_limit, inv_s, u):
+    _f32c(rays_o, 'rays_o'); _f32c(rays_d, 'rays_d'); _f32c(z, 'z'); _f32c(sdf, 'sdf'); _f32c(u, 'u')
+    B, n = z.shape
+    m = u.numel()
+    z_new = torch.empty((B, m), dtype=torch.float32, device=z.device)
+    rc = lib().vqn_neus_upsample(_ptr(rays_o), _ptr(rays_d), _ptr(z), _ptr(sdf), ctypes.c_int64(B), ctypes.c_int(n),
+                                 ctypes.c_float(r_limit), ctypes.c_float(inv_s), _ptr(u), ctypes.c_int(m),
+                                 _ptr(z_new), _stream())
+    _check(rc, 'vqn_neus_upsample')
+    return z_new
+
+
+def neus_merge(z, sdf, z_new, sdf_new):
+    _f32c(z, 'z'); _f32c(z_new, 'z_new')
+    B, n = z.shape
+    m = z_new.shape[1]
+    z_out = torch.empty((B, n + m), dtype=torch.float32, device=z.device)
+    sdf_out = None
+    if sdf is not None and sdf_new is not None:
+        _f32c(sdf, 'sdf'); _f32c(sdf_new, 'sdf_new')
+        sdf_out = torch.empty((B, n + m), dtype=torch.float32, device=z.device)
+    rc = lib().vqn_neus_merge(_ptr(z), _ptr(sdf if sdf_out is not None else None), _ptr(z_new),
+                              _ptr(sdf_new if sdf_out is not None else None), ctypes.c_int64(B), ctypes.c_int(n),
+                              ctypes.c_int(m), _ptr(z_out), _ptr(sdf_out), _stream())
+    _check(rc, 'vqn_neus_merge')
+    return z_out, sdf_out
+
+
+def neus_section_mids(z, sample_dist, sample_dist_per_ray=None):
+    _f32c(z, 'z')
+    B, n = z.shape
+    mid = torch.empty_like(z)
+    dists = torch.empty_like(z)
+    if sample_dist_per_ray is not None:
+        sample_dist_per_ray = _f32c(sample_dist_per_ray.reshape(-1).contiguous(), 'sample_dist_per_ray')
+    rc = lib().vqn_neus_section_mids(_ptr(z), ctypes.c_int64(B), ctypes.c_int(n), ctypes.c_float(float(sample_dist)),
+                                     _ptr(sample_dist_per_ray), _ptr(mid), _ptr(dists), _stream())
+    _check(rc, 'vqn_neus_section_mids')
+    return mid, dists
+
+
+def neus_composite_fwd(rays_o, rays_d, mid_z, dists, sdf, grad, rgb, inv_s, background_rgb, radius,
+                       cos_anneal_ratio, want_alpha=False):
+    for n_, t in (('rays_o', rays_o), ('rays_d', rays_d), ('mid_z', mid_z), ('dists', dists), ('sdf', sdf),
+                  ('grad', grad), ('rgb', rgb), ('inv_s', inv_s)):
+        _f32c(t, n_)
+    B, n = mid_z.shape
+    dev = mid_z.device
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    out = dict(color=f(B, 3), weights=f(B, n), cdf=f(B, n), inside_sphere=f(B, n), surf=f(B, 3), depth=f(B, 1),
+               weight_sum=f(B, 1), weight_max=f(B, 1), gerr=f(B, 2))
+    alpha = f(B, n) if want_alpha else None
+    if background_rgb is not None:
+        background_rgb = _f32c(background_rgb.reshape(-1)[:3].contiguous(), 'background_rgb')
+    rc = lib().vqn_neus_composite_fwd(_ptr(rays_o), _ptr(rays_d), _ptr(mid_z), _ptr(dists), _ptr(sdf), _ptr(grad),
+                                      _ptr(rgb), _ptr(inv_s), _ptr(background_rgb), ctypes.c_int64(B), ctypes.c_int(n),
+                                      ctypes.c_float(float(radius)), ctypes.c_float(float(cos_anneal_ratio)),
+                                      _ptr(out['color']), _ptr(out['weights']), _ptr(out['cdf']),
+                                      _ptr(out['inside_sphere']), _ptr(out['surf']), _ptr(out['depth']),
+                                      _ptr(out['weight_sum']), _ptr(out['weight_max']), _ptr(out['gerr']),
+                                      _ptr(alpha), _stream())
+    _check(rc, 'vqn_neus_composite_fwd')
+    if want_alpha:
+        out['alpha'] = alpha
+    return out

@@ -1,0 +1,280 @@
+"""NeuS networks on MI355X: host-side mirror of geo/NeuS-ours2/models/fields.py (same class names,
+constructor keywords, methods and state_dict keys `lin{l}.weight_g|weight_v|bias`, so reference
+checkpoints `{sdf_network_fine, color_network_fine, variance_network_fine, nerf}` load unchanged).
+
+Inference (`torch.no_grad()` / frozen parameters) runs the fused HIP kernels of csrc/neus_mlp.hip
+through weight packs that are re-gathered only when a parameter changes.  When autograd needs the
+graph (training), the same modules evaluate with torch ops on the GPU; see DESIGN.md "training path".
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from vqnerf_release_amd import _C
+from vqnerf_release_amd.geo import packing
+from vqnerf_release_amd.geo.models.embedder import get_embedder
+
+
+class _Lin(nn.Module):
+    """nn.Linear, optionally re-parameterised like nn.utils.weight_norm(dim=0): w = g * v / ||v||_row."""
+
+    def __init__(self, d_in, d_out, weight_norm):
+        super().__init__()
+        self.weight_norm = weight_norm
+        w = torch.empty(d_out, d_in)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(d_in)
+        self.bias = nn.Parameter(torch.empty(d_out).uniform_(-bound, bound))
+        if weight_norm:
+            self.weight_g = nn.Parameter(w.norm(dim=1, keepdim=True))
+            self.weight_v = nn.Parameter(w)
+        else:
+            self.weight = nn.Parameter(w)
+
+    def set_weight(self, w):
+        with torch.no_grad():
+            if self.weight_norm:
+                self.weight_v.copy_(w)
+                self.weight_g.copy_(w.norm(dim=1, keepdim=True))
+            else:
+                self.weight.copy_(w)
+
+    def effective_weight(self):
+        if self.weight_norm:
+            return self.weight_g * self.weight_v / self.weight_v.norm(dim=1, keepdim=True)
+        return self.weight
+
+    def forward(self, x):
+        return F.linear(x, self.effective_weight(), self.bias)
+
+
+def _needs_graph(module, *tensors):
+    if not torch.is_grad_enabled():
+        return False
+    return any(p.requires_grad for p in module.parameters()) or any(t.requires_grad for t in tensors if t is not None)
+
+
+class _PackCache:
+    def __init__(self):
+        self.key = None
+        self.value = None
+
+    def get(self, params, device, build):
+        key = (str(device),) + tuple((id(p), p._version) for p in params)
+        if key != self.key:
+            with torch.no_grad():
+                self.value = build()
+            self.key = key
+        return self.value
+
+
+class SDFNetwork(nn.Module):
+    def __init__(self, d_in, d_out, d_hidden, n_layers, skip_in=(4,), multires=0, bias=0.5, scale=1,
+                 geometric_init=True, weight_norm=True, inside_outside=False):
+        super().__init__()
+        dims = [d_in] + [d_hidden] * n_layers + [d_out]
+        self.embed_fn_fine = None
+        self.multires = multires
+        if multires > 0:
+            self.embed_fn_fine, dims[0] = get_embedder(multires, input_dims=d_in)
+        self.dims = dims
+        self.num_layers = len(dims)
+        self.skip_in = tuple(skip_in)
+        self.scale = scale
+        self.d_in = d_in
+        for l in range(self.num_layers - 1):
+            out_dim = dims[l + 1] - dims[0] if (l + 1) in self.skip_in else dims[l + 1]
+            lin = _Lin(dims[l], out_dim, weight_norm)
+            if geometric_init:
+                self._geometric_init(lin, l, dims, out_dim, bias, inside_outside)
+            setattr(self, 'lin' + str(l), lin)
+        self.activation = nn.Softplus(beta=100)
+        self._plan = None
+        self._cache = _PackCache()
+
+    def _geometric_init(self, lin, l, dims, out_dim, bias, inside_outside):
+        # sphere initialisation of IDR/NeuS (fields.py:45-63)
+        w = torch.empty(out_dim, dims[l])
+        b = torch.zeros(out_dim)
+        last = self.num_layers - 2
+        if l == last:
+            sgn = -1.0 if inside_outside else 1.0
+            w.normal_(sgn * np.sqrt(np.pi) / np.sqrt(dims[l]), 0.0001)
+            b.fill_(-sgn * bias)
+        else:
+            w.normal_(0.0, np.sqrt(2) / np.sqrt(out_dim))
+            if self.multires > 0 and l == 0:
+                w[:, 3:] = 0.0
+            elif self.multires > 0 and l in self.skip_in:
+                w[:, -(dims[0] - 3):] = 0.0
+        lin.set_weight(w)
+        with torch.no_grad():
+            lin.bias.copy_(b)
+
+    # ---- HIP path -------------------------------------------------------------------------
+    def _hip_supported(self):
+        return self.d_in == 3 and self.multires > 0 and len([s for s in self.skip_in if 0 < s < self.num_layers - 1]) <= 1
+
+    def plan(self, max_tiles=None):
+        if self._plan is None or (max_tiles and self._plan.max_tiles < max_tiles):
+            self._plan = packing.SdfPackPlan(self.dims, self.skip_in, self.multires, self.scale, max_tiles=max_tiles)
+            self._cache = _PackCache()
+        return self._plan
+
+    def packs(self, max_tiles=None):
+        plan = self.plan(max_tiles)
+        lins = [getattr(self, 'lin' + str(l)) for l in range(self.num_layers - 1)]
+        params = list(self.parameters())
+        return self._cache.get(params, params[0].device,
+                               lambda: plan.pack([m.effective_weight() for m in lins], [m.bias for m in lins]))
+
+    # ---- reference API --------------------------------------------------------------------
+    def forward(self, inputs):
+        inputs = inputs * self.scale
+        if self.embed_fn_fine is not None:
+            inputs = self.embed_fn_fine(inputs)
+        x = inputs
+        for l in range(self.num_layers - 1):
+            if l in self.skip_in:
+                x = torch.cat([x, inputs], 1) / np.sqrt(2)
+            x = getattr(self, 'lin' + str(l))(x)
+            if l < self.num_layers - 2:
+                x = self.activation(x)
+        return torch.cat([x[:, :1] / self.scale, x[:, 1:]], dim=-1)
+
+    def sdf(self, x):
+        if _needs_graph(self, x) or not x.is_cuda or not self._hip_supported():
+            return self.forward(x)[:, :1]
+        wbuf, desc = self.packs()
+        return _C.neus_sdf_points(desc, wbuf, pts=x.detach().float().contiguous()).reshape(-1, 1)
+
+    def sdf_hidden_appearance(self, x):
+        return self.forward(x)
+
+    def gradient(self, x):
+        if _needs_graph(self, x) or not x.is_cuda or not self._hip_supported():
+            x.requires_grad_(True)
+            with torch.enable_grad():
+                y = self.forward(x)[:, :1]
+                g = torch.autograd.grad(y, x, torch.ones_like(y), create_graph=True, retain_graph=True,
+                                        only_inputs=True)[0]
+            return g.unsqueeze(1)
+        wbuf, desc = self.packs()
+        xx = x.detach().float().contiguous()
+        no_col = np.zeros(packing.COL_DESC_INTS, np.int32)
+        _, g, _ = _C.neus_fine_points(desc, wbuf, no_col, wbuf, pts=xx, dirs=xx)
+        return g.unsqueeze(1)
+
+
+class RenderingNetwork(nn.Module):
+    def __init__(self, d_feature, mode, d_in, d_out, d_hidden, n_layers, weight_norm=True, multires_view=0,
+                 squeeze_out=True):
+        super().__init__()
+        self.mode = mode
+        self.squeeze_out = squeeze_out
+        self.d_feature = d_feature
+        self.multires_view = multires_view
+        dims = [d_in + d_feature] + [d_hidden] * n_layers + [d_out]
+        self.embedview_fn = None
+        if multires_view > 0:
+            self.embedview_fn, input_ch = get_embedder(multires_view)
+            dims[0] += input_ch - 3
+        self.dims = dims
+        self.num_layers = len(dims)
+        for l in range(self.num_layers - 1):
+            setattr(self, 'lin' + str(l), _Lin(dims[l], dims[l + 1], weight_norm))
+        self.relu = nn.ReLU()
+        self._plan = None
+        self._cache = _PackCache()
+
+    def max_tiles(self):
+        return max((d + 31) // 32 for d in self.dims[1:-1])
+
+    def _hip_supported(self):
+        want = 3 + (3 + 6 * self.multires_view if self.mode in ('idr', 'no_normal') else 0) \
+            + (3 if self.mode in ('idr', 'no_view_dir') else 0) + self.d_feature
+        return self.dims[-1] == 3 and self.multires_view > 0 and self.dims[0] == want
+
+    def packs(self, feat_tiles):
+        if self._plan is None or self._plan.feat_tiles != feat_tiles:
+            self._plan = packing.ColPackPlan(self.d_feature, self.mode, self.dims[1], self.num_layers - 2, self.dims[-1],
+                                             self.multires_view, self.squeeze_out, feat_tiles)
+            self._cache = _PackCache()
+        lins = [getattr(self, 'lin' + str(l)) for l in range(self.num_layers - 1)]
+        params = list(self.parameters())
+        plan = self._plan
+        return self._cache.get(params, params[0].device,
+                               lambda: plan.pack([m.effective_weight() for m in lins], [m.bias for m in lins]))
+
+    def forward(self, points, normals, view_dirs, feature_vectors):
+        if self.embedview_fn is not None:
+            view_dirs = self.embedview_fn(view_dirs)
+        if self.mode == 'idr':
+            x = torch.cat([points, view_dirs, normals, feature_vectors], dim=-1)
+        elif self.mode == 'no_view_dir':
+            x = torch.cat([points, normals, feature_vectors], dim=-1)
+        elif self.mode == 'no_normal':
+            x = torch.cat([points, view_dirs, feature_vectors], dim=-1)
+        else:
+            raise ValueError(self.mode)
+        for l in range(self.num_layers - 1):
+            x = getattr(self, 'lin' + str(l))(x)
+            if l < self.num_layers - 2:
+                x = self.relu(x)
+        return torch.sigmoid(x) if self.squeeze_out else x
+
+
+class SingleVarianceNetwork(nn.Module):
+    def __init__(self, init_val):
+        super().__init__()
+        self.register_parameter('variance', nn.Parameter(torch.tensor(float(init_val))))
+
+    def forward(self, x):
+        return torch.ones([len(x), 1], device=self.variance.device) * torch.exp(self.variance * 10.0)
+
+
+class NeRF(nn.Module):
+    """NeRF++ background net (fields.py:176-254).  Instantiated by every shipped conf but never
+    evaluated (n_outside = 0 everywhere); kept so that checkpoints' `nerf` state_dict loads."""
+
+    def __init__(self, D=8, W=256, d_in=3, d_in_view=3, multires=0, multires_view=0, output_ch=4, skips=[4],
+                 use_viewdirs=False):
+        super().__init__()
+        self.D, self.W, self.skips, self.use_viewdirs = D, W, skips, use_viewdirs
+        self.input_ch, self.input_ch_view = 3, 3
+        self.embed_fn = self.embed_fn_view = None
+        if multires > 0:
+            self.embed_fn, self.input_ch = get_embedder(multires, input_dims=d_in)
+        if multires_view > 0:
+            self.embed_fn_view, self.input_ch_view = get_embedder(multires_view, input_dims=d_in_view)
+        self.pts_linears = nn.ModuleList(
+            [nn.Linear(self.input_ch, W)] +
+            [nn.Linear(W + self.input_ch if i in skips else W, W) for i in range(D - 1)])
+        self.views_linears = nn.ModuleList([nn.Linear(self.input_ch_view + W, W // 2)])
+        if use_viewdirs:
+            self.feature_linear = nn.Linear(W, W)
+            self.alpha_linear = nn.Linear(W, 1)
+            self.rgb_linear = nn.Linear(W // 2, 3)
+        else:
+            self.output_linear = nn.Linear(W, output_ch)
+
+    def forward(self, input_pts, input_views):
+        if self.embed_fn is not None:
+            input_pts = self.embed_fn(input_pts)
+        if self.embed_fn_view is not None:
+            input_views = self.embed_fn_view(input_views)
+        h = input_pts
+        for i, lin in enumerate(self.pts_linears):
+            h = F.relu(lin(h))
+            if i in self.skips:
+                h = torch.cat([input_pts, h], -1)
+        if not self.use_viewdirs:
+            raise AssertionError('NeRF without view directions is not supported (as in the reference)')
+        alpha = self.alpha_linear(h)
+        h = torch.cat([self.feature_linear(h), input_views], -1)
+        for lin in self.views_linears:
+            h = F.relu(lin(h))
+        return alpha, self.rgb_linear(h)
