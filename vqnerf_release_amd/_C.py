@@ -53,6 +53,40 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class KernelClock:
+    """Optional per-kernel device timing: HIP events recorded on the stream the kernel is launched on
+    (torch's current stream).  Off by default; bench.py switches it on for the timed region."""
+    enabled = False
+    pairs = {}
+
+    @classmethod
+    def reset(cls, enabled=True):
+        cls.enabled = enabled
+        cls.pairs = {}
+
+    @classmethod
+    def summary(cls):
+        """{name: (launches, total_ms)} -- call after torch.cuda.synchronize()."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in cls.pairs.items()}
+
+
+class _clock:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if KernelClock.enabled:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if KernelClock.enabled:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            KernelClock.pairs.setdefault(self.name, []).append((self.e0, e1))
+        return False
+
+
 def _f32c(t, name):
     if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
         raise VqnError(f'{name}: expected a contiguous float32 device tensor, got {t.dtype} '
@@ -75,8 +109,9 @@ def vq_assign(x, codebook, sel_mask=None, want_quant=True, want_dist=False):
         sel_mask = _f32c(sel_mask.reshape(-1).to(torch.float32).contiguous(), 'sel_mask')
         assert sel_mask.numel() == K
         ws = torch.empty((4,), dtype=torch.float32, device=x.device)
-    rc = lib().vqn_vq_assign(_ptr(x), ctypes.c_int64(N), ctypes.c_int(D), _ptr(codebook), ctypes.c_int(K),
-                             _ptr(sel_mask), _ptr(ws), _ptr(idx), _ptr(quant), _ptr(dist), _stream())
+    with _clock('vqn_vq_assign'):
+        rc = lib().vqn_vq_assign(_ptr(x), ctypes.c_int64(N), ctypes.c_int(D), _ptr(codebook), ctypes.c_int(K),
+                                 _ptr(sel_mask), _ptr(ws), _ptr(idx), _ptr(quant), _ptr(dist), _stream())
     _check(rc, 'vqn_vq_assign')
     return idx, quant, dist
 
@@ -88,8 +123,9 @@ def vq_ema_stats(x, idx, K):
     assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() == N
     counts = torch.empty((K,), dtype=torch.float32, device=x.device)
     dw = torch.empty((D, K), dtype=torch.float32, device=x.device)
-    rc = lib().vqn_vq_ema_stats(_ptr(x), _ptr(idx), ctypes.c_int64(N), ctypes.c_int(D), ctypes.c_int(K),
-                                _ptr(counts), _ptr(dw), _stream())
+    with _clock('vqn_vq_ema_stats'):
+        rc = lib().vqn_vq_ema_stats(_ptr(x), _ptr(idx), ctypes.c_int64(N), ctypes.c_int(D), ctypes.c_int(K),
+                                    _ptr(counts), _ptr(dw), _stream())
     _check(rc, 'vqn_vq_ema_stats')
     return counts, dw
 
@@ -118,8 +154,9 @@ def neus_sdf_points(sdf_desc, wbuf_sdf, rays_o=None, rays_d=None, z=None, pts=No
         P = B * S
         dev = z.device
     out = torch.empty((P,), dtype=torch.float32, device=dev)
-    rc = lib().vqn_neus_sdf_points(dp, _ptr(wbuf_sdf), _ptr(rays_o), _ptr(rays_d), _ptr(z), _ptr(pts),
-                                   ctypes.c_int64(P), ctypes.c_int(S), _ptr(out), _stream())
+    with _clock('vqn_neus_sdf_points'):
+        rc = lib().vqn_neus_sdf_points(dp, _ptr(wbuf_sdf), _ptr(rays_o), _ptr(rays_d), _ptr(z), _ptr(pts),
+                                       ctypes.c_int64(P), ctypes.c_int(S), _ptr(out), _stream())
     _check(rc, 'vqn_neus_sdf_points')
     return out
 
@@ -150,9 +187,10 @@ def neus_fine_points(sdf_desc, wbuf_sdf, col_desc, wbuf_col, rays_o=None, rays_d
     sdf = torch.empty((P,), dtype=torch.float32, device=dev)
     grad = torch.empty((P, 3), dtype=torch.float32, device=dev)
     rgb = torch.empty((P, 3), dtype=torch.float32, device=dev)
-    rc = L.vqn_neus_fine_points(sdp, _ptr(wbuf_sdf), cdp, _ptr(wbuf_col), _ptr(rays_o), _ptr(rays_d), _ptr(z),
-                                _ptr(pts), _ptr(dirs), ctypes.c_int64(P), ctypes.c_int(S), _ptr(buf),
-                                ctypes.c_int64(buf.numel()), _ptr(sdf), _ptr(grad), _ptr(rgb), _stream())
+    with _clock('vqn_neus_fine_points'):
+        rc = L.vqn_neus_fine_points(sdp, _ptr(wbuf_sdf), cdp, _ptr(wbuf_col), _ptr(rays_o), _ptr(rays_d), _ptr(z),
+                                    _ptr(pts), _ptr(dirs), ctypes.c_int64(P), ctypes.c_int(S), _ptr(buf),
+                                    ctypes.c_int64(buf.numel()), _ptr(sdf), _ptr(grad), _ptr(rgb), _stream())
     _check(rc, 'vqn_neus_fine_points')
     return sdf, grad, rgb
 
@@ -164,9 +202,10 @@ def neus_upsample(rays_o, rays_d, z, sdf, r_limit, inv_s, u):
     B, n = z.shape
     m = u.numel()
     z_new = torch.empty((B, m), dtype=torch.float32, device=z.device)
-    rc = lib().vqn_neus_upsample(_ptr(rays_o), _ptr(rays_d), _ptr(z), _ptr(sdf), ctypes.c_int64(B), ctypes.c_int(n),
-                                 ctypes.c_float(r_limit), ctypes.c_float(inv_s), _ptr(u), ctypes.c_int(m),
-                                 _ptr(z_new), _stream())
+    with _clock('vqn_neus_upsample'):
+        rc = lib().vqn_neus_upsample(_ptr(rays_o), _ptr(rays_d), _ptr(z), _ptr(sdf), ctypes.c_int64(B), ctypes.c_int(n),
+                                     ctypes.c_float(r_limit), ctypes.c_float(inv_s), _ptr(u), ctypes.c_int(m),
+                                     _ptr(z_new), _stream())
     _check(rc, 'vqn_neus_upsample')
     return z_new
 
@@ -180,9 +219,10 @@ def neus_merge(z, sdf, z_new, sdf_new):
     if sdf is not None and sdf_new is not None:
         _f32c(sdf, 'sdf'); _f32c(sdf_new, 'sdf_new')
         sdf_out = torch.empty((B, n + m), dtype=torch.float32, device=z.device)
-    rc = lib().vqn_neus_merge(_ptr(z), _ptr(sdf if sdf_out is not None else None), _ptr(z_new),
-                              _ptr(sdf_new if sdf_out is not None else None), ctypes.c_int64(B), ctypes.c_int(n),
-                              ctypes.c_int(m), _ptr(z_out), _ptr(sdf_out), _stream())
+    with _clock('vqn_neus_merge'):
+        rc = lib().vqn_neus_merge(_ptr(z), _ptr(sdf if sdf_out is not None else None), _ptr(z_new),
+                                  _ptr(sdf_new if sdf_out is not None else None), ctypes.c_int64(B), ctypes.c_int(n),
+                                  ctypes.c_int(m), _ptr(z_out), _ptr(sdf_out), _stream())
     _check(rc, 'vqn_neus_merge')
     return z_out, sdf_out
 
@@ -194,8 +234,9 @@ def neus_section_mids(z, sample_dist, sample_dist_per_ray=None):
     dists = torch.empty_like(z)
     if sample_dist_per_ray is not None:
         sample_dist_per_ray = _f32c(sample_dist_per_ray.reshape(-1).contiguous(), 'sample_dist_per_ray')
-    rc = lib().vqn_neus_section_mids(_ptr(z), ctypes.c_int64(B), ctypes.c_int(n), ctypes.c_float(float(sample_dist)),
-                                     _ptr(sample_dist_per_ray), _ptr(mid), _ptr(dists), _stream())
+    with _clock('vqn_neus_section_mids'):
+        rc = lib().vqn_neus_section_mids(_ptr(z), ctypes.c_int64(B), ctypes.c_int(n), ctypes.c_float(float(sample_dist)),
+                                         _ptr(sample_dist_per_ray), _ptr(mid), _ptr(dists), _stream())
     _check(rc, 'vqn_neus_section_mids')
     return mid, dists
 
@@ -213,13 +254,14 @@ def neus_composite_fwd(rays_o, rays_d, mid_z, dists, sdf, grad, rgb, inv_s, back
     alpha = f(B, n) if want_alpha else None
     if background_rgb is not None:
         background_rgb = _f32c(background_rgb.reshape(-1)[:3].contiguous(), 'background_rgb')
-    rc = lib().vqn_neus_composite_fwd(_ptr(rays_o), _ptr(rays_d), _ptr(mid_z), _ptr(dists), _ptr(sdf), _ptr(grad),
-                                      _ptr(rgb), _ptr(inv_s), _ptr(background_rgb), ctypes.c_int64(B), ctypes.c_int(n),
-                                      ctypes.c_float(float(radius)), ctypes.c_float(float(cos_anneal_ratio)),
-                                      _ptr(out['color']), _ptr(out['weights']), _ptr(out['cdf']),
-                                      _ptr(out['inside_sphere']), _ptr(out['surf']), _ptr(out['depth']),
-                                      _ptr(out['weight_sum']), _ptr(out['weight_max']), _ptr(out['gerr']),
-                                      _ptr(alpha), _stream())
+    with _clock('vqn_neus_composite_fwd'):
+        rc = lib().vqn_neus_composite_fwd(_ptr(rays_o), _ptr(rays_d), _ptr(mid_z), _ptr(dists), _ptr(sdf), _ptr(grad),
+                                          _ptr(rgb), _ptr(inv_s), _ptr(background_rgb), ctypes.c_int64(B), ctypes.c_int(n),
+                                          ctypes.c_float(float(radius)), ctypes.c_float(float(cos_anneal_ratio)),
+                                          _ptr(out['color']), _ptr(out['weights']), _ptr(out['cdf']),
+                                          _ptr(out['inside_sphere']), _ptr(out['surf']), _ptr(out['depth']),
+                                          _ptr(out['weight_sum']), _ptr(out['weight_max']), _ptr(out['gerr']),
+                                          _ptr(alpha), _stream())
     _check(rc, 'vqn_neus_composite_fwd')
     if want_alpha:
         out['alpha'] = alpha
