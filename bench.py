@@ -178,6 +178,8 @@ def main():
             cores = len(os.sched_getaffinity(0))
         except Exception:
             pass
+        # a 1-GPU box shares its host: the CPU share of one GPU is 16 cores (more threads only oversubscribe)
+        cores = int(os.environ.get('VQN_CPU_THREADS', min(cores, 16)))
         torch.set_num_threads(cores)
         og.render(p_sdf, p_col, torch.tensor(0.3), cfg, oc[:32], dc[:32], nc[:32], fc[:32], 2.0,
                   background_rgb=torch.ones(1, 3), cos_anneal_ratio=1.0)          # warm-up
