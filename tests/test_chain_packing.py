@@ -1,0 +1,130 @@
+"""CPU: the layer programs + weight packs of vqnerf_release_amd/decomp/packing.py, executed by a numpy emulator
+of csrc/mlp_chain.hip's data movement (activation image, A-fragment packs, MFMA 32x32x2 operand maps), reproduce the
+oracle's Dense stacks.  This pins the host logic (row allocation, gather indices, descriptor fields) without a GPU."""
+import numpy as np
+import torch
+
+from oracle import decomp as od
+from vqnerf_release_amd.decomp import packing as pk
+
+PHI = np.array([2 * (i & 3) + 8 * (i >> 3) + ((i >> 2) & 1) for i in range(32)])
+
+
+def row_feat(r, h, j):
+    return 32 * (r >> 2) + 2 * (4 * (r & 3) + j) + h
+
+
+def act(a, x):
+    if a == 1:
+        return np.maximum(x, 0)
+    if a == 3:
+        return 1.0 / (1.0 + np.exp(-x))
+    return x
+
+
+def emulate(desc, wbuf, x, out_widths):
+    """x [P<=32, in_stride] -> list of outputs; float64 arithmetic over the packed float32 weights."""
+    d = np.asarray(desc)
+    w4 = np.asarray(wbuf, np.float64).reshape(-1, 4)
+    n_layers, in_mode, in_feats, in_rows, in_row0, n_freqs, total_rows = [int(v) for v in d[:7]]
+    P = x.shape[0]
+    lds = np.full((total_rows, 64, 4), np.nan)
+    if in_mode == 1:
+        feats = od.posenc(torch.tensor(x, dtype=torch.float64), n_freqs).numpy()
+    else:
+        feats = x.astype(np.float64)
+    for r in range(in_rows):
+        for lane in range(64):
+            p, h = lane & 31, lane >> 5
+            for j in range(4):
+                f = row_feat(r, h, j)
+                lds[in_row0 + r, lane, j] = feats[p, f] if (p < P and f < in_feats) else 0.0
+    outs = [np.zeros((P, w)) for w in out_widths]
+    for l in range(n_layers):
+        L = d[16 + 16 * l: 32 + 16 * l]
+        kind, a, tiles, kA0, kA, kB0, kB, dst0, w_off, b_off, slot, out_feats = [int(v) for v in L[:12]]
+        rows = [kA0 + i for i in range(kA)] + [kB0 + i for i in range(kB)]
+        ng = len(rows)
+        if kind == 0:
+            for ot in range(tiles):
+                # D[i][n] = bias + sum_{g,j,h} A[g][lane=(i,h)][j] * B[g][lane=(n,h)][j]
+                A = w4[w_off + ot * ng * 64: w_off + (ot + 1) * ng * 64].reshape(ng, 2, 32, 4)      # [g,h,i,j]
+                B = np.stack([lds[r] for r in rows]).reshape(ng, 2, 32, 4)                              # [g,h,n,j]
+                D = np.einsum('ghij,ghnj->in', A, B)
+                bias = w4[b_off + ot * 8: b_off + (ot + 1) * 8].reshape(2, 16)                          # [h][reg]
+                for lane in range(64):
+                    n_, h = lane & 31, lane >> 5
+                    for reg in range(16):
+                        i = (reg & 3) + 8 * (reg >> 2) + 4 * h
+                        lds[dst0 + ot * 4 + (reg >> 2), lane, reg & 3] = act(a, D[i, n_] + bias[h, reg])
+            if slot >= 0:
+                for f in range(out_feats):
+                    r, fi = f >> 3, f & 7
+                    h, j = fi & 1, fi >> 1
+                    assert row_feat(r, h, j) == f
+                    outs[slot][:, f] = lds[dst0 + r, np.arange(P) + 32 * h, j]
+        else:
+            img = w4[w_off: w_off + tiles * ng * 2].reshape(tiles, ng, 2, 4)
+            B = np.stack([lds[r] for r in rows]).reshape(ng, 2, 32, 4)
+            bias4 = d[16 + 16 * l + 12: 16 + 16 * l + 16].view(np.float32).astype(np.float64)
+            val = np.einsum('oghj,ghnj->no', img, B)
+            outs[slot][:, :tiles] = act(a, val[:P] + bias4[None, :tiles])
+    return outs
+
+
+def _params(names, p):
+    out = {}
+    for n in names:
+        for i, (W, b) in enumerate(p[n]):
+            out[f'{n}/{i}'] = (torch.tensor(W), torch.tensor(b))
+    return out
+
+
+def test_encoder_program_matches_oracle():
+    p, specs = od.make_model_params(seed=3, K=15)
+    fe, bn = specs['fine_enc'], specs['bottleneck']
+    b = pk.ChainBuilder('posenc', 63, n_freqs=10)
+    y = b.mlp('fine_enc', fe['widths'], fe['act'], fe['skip_at'], b.input)
+    b.mlp('bottleneck', bn['widths'], bn['act'], bn['skip_at'], y, out_slot=0, small_last=False)
+    plan = b.build()
+    assert plan.macs_per_point() == 179968
+    assert plan.n_waves == 4 and plan.total_rows <= 72
+    wbuf, desc = plan.pack(_params(['fine_enc', 'bottleneck'], p))
+    xyz = od.make_points(20, seed=5)['xyz']
+    got = emulate(desc, wbuf.numpy(), xyz, [256])[0]
+    pt = {k: [(torch.tensor(W, dtype=torch.float64), torch.tensor(bb, dtype=torch.float64)) for W, bb in v]
+          for k, v in p.items() if isinstance(v, list)}
+    want = od.pred_enc(pt, specs, torch.tensor(xyz, dtype=torch.float64)).numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
+
+
+def test_three_heads_share_the_input_rows():
+    p, specs = od.make_model_params(seed=4, K=15)
+    for fam, widths in (('main', [3, 1, 1]), ('vq', [3, 3, 1])):
+        names = [h + '_' + fam for h in ('diff', 'spec', 'rough')]
+        b = pk.ChainBuilder('raw', 256)
+        for slot, n in enumerate(names):
+            s = specs[n]
+            b.mlp(n, s['widths'], s['act'], s['skip_at'], b.input, keep=[b.input], out_slot=slot)
+        plan = b.build()
+        assert plan.macs_per_point() == (296832 if fam == 'main' else 297600)
+        assert plan.total_rows * 1024 + 4096 <= 160 * 1024
+        wbuf, desc = plan.pack(_params(names, p))
+        z = np.random.default_rng(0).uniform(0, 1, (32, 256)).astype(np.float32)
+        got = emulate(desc, wbuf.numpy(), z, widths)
+        for g, n in zip(got, names):
+            pt = [(torch.tensor(W, dtype=torch.float64), torch.tensor(bb, dtype=torch.float64)) for W, bb in p[n]]
+            want = od.mlp_forward(pt, specs[n], torch.tensor(z, dtype=torch.float64)).numpy()
+            np.testing.assert_allclose(g, want, rtol=0, atol=1e-9)
+
+
+def test_regions_never_overlap_live_data():
+    b = pk.ChainBuilder('raw', 256)
+    x = b.input
+    y0 = b.dense('a/0', [x], 256, 'relu', keep=[x])
+    y1 = b.dense('a/1', [y0], 128, 'relu', keep=[x])
+    y2 = b.dense('a/2', [y1, x], 64, 'relu')                   # y0 is dead here: its rows may be reused
+    plan = b.build()
+    disjoint = lambda a, c: a.row0 >= c.row0 + c.alloc_rows or a.row0 + a.alloc_rows <= c.row0
+    assert disjoint(y0, x) and disjoint(y1, x) and disjoint(y1, y0) and disjoint(y2, y1) and disjoint(y2, x)
+    assert plan.total_rows == 32 + 32 + 16                       # y2 fits into y0's rows

@@ -38,6 +38,14 @@ def lib():
     return _lib
 
 
+def require_device(t, what):
+    """Inference (no autograd graph) runs only on the HIP kernels: CPU tensors are an error, not a fallback."""
+    if not t.is_cuda:
+        raise VqnError(f'{what}: got a {t.device} tensor; the no-graph path runs on MI355X HIP kernels only '
+                       '(there is no CPU fallback)')
+    lib()
+
+
 def _check(rc, name):
     if rc != 0:
         raise VqnError(f'{name} failed (rc={rc}): {lib().vqn_last_error().decode()}')
@@ -266,3 +274,59 @@ def neus_composite_fwd(rays_o, rays_d, mid_z, dists, sdf, grad, rgb, inv_s, back
     if want_alpha:
         out['alpha'] = alpha
     return out
+
+
+# --------------------------------------------------------------------------------------
+# reflectance path (csrc/mlp_chain.hip, csrc/brdf_shade.hip)
+def mlp_chain_fwd(desc, wbuf, x, out_widths):
+    """Run a layer program (decomp/packing.py) over x [N, in_stride]; returns one [N, w] tensor per output slot."""
+    _f32c(wbuf, 'wbuf'); _f32c(x, 'x')
+    d, dp = _i32(desc)
+    N = x.shape[0]
+    assert x.shape[1] == int(d[8]), (x.shape, int(d[8]))
+    outs = [torch.empty((N, w), dtype=torch.float32, device=x.device) for w in out_widths]
+    args = []
+    for i in range(4):
+        if i < len(outs):
+            args += [_ptr(outs[i]), ctypes.c_int(out_widths[i])]
+        else:
+            args += [ctypes.c_void_p(0), ctypes.c_int(0)]
+    with _clock('vqn_mlp_chain_fwd'):
+        rc = lib().vqn_mlp_chain_fwd(dp, _ptr(wbuf), _ptr(x), ctypes.c_int64(N), *args, _stream())
+    _check(rc, 'vqn_mlp_chain_fwd')
+    return outs
+
+
+def brdf_shade_fwd(xyz, normal, rayo, lvis, lxyz, lareas, light, materials, gamma=None, want_normal=True,
+                   want_split=False):
+    """materials: [(albedo [N,3], spec [N,3], rough [N,1])] (1 or 2 sets).
+    -> dict(rgb=[...per set], normal=..., rgb_diff=..., rgb_spec=...)."""
+    for n_, t in (('xyz', xyz), ('normal', normal), ('rayo', rayo), ('lxyz', lxyz), ('lareas', lareas), ('light', light)):
+        _f32c(t, n_)
+    N = xyz.shape[0]
+    L = lareas.numel()
+    assert lxyz.numel() == 3 * L and light.numel() == 3 * L
+    if lvis is not None:
+        _f32c(lvis, 'lvis')
+        assert tuple(lvis.shape) == (N, L)
+    mats = []
+    for (a, s, r) in materials:
+        _f32c(a, 'albedo'); _f32c(s, 'spec'); _f32c(r, 'rough')
+        assert tuple(a.shape) == (N, 3) and tuple(s.shape) == (N, 3) and r.numel() == N
+        mats += [a, s, r]
+    while len(mats) < 6:
+        mats.append(None)
+    dev = xyz.device
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    rgb = [f(N, 3) for _ in materials]
+    nout = f(N, 3) if want_normal else None
+    rd, rs = (f(N, 3), f(N, 3)) if want_split else (None, None)
+    if gamma is not None:
+        gamma = _f32c(gamma.reshape(-1).contiguous(), 'gamma')
+    with _clock('vqn_brdf_shade_fwd'):
+        rc = lib().vqn_brdf_shade_fwd(_ptr(xyz), _ptr(normal), _ptr(rayo), _ptr(lvis), _ptr(lxyz), _ptr(lareas),
+                                      _ptr(light), ctypes.c_int64(N), ctypes.c_int(L), ctypes.c_int(len(materials)),
+                                      *[_ptr(m) for m in mats], _ptr(gamma), _ptr(nout), _ptr(rgb[0]),
+                                      _ptr(rgb[1] if len(rgb) > 1 else None), _ptr(rd), _ptr(rs), _stream())
+    _check(rc, 'vqn_brdf_shade_fwd')
+    return dict(rgb=rgb, normal=nout, rgb_diff=rd, rgb_spec=rs)

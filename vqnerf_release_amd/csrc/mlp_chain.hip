@@ -1,0 +1,242 @@
+// Descriptor-driven fused Dense-stack evaluator for gfx950: [posenc ->] layer -> layer -> ... with skip-concats,
+// several heads per launch, activations resident in LDS (the "activation image" of mlp_prims.h), f32 MFMA.
+// Replaces the Keras-Dense chains of the reflectance model, evaluated through `chunk_apply` in the reference:
+//   decomp/nerfvq_nfr3/nerfactor/networks/embedder.py:23-47 + mlp.py:24-50 + seq.py:24-38
+//   decomp/nerfvq_nfr3/nerfactor/models/vq_nfr.py:771-784   (_pred_enc_at: posenc -> fine_enc -> bottleneck -> z)
+//   decomp/nerfvq_nfr3/nerfactor/models/vq_nfr.py:786-828   (_pred_diff_at/_pred_spec_at/_pred_rough_at: z -> heads)
+//   decomp/nerfvq_nfr3/nerfactor/models/shape.py:169-179    (chunk_apply: disappears)
+// The layer program (which LDS rows feed a layer, where its output goes, which outputs leave for HBM) is built
+// on the host (vqnerf_release_amd/decomp/packing.py) -- the kernel is a small interpreter over it.
+#include "mlp_prims.h"
+#include "chain_desc.h"
+
+using namespace eng;
+
+namespace {
+
+struct ChainSmalls {
+  float part[8 * 32 * 4];
+};
+
+__device__ __forceinline__ float act_rt(int act, float x) {
+  switch (act) {
+    case ACT_RELU: return fmaxf(x, 0.f);
+    case ACT_SIGMOID: return fast_rcp(1.f + fast_exp(-x));
+    case ACT_SOFTPLUS100: return act_fwd<ACT_SOFTPLUS100>(x);
+    default: return x;
+  }
+}
+
+struct OutPtrs {
+  float* p[VQN_CHAIN_MAX_OUTS];
+  int ld[VQN_CHAIN_MAX_OUTS];
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_kernel(const ChainDesc d,
+                                                                             const f32x4* __restrict__ wbuf,
+                                                                             const float* __restrict__ in, const long N,
+                                                                             const OutPtrs outs) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+  ChainSmalls* sm = reinterpret_cast<ChainSmalls*>(lds + (size_t)d.total_rows * 64);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+  const long n_tiles = (N + 31) >> 5;
+
+  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long p0 = tile << 5;
+    const long pt = (p0 + p < N) ? p0 + p : N - 1;
+    // ---------------- input image ----------------
+    if (d.in_mode == 1) {                       // positional encoding of a 3-vector (embedder.py:23-47)
+      const float x0 = in[pt * d.in_stride + 0], x1 = in[pt * d.in_stride + 1], x2 = in[pt * d.in_stride + 2];
+      for (int r = wave; r < d.in_rows; r += NW) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int f = row_feat(r, h, j);
+          v[j] = f < d.in_feats ? posenc_feat(f, x0, x1, x2) : 0.f;
+        }
+        lds[(d.in_row0 + r) * 64 + lane] = v;
+      }
+    } else {                                     // raw features [N, in_feats], row stride in_stride
+      const float* xr = in + pt * (long)d.in_stride;
+      const bool vec_ok = (d.in_stride & 3) == 0;
+      for (int r = wave; r < d.in_rows; r += NW) {
+        const int f0 = 32 * (r >> 2) + 8 * (r & 3) + 4 * h;
+        f32x4 v;
+        if (vec_ok && f0 + 3 < d.in_feats) v = *reinterpret_cast<const f32x4*>(xr + f0);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (f0 + j < d.in_feats) ? xr[f0 + j] : 0.f;
+        }
+        // lanes (p,0) and (p,1) hold features f..f+3 and f+4..f+7; the image wants even / odd features
+        const float s0 = h ? v[0] : v[1], s1 = h ? v[2] : v[3];
+        const float r0 = __shfl_xor(s0, 32), r1 = __shfl_xor(s1, 32);
+        f32x4 w;
+        if (h == 0) { w[0] = v[0]; w[1] = v[2]; w[2] = r0; w[3] = r1; }
+        else { w[0] = r0; w[1] = r1; w[2] = v[1]; w[3] = v[3]; }
+        lds[(d.in_row0 + r) * 64 + lane] = w;
+      }
+    }
+    __syncthreads();
+
+    // ---------------- layer program ----------------
+    for (int l = 0; l < d.n_layers; ++l) {
+      const ChainLayer L = d.layers[l];
+      const KSegs ks{L.kA_row0, L.kA_rows, L.kB_row0, L.kB_rows};
+      if (L.kind == 0) {
+        const f32x4* bp = wbuf + L.b_off;
+        const int act = L.act, dst = L.dst_row0;
+        gemm_tiles<NW>(lds, ks, wbuf + L.w_off, L.n_out_tiles, wave, lane,
+                       [&](int ot, f32x16& acc) { init_bias(bp, ot, lane, acc); },
+                       [&](int ot, const f32x16& acc) {
+#pragma unroll
+                         for (int rq = 0; rq < 4; ++rq) {
+                           f32x4 v = acc_quad(acc, rq);
+#pragma unroll
+                           for (int j = 0; j < 4; ++j) v[j] = act_rt(act, v[j]);
+                           lds[(dst + ot * 4 + rq) * 64 + lane] = v;
+                         }
+                       });
+        __syncthreads();
+        if (L.out_slot >= 0) {                   // image rows -> [N, out_feats] in HBM (16 B per lane)
+          float* o = outs.p[L.out_slot];
+          const int ld = outs.ld[L.out_slot];
+          const bool vec_ok = (ld & 3) == 0;
+          const int n_rows = (L.out_feats + 7) >> 3;
+          for (int r = wave; r < n_rows; r += NW) {
+            const f32x4 v = lds[(dst + r) * 64 + lane];
+            const float s0 = h ? v[0] : v[2], s1 = h ? v[1] : v[3];
+            const float r0 = __shfl_xor(s0, 32), r1 = __shfl_xor(s1, 32);
+            f32x4 w;
+            if (h == 0) { w[0] = v[0]; w[1] = r0; w[2] = v[1]; w[3] = r1; }
+            else { w[0] = r0; w[1] = v[2]; w[2] = r1; w[3] = v[3]; }
+            const int f0 = 32 * (r >> 2) + 8 * (r & 3) + 4 * h;
+            if (p0 + p < N) {
+              float* op = o + (p0 + p) * (long)ld + f0;
+              if (vec_ok && f0 + 3 < L.out_feats) *reinterpret_cast<f32x4*>(op) = w;
+              else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                  if (f0 + j < L.out_feats) op[j] = w[j];
+              }
+            }
+          }
+          __syncthreads();
+        }
+      } else {                                    // <= 4 outputs: VALU row-dots, fixed-order combine
+        const int nout = L.n_out_tiles;
+        const int n_rows = L.kA_rows + L.kB_rows;
+        const f32x4* wimg = wbuf + L.w_off;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int r = wave; r < n_rows; r += NW) {
+          const int row = r < L.kA_rows ? L.kA_row0 + r : L.kB_row0 + (r - L.kA_rows);
+          const f32x4 b = lds[row * 64 + lane];
+#pragma unroll
+          for (int o = 0; o < 4; ++o)
+            if (o < nout) {
+              const f32x4 wv = wimg[(o * n_rows + r) * 2 + h];
+              s[o] = fmaf(b[0], wv[0], s[o]); s[o] = fmaf(b[1], wv[1], s[o]);
+              s[o] = fmaf(b[2], wv[2], s[o]); s[o] = fmaf(b[3], wv[3], s[o]);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          s[o] += __shfl_xor(s[o], 32);
+          if (h == 0) sm->part[(wave * 32 + p) * 4 + o] = s[o];
+        }
+        __syncthreads();
+        if (tid < 128) {
+          const int pp = tid & 31, o = tid >> 5;
+          if (o < nout && p0 + pp < N) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += sm->part[(w * 32 + pp) * 4 + o];
+            v = act_rt(L.act, v + L.bias4[o]);
+            outs.p[L.out_slot][(p0 + pp) * (long)outs.ld[L.out_slot] + o] = v;
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+int check_desc(const ChainDesc& d) {
+  if (d.n_layers < 1 || d.n_layers > VQN_CHAIN_MAX_LAYERS) return 1;
+  if (d.n_waves != 4 && d.n_waves != 8) return 2;
+  if (d.total_rows < 1 || (size_t)d.total_rows * 1024 + sizeof(ChainSmalls) > 160 * 1024) return 3;
+  if (d.in_rows < 1 || d.in_row0 < 0 || d.in_row0 + d.in_rows > d.total_rows) return 4;
+  if (d.in_mode == 1 && (d.in_feats != 3 + 6 * d.n_freqs || d.n_freqs > 16)) return 5;
+  if (d.in_feats < 1 || d.in_feats > 8 * d.in_rows || d.in_stride < 1) return 6;
+  for (int l = 0; l < d.n_layers; ++l) {
+    const ChainLayer& L = d.layers[l];
+    if (L.kA_rows < 0 || L.kB_rows < 0 || L.kA_rows + L.kB_rows < 1) return 10;
+    if (L.kA_row0 < 0 || L.kA_row0 + L.kA_rows > d.total_rows) return 11;
+    if (L.kB_rows > 0 && (L.kB_row0 < 0 || L.kB_row0 + L.kB_rows > d.total_rows)) return 12;
+    if (L.out_slot >= VQN_CHAIN_MAX_OUTS) return 13;
+    if (L.kind == 0) {
+      if (L.n_out_tiles < 1 || L.dst_row0 < 0 || L.dst_row0 + 4 * L.n_out_tiles > d.total_rows) return 14;
+      if (L.out_slot >= 0 && (L.out_feats < 1 || L.out_feats > 32 * L.n_out_tiles)) return 15;
+      // a layer must not overwrite its own K rows
+      const int d0 = L.dst_row0, d1 = L.dst_row0 + 4 * L.n_out_tiles;
+      if (d0 < L.kA_row0 + L.kA_rows && L.kA_row0 < d1) return 16;
+      if (L.kB_rows > 0 && d0 < L.kB_row0 + L.kB_rows && L.kB_row0 < d1) return 17;
+    } else if (L.kind == 1) {
+      if (L.n_out_tiles < 1 || L.n_out_tiles > 4 || L.out_slot < 0) return 18;
+    } else return 19;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int vqn_mlp_chain_fwd(const int32_t* desc, const float* wbuf, const float* in, int64_t N, float* out0,
+                                 int ld0, float* out1, int ld1, float* out2, int ld2, float* out3, int ld3,
+                                 void* stream) {
+  VQN_CHECK_ARG(desc && wbuf, "desc and wbuf must be non-null");
+  VQN_CHECK_ARG(N >= 0, "N >= 0");
+  if (N == 0) return VQN_OK;
+  VQN_CHECK_ARG(in != nullptr, "in must be non-null");
+  ChainDesc d;
+  memcpy(&d, desc, sizeof(ChainDesc));
+  const int bad = check_desc(d);
+  if (bad) {
+    vqn_set_error("vqn_mlp_chain_fwd: unsupported shape: invalid chain descriptor (check %d)", bad);
+    return VQN_ESHAPE;
+  }
+  OutPtrs o;
+  o.p[0] = out0; o.p[1] = out1; o.p[2] = out2; o.p[3] = out3;
+  o.ld[0] = ld0; o.ld[1] = ld1; o.ld[2] = ld2; o.ld[3] = ld3;
+  for (int l = 0; l < d.n_layers; ++l) {
+    const int s = d.layers[l].out_slot;
+    if (s >= 0) {
+      VQN_CHECK_ARG(o.p[s] != nullptr, "an output the descriptor writes is null");
+      VQN_CHECK_ARG(o.ld[s] >= (d.layers[l].kind == 0 ? d.layers[l].out_feats : d.layers[l].n_out_tiles),
+                    "output leading dimension smaller than the layer's width");
+      if (d.layers[l].kind == 0 && (o.ld[s] & 3) == 0)
+        VQN_CHECK_ARG(((uintptr_t)o.p[s] & 15) == 0, "outputs with ld % 4 == 0 must be 16-byte aligned");
+    }
+  }
+  if (d.in_mode == 0 && (d.in_stride & 3) == 0) VQN_CHECK_ARG(((uintptr_t)in & 15) == 0, "in must be 16-byte aligned");
+  const size_t lds = (size_t)d.total_rows * 1024 + sizeof(ChainSmalls);
+  const long n_tiles = (N + 31) / 32;
+  hipStream_t s = (hipStream_t)stream;
+  if (d.n_waves == 4) {
+    if (lds > 64 * 1024)
+      VQN_HIP(hipFuncSetAttribute((const void*)mlp_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int per_cu = (2 * lds <= 160 * 1024) ? 2 : 1;
+    long grid = (long)vqn_num_cus() * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    hipLaunchKernelGGL(mlp_chain_kernel<4>, dim3((unsigned)grid), dim3(256), lds, s, d,
+                       reinterpret_cast<const f32x4*>(wbuf), in, (long)N, o);
+  } else {
+    if (lds > 64 * 1024)
+      VQN_HIP(hipFuncSetAttribute((const void*)mlp_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    long grid = (long)vqn_num_cus();
+    if (grid > n_tiles) grid = n_tiles;
+    hipLaunchKernelGGL(mlp_chain_kernel<8>, dim3((unsigned)grid), dim3(512), lds, s, d,
+                       reinterpret_cast<const f32x4*>(wbuf), in, (long)N, o);
+  }
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}

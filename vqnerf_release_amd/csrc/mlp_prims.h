@@ -48,12 +48,12 @@ struct KSegs {   // the K dimension of a layer = up to two runs of consecutive L
 };
 
 // out[32 x 32-point tile `ot`] = sum over K rows;  wave w owns tiles w, w+4, ...
-template <class Init, class Epi>
+template <int NW = 4, class Init, class Epi>
 __device__ __forceinline__ void gemm_tiles(const f32x4* __restrict__ lds, const KSegs ks,
                                            const f32x4* __restrict__ w, const int n_out_tiles, const int wave,
                                            const int lane, Init init, Epi epi) {
   const int ng = ks.nA + ks.nB;
-  for (int ot = wave; ot < n_out_tiles; ot += 4) {
+  for (int ot = wave; ot < n_out_tiles; ot += NW) {
     f32x16 acc;
     init(ot, acc);
     const f32x4* __restrict__ wp = w + (size_t)ot * ng * 64 + lane;
@@ -137,7 +137,7 @@ __device__ __forceinline__ int row_feat(int r, int h, int j) { return 32 * (r >>
 
 // part[(wave*32 + p)*NOUT + o] = this wave's share of sum_f wimg[o][f] * act[f][p] over rows
 // [row0, row0+n_rows); the caller adds the four partials in a fixed order (deterministic)
-template <int NOUT>
+template <int NOUT, int NW = 4>
 __device__ __forceinline__ void rowdot(const f32x4* __restrict__ lds, int row0, int n_rows,
                                        const f32x4* __restrict__ wimg /* [NOUT][n_rows][2] float4 */, float* out_s,
                                        int wave, int lane) {
@@ -145,7 +145,7 @@ __device__ __forceinline__ void rowdot(const f32x4* __restrict__ lds, int row0, 
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) s[o] = 0.f;
   const int h = lane >> 5;
-  for (int r = wave; r < n_rows; r += 4) {
+  for (int r = wave; r < n_rows; r += NW) {
     const f32x4 b = lds[(row0 + r) * 64 + lane];
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {

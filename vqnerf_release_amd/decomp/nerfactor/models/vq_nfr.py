@@ -1,0 +1,316 @@
+"""Stage-2 VQ reflectance model: mirror of decomp/nerfvq_nfr3/nerfactor/models/vq_nfr.py
+(nets :135-164, init_z :183-195, fast_embed :209-256, fast_render :262-398, vis_mat :400-465, vq_test :467-532,
+call :534-692, _render :694-733, light/gamma/get_codebook :735-769, heads :771-828, compute_loss :876-986).
+The vis/HTML/video half of the reference file (:988-1302) is out of scope.
+
+Execution paths as in models/nfr_unit.py: fused HIP kernels when no autograd graph is needed, torch statements of
+the same arithmetic on the GPU when it is.  The nearest-code search and the EMA statistics are HIP in both
+(networks/vq_layers.py)."""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from vqnerf_release_amd.decomp.nerfactor.models.nfr_unit import BrdfModel, scatter_rows
+from vqnerf_release_amd.decomp.nerfactor.networks import mlp
+from vqnerf_release_amd.decomp.nerfactor.networks.vq_layers import VectorQuantizerEMA
+from vqnerf_release_amd.decomp.nerfactor.util import img as imgutil, math as mathutil
+
+
+class Model(BrdfModel):
+    def __init__(self, config, debug=False):
+        self.no_brdf_chunk = config.getboolean('DEFAULT', 'no_brdf_chunk', fallback=True)
+        self.seed = config.getint('DEFAULT', 'random_seed', fallback=0)
+        self.nfr_ckpt = config.get('DEFAULT', 'nfr_model_ckpt', fallback='')
+        super().__init__(config, debug=debug)
+        self.brdf_chunk_size = self.config.getint('DEFAULT', 'brdf_chunk_size', fallback=50000)
+        self._codebook = None
+
+    def _init_net(self):
+        self.num_embed = self.config.getint('DEFAULT', 'num_embed')
+        commitment_cost = self.config.getfloat('DEFAULT', 'commitment_cost')
+        z = self.z_dim
+        vq_head = lambda out: mlp.Network([z, z // 2, out], act=['relu'] * 2 + ['sigmoid'], skip_at=[1])
+        net = {'diff_vq': vq_head(3), 'spec_vq': vq_head(3), 'rough_vq': vq_head(1)}    # spec_vq has 3 outputs (vq_nfr.py:143)
+        net.update(self._encoder_nets())          # in the reference these five come from the stage-1 checkpoint (:148-155)
+        net.update(self._standard_nets('main'))
+        self.vq_layer = VectorQuantizerEMA(embedding_dim=z, num_embeddings=self.num_embed,
+                                           commitment_cost=commitment_cost, seed=self.seed)
+        return net
+
+    def load_stage1(self, nfr_model):
+        """Stage hand-off (vq_nfr.py:148-155): share the stage-1 encoder and heads."""
+        for dst, src in (('fine_enc', 'fine_enc'), ('bottleneck', 'bottleneck'), ('diff_main', 'diff_out'),
+                         ('spec_main', 'spec_out'), ('rough_main', 'rough_out')):
+            self.net[dst].load_state_dict(nfr_model.net[src].state_dict())
+        if nfr_model._light is not None:
+            self.set_light(nfr_model._light.detach().clone())
+
+    # ------------------------------------------------------------------ codebook
+    def set_codebook(self, cluster_center):
+        """cluster_center [K, z_dim] (k-means centres, the layout of output/cluster/<scene>.npy) -> _codebook [z_dim, K]."""
+        cb = torch.as_tensor(cluster_center, dtype=torch.float32).t().contiguous()
+        assert tuple(cb.shape) == (self.z_dim, self.num_embed), tuple(cb.shape)
+        self._codebook = nn.Parameter(cb.to(self.lxyz.device))
+
+    def get_codebook(self):
+        if self._codebook is None:
+            path = self.config.get('DEFAULT', 'cluster_center_path')
+            self.set_codebook(np.load(path))
+        cb = mathutil.clip_preserve_gradient(self._codebook, 0.0, 1.0)
+        return mathutil.safe_l2_normalize(cb, axis=0)
+
+    # ------------------------------------------------------------------ reference-named pieces
+    def _pred_enc_at(self, pts):
+        return self._pred_bias_at(pts)
+
+    def _pred_diff_at(self, z, vq=False):
+        return self._albedo_affine(self._head('diff_vq' if vq else 'diff_main', z))
+
+    def _pred_spec_at(self, z, vq=False):
+        return self._head('spec_vq' if vq else 'spec_main', z)
+
+    def _pred_rough_at(self, z, vq=False):
+        return self._head('rough_vq' if vq else 'rough_main', z)
+
+    def _thres(self, thres, device):
+        if thres is None:
+            return None
+        return torch.as_tensor(thres, dtype=torch.float32, device=device).reshape(1, self.num_embed)
+
+    def _quantise(self, z_enc, mode, thres, roll=None):
+        z_norm = mathutil.safe_l2_normalize(z_enc, axis=1)
+        codebook = self.get_codebook()
+        vq = self.vq_layer(z_norm, codebook, is_training=(mode == 'train'), thres=self._thres(thres, z_enc.device), roll=roll)
+        return vq, vq['quantize'], vq['loss'], vq['encoding_indices'] + 1
+
+    # ------------------------------------------------------------------ entry points
+    def init_z(self, batch):
+        id_, hw, _, _, _, alpha, pred_alpha, xyz = batch[:8]
+        mask = alpha[:, 0] > 0
+        return {'id': id_, 'hw': hw, 'z_pred': self._pred_enc_at(xyz[mask])}
+
+    def init_mat(self, z_pred):
+        basecolor, ks, rough = self._all_heads(z_pred, 'main')
+        return torch.cat([(1 - ks) * basecolor, ks * basecolor, rough], -1)
+
+    def fast_embed(self, batch, mode='train', thres=None, ref_batch=True):
+        self._validate_mode(mode)
+        id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz = batch[:8]
+        mask = alpha[:, 0] > 0
+        n = alpha.shape[0]
+        xyz_m = xyz[mask]
+        _, _, _, embed_ind = self._quantise(self._pred_enc_at(xyz_m), mode, thres)
+        pred, gt = {'alpha': pred_alpha}, {'alpha': alpha}
+        to_vis = {'id': id_, 'hw': hw, 'embed': scatter_rows(mask, embed_ind[:, None], n), 'xyz': scatter_rows(mask, xyz_m, n),
+                  'pred_alpha': pred_alpha, 'gt_alpha': alpha}
+        return pred, gt, {'mode': mode}, to_vis
+
+    def vq_test(self, batch, mode='vali', thres=None):
+        id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz, normal, lvis = self._unpack(batch)
+        mask = alpha[:, 0] > 0
+        rayo, rgb_m, xyz_m, normal_m = rayo[mask], rgb[mask], xyz[mask], normal[mask]
+        lvis_m = lvis[mask] if lvis is not None else None
+        vq, z_vq, vq_loss, _ = self._quantise(self._pred_enc_at(xyz_m), mode, thres)
+        usage = (vq['encodings'].max(0, keepdim=True)[0] > 0).to(torch.float32)
+        vq_albedo, vq_spec, vq_rough = self._all_heads(z_vq, 'vq')
+        vq_rgb = self._shade_or_render(xyz_m, normal_m, rayo, lvis_m, [(vq_albedo, vq_spec, vq_rough)])['rgb'][0]
+        loss_kwargs = {'vqloss': vq_loss, 'vqrgb': vq_rgb, 'mode': mode, 'gtc': rgb_m, 'rgb': vq_rgb, 'usage': usage}
+        return {'alpha': pred_alpha}, {'alpha': alpha}, loss_kwargs, {'id': id_, 'hw': hw}
+
+    def _shade_or_render(self, xyz, normal, rayo, lvis, materials, split=False, light=None, probes=False):
+        """dict(rgb=[per set], normal, rgb_diff, rgb_spec[, rgb_probes]) -- fused kernel without a graph, torch with."""
+        if self._fused(xyz, *[t for m in materials for t in m]):
+            out = self._shade(xyz, normal, rayo, lvis, materials, split=split, light=light)
+            if probes:
+                out['rgb_probes'] = torch.stack(
+                    [self._shade(xyz, normal, rayo, lvis, materials[:1], light=lp)['rgb'][0] for lp in self.novel_probes.values()], 1)
+            return out
+        surf2l = self._calc_ldir(xyz)
+        surf2c = self._calc_vdir(rayo, xyz)
+        n_pred = self._normal_correct(normal, surf2c)
+        out = {'rgb': [], 'normal': n_pred, 'rgb_diff': None, 'rgb_spec': None}
+        for i, (a, s, r) in enumerate(materials):
+            brdf, brdf_s, brdf_d = self._eval_brdf_at(surf2l, surf2c, n_pred, a, s, r)
+            rgb, _, rp = self._render(brdf, surf2l, n_pred, lvis, relight_probes=(probes and i == 0), light=light)
+            out['rgb'].append(rgb)
+            if probes and i == 0:
+                out['rgb_probes'] = rp
+            if split and i == 0:
+                out['rgb_diff'] = self._render(brdf_d, surf2l, n_pred, lvis)[0]
+                out['rgb_spec'] = self._render(brdf_s, surf2l, n_pred, lvis)[0]
+        return out
+
+    def call(self, batch, mode='train', thres=None, full_vis=False, roll=None):
+        self._validate_mode(mode)
+        id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz, normal, lvis = self._unpack(batch)
+        mask = alpha[:, 0] > 0
+        n = alpha.shape[0]
+        rayo, rgb_m, xyz_m, normal_m = rayo[mask], rgb[mask], xyz[mask], normal[mask]
+        lvis_m = lvis[mask] if lvis is not None else None
+
+        z_enc = self._pred_enc_at(xyz_m)
+        vq, z_vq, vq_loss, embed_ind = self._quantise(z_enc, mode, thres, roll=roll)
+        if mode == 'train':                                   # codebook is moved by the EMA, outside the optimiser (:582-583)
+            with torch.no_grad():
+                self._codebook.copy_(vq['update'])
+
+        basecolor, ks, rough = self._all_heads(z_enc, 'main')
+        spec = ks * basecolor
+        albedo = (1 - ks) * basecolor
+        vq_albedo, vq_spec, vq_rough = self._all_heads(z_vq, 'vq')
+        sh = self._shade_or_render(xyz_m, normal_m, rayo, lvis_m, [(albedo, spec, rough), (vq_albedo, vq_spec, vq_rough)],
+                                   split=(mode != 'train'))
+        rgb_pred, vq_rgb, normal_pred = sh['rgb'][0], sh['rgb'][1], sh['normal']
+
+        loss_kwargs = {'vqloss': vq_loss, 'vqrgb': vq_rgb, 'mode': mode, 'gtc': rgb_m, 'rgb': rgb_pred, 'spec': spec,
+                       'rough': rough, 'z': z_vq, 'embed': self._codebook}
+        srgb = (lambda t: imgutil.linear2srgb(t)) if self.data_type == 'nerf' else (lambda t: t)
+        pred = {'rgb': scatter_rows(mask, srgb(rgb_pred), n), 'normal': scatter_rows(mask, normal_pred, n),
+                'albedo': scatter_rows(mask, albedo, n), 'alpha': pred_alpha, 'spec': scatter_rows(mask, spec, n),
+                'rough': scatter_rows(mask, rough, n), 'ks': scatter_rows(mask, ks, n)}
+        if mode != 'train':
+            pred['rgb_diff'] = scatter_rows(mask, sh['rgb_diff'], n)
+            pred['rgb_spec'] = scatter_rows(mask, sh['rgb_spec'], n)
+        gt = {'rgb': scatter_rows(mask, rgb_m, n), 'normal': scatter_rows(mask, normal_m, n), 'alpha': alpha}
+        to_vis = {'id': id_, 'hw': hw}
+        if full_vis:
+            to_vis['enc_z'] = scatter_rows(mask, z_enc, n)
+        if mode != 'train':
+            pred['embed'] = scatter_rows(mask, embed_ind[:, None], n)
+            pred['vq_rgb'] = scatter_rows(mask, srgb(vq_rgb), n)
+            pred['vq_albedo'] = scatter_rows(mask, vq_albedo, n)
+            pred['vq_spec'] = scatter_rows(mask, vq_spec, n)
+            pred['vq_rough'] = scatter_rows(mask, vq_rough, n)
+        for k, v in pred.items():
+            to_vis['pred_' + k] = v
+        for k, v in gt.items():
+            to_vis['gt_' + k] = v
+        return pred, gt, loss_kwargs, to_vis
+
+    def fast_render(self, batch, mode='train', relight_olat=False, relight_probes=False, opt_scale=None, edit_mask=None,
+                    edit_material=None, ref_batch=False, dst_env=None, gen_embed=False, thres=None, vis_scale=False):
+        self._validate_mode(mode)
+        id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz, normal = batch[:9]
+        lvis = batch[-1] if self.data_type == 'nerf' else None
+        mask = alpha[:, 0] > 0
+        n = alpha.shape[0]
+        rayo, rgb_m, xyz_m, normal_m = rayo[mask], rgb[mask], xyz[mask], normal[mask]
+        lvis_m = lvis[mask] if lvis is not None else None
+        if edit_mask is not None:
+            edit_mask = (edit_mask[mask][..., 0:1] > 0).to(torch.float32)
+        z_enc = self._pred_enc_at(xyz_m)
+        if gen_embed:
+            _, _, _, embed_ind = self._quantise(z_enc, mode, thres)
+        basecolor, ks, rough = self._all_heads(z_enc, 'main')
+        spec = ks * basecolor
+        albedo = (1 - ks) * basecolor
+        if edit_mask is not None:
+            upd = lambda src, v: src * (1 - edit_mask) + edit_mask * torch.as_tensor([v], dtype=torch.float32, device=src.device)
+            if not edit_material['diff'][0] < 0:
+                albedo = upd(albedo, edit_material['diff'])
+            if not edit_material['spec'][0] < 0:
+                spec = upd(spec, edit_material['spec'])
+            if not edit_material['rough'][0] < 0:
+                rough = upd(rough, edit_material['rough'])
+        scaled = (opt_scale is not None) and (not vis_scale)
+        s_albedo, s_spec = (albedo * opt_scale, spec * opt_scale) if scaled else (albedo, spec)
+        light = None if dst_env is None else self.novel_probes[dst_env]
+        sh = self._shade_or_render(xyz_m, normal_m, rayo, lvis_m, [(s_albedo, s_spec, rough)], light=light,
+                                   probes=relight_probes)
+        rgb_pred = sh['rgb'][0]
+        srgb = (lambda t: imgutil.linear2srgb(t)) if self.data_type == 'nerf' else (lambda t: t)
+        if (opt_scale is not None) and vis_scale:
+            basecolor = imgutil.linear2srgb(basecolor) * opt_scale
+            spec = imgutil.linear2srgb(spec) * opt_scale
+        pred = {'alpha': pred_alpha, 'basecolor': scatter_rows(mask, basecolor, n), 'albedo': scatter_rows(mask, albedo, n),
+                'spec': scatter_rows(mask, spec, n), 'rough': scatter_rows(mask, rough, n)}
+        if gen_embed:
+            pred['embed'] = scatter_rows(mask, embed_ind[:, None], n)
+        if dst_env is not None:
+            pred['rgb'] = scatter_rows(mask, srgb(rgb_pred), n)
+        if relight_probes:
+            pred['rgb_probes'] = scatter_rows(mask, srgb(sh['rgb_probes']), n)
+        gt = {'rgb': scatter_rows(mask, rgb_m, n), 'alpha': alpha}
+        to_vis = {'id': id_, 'hw': hw}
+        for k, v in pred.items():
+            to_vis['pred_' + k] = v
+        for k, v in gt.items():
+            to_vis['gt_' + k] = v
+        return pred, gt, {'mode': mode, 'gtc': rgb_m}, to_vis
+
+    def vis_mat(self, batch, mode='train', opt_scale=None, ref_batch=False, thres=None):
+        self._validate_mode(mode)
+        id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz = batch[:8]
+        mask = alpha[:, 0] > 0
+        n = alpha.shape[0]
+        z_enc = self._pred_enc_at(xyz[mask])
+        _, _, _, embed_ind = self._quantise(z_enc, mode, thres)
+        basecolor, ks, rough = self._all_heads(z_enc, 'main')
+        pred = {'alpha': pred_alpha, 'albedo': scatter_rows(mask, (1 - ks) * basecolor, n),
+                'spec': scatter_rows(mask, ks * basecolor, n), 'rough': scatter_rows(mask, rough, n),
+                'embed': scatter_rows(mask, embed_ind[:, None], n)}
+        gt = {'alpha': alpha}
+        to_vis = {'id': id_, 'hw': hw}
+        for k, v in pred.items():
+            to_vis['pred_' + k] = v
+        to_vis['gt_alpha'] = alpha
+        return pred, gt, {'mode': mode}, to_vis
+
+    # ------------------------------------------------------------------ loss
+    @staticmethod
+    def _rgb2chromaticity(rgb):
+        den = torch.sqrt((rgb * rgb).sum(-1, keepdim=True))
+        return mathutil.divide_no_nan(rgb, den * torch.ones_like(rgb))
+
+    def compute_loss(self, pred, gt, **kwargs):
+        cfg = lambda k: self.config.getfloat('DEFAULT', k)
+        mse = lambda a, b: ((a - b) ** 2).mean(-1)
+        mode = kwargs.pop('mode')
+        rgb_gt, rgb_pred = kwargs.pop('gtc'), kwargs.pop('rgb')
+        if self.data_type == 'nerf':
+            linear_gt, srgb_pred = imgutil.srgb2linear(rgb_gt), imgutil.linear2srgb(rgb_pred)
+        else:
+            linear_gt, srgb_pred = rgb_gt, rgb_pred
+        ld = {}
+        vq_rgb = kwargs.pop('vqrgb')
+        if mode != 'train':
+            ld['rgb'] = mse(rgb_gt, srgb_pred)
+            ld['vqrgb'] = mse(rgb_gt, imgutil.linear2srgb(vq_rgb))
+            ld['chromaticity'] = mse(self._rgb2chromaticity(linear_gt), self._rgb2chromaticity(vq_rgb))
+            return ld['rgb'] + ld['vqrgb'] + ld['chromaticity'], ld
+        ld['rgb'] = cfg('combine_weight') * mse(linear_gt, rgb_pred)
+        ld['vqrgb'] = mse(linear_gt, vq_rgb)
+        ld['vqloss'] = cfg('vq_loss_weight') * kwargs.pop('vqloss')
+        loss = ld['rgb'] + ld['vqrgb'] + ld['vqloss']
+        schr_gt = self._rgb2chromaticity(rgb_gt)
+        if cfg('chromaticity_loss_weight') > 0:
+            ld['chromaticity'] = cfg('chromaticity_loss_weight') * mse(self._rgb2chromaticity(linear_gt),
+                                                                        self._rgb2chromaticity(vq_rgb))
+            loss = loss + ld['chromaticity']
+        if cfg('mat_sloss_weight') > 0:                       # pairs [p, p_neighbour] are interleaved (train_nfr.py:447-448)
+            z_vq = kwargs.pop('z')
+            e = torch.sqrt(((schr_gt[::2] - schr_gt[1::2]) ** 2).sum(-1))
+            e = torch.where(e > cfg('chr_thres'), e, torch.zeros_like(e))
+            sl = torch.exp(-cfg('chr_alpha') * e) * (1.0 - (z_vq[::2] * z_vq[1::2]).sum(-1))
+            ld['chr_smooth'] = cfg('mat_sloss_weight') * torch.stack([sl, sl], -1).reshape(-1)
+            loss = loss + ld['chr_smooth']
+        if cfg('sim_loss_weight') > 0:                        # keep the code vectors apart (:955-968)
+            cb = self.get_codebook().t()
+            K = cb.shape[0]
+            eye = torch.eye(K, dtype=cb.dtype, device=cb.device)
+            # the diagonal is exactly 0 and masked below; "+ eye" only keeps d sqrt / dx finite there (TF's SqrtGrad
+            # yields 0 for a 0 incoming gradient, torch would give 0 * inf)
+            dist = torch.sqrt(((cb[:, None, :] - cb[None, :, :]) ** 2).sum(-1) + eye) * (1 - eye)
+            masked = dist * (1 - eye) + eye * dist.max()
+            ld['sim_smooth'] = cfg('sim_loss_weight') * (-torch.log(masked.min()))
+            loss = loss + ld['sim_smooth']
+        if cfg('lambert_weight') > 0:
+            spec, rough = kwargs.pop('spec'), kwargs.pop('rough')
+            r = rough.detach()
+            r = torch.where(r < 0.5, torch.zeros_like(r), 2 * r - 1.0)
+            ld['lambert'] = cfg('lambert_weight') * spec.max(-1)[0] * r[:, 0]
+            loss = loss + ld['lambert']
+        ld['loss'] = loss
+        return loss, ld

@@ -1,0 +1,19 @@
+"""Mirror of the pieces of decomp/nerfvq_nfr3/nerfactor/util/math.py the hot path uses (torch statement)."""
+import torch
+
+
+def safe_l2_normalize(x, axis=None, eps=1e-6):
+    """tf.linalg.l2_normalize (math.py:63-64): x * rsqrt(max(sum(x^2, axis), eps))."""
+    sq = (x * x).sum(dim=axis, keepdim=True) if axis is not None else (x * x).sum()
+    return x * torch.rsqrt(torch.clamp(sq, min=eps))
+
+
+def clip_preserve_gradient(x, lo, hi):
+    """tfp.math.clip_by_value_preserve_gradient: clipped value, identity gradient."""
+    return x + (x.clamp(lo, hi) - x).detach()
+
+
+def divide_no_nan(a, b):
+    """tf.math.divide_no_nan: 0 where b == 0 (value and gradient)."""
+    zero = b == 0
+    return torch.where(zero, torch.zeros_like(a * b), a / torch.where(zero, torch.ones_like(b), b))

@@ -145,9 +145,15 @@ class SDFNetwork(nn.Module):
                 x = self.activation(x)
         return torch.cat([x[:, :1] / self.scale, x[:, 1:]], dim=-1)
 
+    def _require_hip(self, x, what):
+        _C.require_device(x, what)
+        if not self._hip_supported():
+            raise _C.VqnError(f'{what}: the fused kernels need d_in == 3, multires > 0 and at most one skip layer')
+
     def sdf(self, x):
-        if _needs_graph(self, x) or not x.is_cuda or not self._hip_supported():
+        if _needs_graph(self, x):
             return self.forward(x)[:, :1]
+        self._require_hip(x, 'SDFNetwork.sdf')
         wbuf, desc = self.packs()
         return _C.neus_sdf_points(desc, wbuf, pts=x.detach().float().contiguous()).reshape(-1, 1)
 
@@ -155,13 +161,14 @@ class SDFNetwork(nn.Module):
         return self.forward(x)
 
     def gradient(self, x):
-        if _needs_graph(self, x) or not x.is_cuda or not self._hip_supported():
+        if _needs_graph(self, x):
             x.requires_grad_(True)
             with torch.enable_grad():
                 y = self.forward(x)[:, :1]
                 g = torch.autograd.grad(y, x, torch.ones_like(y), create_graph=True, retain_graph=True,
                                         only_inputs=True)[0]
             return g.unsqueeze(1)
+        self._require_hip(x, 'SDFNetwork.gradient')
         wbuf, desc = self.packs()
         xx = x.detach().float().contiguous()
         no_col = np.zeros(packing.COL_DESC_INTS, np.int32)
