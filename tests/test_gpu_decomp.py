@@ -2,7 +2,7 @@
 
 The decomp oracle is a from-source restatement (PARITY UNPINNED against the TF reference); these tests
 pin the HIP path to it.  Tolerances (fp32): MLP outputs 3e-6 abs (sigmoid outputs in (0,1), K <= 384 fmaf chains vs
-torch's blocked GEMM); shaded rgb 2e-5 abs (512-term sums in a different order); VQ indices exact."""
+torch's blocked GEMM); shaded rgb judged against the fp64 oracle (see _assert_as_accurate_as_fp32_oracle); VQ indices exact."""
 import numpy as np
 import pytest
 import torch
@@ -55,6 +55,36 @@ def test_chain_ragged_sizes(setup, n):
     np.testing.assert_allclose(_np(z), od.pred_enc(pt, specs, od.T(pts['xyz'])).numpy(), rtol=0, atol=3e-6)
 
 
+def _oracle_shade(od, setup, pts, mats, light, with_lvis, dtype, gamma=None):
+    T = lambda a: od.T(a, dtype)
+    xyz, normal, rayo = T(pts['xyz']), T(pts['normal']), T(pts['rayo'])
+    lvis = T(pts['lvis']) if with_lvis else None
+    lxyz, lareas = setup['lxyz'].to(dtype), setup['lareas'].to(dtype)
+    surf2l = od.calc_ldir(lxyz, xyz)
+    surf2c = od.calc_vdir(rayo, xyz)
+    n_pred = od.normal_correct(normal, surf2c)
+    out = dict(normal=n_pred, rgb=[])
+    for i, (a, s, r) in enumerate(mats):
+        brdf, bs, bd = od.get_brdf(surf2l, surf2c, n_pred, T(a), T(r), T(s))
+        out['rgb'].append(od.render_integrate(brdf, surf2l, n_pred, lareas, T(light), lvis, gamma))
+        if i == 0:
+            out['rgb_diff'] = od.render_integrate(bd, surf2l, n_pred, lareas, T(light), lvis, gamma)
+            out['rgb_spec'] = od.render_integrate(bs, surf2l, n_pred, lareas, T(light), lvis, gamma)
+    return out
+
+
+def _assert_as_accurate_as_fp32_oracle(got, ref32, ref64, what):
+    """GGX with small roughness is ill-conditioned in fp32 (t = cos_m^2 (a^2 - 1) + 1 cancels to ~a^2 = rough^4), so
+    two correct fp32 evaluations differ by ~1e-4 on glossy peaks.  Ground truth = the oracle in fp64; the kernel must
+    be as close to it as the fp32 oracle is (max error within x3, rms within x2, median <= 2e-6)."""
+    e_hip = np.abs(got.astype(np.float64) - ref64)
+    e_o32 = np.abs(ref32.astype(np.float64) - ref64)
+    assert e_hip.max() <= max(3.0 * e_o32.max(), 2e-5), (what, e_hip.max(), e_o32.max())
+    assert np.median(e_hip) <= 2e-6, (what, np.median(e_hip))
+    rms = lambda e: float(np.sqrt((e ** 2).mean()))
+    assert rms(e_hip) <= max(2.0 * rms(e_o32), 2e-6), (what, rms(e_hip), rms(e_o32))
+
+
 @pytest.mark.parametrize('with_lvis', [True, False])
 def test_shade_kernel_vs_oracle(setup, with_lvis):
     od = setup['od']
@@ -65,36 +95,24 @@ def test_shade_kernel_vs_oracle(setup, with_lvis):
     mats = [(rng.uniform(0, 1, (N, 3)), rng.uniform(0, 1, (N, 3)), rng.uniform(0.02, 1, (N, 1))) for _ in range(2)]
     mats[0][2][:5] = 0.0                                    # rough = 0 -> D = divide_no_nan(0, .) paths
     light = rng.uniform(0, 1, (16, 32, 3))
-    T = od.T
-    xyz, normal, rayo = T(pts['xyz']), T(pts['normal']), T(pts['rayo'])
-    lvis = T(pts['lvis']) if with_lvis else None
-    surf2l = od.calc_ldir(setup['lxyz'], xyz)
-    surf2c = od.calc_vdir(rayo, xyz)
-    n_pred = od.normal_correct(normal, surf2c)
-    want, want_split = [], None
-    for i, (a, s, r) in enumerate(mats):
-        brdf, bs, bd = od.get_brdf(surf2l, surf2c, n_pred, T(a), T(r), T(s))
-        want.append(od.render_integrate(brdf, surf2l, n_pred, setup['lareas'], T(light), lvis))
-        if i == 0:
-            want_split = (od.render_integrate(bd, surf2l, n_pred, setup['lareas'], T(light), lvis),
-                          od.render_integrate(bs, surf2l, n_pred, setup['lareas'], T(light), lvis))
+    r32 = _oracle_shade(od, setup, pts, mats, light, with_lvis, torch.float32)
+    r64 = _oracle_shade(od, setup, pts, mats, light, with_lvis, torch.float64)
     c = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32).cuda().contiguous()
-    got = _C.brdf_shade_fwd(c(pts['xyz']), c(pts['normal']), c(pts['rayo']), None if lvis is None else c(pts['lvis']),
-                            c(setup['lxyz'].reshape(-1, 3)), c(setup['lareas'].reshape(-1)), c(light.reshape(-1, 3)),
+    geo = (c(pts['xyz']), c(pts['normal']), c(pts['rayo']))
+    lights = (c(setup['lxyz'].reshape(-1, 3)), c(setup['lareas'].reshape(-1)), c(light.reshape(-1, 3)))
+    got = _C.brdf_shade_fwd(*geo, c(pts['lvis']) if with_lvis else None, *lights,
                             [(c(a), c(s), c(r)) for a, s, r in mats], want_normal=True, want_split=True)
-    np.testing.assert_array_equal(_np(got['normal']), n_pred.numpy())
-    for g, w in zip(got['rgb'], want):
-        np.testing.assert_allclose(_np(g), w.numpy(), rtol=0, atol=2e-5)
-    np.testing.assert_allclose(_np(got['rgb_diff']), want_split[0].numpy(), rtol=0, atol=2e-5)
-    np.testing.assert_allclose(_np(got['rgb_spec']), want_split[1].numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_array_equal(_np(got['normal']), r32['normal'].numpy())
+    for i in range(2):
+        _assert_as_accurate_as_fp32_oracle(_np(got['rgb'][i]), r32['rgb'][i].numpy(), r64['rgb'][i].numpy(), f'rgb{i}')
+    np.testing.assert_allclose(_np(got['rgb_diff']), r32['rgb_diff'].numpy(), rtol=0, atol=2e-6)   # Lambert part: well conditioned
+    _assert_as_accurate_as_fp32_oracle(_np(got['rgb_spec']), r32['rgb_spec'].numpy(), r64['rgb_spec'].numpy(), 'rgb_spec')
     # non-nerf data: learnable gamma (vq_nfr.py:715-716)
     gam = torch.tensor([1.3, 0.8]).cuda()
-    got_g = _C.brdf_shade_fwd(c(pts['xyz']), c(pts['normal']), c(pts['rayo']), None, c(setup['lxyz'].reshape(-1, 3)),
-                              c(setup['lareas'].reshape(-1)), c(light.reshape(-1, 3)), [(c(mats[0][0]), c(mats[0][1]), c(mats[0][2]))],
-                              gamma=gam)
-    brdf, _, _ = od.get_brdf(surf2l, surf2c, n_pred, T(mats[0][0]), T(mats[0][2]), T(mats[0][1]))
-    want_g = od.render_integrate(brdf, surf2l, n_pred, setup['lareas'], T(light), None, gamma=(1.3, 0.8))
-    np.testing.assert_allclose(_np(got_g['rgb'][0]), want_g.numpy(), rtol=0, atol=3e-5)
+    got_g = _C.brdf_shade_fwd(*geo, None, *lights, [(c(mats[0][0]), c(mats[0][1]), c(mats[0][2]))], gamma=gam)
+    g32 = _oracle_shade(od, setup, pts, mats[:1], light, False, torch.float32, gamma=(1.3, 0.8))
+    g64 = _oracle_shade(od, setup, pts, mats[:1], light, False, torch.float64, gamma=(1.3, 0.8))
+    _assert_as_accurate_as_fp32_oracle(_np(got_g['rgb'][0]), g32['rgb'][0].numpy(), g64['rgb'][0].numpy(), 'gamma')
 
 
 def test_shade_known_answers():
@@ -152,7 +170,9 @@ def test_model_call_vs_oracle(setup, mode):
         # the EMA moved the codebook (vq_nfr.py:582-583)
         np.testing.assert_allclose(_np(model._codebook), want['vq']['update'].numpy(), rtol=0, atol=2e-6)
     loss, ld = model.compute_loss(pred, gt, **dict(lk))
-    wl, wd = od.compute_loss(want, ob['rgb'], pt['codebook_raw'], mode=mode)
+    # compute_loss runs after call(): in train mode it sees the codebook the EMA has just written (vq_nfr.py:582-583, :956)
+    cb_for_loss = want['vq']['update'] if mode == 'train' else pt['codebook_raw']
+    wl, wd = od.compute_loss(want, ob['rgb'], cb_for_loss, mode=mode)
     np.testing.assert_allclose(_np(loss), wl.numpy(), rtol=1e-4, atol=2e-6)
 
 

@@ -1,0 +1,132 @@
+"""VQ-stage trainer pieces: mirror of decomp/nerfvq_nfr3/nerfactor/train_nfr.py -- optimiser construction
+(:121-139), `outer_sample` (:380-467), `train_iter` / `vali_iter` / `vali_vq` (:562-594) -- on the MI355X model
+classes, with rank-sharded data parallelism added (the reference's VQ stage is single-device; its only DP site is
+trainvali.py:436-486 for stages 1/3, which `train_iter` covers as well since the step contract is the same).
+
+Out of scope here: tf.data view loaders, checkpoint managers, TensorBoard, the k-means codebook init.
+"""
+import torch
+
+from vqnerf_release_amd import parallel
+
+
+def make_optimizer(config, params):
+    """Keras Adam(lr, amsgrad=True) (train_nfr.py:121-139): epsilon 1e-7 (Keras default, torch's is 1e-8), optional
+    ExponentialDecay(lr_decay_steps, lr_decay_rate) -> returned as a LambdaLR, clipnorm / clipvalue as a closure."""
+    lr = config.getfloat('DEFAULT', 'lr')
+    opt = torch.optim.Adam(params, lr=lr, eps=1e-7, amsgrad=True)
+    decay_steps = config.getint('DEFAULT', 'lr_decay_steps', fallback=-1)
+    sched = None
+    if decay_steps > 0:
+        rate = config.getfloat('DEFAULT', 'lr_decay_rate')
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda step: rate ** (step / decay_steps))
+    clipnorm = config.getfloat('DEFAULT', 'clipnorm', fallback=-1)
+    clipvalue = config.getfloat('DEFAULT', 'clipvalue', fallback=-1)
+    assert not (clipnorm > 0 and clipvalue > 0), 'Both `clipnorm` and `clipvalue` are active -- turn one off'
+    return opt, sched, (clipnorm, clipvalue)
+
+
+def compute_average_loss(per_example_loss, global_batch_size):
+    """tf.nn.compute_average_loss: sum(per_example) / global_batch_size (NOT the local mean)."""
+    return per_example_loss.sum() / global_batch_size
+
+
+class Trainer:
+    """Holds the DP plumbing of one model: flat gradient bucket + VQ statistics reducer."""
+
+    def __init__(self, model, optimizer, clip=(-1, -1), sched=None):
+        assert model.trainable_registered, 'Register the trainable layers before using `trainable_variables`'
+        self.model, self.optimizer, self.clip, self.sched = model, optimizer, clip, sched
+        self.bucket = None
+        # lazily created variables (light, gamma, codebook) must exist before the gradient bucket is laid out
+        _ = model.light
+        if getattr(model, 'data_type', 'nerf') != 'nerf':
+            _ = model.gamma
+        if hasattr(model, 'vq_layer'):
+            model.get_codebook()
+            model.vq_layer.stats_all_reduce = parallel.VQStatsReducer()
+
+    def train_iter(self, batch, global_bs, thres=None, roll=None):
+        """One step (train_nfr.py:562-576).  `global_bs` is the reference's normaliser (n_rays_per_step, :571-572) times
+        the number of ranks when each rank draws its own rays.  Returns (weighted_loss summed over ranks, to_vis, loss_dict)."""
+        model = self.model
+        if self.bucket is None:
+            self.bucket = parallel.FlatBucket(model.trainable_variables, n_extra=1)
+        self.optimizer.zero_grad(set_to_none=True)
+        self.bucket.attach()
+        kw = {'thres': thres}
+        if roll is not None:
+            kw['roll'] = roll
+        pred, gt, loss_kwargs, to_vis = model(batch, mode='train', **kw) if hasattr(model, 'vq_layer') else model(batch, mode='train')
+        loss_kwargs.pop('pretrain', None), loss_kwargs.pop('env', None)
+        per_example, loss_dict = model.compute_loss(pred, gt, **loss_kwargs)
+        weighted = compute_average_loss(per_example, global_bs)
+        weighted.backward()
+        with torch.no_grad():
+            self.bucket.extra[0] = weighted
+        extra = self.bucket.all_reduce()
+        clipnorm, clipvalue = self.clip
+        if clipnorm > 0:
+            # Keras clips every gradient tensor by its own norm
+            for p in self.bucket.params:
+                n = p.grad.norm()
+                p.grad.mul_(torch.clamp(clipnorm / (n + 1e-12), max=1.0))
+        if clipvalue > 0:
+            self.bucket.flat[:self.bucket.n_grad].clamp_(-clipvalue, clipvalue)
+        self.optimizer.step()
+        if self.sched is not None:
+            self.sched.step()
+        return extra[0], to_vis, loss_dict
+
+
+def train_iter(model, batch, optimizer, global_bs, thres=None, _trainers={}):
+    """Function form with the reference's signature (train_nfr.py:562)."""
+    key = (id(model), id(optimizer))
+    if key not in _trainers:
+        _trainers[key] = Trainer(model, optimizer)
+    return _trainers[key].train_iter(batch, global_bs, thres=thres)
+
+
+@torch.no_grad()
+def vali_iter(model, batch, global_bs, thres=None, full_vis=False):
+    pred, gt, loss_kwargs, to_vis = model(batch, mode='vali', thres=thres, full_vis=full_vis)
+    per_example, loss_dict = model.compute_loss(pred, gt, **loss_kwargs)
+    return compute_average_loss(per_example, global_bs), to_vis, loss_dict
+
+
+@torch.no_grad()
+def vali_vq(model, batch, thres=None, full_vis=False):
+    pred, gt, loss_kwargs, _ = model.vq_test(batch, mode='vali', thres=thres)
+    _, loss_dict = model.compute_loss(pred, gt, **loss_kwargs)
+    return loss_dict
+
+
+@torch.no_grad()
+def outer_sample(batch, config, data_type, alpha_thres=0.9, generator=None):
+    """Pair sampler (train_nfr.py:380-467): `n_rays_per_step` interior foreground pixels, each with one random
+    8-neighbour, interleaved [p1, p1_n, p2, p2_n, ...] -- entirely on the device (the reference syncs `hw[0,:]`
+    to the host and gathers with TF ops).  `batch` holds one full view, rays on dim 0 in row-major (h, w) order."""
+    bs = config.getint('DEFAULT', 'n_rays_per_step')
+    tensors = list(batch)
+    id_, hw, alpha = tensors[0], tensors[1], tensors[5]
+    H, W = int(hw[0, 0]), int(hw[0, 1])
+    dev = alpha.device
+    jit = torch.tensor([[-1, -1], [-1, 0], [-1, 1], [0, -1], [0, 1], [1, -1], [1, 0], [1, 1]], device=dev)
+    ii, jj = torch.meshgrid(torch.arange(1, H - 1, device=dev), torch.arange(1, W - 1, device=dev), indexing='ij')
+    coords = torch.stack([ii, jj], -1).reshape(-1, 2)
+    pick = torch.randint(0, 8, (coords.shape[0],), device=dev, generator=generator)
+    coords_n = coords + jit[pick]
+    a2 = alpha.reshape(H, W)
+    if alpha_thres is not None:
+        keep = (a2[coords[:, 0], coords[:, 1]] > alpha_thres) & (a2[coords_n[:, 0], coords_n[:, 1]] > alpha_thres)
+        coords, coords_n = coords[keep], coords_n[keep]
+    sel = torch.randint(0, coords.shape[0], (bs,), device=dev, generator=generator)
+    pairs = torch.stack([coords[sel], coords_n[sel]], 1).reshape(-1, 2)           # [p1, p1_n, p2, p2_n, ...]
+    flat = pairs[:, 0] * W + pairs[:, 1]
+    out = []
+    for t in tensors:
+        if torch.is_tensor(t):
+            out.append(t[flat])
+        else:
+            out.append([t[int(i)] for i in flat.tolist()] if isinstance(t, (list, tuple)) else t)
+    return tuple(out)

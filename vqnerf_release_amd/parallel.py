@@ -1,0 +1,119 @@
+"""Data parallelism for the two trainers: one process per GPU, `torch.distributed` over RCCL (backend "nccl" on
+ROCm) -- gloo on CPU for tests.  Replaces the only DP site of the reference, `tf.distribute.MirroredStrategy`
+(decomp/nerfvq_nfr3/nerfactor/trainvali.py:436-446,450-486,518-535), and adds DP for the VQ stage, which the
+reference runs single-device (train_nfr.py:562-576).
+
+Design: every message of a step is small (<= 6 MB: 1.4 M geo parameters, 0.78 M decomp parameters,
+(D+1)*K codebook statistics, a few scalars), so the step is latency-bound on xGMI.  Hence ONE flat fp32 bucket per
+step -- [grads || extras (loss, n_fg, ...)] -- and ONE all-reduce(sum); the VQ layer's EMA statistics
+[counts (K) || dw (D*K)] need their reduction in the middle of the forward pass (the codebook update and the
+`used` mask depend on the global counts) and go in a second, tiny all-reduce.  After the reduce every rank applies
+the identical EMA update and optimiser step, so weights and codebooks stay bit-identical across ranks without any
+broadcast.  Rays / surface points are sharded by rank with no data-path collective.
+"""
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size():
+    return dist.get_world_size() if is_dist() else 1
+
+
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+class FlatBucket:
+    """Persistent flat fp32 buffer viewed as the gradients of `params` followed by `n_extra` scalars."""
+
+    def __init__(self, params, n_extra=0):
+        self.params = [p for p in params if p.requires_grad]
+        assert self.params, 'no trainable parameters'
+        self.n_extra = n_extra
+        dev = self.params[0].device
+        self.sizes = [p.numel() for p in self.params]
+        self.n_grad = sum(self.sizes)
+        self.flat = torch.zeros(self.n_grad + n_extra, dtype=torch.float32, device=dev)
+        self.views, o = [], 0
+        for p, n in zip(self.params, self.sizes):
+            self.views.append(self.flat[o:o + n].view_as(p))
+            o += n
+        self.extra = self.flat[self.n_grad:]
+
+    def attach(self):
+        """Make every p.grad a view into the bucket: backward then writes straight into it (no pack copy)."""
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        return self
+
+    def gather_grads(self):
+        """For parameters whose .grad is not (or no longer) a view of the bucket."""
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+                p.grad = v
+
+    def all_reduce(self, average_grads=False, group=None):
+        """One collective for the whole step.  Gradients are summed (the trainers normalise their loss by the GLOBAL
+        batch, as train_nfr.py:571-572 does with `global_batch_size`), or averaged on request."""
+        self.gather_grads()
+        if is_dist():
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            if average_grads:
+                self.flat[:self.n_grad].div_(dist.get_world_size(group))
+        return self.extra
+
+
+class VQStatsReducer:
+    """`VectorQuantizerEMA.stats_all_reduce` hook: sums [counts || dw] over ranks in one small all-reduce."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self._buf = None
+
+    def __call__(self, counts, dw):
+        if not is_dist():
+            return counts, dw
+        K, n = counts.numel(), counts.numel() + dw.numel()
+        if self._buf is None or self._buf.numel() != n or self._buf.device != counts.device:
+            self._buf = torch.empty(n, dtype=torch.float32, device=counts.device)
+        self._buf[:K].copy_(counts.reshape(-1))
+        self._buf[K:].copy_(dw.reshape(-1))
+        dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)
+        return self._buf[:K].clone().view_as(counts), self._buf[K:].clone().view_as(dw)
+
+
+def shard_range(n, r=None, w=None):
+    """Contiguous [lo, hi) share of n independent units (rays, views, surface points) for rank r of w."""
+    r = rank() if r is None else r
+    w = world_size() if w is None else w
+    base, rem = divmod(n, w)
+    lo = r * base + min(r, rem)
+    return lo, lo + base + (1 if r < rem else 0)
+
+
+def broadcast_module(module, src=0):
+    """Start-up only (e.g. after rank 0 ran the k-means codebook init): make every rank's state identical."""
+    if not is_dist():
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src)
+
+
+def assert_replicas_identical(tensors, what='parameters'):
+    """Debug check used by tests: every rank holds bit-identical tensors."""
+    if not is_dist():
+        return True
+    for t in tensors:
+        ref = t.detach().clone()
+        dist.broadcast(ref, src=0)
+        if not torch.equal(ref, t.detach()):
+            raise AssertionError(f'{what} diverged across ranks')
+    return True
