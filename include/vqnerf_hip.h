@@ -126,6 +126,38 @@ int vqn_neus_composite_fwd(const float* rays_o, const float* rays_d, const float
                            float* color, float* weights, float* cdf, float* inside, float* surf, float* depth,
                            float* weight_sum, float* weight_max, float* gerr, float* alpha, void* stream);
 
+/* Reverse of vqn_neus_composite_fwd (autograd in the reference: loss.backward() through renderer.py:229-282)
+ * for the outputs a loss touches: d loss / d color [B,3] (required), d loss / d weight_sum [B] (or NULL),
+ * d loss / d weights [B,n] (or NULL), d loss / d gradient_error (device scalar or NULL; gerr_den = device scalar
+ * sum of gerr[:,1] over the rays of the batch).  Outputs: g_sdf [B,n], g_grad [B,n,3] (w.r.t. the SDF
+ * gradients fed to the forward), g_rgb [B,n,3], g_inv_s [B] (per-ray partials of d loss / d inv_s; 0 outside
+ * the [1e-6,1e6] clip). */
+int vqn_neus_composite_bwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists,
+                           const float* sdf, const float* grad, const float* rgb, const float* inv_s,
+                           const float* background_rgb, int64_t B, int n, float radius, float cos_anneal_ratio,
+                           const float* g_color, const float* g_weight_sum, const float* g_weights,
+                           const float* g_gradient_error, const float* gerr_den, float* g_sdf, float* g_grad,
+                           float* g_rgb, float* g_inv_s, void* stream);
+
+/* ---- training engine of the fused NeuS networks ------------------------------------------------- */
+
+/* Tile-program interpreter (csrc/tile_vm.hip, descriptor csrc/vm_desc.h): runs a host-built op list over
+ * the LDS activation image of 32-point tiles.  The training passes the reference gets from autograd
+ * (loss.backward() through fields.py:72-107,147-172 with create_graph=True for the eikonal term) are such
+ * programs (vqnerf_release_amd/geo/train_programs.py): forward with saved activations, colour-net reverse
+ * sweep, SDF tangent pass + reverse sweep with second-order source terms.
+ *   desc_dev / desc_host: the same descriptor in device and host memory (the host copy is validated);
+ *   tensors[i] / tensor_ld[i]: device pointers and leading dims (VEC: row stride, TFMT: feature tiles). */
+int vqn_tile_program(const void* desc_dev, const int32_t* desc_host, const float* wbuf, float* const* tensors,
+                     const int32_t* tensor_ld, int n_tensors, int64_t N, void* stream);
+
+/* Weight-gradient contraction over points (autograd's grad_weight GEMMs): partial blocks
+ * ws[s][a_nt*32][b_nt*32] = sum over the point tiles of split s of A[o][p] * B[i][p], A/B in TFMT with
+ * a_tiles/b_tiles feature tiles of which [t0, t0+nt) are used.  Returns the number of partial blocks written
+ * (> 0; the caller sums them in order) or a negative error code. */
+int vqn_wgrad_partials(const float* A, int a_tiles, int a_t0, int a_nt, const float* B, int b_tiles, int b_t0, int b_nt,
+                       int64_t n_point_tiles, int n_split, float* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,3 +91,43 @@ def test_outer_sample_pairs_are_neighbours():
     d = (p[0::2, :2] - p[1::2, :2]).abs()
     assert d.max() <= 1 and (d.sum(-1) > 0).all()                  # each pair = a pixel and one of its 8 neighbours
     assert (p[:, 1] >= 10).all() and (out[5] > 0.9).all()          # both foreground
+
+
+@pytest.mark.parametrize('name,B', [('small', 96), ('full', 48)])
+def test_hip_training_programs_match_torch_autograd(name, B):
+    """The explicit forward / backward tile programs (+ compositing backward kernel + weight-gradient contraction)
+    against torch autograd over the torch statements of the same modules: loss, every parameter gradient."""
+    from oracle import geo as og
+    from tests.test_gpu_neus_render import _build
+    cfg, sdf, col, var, ren = _build(name)
+    if cfg['renderer']['n_importance'] == 0:
+        ren.n_importance, ren.up_sample_steps = 16, 4            # exercise the up-sampled path for the small nets too
+    o, d, near, far = [torch.tensor(a).cuda() for a in og.make_rays(B, 21)]
+    tgt = torch.tensor(np.random.default_rng(4).uniform(0, 1, (B, 3)).astype(np.float32)).cuda()
+    mask = (torch.arange(B, device='cuda') % 3 != 0).float()[:, None]
+    res = {}
+    for backend in ('torch', 'hip'):
+        ren.train_backend = backend
+        for m in (sdf, col, var):
+            m.zero_grad(set_to_none=True)
+        rr = ren.render(o, d, near, far, 2.0, perturb_overwrite=0, background_rgb=torch.ones(1, 3).cuda(), cos_anneal_ratio=0.7)
+        loss = ((rr['color_fine'] - tgt) * mask).abs().sum() / mask.sum() + 0.1 * rr['gradient_error'] + \
+            0.1 * torch.nn.functional.binary_cross_entropy(rr['weight_sum'].clip(1e-3, 1 - 1e-3), mask)
+        loss.backward()
+        res[backend] = (loss.item(), {f'{nm}.{k}': p.grad.detach().clone() for nm, m in (('sdf', sdf), ('col', col), ('var', var))
+                                      for k, p in m.named_parameters()},
+                        {k: v.detach().clone() for k, v in rr.items() if torch.is_tensor(v)})
+    lt, gt, rt = res['torch']
+    lh, gh, rh = res['hip']
+    np.testing.assert_allclose(lh, lt, rtol=2e-5)
+    for k in ('color_fine', 'weight_sum', 'weights', 'gradients', 'surf', 'depth', 'cdf_fine', 'inside_sphere', 'weight_max'):
+        np.testing.assert_allclose(rh[k].cpu().numpy(), rt[k].cpu().numpy().reshape(rh[k].shape), rtol=0, atol=5e-4, err_msg=k)
+    worst = 0.0
+    for k, ref in gt.items():
+        got = gh[k]
+        assert got is not None and got.shape == ref.shape, k
+        scale = max(float(ref.abs().max()), 1e-7)
+        err = float((got - ref).abs().max()) / scale
+        worst = max(worst, err)
+        assert err <= 5e-3, (k, err, scale)
+    print(f'{name}: loss {lh:.6f} vs {lt:.6f}; worst relative gradient error {worst:.2e}')

@@ -330,3 +330,28 @@ def brdf_shade_fwd(xyz, normal, rayo, lvis, lxyz, lareas, light, materials, gamm
                                       _ptr(rgb[1] if len(rgb) > 1 else None), _ptr(rd), _ptr(rs), _stream())
     _check(rc, 'vqn_brdf_shade_fwd')
     return dict(rgb=rgb, normal=nout, rgb_diff=rd, rgb_spec=rs)
+
+
+def neus_composite_bwd(rays_o, rays_d, mid_z, dists, sdf, grad, rgb, inv_s, background_rgb, radius, cos_anneal_ratio,
+                       g_color, g_weight_sum=None, g_weights=None, g_gradient_error=None, gerr_den=None):
+    """Reverse of neus_composite_fwd -> (g_sdf [B,n], g_grad [B,n,3], g_rgb [B,n,3], g_inv_s [B])."""
+    for n_, t in (('rays_o', rays_o), ('rays_d', rays_d), ('mid_z', mid_z), ('dists', dists), ('sdf', sdf), ('grad', grad),
+                  ('rgb', rgb), ('inv_s', inv_s), ('g_color', g_color)):
+        _f32c(t, n_)
+    B, n = mid_z.shape
+    dev = mid_z.device
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    g_sdf, g_grad, g_rgb, g_inv_s = f(B, n), f(B, n, 3), f(B, n, 3), f(B)
+    opt = lambda t, nm: None if t is None else _f32c(t.contiguous(), nm)
+    g_weight_sum, g_weights = opt(g_weight_sum, 'g_weight_sum'), opt(g_weights, 'g_weights')
+    g_gradient_error, gerr_den = opt(g_gradient_error, 'g_gradient_error'), opt(gerr_den, 'gerr_den')
+    if background_rgb is not None:
+        background_rgb = _f32c(background_rgb.reshape(-1)[:3].contiguous(), 'background_rgb')
+    with _clock('vqn_neus_composite_bwd'):
+        rc = lib().vqn_neus_composite_bwd(_ptr(rays_o), _ptr(rays_d), _ptr(mid_z), _ptr(dists), _ptr(sdf), _ptr(grad), _ptr(rgb),
+                                          _ptr(inv_s), _ptr(background_rgb), ctypes.c_int64(B), ctypes.c_int(n),
+                                          ctypes.c_float(float(radius)), ctypes.c_float(float(cos_anneal_ratio)), _ptr(g_color),
+                                          _ptr(g_weight_sum), _ptr(g_weights), _ptr(g_gradient_error), _ptr(gerr_den),
+                                          _ptr(g_sdf), _ptr(g_grad), _ptr(g_rgb), _ptr(g_inv_s), _stream())
+    _check(rc, 'vqn_neus_composite_bwd')
+    return g_sdf, g_grad, g_rgb, g_inv_s

@@ -276,6 +276,133 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const CompArgs a) {
   }
 }
 
+// exclusive suffix sum over lanes: result(lane) = sum_{l > lane} v(l)
+__device__ __forceinline__ float wave_excl_suffix_sum(float v, int lane) {
+  float inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    float o = __shfl_down(inc, d);
+    if (lane + d < 64) inc += o;
+  }
+  float ex = __shfl_down(inc, 1);
+  return lane == 63 ? 0.f : ex;
+}
+
+struct CompBwdArgs {
+  const float *rays_d, *mid_z, *dists, *sdf, *grad, *rgb, *inv_s, *bg;
+  const float *g_color, *g_wsum, *g_weights;   // [B,3], [B] or null, [B,n] or null
+  const float* g_gerr;                         // device scalar: d loss / d gradient_error (or null)
+  const float* gerr_den;                       // device scalar: sum over rays of gerr[:,1]
+  const float *rays_o;
+  long B;
+  int n;
+  float radius, car;
+  float *g_sdf, *g_grad, *g_rgb, *g_inv_s;     // [B,n], [B,n,3], [B,n,3], [B]
+};
+
+// reverse of composite_fwd_kernel for the outputs a loss can touch: color, weight_sum, weights, gradient_error
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const CompBwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long n_groups = (a.B + 3) >> 2;
+  const int n = a.n;
+  const float s_raw = *a.inv_s;
+  const float inv_s = fminf(fmaxf(s_raw, 1e-6f), 1e6f);
+  const float ge_coef = (a.g_gerr != nullptr) ? (*a.g_gerr) / (*a.gerr_den + 1e-5f) : 0.f;
+  for (long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const long ray = grp * 4 + wave;
+    if (ray >= a.B) continue;
+    const float ox = a.rays_o[ray * 3], oy = a.rays_o[ray * 3 + 1], oz = a.rays_o[ray * 3 + 2];
+    const float dx = a.rays_d[ray * 3], dy = a.rays_d[ray * 3 + 1], dz = a.rays_d[ray * 3 + 2];
+    const float gcr = a.g_color[ray * 3], gcg = a.g_color[ray * 3 + 1], gcb = a.g_color[ray * 3 + 2];
+    const float gws = a.g_wsum ? a.g_wsum[ray] : 0.f;
+    float bgdot = 0.f;
+    if (a.bg) bgdot = gcr * a.bg[0] + gcg * a.bg[1] + gcb * a.bg[2];
+    float alpha[IT], q[IT], gw[IT], draw_dpc[IT], draw_dnc[IT], pcv[IT], ncv[IT], epv[IT], env[IT], dist_[IT], dic_dtc[IT];
+    bool pass[IT];
+    float lprod = 1.f;
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      const int i = lane * IT + k;
+      alpha[k] = 0.f; q[k] = 1.f; gw[k] = 0.f; pass[k] = false;
+      draw_dpc[k] = draw_dnc[k] = pcv[k] = ncv[k] = epv[k] = env[k] = dist_[k] = dic_dtc[k] = 0.f;
+      if (i < n) {
+        const long p = ray * n + i;
+        const float dist = a.dists[p], sdf = a.sdf[p];
+        const float gx = a.grad[p * 3], gy = a.grad[p * 3 + 1], gz = a.grad[p * 3 + 2];
+        const float tc = __fmul_rn(dx, gx) + __fmul_rn(dy, gy) + __fmul_rn(dz, gz);
+        const float ic = -(fmaxf(-tc * 0.5f + 0.5f, 0.f) * (1.f - a.car) + fmaxf(-tc, 0.f) * a.car);
+        dic_dtc[k] = ((-tc * 0.5f + 0.5f) > 0.f ? 0.5f * (1.f - a.car) : 0.f) + ((-tc) > 0.f ? a.car : 0.f);
+        const float en = sdf + ic * dist * 0.5f, ep = sdf - ic * dist * 0.5f;
+        const float pc = sigmoidf_(ep * inv_s), nc = sigmoidf_(en * inv_s);
+        const float Dn = pc + 1e-5f;
+        const float raw = (pc - nc + 1e-5f) / Dn;
+        pass[k] = (raw >= 0.f) && (raw <= 1.f);
+        alpha[k] = fminf(fmaxf(raw, 0.f), 1.f);
+        q[k] = 1.f - alpha[k] + 1e-7f;
+        lprod *= q[k];
+        draw_dpc[k] = nc / (Dn * Dn);
+        draw_dnc[k] = -1.f / Dn;
+        pcv[k] = pc; ncv[k] = nc; epv[k] = ep; env[k] = en; dist_[k] = dist;
+        gw[k] = (gcr * a.rgb[p * 3] + gcg * a.rgb[p * 3 + 1] + gcb * a.rgb[p * 3 + 2]) - bgdot + gws +
+                (a.g_weights ? a.g_weights[p] : 0.f);
+      }
+    }
+    float T = wave_excl_prod(lprod, lane);
+    float Tk[IT], c[IT], lsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      Tk[k] = T;
+      const float w = alpha[k] * T;
+      T *= q[k];
+      c[k] = gw[k] * w;
+      lsum += c[k];
+      const int i = lane * IT + k;
+      if (i < n) {
+        const long p = ray * n + i;
+        a.g_rgb[p * 3] = w * gcr; a.g_rgb[p * 3 + 1] = w * gcg; a.g_rgb[p * 3 + 2] = w * gcb;
+      }
+    }
+    float suf = wave_excl_suffix_sum(lsum, lane);          // sum of c over later lanes
+    float g_s = 0.f;
+#pragma unroll
+    for (int k = IT - 1; k >= 0; --k) {
+      const int i = lane * IT + k;
+      if (i < n) {
+        const long p = ray * n + i;
+        // d loss / d alpha_i = gw_i T_i - (sum_{j>i} gw_j w_j) / q_i
+        float g_alpha = gw[k] * Tk[k] - suf / q[k];
+        const float g_raw = pass[k] ? g_alpha : 0.f;
+        const float g_pc = g_raw * draw_dpc[k], g_nc = g_raw * draw_dnc[k];
+        const float dpc = pcv[k] * (1.f - pcv[k]), dnc = ncv[k] * (1.f - ncv[k]);
+        const float g_ep = g_pc * dpc * inv_s, g_en = g_nc * dnc * inv_s;
+        g_s += g_pc * dpc * epv[k] + g_nc * dnc * env[k];
+        a.g_sdf[p] = g_ep + g_en;
+        const float g_ic = (g_en - g_ep) * dist_[k] * 0.5f;
+        const float g_tc = g_ic * dic_dtc[k];
+        // eikonal term
+        const float gx = a.grad[p * 3], gy = a.grad[p * 3 + 1], gz = a.grad[p * 3 + 2];
+        float ex = 0.f, ey = 0.f, ez = 0.f;
+        if (ge_coef != 0.f) {
+          const float mz = a.mid_z[p];
+          const float px = ox + __fmul_rn(dx, mz), py = oy + __fmul_rn(dy, mz), pz = oz + __fmul_rn(dz, mz);
+          const float pr = sqrtf(__fmul_rn(px, px) + __fmul_rn(py, py) + __fmul_rn(pz, pz));
+          if (pr < a.radius * 1.1f) {
+            const float gn = sqrtf(__fmul_rn(gx, gx) + __fmul_rn(gy, gy) + __fmul_rn(gz, gz));
+            if (gn > 0.f) {
+              const float f = ge_coef * 2.f * (gn - 1.f) / gn;
+              ex = f * gx; ey = f * gy; ez = f * gz;
+            }
+          }
+        }
+        a.g_grad[p * 3] = g_tc * dx + ex; a.g_grad[p * 3 + 1] = g_tc * dy + ey; a.g_grad[p * 3 + 2] = g_tc * dz + ez;
+      }
+      suf += c[k];
+    }
+    g_s = wave_sum(g_s);
+    if (lane == 0) a.g_inv_s[ray] = (s_raw >= 1e-6f && s_raw <= 1e6f) ? g_s : 0.f;
+  }
+}
+
 int ray_grid(long B) {
   long g = (B + 3) / 4;
   const long cap = (long)vqn_num_cus() * 8;
@@ -339,6 +466,28 @@ extern "C" int vqn_neus_composite_fwd(const float* rays_o, const float* rays_d, 
   CompArgs a{rays_o, rays_d, mid_z, dists, sdf, grad, rgb, inv_s, background_rgb, (long)B, n, radius, cos_anneal_ratio,
              color, weights, cdf, inside, surf, depth, weight_sum, weight_max, gerr, alpha};
   hipLaunchKernelGGL(composite_fwd_kernel, dim3(ray_grid(B)), dim3(256), 0, (hipStream_t)stream, a);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
+
+extern "C" int vqn_neus_composite_bwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists,
+                                      const float* sdf, const float* grad, const float* rgb, const float* inv_s,
+                                      const float* background_rgb, int64_t B, int n, float radius,
+                                      float cos_anneal_ratio, const float* g_color, const float* g_weight_sum,
+                                      const float* g_weights, const float* g_gradient_error, const float* gerr_den,
+                                      float* g_sdf, float* g_grad, float* g_rgb, float* g_inv_s, void* stream) {
+  VQN_CHECK_ARG(B >= 0, "B >= 0");
+  if (B == 0) return VQN_OK;
+  VQN_CHECK_ARG(rays_o && rays_d && mid_z && dists && sdf && grad && rgb && inv_s && g_color, "null input pointer");
+  VQN_CHECK_ARG(g_sdf && g_grad && g_rgb && g_inv_s, "null output pointer");
+  VQN_CHECK_ARG(g_gradient_error == nullptr || gerr_den != nullptr, "g_gradient_error needs gerr_den");
+  VQN_CHECK_SHAPE(n >= 1 && n <= MAXN, "1 <= n <= 256 samples per ray");
+  CompBwdArgs a;
+  a.rays_d = rays_d; a.mid_z = mid_z; a.dists = dists; a.sdf = sdf; a.grad = grad; a.rgb = rgb; a.inv_s = inv_s;
+  a.bg = background_rgb; a.g_color = g_color; a.g_wsum = g_weight_sum; a.g_weights = g_weights;
+  a.g_gerr = g_gradient_error; a.gerr_den = gerr_den; a.rays_o = rays_o; a.B = B; a.n = n; a.radius = radius;
+  a.car = cos_anneal_ratio; a.g_sdf = g_sdf; a.g_grad = g_grad; a.g_rgb = g_rgb; a.g_inv_s = g_inv_s;
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3(ray_grid(B)), dim3(256), 0, (hipStream_t)stream, a);
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }

@@ -1,0 +1,93 @@
+// Weight-gradient contraction over points for gfx950:  G[o][i] = sum_p A[o][p] * B[i][p]  with A, B in the
+// feature-major TFMT layout written by csrc/tile_vm.hip (csrc/vm_desc.h).  In the reference these are the
+// `grad_weight` GEMMs autograd runs inside loss.backward() for every nn.Linear of fields.py (SDFNetwork,
+// RenderingNetwork), once per adjoint stream.
+//
+// One workgroup = 4 waves owns the whole [<=256 x <=256] output block for a strided subset of the 32-point tiles
+// (split-K over points); wave w accumulates output tiles (ot in {w, w+4}) x (it in 0..7) in 256 accumulator
+// registers.  Operands stream straight from HBM into MFMA fragments: lane (feature, kk) reads 4 consecutive points
+// (one dwordx4) per 4 MFMAs; the point -> K-slot assignment is a fixed permutation shared by A and B, which a sum
+// over points does not care about.  Partial blocks go to a workspace [n_split][rows][cols]; the caller reduces them
+// in a fixed order (deterministic, no float atomics).
+#include "common.h"
+
+namespace {
+
+template <int NOT /* ot per wave */>
+__global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__ A, int a_tiles, int a_t0, int a_nt,
+                                                       const float* __restrict__ B, int b_tiles, int b_t0, int b_nt,
+                                                       long n_ptiles, float* __restrict__ ws) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fi = lane & 31, kk = lane >> 5;
+  f32x16 acc[NOT][8];
+#pragma unroll
+  for (int a = 0; a < NOT; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  for (long t = blockIdx.x; t < n_ptiles; t += gridDim.x) {
+    const float* At = A + ((t * a_tiles + a_t0) * 32 + fi) * 32 + 4 * kk;
+    const float* Bt = B + ((t * b_tiles + b_t0) * 32 + fi) * 32 + 4 * kk;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      f32x4 af[NOT], bf[8];
+#pragma unroll
+      for (int a = 0; a < NOT; ++a) {
+        const int ot = wave + 4 * a;
+        af[a] = ot < a_nt ? *reinterpret_cast<const f32x4*>(At + (long)ot * 1024 + 8 * u) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+        bf[b] = b < b_nt ? *reinterpret_cast<const f32x4*>(Bt + (long)b * 1024 + 8 * u) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < NOT; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+          if (wave + 4 * a < a_nt && b < b_nt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+          }
+    }
+  }
+  // partial block of this workgroup: ws[blockIdx][a_nt*32][b_nt*32]; accumulator reg e of lane (n, hh): row (e&3) + 8 (e>>2) + 4 hh, col n
+  const int cols = b_nt * 32;
+  float* w = ws + (size_t)blockIdx.x * (size_t)(a_nt * 32) * cols;
+#pragma unroll
+  for (int a = 0; a < NOT; ++a) {
+    const int ot = wave + 4 * a;
+    if (ot >= a_nt) continue;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      if (b >= b_nt) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * kk;
+        w[(size_t)(ot * 32 + row) * cols + b * 32 + fi] = acc[a][b][e];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vqn_wgrad_partials(const float* A, int a_tiles, int a_t0, int a_nt, const float* B, int b_tiles, int b_t0,
+                                  int b_nt, int64_t n_point_tiles, int n_split, float* ws, void* stream) {
+  VQN_CHECK_ARG(A && B && ws, "null pointer");
+  VQN_CHECK_ARG(n_point_tiles >= 1 && n_split >= 1, "n_point_tiles >= 1, n_split >= 1");
+  VQN_CHECK_SHAPE(a_nt >= 1 && a_nt <= 8 && b_nt >= 1 && b_nt <= 8, "1..8 feature tiles per operand and call");
+  VQN_CHECK_SHAPE(a_t0 >= 0 && a_t0 + a_nt <= a_tiles && b_t0 >= 0 && b_t0 + b_nt <= b_tiles, "feature-tile range outside the tensor");
+  VQN_CHECK_SHAPE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "operands must be 16-byte aligned");
+  long grid = n_split;
+  if (grid > n_point_tiles) grid = n_point_tiles;
+  hipStream_t s = (hipStream_t)stream;
+  if (a_nt <= 4)
+    hipLaunchKernelGGL(wgrad_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, A, a_tiles, a_t0, a_nt, B, b_tiles, b_t0, b_nt,
+                       (long)n_point_tiles, ws);
+  else
+    hipLaunchKernelGGL(wgrad_kernel<2>, dim3((unsigned)grid), dim3(256), 0, s, A, a_tiles, a_t0, a_nt, B, b_tiles, b_t0, b_nt,
+                       (long)n_point_tiles, ws);
+  VQN_LAUNCH_CHECK();
+  return (int)grid;      // number of partial blocks written (>= 1)
+}

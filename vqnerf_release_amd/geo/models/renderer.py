@@ -21,6 +21,37 @@ from vqnerf_release_amd import _C
 from vqnerf_release_amd.geo.models.fields import _needs_graph
 
 
+class CompositeFunction(torch.autograd.Function):
+    """renderer.py:229-282 as one differentiable op: vqn_neus_composite_fwd / vqn_neus_composite_bwd.
+    Differentiable inputs: sdf [B,n], grad [B,n,3], rgb [B,n,3], inv_s [1]; differentiable outputs: color, weight_sum,
+    gradient_error, weights.  The other outputs are detached statistics."""
+
+    @staticmethod
+    def forward(ctx, sdf, grad, rgb, inv_s, rays_o, rays_d, mid_z, dists, bg, radius, car):
+        sdf, grad, rgb = sdf.detach().contiguous(), grad.detach().contiguous(), rgb.detach().contiguous()
+        inv_s = inv_s.detach().reshape(1).contiguous()
+        o = _C.neus_composite_fwd(rays_o, rays_d, mid_z, dists, sdf, grad, rgb, inv_s, bg, radius, car)
+        gsum = o['gerr'].sum(0)
+        gerr = gsum[0] / (gsum[1] + 1e-5)
+        ctx.save_for_backward(sdf, grad, rgb, inv_s, rays_o, rays_d, mid_z, dists, gsum[1:2].contiguous())
+        ctx.bg, ctx.radius, ctx.car = bg, radius, car
+        ctx.mark_non_differentiable(o['cdf'], o['inside_sphere'], o['surf'], o['depth'], o['weight_max'])
+        return o['color'], o['weight_sum'], gerr, o['weights'], o['cdf'], o['inside_sphere'], o['surf'], o['depth'], o['weight_max']
+
+    @staticmethod
+    def backward(ctx, g_color, g_wsum, g_gerr, g_weights, *unused):
+        sdf, grad, rgb, inv_s, rays_o, rays_d, mid_z, dists, den = ctx.saved_tensors
+        B, n = mid_z.shape
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=mid_z.device)
+        g_color = z(B, 3) if g_color is None else g_color.contiguous()
+        gw = None if g_wsum is None else g_wsum.reshape(B).contiguous()
+        gwt = None if g_weights is None else g_weights.contiguous()
+        gg = None if g_gerr is None else g_gerr.reshape(1).contiguous()
+        g_sdf, g_grad, g_rgb, g_is = _C.neus_composite_bwd(rays_o, rays_d, mid_z, dists, sdf, grad, rgb, inv_s, ctx.bg, ctx.radius,
+                                                           ctx.car, g_color, gw, gwt, gg, den)
+        return g_sdf, g_grad, g_rgb, g_is.sum().reshape(1), None, None, None, None, None, None, None
+
+
 def extract_fields(bound_min, bound_max, resolution, query_func):
     N = 64
     X = torch.linspace(bound_min[0], bound_max[0], resolution).split(N)
@@ -83,6 +114,8 @@ class NeuSRenderer:
         self.up_sample_steps = up_sample_steps
         self.perturb = perturb
         self._u = {}
+        self._engines = {}
+        self.train_backend = 'hip'        # 'hip': tile programs of geo/train_programs.py; 'torch': autograd over torch ops
 
     # ---- packs shared by all kernels --------------------------------------------------------
     def _packs(self):
@@ -133,6 +166,9 @@ class NeuSRenderer:
                                       'every shipped conf sets n_outside = 0')
         if _needs_graph(sdf_network, rays_o) or any(p.requires_grad and torch.is_grad_enabled()
                                                     for m in (deviation_network, color_network) for p in m.parameters()):
+            if self.train_backend == 'hip' and rays_o.is_cuda and self._train_engine(sdf_network, color_network) is not None:
+                return self._render_core_train_hip(rays_o, rays_d, z_vals, sample_dist, radius, sdf_network,
+                                                   deviation_network, color_network, background_rgb, cos_anneal_ratio, to_light)
             return self._render_core_autograd(rays_o, rays_d, z_vals, sample_dist, radius, sdf_network,
                                               deviation_network, color_network, background_rgb, cos_anneal_ratio, to_light)
         B, n = z_vals.shape
@@ -151,6 +187,43 @@ class NeuSRenderer:
             'cdf': o['cdf'], 'gradient_error': gerr[0] / (gerr[1] + 1e-5), 'inside_sphere': o['inside_sphere'],
             'surf': o['surf'], 'depth': o['depth'], 'weight_sum': o['weight_sum'], 'weight_max': o['weight_max'],
             'sampled_color': rgb.reshape(B, n, 3),
+        }
+
+    # ---- training: explicit forward / backward tile programs (geo/train_programs.py) ----------------
+    def _train_engine(self, sdf_network, color_network):
+        key = (id(sdf_network), id(color_network))
+        if key not in self._engines:
+            try:
+                from vqnerf_release_amd.geo.train_programs import NeusTrainEngine
+                self._engines[key] = NeusTrainEngine(sdf_network, color_network)
+            except AssertionError:
+                self._engines[key] = None          # network shape outside what the tile programs cover -> torch autograd path
+        return self._engines[key]
+
+    def _render_core_train_hip(self, rays_o, rays_d, z_vals, sample_dist, radius, sdf_network, deviation_network,
+                               color_network, background_rgb, cos_anneal_ratio, to_light):
+        from vqnerf_release_amd.geo.train_programs import NeusCoreFunction
+        B, n = z_vals.shape
+        per_ray = sample_dist.reshape(-1).float().contiguous() if to_light else None
+        mid_z, dists = _C.neus_section_mids(z_vals.detach().contiguous(), 0.0 if to_light else float(sample_dist), per_ray)
+        pts = (rays_o[:, None, :] + rays_d[:, None, :] * mid_z[..., None]).reshape(-1, 3)
+        dirs = rays_d[:, None, :].expand(B, n, 3).reshape(-1, 3)
+        engine = self._train_engine(sdf_network, color_network)
+        s_lins = [getattr(sdf_network, 'lin%d' % l) for l in range(sdf_network.num_layers - 1)]
+        c_lins = [getattr(color_network, 'lin%d' % l) for l in range(color_network.num_layers - 1)]
+        params = [m.effective_weight() for m in s_lins] + [m.bias for m in s_lins] + \
+                 [m.effective_weight() for m in c_lins] + [m.bias for m in c_lins]
+        sdf, grad, rgb = NeusCoreFunction.apply(engine, pts, dirs, *params)
+        inv_s = torch.exp(deviation_network.variance * 10.0).reshape(1)
+        bg = None if background_rgb is None else background_rgb.detach().float().to(z_vals.device)
+        color, wsum, gerr, weights, cdf, inside, surf, depth, wmax = CompositeFunction.apply(
+            sdf.reshape(B, n), grad.reshape(B, n, 3), rgb.reshape(B, n, 3), inv_s, rays_o, rays_d, mid_z, dists, bg,
+            float(radius), float(cos_anneal_ratio))
+        return {
+            'color': color, 'sdf': sdf.reshape(-1, 1), 'dists': dists, 'gradients': grad.reshape(B, n, 3),
+            's_val': (1.0 / inv_s.clip(1e-6, 1e6)).reshape(1, 1).expand(B * n, 1), 'mid_z_vals': mid_z, 'weights': weights,
+            'cdf': cdf, 'gradient_error': gerr, 'inside_sphere': inside, 'surf': surf, 'depth': depth, 'weight_sum': wsum,
+            'weight_max': wmax, 'sampled_color': rgb.reshape(B, n, 3),
         }
 
     def _render_core_autograd(self, rays_o, rays_d, z_vals, sample_dist, radius, sdf_network, deviation_network,

@@ -1,0 +1,444 @@
+"""Training passes of the fused NeuS networks as tile programs for csrc/tile_vm.hip (+ csrc/wgrad.hip).
+
+The reference gets these from autograd: `loss.backward()` through SDFNetwork / RenderingNetwork
+(geo/NeuS-ours2/models/fields.py:72-107,147-172), with `create_graph=True` in SDFNetwork.gradient (fields.py:100-106)
+so that the eikonal term and the normal-dependent colour differentiate through d sdf / dx.  Here, per 32-point tile:
+
+  forward   e = posenc(x);  u_{l+1} = softplus(W_l in_l + b_l)   (in_l = u_l, or [u_l ; e]/sqrt2 at the skip layer)
+            out = W_L u_L + b_L = [sdf ; feat]
+            reverse sweep  g^_l = (W_{l+1}^T g^_{l+1}) * softplus'(a_l)  ->  n = J_posenc^T e_bar          (= d sdf / dx)
+            colour net on [x, posenc(view), n, feat]
+  backward  colour reverse sweep -> d/d feat, d/d n;   v = d loss / d n (compositing + eikonal + colour)
+            tangent pass along v:  u'_{l+1} = softplus'(a_l) * (W_l in'_l),  source S_l = g^_l * (W_l in'_l) * softplus''/softplus'
+            reverse sweep          a_bar_l = (W_{l+1}^T a_bar_{l+1}) * softplus'(a_l) + S_l
+  weights   dW_l = a_bar_l (x) in_l + g^_l (x) in'_l   (contractions over points: csrc/wgrad.hip),  db_l = sum a_bar_l
+(the adjoint of the tangent stream IS the forward's reverse sweep, which is why g^_l is saved rather than recomputed).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from vqnerf_release_amd import _C
+from vqnerf_release_amd.geo.packing import gemm_index, bias_index, _take
+
+K_LD_POSENC, K_LD_POSENC_JVP, K_LD_T, K_LD_VEC, K_LD_EXTRAS, K_GEMM, K_ST_VEC, K_POSENC_VJP = 1, 2, 3, 4, 5, 6, 7, 8
+EPI_ACT, EPI_MUL_DACT, EPI_TANGENT, EPI_BWD2 = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_SIGMOID = 0, 1, 2, 3
+MAX_OPS, MAX_TENSORS = 96, 96
+DESC_INTS = 16 + MAX_OPS * 16
+
+
+def _f2i(x):
+    return int(np.float32(x).view(np.int32))
+
+
+class Region:
+    def __init__(self, row0, feats, alloc_rows):
+        self.row0, self.feats, self.alloc_rows = row0, feats, alloc_rows
+        self.rows = (feats + 7) // 8
+
+
+class Program:
+    """Op list + first-fit LDS row allocation + the weight gathers its GEMMs need."""
+
+    def __init__(self, tensor_names, seed=None):
+        self.tn = {n: i for i, n in enumerate(tensor_names)}
+        assert len(self.tn) <= MAX_TENSORS
+        self.ops, self.gathers, self.total_rows = [], [], 0
+        self.rng = None if seed is None else np.random.default_rng(seed)
+        self.ends = {0}
+
+    def t(self, name):
+        return -1 if name is None else self.tn[name]
+
+    def alloc(self, feats, live, tiles=None, high=False):
+        """Rows for a new region that overlaps none of `live`.  Deterministic first-fit when the program was made without
+        a seed; with a seed, a random valid candidate (the engine keeps the tightest of many seeded builds)."""
+        rows = 4 * tiles if tiles is not None else (feats + 7) // 8
+        free = lambda r0: not any(r0 < r.row0 + r.alloc_rows and r.row0 < r0 + rows for r in live)
+        cands = sorted(c for c in (self.ends | {r.row0 + r.alloc_rows for r in live}) if free(c))
+        if self.rng is None or len(cands) == 1:
+            row0 = cands[0]
+        else:
+            cands = cands[:4]
+            row0 = cands[int(self.rng.choice(len(cands), p=np.array([0.55, 0.25, 0.12, 0.08][:len(cands)]) / sum([0.55, 0.25, 0.12, 0.08][:len(cands)])))]
+        self.ends.add(row0 + rows)
+        self.total_rows = max(self.total_rows, row0 + rows)
+        return Region(row0, feats, rows)
+
+    def gemm(self, key, M_shape, segs, col_fns, out_feats, live, epi=EPI_ACT, act=ACT_NONE, bias_key=None, aux1=None, aux2=None,
+             store=None, store2=None, dst=None, accumulate=False, want_dst=True, high=False):
+        """segs: Regions forming K; col_fns[i](f) -> column of M for local feature f of segs[i] (or -1)."""
+        tiles = (out_feats + 31) // 32
+        if dst is None and want_dst:
+            dst = self.alloc(out_feats, list(segs) + list(live), tiles=tiles, high=high)
+        seg_desc = [(s.rows, fn) for s, fn in zip(segs, col_fns)]
+        self.gathers.append((key, (M_shape[0], M_shape[1], seg_desc), bias_key, out_feats if bias_key else None, len(self.ops)))
+        kA, kB = segs[0], (segs[1] if len(segs) > 1 else None)
+        self.ops.append([K_GEMM, tiles, kA.row0, kA.rows, kB.row0 if kB else 0, kB.rows if kB else 0, -1, -1,
+                         dst.row0 if dst is not None else -1, epi, act, self.t(aux1), self.t(aux2), self.t(store), self.t(store2),
+                         1 if accumulate else 0])
+        return dst
+
+    def op(self, kind, *p):
+        self.ops.append([kind] + list(p) + [0] * (15 - len(p)))
+
+    def materialize(self):
+        """build the (large) gather index arrays -- only for the program build that is kept"""
+        self.gathers = [(key, gemm_index(*spec), bkey, None if bo is None else bias_index(bo), oi)
+                        for key, spec, bkey, bo, oi in self.gathers]
+        return self
+
+    def finalize(self, n_waves=None):
+        lds = self.total_rows * 1024
+        self.n_waves = n_waves or (4 if 2 * lds <= 160 * 1024 else 8)
+        assert len(self.ops) <= MAX_OPS, len(self.ops)
+        return self
+
+
+def _ident(n_valid, base=0):
+    return lambda f: np.where(f < n_valid, f + base, -1)
+
+
+def _shift(lo, hi, base):
+    """local features lo..hi-1 -> columns base.., everything else padding"""
+    return lambda f: np.where((f >= lo) & (f < hi), f - lo + base, -1)
+
+
+class NeusTrainEngine:
+    """Programs, packs and launches for one (SDFNetwork, RenderingNetwork) pair."""
+
+    def __init__(self, sdf_net, col_net, n_split=128):
+        self.sdf_net, self.col_net = sdf_net, col_net
+        d = sdf_net.dims
+        self.nL = len(d) - 2                                   # hidden layers 0..nL-1, final layer nL
+        skips = [l for l in sdf_net.skip_in if 0 < l < self.nL + 1]
+        assert len(skips) <= 1 and sdf_net.d_in == 3 and sdf_net.multires > 0
+        self.skip = skips[0] if skips else -1
+        self.E = d[0]
+        self.mr = sdf_net.multires
+        self.scale = float(sdf_net.scale)
+        self.out = [(d[l + 1] - d[0] if (l + 1) == self.skip else d[l + 1]) for l in range(self.nL + 1)]
+        self.inn = [d[l] for l in range(self.nL + 1)]
+        assert self.skip != self.nL, 'skip into the last layer is not supported'
+        self.F = self.out[self.nL]                             # 257 = sdf + features
+        c = col_net
+        assert c.mode == 'idr' and c.multires_view > 0 and c.dims[-1] == 3
+        self.nC = len(c.dims) - 2                              # colour hidden layers 0..nC-1, final nC
+        self.mrv = c.multires_view
+        self.X = 3 + (3 + 6 * self.mrv) + 3                    # extras: pts, posenc(view), normals
+        assert c.dims[0] == self.X + (self.F - 1)
+        self.cout = [c.dims[l + 1] for l in range(self.nC + 1)]
+        self.cin = [c.dims[l] for l in range(self.nC + 1)]
+        self.squeeze = bool(c.squeeze_out)
+        self.n_split = n_split
+        for name, build in (('prog_fwd', self._build_forward), ('prog_cbwd', self._build_colour_backward),
+                            ('prog_sbwd', self._build_sdf_backward)):
+            best = build(None)
+            for seed in range(200):                           # LDS row packing: keep the tightest of many seeded builds
+                if best.total_rows <= 79:
+                    break
+                cand = build(seed)
+                if cand.total_rows < best.total_rows:
+                    best = cand
+            assert best.total_rows * 1024 <= 160 * 1024, f'{name}: {best.total_rows} KB of LDS'
+            setattr(self, name, best.materialize())
+        self._dev = {}
+        self._desc_dev = {}
+
+    # tensor tables -------------------------------------------------------------------------------
+    def _tiles(self, f):
+        return (f + 31) // 32
+
+    def _tensor_specs(self):
+        """name -> ('vec', width) | ('t', feature tiles)"""
+        s = {'X': ('vec', 3), 'DIRS': ('vec', 3), 'ONES': ('vec', 1), 'SDF': ('vec', 1), 'N': ('vec', 3), 'RGB': ('vec', 3),
+             'DOUT': ('vec', 3), 'GNCOL': ('vec', 3), 'V': ('vec', 3), 'GS': ('vec', 1),
+             'E': ('t', self._tiles(self.E)), 'ED': ('t', self._tiles(self.E)), 'OUTF': ('t', self._tiles(self.F)),
+             'GOUTF': ('t', self._tiles(self.F)), 'EXTR': ('t', self._tiles(self.X)), 'DC%d' % self.nC: ('t', 1)}
+        for l in range(self.nL):
+            for nm in ('U%d' % (l + 1), 'UD%d' % (l + 1), 'GH%d' % l, 'S%d' % l, 'AB%d' % l):
+                s[nm] = ('t', self._tiles(self.out[l]))
+        for l in range(self.nC):
+            s['C%d' % (l + 1)] = ('t', self._tiles(self.cout[l]))
+            s['DC%d' % l] = ('t', self._tiles(self.cout[l]))
+        return s
+
+    # programs --------------------------------------------------------------------------------------
+    def _names(self):
+        return list(self._tensor_specs().keys())
+
+    def _sdf_fwd_cols(self, l, prev, emb):
+        """column maps of W_l for K = [prev (, emb at the skip layer)]"""
+        if l == 0:
+            return [emb], [_ident(self.E)]
+        if l == self.skip:
+            return [prev, emb], [_ident(self.out[l - 1]), _ident(self.E, base=self.out[l - 1])]
+        return [prev], [_ident(self.inn[l])]
+
+    def _build_forward(self, seed):
+        P = Program(self._names(), seed)
+        nL, nC = self.nL, self.nC
+        rE = P.alloc(self.E, [])
+        P.op(K_LD_POSENC, P.t('X'), rE.row0, self.mr, self.E, P.t('E'), _f2i(self.scale))
+        prev = None
+        for l in range(nL):
+            segs, cols = self._sdf_fwd_cols(l, prev, rE)
+            prev = P.gemm(('W', l), (self.out[l], self.inn[l]), segs, cols, self.out[l], live=[rE], act=ACT_SOFTPLUS,
+                          bias_key=('b', l), store='U%d' % (l + 1))
+        rU = prev
+        rOUT = P.gemm(('W', nL), (self.F, self.inn[nL]), [rU], [_ident(self.inn[nL])], self.F, live=[], bias_key=('b', nL), store='OUTF')
+        P.op(K_ST_VEC, rOUT.row0, 0, 1, P.t('SDF'), ACT_NONE, _f2i(1.0 / self.scale))
+        # reverse sweep for n = d sdf / dx.  rOUT is NOT kept in LDS meanwhile (it is re-read from OUTF for the colour net):
+        # that keeps the program under 80 KB, i.e. two workgroups per CU.
+        rONE = P.alloc(1, [])
+        P.op(K_LD_VEC, P.t('ONES'), rONE.row0, 1, _f2i(1.0), -1, 0)
+        g = P.gemm(('WT_sdfrow',), (self.out[nL - 1], 1), [rONE], [_ident(1)], self.out[nL - 1], live=[],
+                   epi=EPI_MUL_DACT, act=ACT_SOFTPLUS, aux1='U%d' % nL, store='GH%d' % (nL - 1))
+        rEB, have_eb = None, False
+        for l in range(nL - 1, 0, -1):
+            # adjoint of in_l = W_l^T g^_l ; its u-part times softplus'(a_{l-1}) is g^_{l-1}
+            if l == self.skip:
+                rEB = P.gemm(('WT_e', l), (self.E, self.out[l]), [g], [_ident(self.out[l])], self.E, live=[g])
+                have_eb = True
+            keep = [g] + ([rEB] if have_eb else [])
+            g = P.gemm(('WT_u', l), (self.out[l - 1], self.out[l]), [g], [_ident(self.out[l])], self.out[l - 1], live=keep,
+                       epi=EPI_MUL_DACT, act=ACT_SOFTPLUS, aux1='U%d' % l, store='GH%d' % (l - 1))
+        if have_eb:
+            P.gemm(('WT_e', 0), (self.E, self.out[0]), [g], [_ident(self.out[0])], self.E, live=[], dst=rEB, accumulate=True)
+        else:
+            rEB = P.gemm(('WT_e', 0), (self.E, self.out[0]), [g], [_ident(self.out[0])], self.E, live=[g])
+        P.op(K_POSENC_VJP, rEB.row0, P.t('X'), P.t('N'), self.mr, _f2i(self.scale))
+        # colour network on [pts, posenc(view), normals, feat]
+        rOUT = P.alloc(self.F, [], tiles=self._tiles(self.F))
+        P.op(K_LD_T, P.t('OUTF'), rOUT.row0, rOUT.rows)
+        rEX = P.alloc(self.X, [rOUT])
+        P.op(K_LD_EXTRAS, P.t('X'), P.t('DIRS'), P.t('N'), rEX.row0, self.mrv, P.t('EXTR'), self.X)
+        prev = P.gemm(('Wc', 0), (self.cout[0], self.cin[0]), [rOUT, rEX], [_shift(1, self.F, self.X), _ident(self.X)], self.cout[0],
+                      live=[], act=ACT_RELU, bias_key=('bc', 0), store='C1')
+        for l in range(1, nC):
+            prev = P.gemm(('Wc', l), (self.cout[l], self.cin[l]), [prev], [_ident(self.cin[l])], self.cout[l], live=[], act=ACT_RELU,
+                          bias_key=('bc', l), store='C%d' % (l + 1))
+        rRGB = P.gemm(('Wc', nC), (3, self.cin[nC]), [prev], [_ident(self.cin[nC])], 3, live=[],
+                      act=ACT_SIGMOID if self.squeeze else ACT_NONE, bias_key=('bc', nC))
+        P.op(K_ST_VEC, rRGB.row0, 0, 3, P.t('RGB'), ACT_NONE, _f2i(1.0))
+        return P.finalize()
+
+    def _build_colour_backward(self, seed):
+        P = Program(self._names(), seed)
+        nC = self.nC
+        rD = P.alloc(3, [], tiles=1)
+        P.op(K_LD_VEC, P.t('DOUT'), rD.row0, 3, _f2i(1.0), P.t('DC%d' % nC), 0)
+        for l in range(nC, 0, -1):                            # delta_{l-1} = (Wc_l^T delta_l) * relu'(c_l)
+            rD = P.gemm(('WcT', l), (self.cin[l], self.cout[l]), [rD], [_ident(self.cout[l])], self.cin[l], live=[],
+                        epi=EPI_MUL_DACT, act=ACT_RELU, aux1='C%d' % l, store='DC%d' % (l - 1))
+        # adjoints of the colour-net inputs: [sdf(=0) ; feat] in OUTF feature order, and the extras (normals at X-3..X-1)
+        P.gemm(('WcT0_feat',), (self.F, self.cout[0]), [rD], [_ident(self.cout[0])], self.F, live=[rD], store='GOUTF', want_dst=False)
+        rGX = P.gemm(('WcT0_extra',), (self.X, self.cout[0]), [rD], [_ident(self.cout[0])], self.X, live=[rD])
+        P.op(K_ST_VEC, rGX.row0, self.X - 3, 3, P.t('GNCOL'), ACT_NONE, _f2i(1.0))
+        return P.finalize()
+
+    def _build_sdf_backward(self, seed):
+        P = Program(self._names(), seed)
+        nL = self.nL
+        rED = P.alloc(self.E, [])
+        P.op(K_LD_POSENC_JVP, P.t('X'), P.t('V'), rED.row0, self.mr, self.E, P.t('ED'), _f2i(self.scale))
+        prev = None
+        for l in range(nL):                                   # tangent pass (no bias)
+            segs, cols = self._sdf_fwd_cols(l, prev, rED)
+            prev = P.gemm(('W', l), (self.out[l], self.inn[l]), segs, cols, self.out[l], live=[rED], epi=EPI_TANGENT, act=ACT_SOFTPLUS,
+                          aux1='U%d' % (l + 1), aux2='GH%d' % l, store='UD%d' % (l + 1), store2='S%d' % l)
+        # adjoint of u_L from the final layer: W_L[1:]^T g_feat + W_L[0]^T g_sdf / scale
+        rGO = P.alloc(self.F, [])
+        P.op(K_LD_T, P.t('GOUTF'), rGO.row0, rGO.rows)
+        rGS = P.alloc(1, [rGO])
+        P.op(K_LD_VEC, P.t('GS'), rGS.row0, 1, _f2i(1.0 / self.scale), -1, 0)
+        ab = P.gemm(('WT_last',), (self.out[nL - 1], self.F), [rGO, rGS], [_shift(1, self.F, 1), _ident(1)], self.out[nL - 1], live=[],
+                    epi=EPI_BWD2, act=ACT_SOFTPLUS, aux1='U%d' % nL, aux2='S%d' % (nL - 1), store='AB%d' % (nL - 1))
+        for l in range(nL - 1, 0, -1):
+            ab = P.gemm(('WT_u', l), (self.out[l - 1], self.out[l]), [ab], [_ident(self.out[l])], self.out[l - 1], live=[],
+                        epi=EPI_BWD2, act=ACT_SOFTPLUS, aux1='U%d' % l, aux2='S%d' % (l - 1), store='AB%d' % (l - 1))
+        return P.finalize()
+
+    # packs -----------------------------------------------------------------------------------------
+    def _matrix(self, key, W, b, Wc, bc):
+        """the [rows, cols] matrix a gather key refers to"""
+        kind = key[0]
+        s2 = 1.0 / math.sqrt(2.0)
+        if kind == 'W':
+            l = key[1]
+            return W[l] * s2 if l == self.skip else W[l]
+        if kind == 'b':
+            return b[key[1]]
+        if kind == 'Wc':
+            return Wc[key[1]]
+        if kind == 'bc':
+            return bc[key[1]]
+        if kind == 'WT_sdfrow':
+            return W[self.nL][:1].t()
+        if kind == 'WT_u':                                     # rows = features of u_l (the part of in_l that is u_l)
+            l = key[1]
+            M = W[l][:, :self.out[l - 1]].t()
+            return M * s2 if l == self.skip else M
+        if kind == 'WT_e':
+            l = key[1]
+            M = (W[l][:, self.out[l - 1]:] if l == self.skip and l > 0 else W[l]).t()
+            return M * s2 if l == self.skip else M
+        if kind == 'WT_last':
+            return W[self.nL].t()
+        if kind == 'WcT':
+            return Wc[key[1]].t()
+        if kind == 'WcT0_feat':                                 # rows in OUTF order: [0 (sdf) ; feat]
+            M = Wc[0][:, self.X:].t()
+            return torch.cat([M.new_zeros(1, M.shape[1]), M], 0)
+        if kind == 'WcT0_extra':
+            return Wc[0][:, :self.X].t()
+        raise KeyError(key)
+
+    def _dev_gathers(self, prog, device):
+        k = (id(prog), str(device))
+        if k not in self._dev:
+            self._dev[k] = [(key, torch.from_numpy(wi).to(device), bkey, None if bi is None else torch.from_numpy(bi).to(device), oi)
+                            for key, wi, bkey, bi, oi in prog.gathers]
+        return self._dev[k]
+
+    def pack(self, W, b, Wc, bc):
+        """effective weights -> one flat buffer + per-program descriptors (host numpy + device copy)."""
+        dev = W[0].device
+        chunks, off, descs = [], 0, {}
+        for name in ('prog_fwd', 'prog_cbwd', 'prog_sbwd'):
+            prog = getattr(self, name)
+            ops = [list(o) for o in prog.ops]
+            for key, wi, bkey, bi, oi in self._dev_gathers(prog, dev):
+                c = _take(self._matrix(key, W, b, Wc, bc).contiguous(), wi)
+                ops[oi][6] = off // 4
+                chunks.append(c); off += c.numel()
+                if bkey is not None:
+                    cb = _take(self._matrix(bkey, W, b, Wc, bc).contiguous(), bi)
+                    ops[oi][7] = off // 4
+                    chunks.append(cb); off += cb.numel()
+            d = np.zeros(DESC_INTS, np.int32)
+            d[0:4] = [len(ops), prog.total_rows, prog.n_waves, len(prog.tn)]
+            for i, o in enumerate(ops):
+                d[16 + 16 * i: 32 + 16 * i] = o
+            descs[name] = (d, torch.from_numpy(d).to(dev))
+        return torch.cat(chunks).contiguous(), descs
+
+    # launches --------------------------------------------------------------------------------------
+    def alloc_tensors(self, P, device):
+        nt = (P + 31) // 32
+        out = {}
+        for name, (kind, w) in self._tensor_specs().items():
+            out[name] = torch.empty((P, w), dtype=torch.float32, device=device) if kind == 'vec' \
+                else torch.empty((nt, w, 32, 32), dtype=torch.float32, device=device)
+        out['ONES'].fill_(1.0)
+        return out
+
+    def run(self, which, descs, wbuf, tensors, P):
+        prog = getattr(self, which)
+        d_host, d_dev = descs[which]
+        names = list(prog.tn.keys())
+        ptrs = (ctypes.c_void_p * len(names))(*[tensors[n].data_ptr() for n in names])
+        specs = self._tensor_specs()
+        lds = np.array([specs[n][1] for n in names], np.int32)
+        with _C._clock('vqn_tile_program:' + which):
+            rc = _C.lib().vqn_tile_program(ctypes.c_void_p(d_dev.data_ptr()), d_host.ctypes.data_as(ctypes.c_void_p),
+                                           _C._ptr(wbuf), ptrs, lds.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(len(names)),
+                                           ctypes.c_int64(P), _C._stream())
+        _C._check(rc, 'vqn_tile_program')
+
+    def wgrad(self, A, B, a_rows, b_cols, ws):
+        """sum_p A[o][p] B[i][p] -> [a_rows, b_cols] (A, B: TFMT tensors [tiles, ft, 32, 32])."""
+        nt, at, bt = A.shape[0], A.shape[1], B.shape[1]
+        a_nt_all, b_nt_all = (a_rows + 31) // 32, (b_cols + 31) // 32
+        out = torch.empty((a_nt_all * 32, b_nt_all * 32), dtype=torch.float32, device=A.device)
+        for a0 in range(0, a_nt_all, 8):
+            an = min(8, a_nt_all - a0)
+            for b0 in range(0, b_nt_all, 8):
+                bn = min(8, b_nt_all - b0)
+                with _C._clock('vqn_wgrad_partials'):
+                    n = _C.lib().vqn_wgrad_partials(_C._ptr(A), ctypes.c_int(at), ctypes.c_int(a0), ctypes.c_int(an), _C._ptr(B),
+                                                    ctypes.c_int(bt), ctypes.c_int(b0), ctypes.c_int(bn), ctypes.c_int64(nt),
+                                                    ctypes.c_int(self.n_split), _C._ptr(ws), _C._stream())
+                if n <= 0:
+                    _C._check(n if n < 0 else -3, 'vqn_wgrad_partials')
+                part = ws[: n * an * 32 * bn * 32].view(n, an * 32, bn * 32)
+                out[a0 * 32:(a0 + an) * 32, b0 * 32:(b0 + bn) * 32] = part.sum(0)
+        return out[:a_rows, :b_cols]
+
+    def weight_grads(self, T, g_sdf):
+        """dict of gradients w.r.t. the EFFECTIVE weights / biases, from the saved tensors."""
+        nL, nC, s2 = self.nL, self.nC, 1.0 / math.sqrt(2.0)
+        dev = T['X'].device
+        ws = torch.empty(self.n_split * 256 * 256, dtype=torch.float32, device=dev)
+        tsum = lambda t, n: t.sum((0, 3)).reshape(-1)[:n]        # sum over points of a TFMT tensor -> [features]
+        dW, db, dWc, dbc = [None] * (nL + 1), [None] * (nL + 1), [None] * (nC + 1), [None] * (nC + 1)
+        for l in range(nL):
+            ab, gh = T['AB%d' % l], T['GH%d' % l]
+            if l == 0:
+                g = self.wgrad(ab, T['E'], self.out[0], self.E, ws) + self.wgrad(gh, T['ED'], self.out[0], self.E, ws)
+            else:
+                pu = self.out[l - 1]
+                g = self.wgrad(ab, T['U%d' % l], self.out[l], pu, ws) + self.wgrad(gh, T['UD%d' % l], self.out[l], pu, ws)
+                if l == self.skip:
+                    ge = self.wgrad(ab, T['E'], self.out[l], self.E, ws) + self.wgrad(gh, T['ED'], self.out[l], self.E, ws)
+                    g = torch.cat([g, ge], 1) * s2
+            dW[l], db[l] = g, tsum(ab, self.out[l])
+        # final layer: rows 1.. from the feature adjoints, row 0 = (g_sdf/scale) (x) u_L + u'_L
+        gl = self.wgrad(T['GOUTF'], T['U%d' % nL], self.F, self.out[nL - 1], ws)
+        uL, udL = T['U%d' % nL], T['UD%d' % nL]
+        nt = uL.shape[0]
+        gs = torch.zeros(nt * 32, dtype=torch.float32, device=dev)
+        gs[:g_sdf.numel()] = g_sdf.reshape(-1) / self.scale
+        row0 = (uL * gs.view(nt, 1, 1, 32)).sum((0, 3)).reshape(-1)[:self.out[nL - 1]] + tsum(udL, self.out[nL - 1])
+        gl = torch.cat([row0[None], gl[1:]], 0)
+        bl = tsum(T['GOUTF'], self.F).clone()
+        bl[0] = gs.sum()
+        dW[nL], db[nL] = gl, bl
+        # colour net
+        d0 = T['DC0']
+        g_feat = self.wgrad(d0, T['OUTF'], self.cout[0], self.F, ws)[:, 1:]
+        g_ext = self.wgrad(d0, T['EXTR'], self.cout[0], self.X, ws)
+        dWc[0], dbc[0] = torch.cat([g_ext, g_feat], 1), tsum(d0, self.cout[0])
+        for l in range(1, nC + 1):
+            dl = T['DC%d' % l]
+            dWc[l], dbc[l] = self.wgrad(dl, T['C%d' % l], self.cout[l], self.cin[l], ws), tsum(dl, self.cout[l])
+        return dW, db, dWc, dbc
+
+
+class NeusCoreFunction(torch.autograd.Function):
+    """(x, dirs, W_0.., b_0.., Wc_0.., bc_0..) -> (sdf [P,1], n [P,3], rgb [P,3]); backward = the tile programs."""
+
+    @staticmethod
+    def forward(ctx, engine, x, dirs, *params):
+        nS, nCc = engine.nL + 1, engine.nC + 1
+        W, b = list(params[:nS]), list(params[nS:2 * nS])
+        Wc, bc = list(params[2 * nS:2 * nS + nCc]), list(params[2 * nS + nCc:])
+        P = x.shape[0]
+        with torch.no_grad():
+            wbuf, descs = engine.pack([w.detach().float() for w in W], [t.detach().float() for t in b],
+                                      [w.detach().float() for w in Wc], [t.detach().float() for t in bc])
+            T = engine.alloc_tensors(P, x.device)
+            T['X'].copy_(x)
+            T['DIRS'].copy_(dirs)
+            engine.run('prog_fwd', descs, wbuf, T, P)
+        ctx.engine, ctx.T, ctx.descs, ctx.wbuf, ctx.P = engine, T, descs, wbuf, P
+        return T['SDF'], T['N'], T['RGB']
+
+    @staticmethod
+    def backward(ctx, g_sdf, g_n, g_rgb):
+        e, T, P = ctx.engine, ctx.T, ctx.P
+        with torch.no_grad():
+            rgb = T['RGB']
+            g_rgb = torch.zeros_like(rgb) if g_rgb is None else g_rgb
+            T['DOUT'].copy_(g_rgb * rgb * (1.0 - rgb) if e.squeeze else g_rgb)
+            e.run('prog_cbwd', ctx.descs, ctx.wbuf, T, P)
+            T['V'].copy_(T['GNCOL'] if g_n is None else g_n + T['GNCOL'])
+            gs = torch.zeros_like(T['SDF']) if g_sdf is None else g_sdf.reshape(-1, 1).contiguous()
+            T['GS'].copy_(gs)
+            e.run('prog_sbwd', ctx.descs, ctx.wbuf, T, P)
+            dW, db, dWc, dbc = e.weight_grads(T, gs)
+        ctx.T = None
+        return (None, None, None) + tuple(dW) + tuple(db) + tuple(dWc) + tuple(dbc)
