@@ -109,10 +109,21 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
             + 0.1 * torch.nn.functional.binary_cross_entropy(r['weight_sum'].clip(1e-3, 1 - 1e-3), mask)
         loss.backward()
         opt.step()
-    dt = _time_gpu(geo_train, 3)
+    geo_train()
+    _C.KernelClock.reset(True)
+    dt = _time_gpu(geo_train, 3, warm=0)
+    clk = _C.KernelClock.summary()
+    _C.KernelClock.reset(False)
+    S_c, S_f = 64 + 48, 128
+    # algorithmic FLOPs of one step: coarse SDF passes + [fwd, reverse sweep, tangent, reverse, 2 weight
+    # contractions] of the SDF net + [fwd, reverse, weight contraction] of the colour net, per fine sample
+    flop = 2.0 * B * (S_c * m_sdf + S_f * (6 * m_sdf + 3 * m_col))
     out['geo_train'] = {'rays_per_s': B / dt, 'ms_per_step': dt * 1e3, 'batch_rays': B,
-                        'note': 'up-sampling on HIP kernels; render_core forward+backward (incl. second-order eikonal) '
-                                'through torch autograd ops on the GPU'}
+                        'achieved_tflops': flop / dt / 1e12, 'frac_of_f32_mfma_peak': flop / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                        'kernel_ms_per_step': {k: v[1] / 3 for k, v in sorted(clk.items())},
+                        'note': 'all HIP: up-sampling kernels, forward / backward tile programs (second-order eikonal term via '
+                                'a tangent pass), weight-gradient contraction, compositing fwd/bwd; torch only for Adam, the '
+                                'weight-norm chain rule and small reductions'}
 
     # ---- reflectance model (vq_nfr): full-view inference and one training step ----
     model = get_model_class('vq_nfr')(config_from_dict(DECOMP_INI))

@@ -110,7 +110,7 @@ def _shift(lo, hi, base):
 class NeusTrainEngine:
     """Programs, packs and launches for one (SDFNetwork, RenderingNetwork) pair."""
 
-    def __init__(self, sdf_net, col_net, n_split=128):
+    def __init__(self, sdf_net, col_net, n_split=256):
         self.sdf_net, self.col_net = sdf_net, col_net
         d = sdf_net.dims
         self.nL = len(d) - 2                                   # hidden layers 0..nL-1, final layer nL
