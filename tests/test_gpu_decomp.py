@@ -176,11 +176,14 @@ def test_model_call_vs_oracle(setup, mode):
     np.testing.assert_allclose(_np(loss), wl.numpy(), rtol=1e-4, atol=2e-6)
 
 
-def test_training_step_grads_vs_oracle(setup):
-    """Autograd path of the model (torch statements on the GPU + HIP VQ kernels): d loss / d parameters."""
+@pytest.mark.parametrize('backend', ['hip', 'torch'])
+def test_training_step_grads_vs_oracle(setup, backend):
+    """Training path of the model -- 'hip': fused shading forward/backward kernels under autograd (MLPs through torch
+    ops), 'torch': torch statements only; both with the HIP VQ kernels -- d loss / d parameters vs the CPU oracle."""
     od, p, specs = setup['od'], setup['p'], setup['specs']
     from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
     model = load_oracle_params(get_model_class('vq_nfr')(make_config()), p, 'cuda')
+    model.train_backend = backend
     N = 256
     pts = od.make_points(N, seed=9)
     batch = make_batch(pts, 'cuda')

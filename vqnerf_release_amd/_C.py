@@ -298,7 +298,7 @@ def mlp_chain_fwd(desc, wbuf, x, out_widths):
 
 
 def brdf_shade_fwd(xyz, normal, rayo, lvis, lxyz, lareas, light, materials, gamma=None, want_normal=True,
-                   want_split=False):
+                   want_split=False, raw=False):
     """materials: [(albedo [N,3], spec [N,3], rough [N,1])] (1 or 2 sets).
     -> dict(rgb=[...per set], normal=..., rgb_diff=..., rgb_spec=...)."""
     for n_, t in (('xyz', xyz), ('normal', normal), ('rayo', rayo), ('lxyz', lxyz), ('lareas', lareas), ('light', light)):
@@ -327,7 +327,8 @@ def brdf_shade_fwd(xyz, normal, rayo, lvis, lxyz, lareas, light, materials, gamm
         rc = lib().vqn_brdf_shade_fwd(_ptr(xyz), _ptr(normal), _ptr(rayo), _ptr(lvis), _ptr(lxyz), _ptr(lareas),
                                       _ptr(light), ctypes.c_int64(N), ctypes.c_int(L), ctypes.c_int(len(materials)),
                                       *[_ptr(m) for m in mats], _ptr(gamma), _ptr(nout), _ptr(rgb[0]),
-                                      _ptr(rgb[1] if len(rgb) > 1 else None), _ptr(rd), _ptr(rs), _stream())
+                                      _ptr(rgb[1] if len(rgb) > 1 else None), _ptr(rd), _ptr(rs), ctypes.c_int(1 if raw else 0),
+                                      _stream())
     _check(rc, 'vqn_brdf_shade_fwd')
     return dict(rgb=rgb, normal=nout, rgb_diff=rd, rgb_spec=rs)
 
@@ -355,3 +356,32 @@ def neus_composite_bwd(rays_o, rays_d, mid_z, dists, sdf, grad, rgb, inv_s, back
                                           _ptr(g_sdf), _ptr(g_grad), _ptr(g_rgb), _ptr(g_inv_s), _stream())
     _check(rc, 'vqn_neus_composite_bwd')
     return g_sdf, g_grad, g_rgb, g_inv_s
+
+
+def brdf_shade_bwd(xyz, normal, rayo, lvis, lxyz, lareas, light, materials, g_sums):
+    """Reverse of brdf_shade_fwd(raw=True).  materials / g_sums: per set (albedo, spec, rough) and d loss / d sum [N,3].
+    -> ([(g_albedo, g_spec, g_rough [N,1])...], g_light [L,3])."""
+    N, L = xyz.shape[0], lareas.numel()
+    dev = xyz.device
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    args_m, outs = [], []
+    for (a, s, r), g in zip(materials, g_sums):
+        for t in (a, s, r, g):
+            _f32c(t, 'material')
+        args_m += [a, s, r, g]
+        outs.append((f(N, 3), f(N, 3), f(N, 1)))
+    while len(args_m) < 8:
+        args_m.append(None)
+    flat_out = [t for o in outs for t in o]
+    while len(flat_out) < 6:
+        flat_out.append(None)
+    L_ = lib()
+    L_.vqn_brdf_shade_bwd_partials.restype = ctypes.c_int64
+    n_part = int(L_.vqn_brdf_shade_bwd_partials(ctypes.c_int64(N)))
+    part = f(n_part, L, 3)
+    with _clock('vqn_brdf_shade_bwd'):
+        rc = L_.vqn_brdf_shade_bwd(_ptr(xyz), _ptr(normal), _ptr(rayo), _ptr(lvis), _ptr(lxyz), _ptr(lareas), _ptr(light),
+                                   ctypes.c_int64(N), ctypes.c_int(L), ctypes.c_int(len(materials)), *[_ptr(t) for t in args_m],
+                                   *[_ptr(t) for t in flat_out], _ptr(part), _stream())
+    _check(rc, 'vqn_brdf_shade_bwd')
+    return outs, part.sum(0)

@@ -34,6 +34,7 @@ struct ShadeArgs {
   float *normal_out, *rgb[2], *rgb_diff, *rgb_spec;
   long N;
   int n_sets;
+  int raw;                     // 1: write the plain sums over lights (no gamma, no [0,1] clip) -- the training path applies those in torch
 };
 
 struct Material {
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(256) void brdf_shade_kernel(const ShadeArgs a) {
     }
     auto finish = [&](float v) {
       v = wave_sum(v);
+      if (a.raw) return v;
       if (a.gamma) v = powf(v * gam_b, gam_i);
       return clip01(v);
     };
@@ -162,6 +164,144 @@ __global__ __launch_bounds__(256) void brdf_shade_kernel(const ShadeArgs a) {
   }
 }
 
+struct ShadeBwdArgs {
+  const float *xyz, *normal, *rayo, *lvis, *lxyz, *lareas, *light;
+  const float *albedo[2], *spec[2], *rough[2], *g_sum[2];     // g_sum: d loss / d (plain sum over lights) [N,3]
+  float *g_albedo[2], *g_spec[2], *g_rough[2];                // [N,3], [N,3], [N]
+  float* g_light_part;                                        // [n_waves_total][L][3] per-wave partials (summed by the caller, in order)
+  long N;
+  int n_sets;
+};
+
+// d/d a2 of G1(c) = 2c / (c + sqrt|a2 + (1 - a2) c^2|), with divide_no_nan semantics
+__device__ __forceinline__ void g1_and_da2(float c, float a2, float* g1, float* dg1) {
+  const float q = a2 + (1.f - a2) * c * c;
+  const float s = sqrtf(fabsf(q));
+  const float den = c + s;
+  if (den == 0.f) { *g1 = 0.f; *dg1 = 0.f; return; }
+  *g1 = 2.f * c / den;
+  const float ds = s > 0.f ? (q >= 0.f ? 1.f : -1.f) * (1.f - c * c) / (2.f * s) : 0.f;
+  *dg1 = -2.f * c / (den * den) * ds;
+}
+
+template <int LQ>
+__global__ __launch_bounds__(256) void brdf_shade_bwd_kernel(const ShadeBwdArgs a) {
+  constexpr int LP = 4 * LQ;
+  constexpr int L = 64 * LP;
+  const int lane = threadIdx.x & 63;
+  const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long n_waves = (long)gridDim.x * 4;
+  float lx[LP], ly[LP], lz[LP], area[LP], Lr[LP], Lg[LP], Lb[LP], gL[LP][3];
+#pragma unroll
+  for (int g = 0; g < LQ; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int li = 256 * g + 4 * lane + e, k = 4 * g + e;
+      lx[k] = a.lxyz[li * 3 + 0]; ly[k] = a.lxyz[li * 3 + 1]; lz[k] = a.lxyz[li * 3 + 2];
+      area[k] = a.lareas[li];
+      Lr[k] = a.light[li * 3 + 0]; Lg[k] = a.light[li * 3 + 1]; Lb[k] = a.light[li * 3 + 2];
+      gL[k][0] = gL[k][1] = gL[k][2] = 0.f;
+    }
+  for (long n = wave_id; n < a.N; n += n_waves) {
+    f32x4 vis4[LQ];
+#pragma unroll
+    for (int g = 0; g < LQ; ++g)
+      vis4[g] = a.lvis ? *reinterpret_cast<const f32x4*>(a.lvis + n * L + 256 * g + 4 * lane) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    const float px = a.xyz[n * 3], py = a.xyz[n * 3 + 1], pz = a.xyz[n * 3 + 2];
+    float vx = a.rayo[n * 3] - px, vy = a.rayo[n * 3 + 1] - py, vz = a.rayo[n * 3 + 2] - pz;
+    float iv = inv_norm(vx, vy, vz);
+    vx *= iv; vy *= iv; vz *= iv;
+    float nx = a.normal[n * 3], ny = a.normal[n * 3 + 1], nz = a.normal[n * 3 + 2];
+    if (nx * vx + ny * vy + nz * vz < 0.f) { nx = -nx; ny = -ny; nz = -nz; }
+    iv = inv_norm(vx, vy, vz);
+    const float ux = vx * iv, uy = vy * iv, uz = vz * iv;
+    const float in_ = inv_norm(nx, ny, nz);
+    const float mx = nx * in_, my = ny * in_, mz = nz * in_;
+    const float v_dot_n = ux * mx + uy * my + uz * mz;
+    const float cv = clip01(v_dot_n);
+    float alb[2][3], f0[2][3], a2[2], g1v[2], dg1v[2], gs[2][3], rgh[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      if (s < a.n_sets) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          alb[s][c] = a.albedo[s][n * 3 + c]; f0[s][c] = a.spec[s][n * 3 + c]; gs[s][c] = a.g_sum[s][n * 3 + c];
+        }
+        rgh[s] = a.rough[s][n];
+        const float alpha = rgh[s] * rgh[s];
+        a2[s] = alpha * alpha;
+        g1_and_da2(cv, a2[s], &g1v[s], &dg1v[s]);
+      }
+    float acc_alb[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, acc_f0[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, acc_a2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < LP; ++k) {
+      float dx = lx[k] - px, dy = ly[k] - py, dz = lz[k] - pz;
+      float il = inv_norm(dx, dy, dz);
+      dx *= il; dy *= il; dz *= il;
+      const float cosl = dx * nx + dy * ny + dz * nz;
+      const float vis = (cosl > 0.f ? 1.f : 0.f) * vis4[k >> 2][k & 3];
+      il = inv_norm(dx, dy, dz);
+      const float wx = dx * il, wy = dy * il, wz = dz * il;
+      float hx = wx + ux, hy = wy + uy, hz = wz + uz;
+      const float ih = inv_norm(hx, hy, hz);
+      hx *= ih; hy *= ih; hz *= ih;
+      const float cos_vh = clip01(hx * ux + hy * uy + hz * uz);
+      const float om = 1.f - cos_vh, om2 = om * om, om5 = om2 * om2 * om;
+      const float cos_m = clip01(hx * mx + hy * my + hz * mz);
+      const float l_dot_n = wx * mx + wy * my + wz * mz;
+      const float cl = clip01(l_dot_n);
+      const float den = 4.f * fabsf(l_dot_n) * fabsf(v_dot_n);
+      const float inv_den = den == 0.f ? 0.f : 1.f / den;
+      const float wgt = vis * cosl * area[k];                       // geometry weight of this light (without radiance)
+      const float Lc[3] = {Lr[k], Lg[k], Lb[k]};
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        if (s < a.n_sets) {
+          const float t = cos_m * cos_m * (a2[s] - 1.f) + 1.f;
+          const float pd = PI_F * t * t;
+          float D = 0.f, dD = 0.f;
+          if (pd != 0.f) {
+            D = a2[s] / pd;
+            dD = (t - 2.f * a2[s] * cos_m * cos_m) / (PI_F * t * t * t);
+          }
+          float g1l, dg1l;
+          g1_and_da2(cl, a2[s], &g1l, &dg1l);
+          const float G = g1l * g1v[s];
+          const float dG = dg1l * g1v[s] + g1l * dg1v[s];
+          const float gd = G * D * inv_den, dgd = (dG * D + G * dD) * inv_den;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float F = f0[s][c] + (1.f - f0[s][c]) * om5;
+            const float gw = gs[s][c] * wgt;                        // d loss / d (brdf_c * radiance_c)  per unit radiance
+            const float glw = gw * Lc[c];
+            acc_alb[s][c] += glw * (1.f / PI_F);
+            acc_f0[s][c] += glw * (1.f - om5) * gd;
+            acc_a2[s] += glw * F * dgd;
+            gL[k][c] += gw * (F * gd + alb[s][c] / PI_F);
+          }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      if (s < a.n_sets) {
+        float r[7];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { r[c] = wave_sum(acc_alb[s][c]); r[3 + c] = wave_sum(acc_f0[s][c]); }
+        r[6] = wave_sum(acc_a2[s]) * 4.f * rgh[s] * rgh[s] * rgh[s];          // a2 = rough^4
+        if (lane < 3) { a.g_albedo[s][n * 3 + lane] = r[lane]; a.g_spec[s][n * 3 + lane] = r[3 + lane]; }
+        if (lane == 0) a.g_rough[s][n] = r[6];
+      }
+  }
+  float* part = a.g_light_part + (size_t)wave_id * L * 3;
+#pragma unroll
+  for (int g = 0; g < LQ; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int li = 256 * g + 4 * lane + e, k = 4 * g + e;
+      part[li * 3 + 0] = gL[k][0]; part[li * 3 + 1] = gL[k][1]; part[li * 3 + 2] = gL[k][2];
+    }
+}
+
 }  // namespace
 
 extern "C" int vqn_brdf_shade_fwd(const float* xyz, const float* normal, const float* rayo, const float* lvis,
@@ -169,7 +309,7 @@ extern "C" int vqn_brdf_shade_fwd(const float* xyz, const float* normal, const f
                                   int n_sets, const float* albedo0, const float* spec0, const float* rough0,
                                   const float* albedo1, const float* spec1, const float* rough1, const float* gamma,
                                   float* normal_out, float* rgb0, float* rgb1, float* rgb0_diff, float* rgb0_spec,
-                                  void* stream) {
+                                  int raw, void* stream) {
   VQN_CHECK_ARG(N >= 0, "N >= 0");
   if (N == 0) return VQN_OK;
   VQN_CHECK_ARG(xyz && normal && rayo && lxyz && lareas && light, "null geometry / light pointer");
@@ -185,7 +325,7 @@ extern "C" int vqn_brdf_shade_fwd(const float* xyz, const float* normal, const f
   a.albedo[0] = albedo0; a.spec[0] = spec0; a.rough[0] = rough0;
   a.albedo[1] = albedo1; a.spec[1] = spec1; a.rough[1] = rough1;
   a.normal_out = normal_out; a.rgb[0] = rgb0; a.rgb[1] = rgb1; a.rgb_diff = rgb0_diff; a.rgb_spec = rgb0_spec;
-  a.N = N; a.n_sets = n_sets;
+  a.N = N; a.n_sets = n_sets; a.raw = raw;
   long blocks = (N + 3) / 4;
   const long cap = (long)vqn_num_cus() * 8;
   if (blocks > cap) blocks = cap;
@@ -193,6 +333,44 @@ extern "C" int vqn_brdf_shade_fwd(const float* xyz, const float* normal, const f
   if (L == 256) hipLaunchKernelGGL(brdf_shade_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, a);
   else if (L == 512) hipLaunchKernelGGL(brdf_shade_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(brdf_shade_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
+
+extern "C" int64_t vqn_brdf_shade_bwd_partials(int64_t N) {
+  long blocks = (N + 3) / 4;
+  const long cap = (long)vqn_num_cus() * 4;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return blocks * 4;
+}
+
+extern "C" int vqn_brdf_shade_bwd(const float* xyz, const float* normal, const float* rayo, const float* lvis,
+                                  const float* lxyz, const float* lareas, const float* light, int64_t N, int L,
+                                  int n_sets, const float* albedo0, const float* spec0, const float* rough0,
+                                  const float* g_sum0, const float* albedo1, const float* spec1, const float* rough1,
+                                  const float* g_sum1, float* g_albedo0, float* g_spec0, float* g_rough0,
+                                  float* g_albedo1, float* g_spec1, float* g_rough1, float* g_light_partials,
+                                  void* stream) {
+  VQN_CHECK_ARG(N >= 1, "N >= 1");
+  VQN_CHECK_ARG(xyz && normal && rayo && lxyz && lareas && light && g_light_partials, "null geometry / light pointer");
+  VQN_CHECK_ARG(n_sets == 1 || n_sets == 2, "n_sets must be 1 or 2");
+  VQN_CHECK_ARG(albedo0 && spec0 && rough0 && g_sum0 && g_albedo0 && g_spec0 && g_rough0, "material set 0 pointers");
+  VQN_CHECK_ARG(n_sets == 1 || (albedo1 && spec1 && rough1 && g_sum1 && g_albedo1 && g_spec1 && g_rough1), "material set 1 pointers");
+  VQN_CHECK_SHAPE(L == 256 || L == 512 || L == 1024, "L must be 256, 512 or 1024 lights");
+  VQN_CHECK_SHAPE(lvis == nullptr || ((uintptr_t)lvis & 15) == 0, "lvis must be 16-byte aligned");
+  ShadeBwdArgs a;
+  a.xyz = xyz; a.normal = normal; a.rayo = rayo; a.lvis = lvis; a.lxyz = lxyz; a.lareas = lareas; a.light = light;
+  a.albedo[0] = albedo0; a.spec[0] = spec0; a.rough[0] = rough0; a.g_sum[0] = g_sum0;
+  a.albedo[1] = albedo1; a.spec[1] = spec1; a.rough[1] = rough1; a.g_sum[1] = g_sum1;
+  a.g_albedo[0] = g_albedo0; a.g_spec[0] = g_spec0; a.g_rough[0] = g_rough0;
+  a.g_albedo[1] = g_albedo1; a.g_spec[1] = g_spec1; a.g_rough[1] = g_rough1;
+  a.g_light_part = g_light_partials; a.N = N; a.n_sets = n_sets;
+  const long blocks = vqn_brdf_shade_bwd_partials(N) / 4;
+  hipStream_t s = (hipStream_t)stream;
+  if (L == 256) hipLaunchKernelGGL(brdf_shade_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  else if (L == 512) hipLaunchKernelGGL(brdf_shade_bwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(brdf_shade_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, a);
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }

@@ -27,6 +27,34 @@ def scatter_rows(mask, x, n):
     return out
 
 
+class ShadeFunction(torch.autograd.Function):
+    """Directions + microfacet BRDF + rendering-equation sum as one differentiable op (vqn_brdf_shade_fwd(raw) /
+    vqn_brdf_shade_bwd).  Differentiable inputs: light [L,3] and, per material set, albedo [N,3], spec [N,3], rough [N,1];
+    outputs: the plain sums over lights per set (gamma / clip are applied by the caller in torch) and the corrected normal."""
+
+    @staticmethod
+    def forward(ctx, geom, light, *mats):
+        xyz, normal, rayo, lvis, lxyz, lareas = geom
+        light = light.detach().float().reshape(-1, 3).contiguous()
+        sets = [tuple(t.detach().float().contiguous() for t in mats[3 * i:3 * i + 3]) for i in range(len(mats) // 3)]
+        sets = [(a, s.expand(-1, 3).contiguous(), r) for a, s, r in sets]
+        out = _C.brdf_shade_fwd(xyz, normal, rayo, lvis, lxyz, lareas, light, sets, want_normal=True, raw=True)
+        ctx.geom, ctx.light, ctx.sets = geom, light, sets
+        ctx.spec_widths = [mats[3 * i + 1].shape[1] for i in range(len(sets))]
+        ctx.mark_non_differentiable(out['normal'])
+        return (out['normal'],) + tuple(out['rgb'])
+
+    @staticmethod
+    def backward(ctx, _g_normal, *g_sums):
+        xyz, normal, rayo, lvis, lxyz, lareas = ctx.geom
+        gs = [torch.zeros_like(ctx.sets[i][0]) if g is None else g.contiguous() for i, g in enumerate(g_sums)]
+        grads, g_light = _C.brdf_shade_bwd(xyz, normal, rayo, lvis, lxyz, lareas, ctx.light, ctx.sets, gs)
+        flat = []
+        for (ga, gsp, gr), w in zip(grads, ctx.spec_widths):
+            flat += [ga, gsp if w == 3 else gsp.sum(-1, keepdim=True), gr]
+        return (None, g_light) + tuple(flat)
+
+
 class _PackCache:
     def __init__(self):
         self.key, self.value = None, None
@@ -50,6 +78,7 @@ class BrdfModel(ShapeModel):
         self._light = None
         self._gamma_index, self._gamma_bias = None, None
         self._plans, self._packs = {}, {}
+        self.train_backend = 'hip'       # 'hip': fused shading fwd/bwd kernels under autograd; 'torch': torch statements
         self.novel_probes = {}
         self.novel_olat = {}
 
@@ -237,6 +266,23 @@ class BrdfModel(ShapeModel):
                                  light.detach().float().reshape(-1, 3).contiguous(), mats, gamma=gamma,
                                  want_normal=True, want_split=split)
 
+    def _shade_train(self, xyz, normal, rayo, lvis, materials, light=None):
+        """Shading with gradients (albedo / spec / rough / light) through the fused forward + backward kernels."""
+        light = self.light if light is None else light
+        c = lambda t: t.detach().float().contiguous()
+        geom = (c(xyz), c(normal), c(rayo), None if lvis is None else c(lvis), self.lxyz.reshape(-1, 3).contiguous(),
+                self.lareas.reshape(-1).contiguous())
+        flat = [t for m in materials for t in m]
+        res = ShadeFunction.apply(geom, light.reshape(-1, 3), *flat)
+        n_pred, sums = res[0], res[1:]
+        rgb = []
+        for sm in sums:
+            if self.data_type != 'nerf':
+                g = self.gamma
+                sm = (sm * g[0]) ** g[1]
+            rgb.append(mathutil.clip_preserve_gradient(sm, 0.0, 1.0))
+        return {'rgb': rgb, 'normal': n_pred, 'rgb_diff': None, 'rgb_spec': None}
+
     def _unpack(self, batch):
         if self.data_type == 'nerf':
             id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz, normal, lvis = batch
@@ -265,7 +311,10 @@ class Model(BrdfModel):
         basecolor, ks, rough = self._all_heads(z_bias, 'out')
         spec = ks * basecolor
         albedo = (1 - ks) * basecolor
-        if not self._fused(xyz_m, albedo, spec, rough):
+        if not self._fused(xyz_m, albedo, spec, rough) and self.train_backend == 'hip' and xyz_m.is_cuda and mode == 'train':
+            sh = self._shade_train(xyz_m, normal_m, rayo, lvis_m, [(albedo, spec, rough)])
+            rgb_pred, normal_pred = sh['rgb'][0], sh['normal']
+        elif not self._fused(xyz_m, albedo, spec, rough):
             surf2c = self._calc_vdir(rayo, xyz_m)
             surf2l = self._calc_ldir(xyz_m)
             normal_pred = self._normal_correct(normal_m, surf2c)

@@ -127,6 +127,8 @@ class Model(BrdfModel):
                 out['rgb_probes'] = torch.stack(
                     [self._shade(xyz, normal, rayo, lvis, materials[:1], light=lp)['rgb'][0] for lp in self.novel_probes.values()], 1)
             return out
+        if self.train_backend == 'hip' and xyz.is_cuda and not split and not probes:
+            return self._shade_train(xyz, normal, rayo, lvis, materials, light=light)
         surf2l = self._calc_ldir(xyz)
         surf2c = self._calc_vdir(rayo, xyz)
         n_pred = self._normal_correct(normal, surf2c)
