@@ -172,8 +172,8 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     tr = train_nfr.Trainer(model, opt2)
     dt = _time_gpu(lambda: tr.train_iter(small, global_bs=1024), 5, warm=2)
     out['decomp_train'] = {'points_per_s': 2048 / dt, 'ms_per_step': dt * 1e3, 'batch_points': 2048,
-                           'note': 'VQ assign / EMA statistics on HIP kernels; MLPs + shading forward/backward through '
-                                   'torch autograd ops on the GPU'}
+                           'note': 'HIP: VQ assign / EMA statistics, fused shading forward + backward; the Dense stacks run forward/'
+                                   'backward through torch autograd ops on the GPU (latency-bound at 2048 points)'}
 
     # ---- standalone VQ nearest-code assignment + EMA statistics (HBM-bound) ----
     Nv, D, K = 1 << 20, 256, 15
