@@ -280,6 +280,19 @@ def main():
     flop_fine = 2.0 * (2 * m_sdf + m_col) * args.rays * S_f
     avg_ms = ms_fine / n_fine
     achieved = flop_fine / (avg_ms * 1e-3) / 1e12
+    # fabric-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_render.json:
+    # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command); scaled by rays if --rays differs
+    traffic, traffic_note = None, None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_render.json')) as f:
+            pmc = json.load(f)
+        traffic = pmc['dominant_kernel_traffic_bytes_per_launch'] * args.rays / pmc['rays_per_launch']
+        traffic_note = ('2*FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 PMC, separate passes); counts fabric requests incl. '
+                        'Infinity-Cache hits: the per-workgroup activation stash of the reverse sweep (8 x 32 KB per tile, '
+                        '134 MB in flight, Infinity-Cache resident) is written once and read once per tile; algorithmic bytes '
+                        'are 32 B in + 28 B out per sample')
+    except Exception:
+        pass
     result = {
         'metric': 'rays/sec (render) 800x800, 64+64 samples/ray, NeuS SDF 8x256 + colour 4x256',
         'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -290,7 +303,7 @@ def main():
                                'random-init weights', 'rays_per_step_per_gpu': args.rays, 'parallelism': f'rays x{world}'},
         'roofline': {'bound': 'mfma', 'kernel': 'neus_points_kernel<FINE> (vqn_neus_fine_points)', 'achieved': achieved,
                      'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
-                     'traffic': None, 'avg_launch_ms': avg_ms, 'flop_per_launch': flop_fine,
+                     'traffic': traffic, 'traffic_note': traffic_note, 'avg_launch_ms': avg_ms, 'flop_per_launch': flop_fine,
                      'macs_per_point': {'sdf': m_sdf, 'colour': m_col}},
         'kernel_ms_per_step': {k: v[1] / args.steps for k, v in sorted(clock.items())},
     }
