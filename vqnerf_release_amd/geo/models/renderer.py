@@ -18,6 +18,7 @@ import torch
 import torch.nn.functional as F
 
 from vqnerf_release_amd import _C
+from vqnerf_release_amd.geo import packing
 from vqnerf_release_amd.geo.models.fields import _needs_graph
 
 
@@ -115,6 +116,7 @@ class NeuSRenderer:
         self.perturb = perturb
         self._u = {}
         self._engines = {}
+        self.weights_only = False         # True: no-graph renders skip the colour net (weights / weight_sum / surf stay exact)
         self.train_backend = 'hip'        # 'hip': tile programs of geo/train_programs.py; 'torch': autograd over torch ops
 
     # ---- packs shared by all kernels --------------------------------------------------------
@@ -175,7 +177,13 @@ class NeuSRenderer:
         per_ray = sample_dist.reshape(-1).float().contiguous() if to_light else None
         mid_z, dists = _C.neus_section_mids(z_vals.contiguous(), 0.0 if to_light else float(sample_dist), per_ray)
         wb_s, d_s, wb_c, d_c = self._packs()
-        sdf, grad, rgb = _C.neus_fine_points(d_s, wb_s, d_c, wb_c, rays_o=rays_o, rays_d=rays_d, z=mid_z)
+        if self.weights_only:
+            # occupancy queries (gen_geo.py:231-242 uses nothing but weight_sum): the colour network is skipped
+            no_col = np.zeros(packing.COL_DESC_INTS, np.int32)
+            sdf, grad, _ = _C.neus_fine_points(d_s, wb_s, no_col, wb_s, rays_o=rays_o, rays_d=rays_d, z=mid_z)
+            rgb = torch.zeros_like(grad)
+        else:
+            sdf, grad, rgb = _C.neus_fine_points(d_s, wb_s, d_c, wb_c, rays_o=rays_o, rays_d=rays_d, z=mid_z)
         inv_s = torch.exp(deviation_network.variance.detach().float() * 10.0).reshape(1).contiguous()
         bg = None if background_rgb is None else background_rgb.detach().float().to(z_vals.device)
         o = _C.neus_composite_fwd(rays_o, rays_d, mid_z, dists, sdf, grad, rgb, inv_s, bg, radius, cos_anneal_ratio)
