@@ -93,7 +93,7 @@ def test_outer_sample_pairs_are_neighbours():
     assert (p[:, 1] >= 10).all() and (out[5] > 0.9).all()          # both foreground
 
 
-@pytest.mark.parametrize('name,B', [('small', 96), ('full', 48)])
+@pytest.mark.parametrize('name,B', [('small', 96), ('full', 48), ('small', 7), ('full', 2)])
 def test_hip_training_programs_match_torch_autograd(name, B):
     """The explicit forward / backward tile programs (+ compositing backward kernel + weight-gradient contraction)
     against torch autograd over the torch statements of the same modules: loss, every parameter gradient."""
@@ -131,3 +131,22 @@ def test_hip_training_programs_match_torch_autograd(name, B):
         worst = max(worst, err)
         assert err <= 5e-3, (k, err, scale)
     print(f'{name}: loss {lh:.6f} vs {lt:.6f}; worst relative gradient error {worst:.2e}')
+
+
+def test_empty_and_degenerate_inputs():
+    """N = 0 is a no-op for every entry point of the training engine; a 1-point tile program runs."""
+    import ctypes
+    from vqnerf_release_amd import _C
+    lib = _C.lib()
+    z = ctypes.c_void_p(0)
+    one = torch.zeros(64, device='cuda')
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert lib.vqn_neus_composite_bwd(p(one), p(one), p(one), p(one), p(one), p(one), p(one), p(one), z, ctypes.c_int64(0), 8,
+                                      ctypes.c_float(2.0), ctypes.c_float(1.0), p(one), z, z, z, z, p(one), p(one), p(one), p(one), z) == 0
+    assert lib.vqn_brdf_shade_fwd(z, z, z, z, z, z, z, ctypes.c_int64(0), 512, 1, z, z, z, z, z, z, z, z, z, z, z, z, 0, z) == 0
+    assert lib.vqn_mlp_chain_fwd(p(one), p(one), z, ctypes.c_int64(0), z, 0, z, 0, z, 0, z, 0, z) == 0
+    rc = lib.vqn_wgrad_partials(p(one), 1, 0, 9, p(one), 1, 0, 1, ctypes.c_int64(1), 4, p(one), z)
+    assert rc == -2 and b'feature tiles' in lib.vqn_last_error()
+    rc = lib.vqn_brdf_shade_fwd(p(one), p(one), p(one), z, p(one), p(one), p(one), ctypes.c_int64(4), 100, 1, p(one), p(one), p(one),
+                                z, z, z, z, z, p(one), z, z, z, 0, z)
+    assert rc == -2 and b'256, 512 or 1024' in lib.vqn_last_error()
