@@ -140,15 +140,20 @@ __global__ __launch_bounds__(256, 2) void neus_points_kernel(
       const KSegs ks{cur, 4 * L.n_out_tiles, 0, 0};
       const f32x4* sv = save + (size_t)(l - 1) * 4 * MT * 64;
       const int dst = oth;
+      f32x4 hv[4];                                   // stashed forward activations of this tile: requested BEFORE the K loop so that
+                                                     // their (L2 / Infinity-Cache) latency hides under the MFMAs, not behind them
       gemm_tiles(lds, ks, wsdf + L.wT_off, sd.layers[l - 1].n_out_tiles, wave, lane,
-                 [&](int, f32x16& acc) { init_zero(acc); },
+                 [&](int ot, f32x16& acc) {
+#pragma unroll
+                   for (int rq = 0; rq < 4; ++rq) hv[rq] = sv[(ot * 4 + rq) * 64 + lane];
+                   init_zero(acc);
+                 },
                  [&](int ot, const f32x16& acc) {
 #pragma unroll
                    for (int rq = 0; rq < 4; ++rq) {
-                     const f32x4 hv = sv[(ot * 4 + rq) * 64 + lane];
                      f32x4 v = acc_quad(acc, rq);
 #pragma unroll
-                     for (int j = 0; j < 4; ++j) v[j] *= act_bwd_from_out<ACT_SOFTPLUS100>(hv[j]);
+                     for (int j = 0; j < 4; ++j) v[j] *= act_bwd_from_out<ACT_SOFTPLUS100>(hv[rq][j]);
                      lds[(dst + ot * 4 + rq) * 64 + lane] = v;
                    }
                  });
