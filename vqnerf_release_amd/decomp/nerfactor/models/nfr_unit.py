@@ -77,7 +77,7 @@ class BrdfModel(ShapeModel):
         super().__init__(config, debug=debug)
         self._light = None
         self._gamma_index, self._gamma_bias = None, None
-        self._plans, self._packs = {}, {}
+        self._plans, self._packs, self._engines = {}, {}, {}
         self.train_backend = 'hip'       # 'hip': fused shading fwd/bwd kernels under autograd; 'torch': torch statements
         self.novel_probes = {}
         self.novel_olat = {}
@@ -186,11 +186,32 @@ class BrdfModel(ShapeModel):
         widths = [self.net[n].widths[-1] for n in names]
         return _C.mlp_chain_fwd(desc, wbuf, z.detach().float().contiguous(), widths)
 
+    # ------------------------------------------------------------------ training engines (tile programs)
+    def _train_hip(self, x):
+        return self.train_backend == 'hip' and x.is_cuda and getattr(self.embedder['xyz'], 'fused_ok', lambda: False)()
+
+    def _enc_engine(self, device):
+        if 'enc' not in self._engines:
+            from vqnerf_release_amd.decomp.train_programs import EncoderEngine
+            self._engines['enc'] = EncoderEngine(self.net['fine_enc'], self.net['bottleneck'], self.embedder['xyz'].n_freqs, device)
+        return self._engines['enc']
+
+    def _heads_engine(self, names, device):
+        key = 'heads:' + ','.join(names)
+        if key not in self._engines:
+            from vqnerf_release_amd.decomp.train_programs import HeadsEngine
+            self._engines[key] = HeadsEngine([self.net[n] for n in names], self.z_dim, device)
+        return self._engines[key]
+
     # ------------------------------------------------------------------ reference-named pieces
     def _pred_bias_at(self, pts):
         """xyz [N,3] -> z [N,z_dim]  (nfr_unit.py:329-342; vq_nfr.py:771-784 is the same function)."""
         if self._fused(pts):
             return self._fused_enc(pts)
+        if self._train_hip(pts):
+            from vqnerf_release_amd.decomp.train_programs import EncoderFunction
+            layers = list(self.net['fine_enc'].layers) + list(self.net['bottleneck'].layers)
+            return EncoderFunction.apply(self._enc_engine(pts.device), pts, *[l.kernel for l in layers], *[l.bias for l in layers])
         return self.net['bottleneck'](self.net['fine_enc'](self.embedder['xyz'](pts)))
 
     def _head(self, name, z):
@@ -217,6 +238,11 @@ class BrdfModel(ShapeModel):
         names = [h + '_' + suffix for h in self.HEADS]
         if self._fused(z):
             d, s, r = self._fused_heads(z, names)
+        elif self._train_hip(z):
+            from vqnerf_release_amd.decomp.train_programs import HeadsFunction
+            nets = [self.net[n] for n in names]
+            d, s, r = HeadsFunction.apply(self._heads_engine(names, z.device), z, *[l.kernel for n in nets for l in n.layers],
+                                          *[l.bias for n in nets for l in n.layers])
         else:
             d, s, r = (self.net[n](z) for n in names)
         return self._albedo_affine(d), s, r

@@ -1,0 +1,344 @@
+"""Training passes of the reflectance Dense stacks as tile programs (csrc/tile_vm.hip + csrc/wgrad.hip): what the
+reference gets from `tape.gradient` through networks/mlp.py:24-50 as used by vq_nfr.py:771-828 (train_nfr.py:562-576).
+
+Two engines, each with a forward program that saves every activation in TFMT and a reverse-sweep program:
+  EncoderEngine : xyz -> posenc -> fine_enc (skip-concat) -> bottleneck -> z            (weights' gradients only; xyz is data)
+  HeadsEngine   : z -> {diff, spec, rough} heads (skip-concat of z into the last layer) (weights' gradients and d/dz)
+Weights keep the Keras layout (kernel [in, out]); sigmoid' / relu' of the LAST layer of a stack is applied by the caller
+in torch before the reverse program (one elementwise op on [N, <=256])."""
+import ctypes
+
+import numpy as np
+import torch
+
+from vqnerf_release_amd import _C
+from vqnerf_release_amd.geo.packing import _take
+from vqnerf_release_amd.geo.train_programs import (Program, _ident, _f2i, DESC_INTS, K_LD_POSENC, K_LD_T, EPI_ACT, EPI_MUL_DACT,
+                                                   ACT_NONE, ACT_RELU, ACT_SIGMOID)
+
+ACTS = {None: ACT_NONE, 'relu': ACT_RELU, 'sigmoid': ACT_SIGMOID}
+
+
+def to_tfmt(x, tiles=None):
+    """[N, F] row-major -> TFMT [ceil(N/32), ceil(F/32), 32 features, 32 points] (zero padded)."""
+    N, F = x.shape
+    nt, ft = (N + 31) // 32, tiles or (F + 31) // 32
+    buf = x.new_zeros(nt * 32, ft * 32)
+    buf[:N, :F] = x
+    return buf.view(nt, 32, ft, 32).permute(0, 2, 3, 1).contiguous()
+
+
+def from_tfmt(t, N, F):
+    nt, ft = t.shape[0], t.shape[1]
+    return t.permute(0, 3, 1, 2).reshape(nt * 32, ft * 32)[:N, :F]
+
+
+class _Engine:
+    """shared: program packing / launching / weight-gradient contraction"""
+    n_split = 64
+
+    def _finish(self, progs):
+        for name, build in progs:
+            best = build(None)
+            for seed in range(60):
+                if best.total_rows <= 79:
+                    break
+                cand = build(seed)
+                if cand.total_rows < best.total_rows:
+                    best = cand
+            assert best.total_rows * 1024 <= 160 * 1024
+            setattr(self, name, best.materialize())
+        self._dev = {}
+
+    def _gathers(self, prog, device):
+        k = (id(prog), str(device))
+        if k not in self._dev:
+            self._dev[k] = [(key, torch.from_numpy(wi).to(device), bkey, None if bi is None else torch.from_numpy(bi).to(device), oi)
+                            for key, wi, bkey, bi, oi in prog.gathers]
+        return self._dev[k]
+
+    def pack(self, names, mats):
+        """mats(key) -> matrix for a gather key.  Returns (wbuf, {prog name: (desc host, desc dev)})."""
+        chunks, off, descs, dev = [], 0, {}, None
+        for name in names:
+            prog = getattr(self, name)
+            ops = [list(o) for o in prog.ops]
+            for key, wi, bkey, bi, oi in self._gathers(prog, self.device):
+                c = _take(mats(key).contiguous(), wi)
+                ops[oi][6] = off // 4
+                chunks.append(c); off += c.numel()
+                if bkey is not None:
+                    cb = _take(mats(bkey).contiguous(), bi)
+                    ops[oi][7] = off // 4
+                    chunks.append(cb); off += cb.numel()
+            d = np.zeros(DESC_INTS, np.int32)
+            d[0:4] = [len(ops), prog.total_rows, prog.n_waves, len(prog.tn)]
+            for i, o in enumerate(ops):
+                d[16 + 16 * i: 32 + 16 * i] = o
+            descs[name] = (d, torch.from_numpy(d).to(self.device))
+        return torch.cat(chunks).contiguous(), descs
+
+    def run(self, which, descs, wbuf, tensors, specs, N):
+        prog = getattr(self, which)
+        d_host, d_dev = descs[which]
+        names = list(prog.tn.keys())
+        ptrs = (ctypes.c_void_p * len(names))(*[tensors[n].data_ptr() if n in tensors else 0 for n in names])
+        lds = np.array([specs[n][1] for n in names], np.int32)
+        with _C._clock('vqn_tile_program:' + type(self).__name__ + '.' + which):
+            rc = _C.lib().vqn_tile_program(ctypes.c_void_p(d_dev.data_ptr()), d_host.ctypes.data_as(ctypes.c_void_p), _C._ptr(wbuf),
+                                           ptrs, lds.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(len(names)), ctypes.c_int64(N),
+                                           _C._stream())
+        _C._check(rc, 'vqn_tile_program')
+
+    def wgrad(self, A, B, a_rows, b_cols, ws):
+        nt, at, bt = A.shape[0], A.shape[1], B.shape[1]
+        an, bn = (a_rows + 31) // 32, (b_cols + 31) // 32
+        assert an <= 8 and bn <= 8
+        with _C._clock('vqn_wgrad_partials'):
+            n = _C.lib().vqn_wgrad_partials(_C._ptr(A), ctypes.c_int(at), ctypes.c_int(0), ctypes.c_int(an), _C._ptr(B), ctypes.c_int(bt),
+                                            ctypes.c_int(0), ctypes.c_int(bn), ctypes.c_int64(nt), ctypes.c_int(self.n_split),
+                                            _C._ptr(ws), _C._stream())
+        if n <= 0:
+            _C._check(n if n < 0 else -3, 'vqn_wgrad_partials')
+        return ws[: n * an * 32 * bn * 32].view(n, an * 32, bn * 32).sum(0)[:a_rows, :b_cols]
+
+    @staticmethod
+    def alloc(specs, N, device, only=None):
+        nt = (N + 31) // 32
+        out = {}
+        for name, (kind, w) in specs.items():
+            if only is not None and name not in only:
+                continue
+            out[name] = torch.empty((N, w), dtype=torch.float32, device=device) if kind == 'vec' \
+                else torch.empty((nt, w, 32, 32), dtype=torch.float32, device=device)
+        return out
+
+
+class EncoderEngine(_Engine):
+    def __init__(self, fine_enc, bottleneck, n_freqs, device):
+        self.device = device
+        self.nets = [fine_enc, bottleneck]
+        self.E = 3 + 6 * n_freqs
+        self.mr = n_freqs
+        # flat layer list: (net idx, layer idx, in_feats of the y-part, out, act, takes_skip_input)
+        self.layers = []
+        d_prev = self.E
+        for ni, net in enumerate(self.nets):
+            d_in_net = d_prev
+            for li, (w, a) in enumerate(zip(net.widths, net.act)):
+                skip_in = net.skip_at is not None and (li - 1) in net.skip_at      # input of layer li = [y_{li-1} ; net input]
+                assert not (skip_in and ni != 0), 'skip-concat of a non-posenc input is not needed by the shipped nets'
+                self.layers.append(dict(net=ni, li=li, in_y=d_prev, out=w, act=ACTS[a], skip=skip_in))
+                d_prev = w
+            assert d_in_net is not None
+        self.nl = len(self.layers)
+        self.specs = {'X': ('vec', 3), 'E': ('t', (self.E + 31) // 32), 'GZ': ('t', (self.layers[-1]['out'] + 31) // 32)}
+        for k, L in enumerate(self.layers):
+            self.specs['Y%d' % k] = ('t', (L['out'] + 31) // 32)
+            self.specs['D%d' % k] = ('t', (L['out'] + 31) // 32)
+        self._finish([('prog_fwd', self._build_fwd), ('prog_bwd', self._build_bwd)])
+
+    def _build_fwd(self, seed):
+        P = Program(list(self.specs.keys()), seed)
+        rE = P.alloc(self.E, [])
+        P.op(K_LD_POSENC, P.t('X'), rE.row0, self.mr, self.E, P.t('E'), _f2i(1.0))
+        prev = rE
+        for k, L in enumerate(self.layers):
+            if L['skip']:
+                segs, cols, shape = [prev, rE], [_ident(L['in_y']), _ident(self.E, base=L['in_y'])], (L['out'], L['in_y'] + self.E)
+            else:
+                segs, cols, shape = [prev], [_ident(L['in_y'])], (L['out'], L['in_y'])
+            prev = P.gemm(('Wt', k), shape, segs, cols, L['out'], live=[rE], act=L['act'], bias_key=('b', k), store='Y%d' % k)
+        return P.finalize()
+
+    def _build_bwd(self, seed):
+        P = Program(list(self.specs.keys()), seed)
+        top = self.nl - 1
+        r = P.alloc(self.layers[top]['out'], [], tiles=(self.layers[top]['out'] + 31) // 32)
+        P.op(K_LD_T, P.t('GZ'), r.row0, r.rows)                       # = delta_top (act' of the top layer applied by the caller)
+        for k in range(top, 0, -1):                                   # delta_{k-1} = (W_k[y-part] delta_k) * act'_{k-1}(Y_{k-1})
+            L, Lp = self.layers[k], self.layers[k - 1]
+            r = P.gemm(('Wy', k), (L['in_y'], L['out']), [r], [_ident(L['out'])], L['in_y'], live=[], epi=EPI_MUL_DACT, act=Lp['act'],
+                       aux1='Y%d' % (k - 1), store='D%d' % (k - 1))
+        return P.finalize()
+
+    def _kernels(self):
+        ks = []
+        for net in self.nets:
+            for layer in net.layers:
+                ks.append((layer.kernel, layer.bias))
+        return ks
+
+    def _mats(self, W, b):
+        def m(key):
+            kind, k = key
+            if kind == 'Wt':
+                return W[k].t()
+            if kind == 'b':
+                return b[k]
+            if kind == 'Wy':
+                return W[k][:self.layers[k]['in_y'], :]
+            raise KeyError(key)
+        return m
+
+    def forward(self, xyz, W, b):
+        N = xyz.shape[0]
+        wbuf, descs = self.pack(['prog_fwd', 'prog_bwd'], self._mats(W, b))
+        T = self.alloc(self.specs, N, xyz.device)
+        T['X'].copy_(xyz)
+        self.run('prog_fwd', descs, wbuf, T, self.specs, N)
+        return T, wbuf, descs
+
+    def backward(self, T, wbuf, descs, g_z, N):
+        top = self.nl - 1
+        z = from_tfmt(T['Y%d' % top], N, self.layers[top]['out'])
+        act = self.layers[top]['act']
+        delta = g_z * z * (1 - z) if act == ACT_SIGMOID else (g_z * (z > 0) if act == ACT_RELU else g_z)
+        T['GZ'].copy_(to_tfmt(delta, self.specs['GZ'][1]))
+        T['D%d' % top] = T['GZ']
+        self.run('prog_bwd', descs, wbuf, T, self.specs, N)
+        ws = torch.empty(self.n_split * 256 * 256, dtype=torch.float32, device=g_z.device)
+        dW, db = [], []
+        for k, L in enumerate(self.layers):
+            D = T['D%d' % k]
+            src = T['E'] if k == 0 else T['Y%d' % (k - 1)]
+            g = self.wgrad(D, src, L['out'], L['in_y'], ws)
+            if L['skip']:
+                g = torch.cat([g, self.wgrad(D, T['E'], L['out'], self.E, ws)], 1)
+            dW.append(g.t().contiguous())                              # Keras layout [in, out]
+            db.append(D.sum((0, 3)).reshape(-1)[:L['out']])
+        return dW, db
+
+
+class EncoderFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, engine, xyz, *params):
+        n = engine.nl
+        W, b = [p.detach().float() for p in params[:n]], [p.detach().float() for p in params[n:]]
+        with torch.no_grad():
+            T, wbuf, descs = engine.forward(xyz.detach().float().contiguous(), W, b)
+        ctx.engine, ctx.T, ctx.wbuf, ctx.descs, ctx.N = engine, T, wbuf, descs, xyz.shape[0]
+        top = n - 1
+        return from_tfmt(T['Y%d' % top], xyz.shape[0], engine.layers[top]['out']).contiguous()
+
+    @staticmethod
+    def backward(ctx, g_z):
+        with torch.no_grad():
+            dW, db = ctx.engine.backward(ctx.T, ctx.wbuf, ctx.descs, g_z.contiguous(), ctx.N)
+        ctx.T = None
+        return (None, None) + tuple(dW) + tuple(db)
+
+
+class HeadsEngine(_Engine):
+    """Heads of one family sharing the input z: widths [z, z/2, c], relu relu sigmoid, skip_at=[1] (input of the last
+    layer = [y1 ; z])."""
+
+    def __init__(self, nets, z_dim, device):
+        self.device, self.nets, self.Z = device, nets, z_dim
+        for net in nets:
+            assert len(net.widths) == 3 and net.skip_at == [1] and net.act == ['relu', 'relu', 'sigmoid']
+        self.specs = {'Z': ('t', (z_dim + 31) // 32), 'GZ': ('t', (z_dim + 31) // 32)}
+        for h, net in enumerate(nets):
+            for k, w in enumerate(net.widths):
+                self.specs['Y%d_%d' % (h, k)] = ('t', (w + 31) // 32)
+                self.specs['D%d_%d' % (h, k)] = ('t', (w + 31) // 32)
+        self._finish([('prog_fwd', self._build_fwd), ('prog_bwd', self._build_bwd)])
+
+    def _build_fwd(self, seed):
+        P = Program(list(self.specs.keys()), seed)
+        rZ = P.alloc(self.Z, [])
+        P.op(K_LD_T, P.t('Z'), rZ.row0, rZ.rows)
+        for h, net in enumerate(self.nets):
+            w0, w1, c = net.widths
+            y0 = P.gemm(('Wt', h, 0), (w0, self.Z), [rZ], [_ident(self.Z)], w0, live=[rZ], act=ACT_RELU, bias_key=('b', h, 0), store='Y%d_0' % h)
+            y1 = P.gemm(('Wt', h, 1), (w1, w0), [y0], [_ident(w0)], w1, live=[rZ], act=ACT_RELU, bias_key=('b', h, 1), store='Y%d_1' % h)
+            P.gemm(('Wt', h, 2), (c, w1 + self.Z), [y1, rZ], [_ident(w1), _ident(self.Z, base=w1)], c, live=[rZ], act=ACT_SIGMOID,
+                   bias_key=('b', h, 2), store='Y%d_2' % h, want_dst=False)
+        return P.finalize()
+
+    def _build_bwd(self, seed):
+        P = Program(list(self.specs.keys()), seed)
+        rGZ = None
+        last = len(self.nets) - 1
+        for h, net in enumerate(self.nets):
+            w0, w1, c = net.widths
+            r2 = P.alloc(c, [rGZ] if rGZ else [], tiles=1)
+            P.op(K_LD_T, P.t('D%d_2' % h), r2.row0, r2.rows)           # delta_2 = g_out * sigmoid'(out), from the caller
+            keep = [rGZ] if rGZ else []
+            # z-part of the last layer's input: GZ (+)= W2[w1:, :] delta_2
+            if rGZ is None:
+                rGZ = P.gemm(('W2z', h), (self.Z, c), [r2], [_ident(c)], self.Z, live=[r2])
+            else:
+                P.gemm(('W2z', h), (self.Z, c), [r2], [_ident(c)], self.Z, live=[r2], dst=rGZ, accumulate=True)
+            d1 = P.gemm(('W2y', h), (w1, c), [r2], [_ident(c)], w1, live=[rGZ], epi=EPI_MUL_DACT, act=ACT_RELU, aux1='Y%d_1' % h,
+                        store='D%d_1' % h)
+            d0 = P.gemm(('W1', h), (w0, w1), [d1], [_ident(w1)], w0, live=[rGZ], epi=EPI_MUL_DACT, act=ACT_RELU, aux1='Y%d_0' % h,
+                        store='D%d_0' % h)
+            P.gemm(('W0', h), (self.Z, w0), [d0], [_ident(w0)], self.Z, live=[], dst=rGZ, accumulate=True,
+                   store='GZ' if h == last else None)
+        return P.finalize()
+
+    def _mats(self, W, b):
+        def m(key):
+            kind, h = key[0], key[1]
+            w1 = self.nets[h].widths[1]
+            if kind == 'Wt':
+                return W[h][key[2]].t()
+            if kind == 'b':
+                return b[h][key[2]]
+            if kind == 'W2z':
+                return W[h][2][w1:, :]
+            if kind == 'W2y':
+                return W[h][2][:w1, :]
+            if kind == 'W1':
+                return W[h][1]
+            if kind == 'W0':
+                return W[h][0]
+            raise KeyError(key)
+        return m
+
+    def forward(self, z, W, b):
+        N = z.shape[0]
+        wbuf, descs = self.pack(['prog_fwd', 'prog_bwd'], self._mats(W, b))
+        T = self.alloc(self.specs, N, z.device)
+        T['Z'].copy_(to_tfmt(z, self.specs['Z'][1]))
+        self.run('prog_fwd', descs, wbuf, T, self.specs, N)
+        return T, wbuf, descs
+
+    def backward(self, T, wbuf, descs, g_outs, N):
+        for h, (net, g) in enumerate(zip(self.nets, g_outs)):
+            c = net.widths[2]
+            out = from_tfmt(T['Y%d_2' % h], N, c)
+            gg = torch.zeros_like(out) if g is None else g
+            T['D%d_2' % h].copy_(to_tfmt(gg * out * (1 - out), 1))
+        self.run('prog_bwd', descs, wbuf, T, self.specs, N)
+        ws = torch.empty(self.n_split * 256 * 256, dtype=torch.float32, device=T['Z'].device)
+        dW, db = [], []
+        for h, net in enumerate(self.nets):
+            w0, w1, c = net.widths
+            D0, D1, D2 = T['D%d_0' % h], T['D%d_1' % h], T['D%d_2' % h]
+            g0 = self.wgrad(D0, T['Z'], w0, self.Z, ws).t().contiguous()
+            g1 = self.wgrad(D1, T['Y%d_0' % h], w1, w0, ws).t().contiguous()
+            g2 = torch.cat([self.wgrad(D2, T['Y%d_1' % h], c, w1, ws), self.wgrad(D2, T['Z'], c, self.Z, ws)], 1).t().contiguous()
+            dW += [g0, g1, g2]
+            db += [D0.sum((0, 3)).reshape(-1)[:w0], D1.sum((0, 3)).reshape(-1)[:w1], D2.sum((0, 3)).reshape(-1)[:c]]
+        return from_tfmt(T['GZ'], N, self.Z), dW, db
+
+
+class HeadsFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, engine, z, *params):
+        nh = len(engine.nets)
+        W = [[p.detach().float() for p in params[3 * h:3 * h + 3]] for h in range(nh)]
+        b = [[p.detach().float() for p in params[3 * nh + 3 * h:3 * nh + 3 * h + 3]] for h in range(nh)]
+        with torch.no_grad():
+            T, wbuf, descs = engine.forward(z.detach().float().contiguous(), W, b)
+        ctx.engine, ctx.T, ctx.wbuf, ctx.descs, ctx.N = engine, T, wbuf, descs, z.shape[0]
+        return tuple(from_tfmt(T['Y%d_2' % h], z.shape[0], net.widths[2]).contiguous() for h, net in enumerate(engine.nets))
+
+    @staticmethod
+    def backward(ctx, *g_outs):
+        with torch.no_grad():
+            g_z, dW, db = ctx.engine.backward(ctx.T, ctx.wbuf, ctx.descs, g_outs, ctx.N)
+        ctx.T = None
+        return (None, g_z.contiguous()) + tuple(dW) + tuple(db)
