@@ -172,8 +172,13 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     tr = train_nfr.Trainer(model, opt2)
     dt = _time_gpu(lambda: tr.train_iter(small, global_bs=1024), 5, warm=2)
     out['decomp_train'] = {'points_per_s': 2048 / dt, 'ms_per_step': dt * 1e3, 'batch_points': 2048,
-                           'note': 'HIP: VQ assign / EMA statistics, fused shading forward + backward; the Dense stacks run forward/'
-                                   'backward through torch autograd ops on the GPU (latency-bound at 2048 points)'}
+                           'note': 'all HIP: encoder / heads forward + backward tile programs, weight-gradient contraction, fused '
+                                   'shading forward + backward, VQ assign / EMA statistics; torch for the loss, Adam and glue '
+                                   '(launch-latency-bound at the reference batch of 2048 points)'}
+    big_tr = points(262144)
+    dt = _time_gpu(lambda: tr.train_iter(big_tr, global_bs=262144), 3, warm=1)
+    out['decomp_train_256k'] = {'points_per_s': 262144 / dt, 'ms_per_step': dt * 1e3, 'batch_points': 262144,
+                                'note': 'same step on a 128x larger batch (what a data-parallel / large-batch run would use)'}
 
     # ---- standalone VQ nearest-code assignment + EMA statistics (HBM-bound) ----
     Nv, D, K = 1 << 20, 256, 15

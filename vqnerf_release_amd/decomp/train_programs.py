@@ -12,9 +12,8 @@ import numpy as np
 import torch
 
 from vqnerf_release_amd import _C
-from vqnerf_release_amd.geo.packing import _take
 from vqnerf_release_amd.geo.train_programs import (Program, _ident, _f2i, DESC_INTS, K_LD_POSENC, K_LD_T, EPI_ACT, EPI_MUL_DACT,
-                                                   ACT_NONE, ACT_RELU, ACT_SIGMOID)
+                                                   ACT_NONE, ACT_RELU, ACT_SIGMOID, FlatLayout, build_static_packs)
 
 ACTS = {None: ACT_NONE, 'relu': ACT_RELU, 'sigmoid': ACT_SIGMOID}
 
@@ -50,33 +49,20 @@ class _Engine:
             setattr(self, name, best.materialize())
         self._dev = {}
 
-    def _gathers(self, prog, device):
-        k = (id(prog), str(device))
-        if k not in self._dev:
-            self._dev[k] = [(key, torch.from_numpy(wi).to(device), bkey, None if bi is None else torch.from_numpy(bi).to(device), oi)
-                            for key, wi, bkey, bi, oi in prog.gathers]
-        return self._dev[k]
+    def _static(self, names):
+        """weight-independent part of the packs (global gather index + descriptors), built once."""
+        if 'static' not in self._dev:
+            L = self.layout()
+            progs = {n: getattr(self, n) for n in names}
+            gidx, descs = build_static_packs(progs, L, lambda key: self.mat_index(key, L))
+            self._dev['static'] = (L, torch.from_numpy(gidx).to(self.device),
+                                   {n: (d, torch.from_numpy(d).to(self.device)) for n, d in descs.items()})
+        return self._dev['static']
 
-    def pack(self, names, mats):
-        """mats(key) -> matrix for a gather key.  Returns (wbuf, {prog name: (desc host, desc dev)})."""
-        chunks, off, descs, dev = [], 0, {}, None
-        for name in names:
-            prog = getattr(self, name)
-            ops = [list(o) for o in prog.ops]
-            for key, wi, bkey, bi, oi in self._gathers(prog, self.device):
-                c = _take(mats(key).contiguous(), wi)
-                ops[oi][6] = off // 4
-                chunks.append(c); off += c.numel()
-                if bkey is not None:
-                    cb = _take(mats(bkey).contiguous(), bi)
-                    ops[oi][7] = off // 4
-                    chunks.append(cb); off += cb.numel()
-            d = np.zeros(DESC_INTS, np.int32)
-            d[0:4] = [len(ops), prog.total_rows, prog.n_waves, len(prog.tn)]
-            for i, o in enumerate(ops):
-                d[16 + 16 * i: 32 + 16 * i] = o
-            descs[name] = (d, torch.from_numpy(d).to(self.device))
-        return torch.cat(chunks).contiguous(), descs
+    def pack(self, names, sources):
+        """sources: dict name -> tensor as declared by layout().  ONE gather builds the whole weight buffer."""
+        L, gidx, descs = self._static(names)
+        return L.flatten(sources)[gidx], descs
 
     def run(self, which, descs, wbuf, tensors, specs, N):
         prog = getattr(self, which)
@@ -169,21 +155,29 @@ class EncoderEngine(_Engine):
                 ks.append((layer.kernel, layer.bias))
         return ks
 
-    def _mats(self, W, b):
-        def m(key):
-            kind, k = key
-            if kind == 'Wt':
-                return W[k].t()
-            if kind == 'b':
-                return b[k]
-            if kind == 'Wy':
-                return W[k][:self.layers[k]['in_y'], :]
-            raise KeyError(key)
-        return m
+    def layout(self):
+        shp = []
+        for k, L in enumerate(self.layers):
+            shp.append(('W%d' % k, (L['in_y'] + (self.E if L['skip'] else 0), L['out'])))
+        for k, L in enumerate(self.layers):
+            shp.append(('b%d' % k, (L['out'],)))
+        return FlatLayout(shp)
+
+    def mat_index(self, key, L):
+        kind, k = key
+        if kind == 'Wt':
+            return L['W%d' % k].T
+        if kind == 'b':
+            return L['b%d' % k]
+        if kind == 'Wy':
+            return L['W%d' % k][:self.layers[k]['in_y'], :]
+        raise KeyError(key)
 
     def forward(self, xyz, W, b):
         N = xyz.shape[0]
-        wbuf, descs = self.pack(['prog_fwd', 'prog_bwd'], self._mats(W, b))
+        src = {'W%d' % k: w for k, w in enumerate(W)}
+        src.update({'b%d' % k: t for k, t in enumerate(b)})
+        wbuf, descs = self.pack(['prog_fwd', 'prog_bwd'], src)
         T = self.alloc(self.specs, N, xyz.device)
         T['X'].copy_(xyz)
         self.run('prog_fwd', descs, wbuf, T, self.specs, N)
@@ -278,28 +272,38 @@ class HeadsEngine(_Engine):
                    store='GZ' if h == last else None)
         return P.finalize()
 
-    def _mats(self, W, b):
-        def m(key):
-            kind, h = key[0], key[1]
-            w1 = self.nets[h].widths[1]
-            if kind == 'Wt':
-                return W[h][key[2]].t()
-            if kind == 'b':
-                return b[h][key[2]]
-            if kind == 'W2z':
-                return W[h][2][w1:, :]
-            if kind == 'W2y':
-                return W[h][2][:w1, :]
-            if kind == 'W1':
-                return W[h][1]
-            if kind == 'W0':
-                return W[h][0]
-            raise KeyError(key)
-        return m
+    def layout(self):
+        shp = []
+        for h, net in enumerate(self.nets):
+            w0, w1, c = net.widths
+            shp += [('W%d_0' % h, (self.Z, w0)), ('W%d_1' % h, (w0, w1)), ('W%d_2' % h, (w1 + self.Z, c)),
+                    ('b%d_0' % h, (w0,)), ('b%d_1' % h, (w1,)), ('b%d_2' % h, (c,))]
+        return FlatLayout(shp)
+
+    def mat_index(self, key, L):
+        kind, h = key[0], key[1]
+        w1 = self.nets[h].widths[1]
+        if kind == 'Wt':
+            return L['W%d_%d' % (h, key[2])].T
+        if kind == 'b':
+            return L['b%d_%d' % (h, key[2])]
+        if kind == 'W2z':
+            return L['W%d_2' % h][w1:, :]
+        if kind == 'W2y':
+            return L['W%d_2' % h][:w1, :]
+        if kind == 'W1':
+            return L['W%d_1' % h]
+        if kind == 'W0':
+            return L['W%d_0' % h]
+        raise KeyError(key)
 
     def forward(self, z, W, b):
         N = z.shape[0]
-        wbuf, descs = self.pack(['prog_fwd', 'prog_bwd'], self._mats(W, b))
+        src = {}
+        for h in range(len(self.nets)):
+            for k in range(3):
+                src['W%d_%d' % (h, k)], src['b%d_%d' % (h, k)] = W[h][k], b[h][k]
+        wbuf, descs = self.pack(['prog_fwd', 'prog_bwd'], src)
         T = self.alloc(self.specs, N, z.device)
         T['Z'].copy_(to_tfmt(z, self.specs['Z'][1]))
         self.run('prog_fwd', descs, wbuf, T, self.specs, N)

@@ -107,6 +107,54 @@ def _shift(lo, hi, base):
     return lambda f: np.where((f >= lo) & (f < hi), f - lo + base, -1)
 
 
+class FlatLayout:
+    """Positions of named source tensors inside one flat vector (the last slot is a constant zero): any transpose / slice
+    of a source is then just an integer index array, so a whole weight pack is ONE gather from the flat vector."""
+
+    def __init__(self, shapes):
+        self.names = [n for n, _ in shapes]
+        self.views, off = {}, 0
+        for n, shp in shapes:
+            k = int(np.prod(shp))
+            self.views[n] = np.arange(off, off + k, dtype=np.int64).reshape(shp)
+            off += k
+        self.zero = off
+        self.size = off + 1
+
+    def __getitem__(self, name):
+        return self.views[name]
+
+    def flatten(self, tensors):
+        """tensors: dict name -> tensor (same shapes as declared) -> flat vector on their device"""
+        first = tensors[self.names[0]]
+        return torch.cat([tensors[n].reshape(-1).float() for n in self.names] + [first.new_zeros(1, dtype=torch.float32)])
+
+
+def build_static_packs(programs, layout, mat_index):
+    """programs: {name: Program (materialized)}.  mat_index(key) -> int64 array (positions in the flat vector, layout.zero for
+    structural zeros) shaped like the matrix / bias the gather key denotes.
+    Returns (global gather index [wbuf_len] int64 numpy, {name: desc int32 numpy}) -- both independent of the weight values."""
+    chunks, off, descs = [], 0, {}
+    for name, prog in programs.items():
+        ops = [list(o) for o in prog.ops]
+        for key, wi, bkey, bi, oi in prog.gathers:
+            src = np.append(np.ascontiguousarray(mat_index(key)).reshape(-1), layout.zero)
+            c = src[wi.reshape(-1)]
+            ops[oi][6] = off // 4
+            chunks.append(c); off += c.size
+            if bkey is not None:
+                srcb = np.append(np.ascontiguousarray(mat_index(bkey)).reshape(-1), layout.zero)
+                cb = srcb[bi.reshape(-1)]
+                ops[oi][7] = off // 4
+                chunks.append(cb); off += cb.size
+        d = np.zeros(DESC_INTS, np.int32)
+        d[0:4] = [len(ops), prog.total_rows, prog.n_waves, len(prog.tn)]
+        for i, o in enumerate(ops):
+            d[16 + 16 * i: 32 + 16 * i] = o
+        descs[name] = d
+    return np.concatenate(chunks), descs
+
+
 class NeusTrainEngine:
     """Programs, packs and launches for one (SDFNetwork, RenderingNetwork) pair."""
 
@@ -263,68 +311,64 @@ class NeusTrainEngine:
         return P.finalize()
 
     # packs -----------------------------------------------------------------------------------------
-    def _matrix(self, key, W, b, Wc, bc):
-        """the [rows, cols] matrix a gather key refers to"""
+    def _layout(self):
+        shapes = [('W%d' % l, (self.out[l], self.inn[l])) for l in range(self.nL + 1)] + \
+                 [('b%d' % l, (self.out[l],)) for l in range(self.nL + 1)] + \
+                 [('Wc%d' % l, (self.cout[l], self.cin[l])) for l in range(self.nC + 1)] + \
+                 [('bc%d' % l, (self.cout[l],)) for l in range(self.nC + 1)]
+        return FlatLayout(shapes)
+
+    def _matrix_index(self, key, L):
+        """positions (in the flat source vector) of the [rows, cols] matrix a gather key refers to.  The skip layer's 1/sqrt2
+        (fields.py:82) is applied to its source W before flattening (see pack)."""
         kind = key[0]
-        s2 = 1.0 / math.sqrt(2.0)
         if kind == 'W':
-            l = key[1]
-            return W[l] * s2 if l == self.skip else W[l]
+            return L['W%d' % key[1]]
         if kind == 'b':
-            return b[key[1]]
+            return L['b%d' % key[1]]
         if kind == 'Wc':
-            return Wc[key[1]]
+            return L['Wc%d' % key[1]]
         if kind == 'bc':
-            return bc[key[1]]
+            return L['bc%d' % key[1]]
         if kind == 'WT_sdfrow':
-            return W[self.nL][:1].t()
+            return L['W%d' % self.nL][:1].T
         if kind == 'WT_u':                                     # rows = features of u_l (the part of in_l that is u_l)
             l = key[1]
-            M = W[l][:, :self.out[l - 1]].t()
-            return M * s2 if l == self.skip else M
+            return L['W%d' % l][:, :self.out[l - 1]].T
         if kind == 'WT_e':
             l = key[1]
-            M = (W[l][:, self.out[l - 1]:] if l == self.skip and l > 0 else W[l]).t()
-            return M * s2 if l == self.skip else M
+            return (L['W%d' % l][:, self.out[l - 1]:] if l == self.skip and l > 0 else L['W%d' % l]).T
         if kind == 'WT_last':
-            return W[self.nL].t()
+            return L['W%d' % self.nL].T
         if kind == 'WcT':
-            return Wc[key[1]].t()
+            return L['Wc%d' % key[1]].T
         if kind == 'WcT0_feat':                                 # rows in OUTF order: [0 (sdf) ; feat]
-            M = Wc[0][:, self.X:].t()
-            return torch.cat([M.new_zeros(1, M.shape[1]), M], 0)
+            M = L['Wc0'][:, self.X:].T
+            return np.concatenate([np.full((1, M.shape[1]), L.zero, np.int64), M], 0)
         if kind == 'WcT0_extra':
-            return Wc[0][:, :self.X].t()
+            return L['Wc0'][:, :self.X].T
         raise KeyError(key)
 
-    def _dev_gathers(self, prog, device):
-        k = (id(prog), str(device))
+    def _static(self, device):
+        """weight-independent part of the packs: one global gather index + the three descriptors (cached per device)."""
+        k = str(device)
         if k not in self._dev:
-            self._dev[k] = [(key, torch.from_numpy(wi).to(device), bkey, None if bi is None else torch.from_numpy(bi).to(device), oi)
-                            for key, wi, bkey, bi, oi in prog.gathers]
+            L = self._layout()
+            progs = {n: getattr(self, n) for n in ('prog_fwd', 'prog_cbwd', 'prog_sbwd')}
+            gidx, descs = build_static_packs(progs, L, lambda key: self._matrix_index(key, L))
+            self._dev[k] = (L, torch.from_numpy(gidx).to(device), {n: (d, torch.from_numpy(d).to(device)) for n, d in descs.items()})
         return self._dev[k]
 
     def pack(self, W, b, Wc, bc):
-        """effective weights -> one flat buffer + per-program descriptors (host numpy + device copy)."""
-        dev = W[0].device
-        chunks, off, descs = [], 0, {}
-        for name in ('prog_fwd', 'prog_cbwd', 'prog_sbwd'):
-            prog = getattr(self, name)
-            ops = [list(o) for o in prog.ops]
-            for key, wi, bkey, bi, oi in self._dev_gathers(prog, dev):
-                c = _take(self._matrix(key, W, b, Wc, bc).contiguous(), wi)
-                ops[oi][6] = off // 4
-                chunks.append(c); off += c.numel()
-                if bkey is not None:
-                    cb = _take(self._matrix(bkey, W, b, Wc, bc).contiguous(), bi)
-                    ops[oi][7] = off // 4
-                    chunks.append(cb); off += cb.numel()
-            d = np.zeros(DESC_INTS, np.int32)
-            d[0:4] = [len(ops), prog.total_rows, prog.n_waves, len(prog.tn)]
-            for i, o in enumerate(ops):
-                d[16 + 16 * i: 32 + 16 * i] = o
-            descs[name] = (d, torch.from_numpy(d).to(dev))
-        return torch.cat(chunks).contiguous(), descs
+        """effective weights -> one flat buffer (ONE gather) + the cached per-program descriptors."""
+        L, gidx, descs = self._static(W[0].device)
+        src = {}
+        for l in range(self.nL + 1):
+            src['W%d' % l] = W[l] * (1.0 / math.sqrt(2.0)) if l == self.skip else W[l]
+            src['b%d' % l] = b[l]
+        for l in range(self.nC + 1):
+            src['Wc%d' % l], src['bc%d' % l] = Wc[l], bc[l]
+        return L.flatten(src)[gidx], descs
 
     # launches --------------------------------------------------------------------------------------
     def alloc_tensors(self, P, device):
