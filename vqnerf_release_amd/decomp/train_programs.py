@@ -39,12 +39,6 @@ class _Engine:
     def _finish(self, progs):
         for name, build in progs:
             best = build(None)
-            for seed in range(60):
-                if best.total_rows <= 79:
-                    break
-                cand = build(seed)
-                if cand.total_rows < best.total_rows:
-                    best = cand
             assert best.total_rows * 1024 <= 160 * 1024
             setattr(self, name, best.materialize())
         self._dev = {}
@@ -127,7 +121,7 @@ class EncoderEngine(_Engine):
     def _build_fwd(self, seed):
         P = Program(list(self.specs.keys()), seed)
         rE = P.alloc(self.E, [])
-        P.op(K_LD_POSENC, P.t('X'), rE.row0, self.mr, self.E, P.t('E'), _f2i(1.0))
+        P.op(K_LD_POSENC, P.t('X'), P.row(rE), self.mr, self.E, P.t('E'), _f2i(1.0))
         prev = rE
         for k, L in enumerate(self.layers):
             if L['skip']:
@@ -141,7 +135,7 @@ class EncoderEngine(_Engine):
         P = Program(list(self.specs.keys()), seed)
         top = self.nl - 1
         r = P.alloc(self.layers[top]['out'], [], tiles=(self.layers[top]['out'] + 31) // 32)
-        P.op(K_LD_T, P.t('GZ'), r.row0, r.rows)                       # = delta_top (act' of the top layer applied by the caller)
+        P.op(K_LD_T, P.t('GZ'), P.row(r), r.rows)                       # = delta_top (act' of the top layer applied by the caller)
         for k in range(top, 0, -1):                                   # delta_{k-1} = (W_k[y-part] delta_k) * act'_{k-1}(Y_{k-1})
             L, Lp = self.layers[k], self.layers[k - 1]
             r = P.gemm(('Wy', k), (L['in_y'], L['out']), [r], [_ident(L['out'])], L['in_y'], live=[], epi=EPI_MUL_DACT, act=Lp['act'],
@@ -241,7 +235,7 @@ class HeadsEngine(_Engine):
     def _build_fwd(self, seed):
         P = Program(list(self.specs.keys()), seed)
         rZ = P.alloc(self.Z, [])
-        P.op(K_LD_T, P.t('Z'), rZ.row0, rZ.rows)
+        P.op(K_LD_T, P.t('Z'), P.row(rZ), rZ.rows)
         for h, net in enumerate(self.nets):
             w0, w1, c = net.widths
             y0 = P.gemm(('Wt', h, 0), (w0, self.Z), [rZ], [_ident(self.Z)], w0, live=[rZ], act=ACT_RELU, bias_key=('b', h, 0), store='Y%d_0' % h)
@@ -257,7 +251,7 @@ class HeadsEngine(_Engine):
         for h, net in enumerate(self.nets):
             w0, w1, c = net.widths
             r2 = P.alloc(c, [rGZ] if rGZ else [], tiles=1)
-            P.op(K_LD_T, P.t('D%d_2' % h), r2.row0, r2.rows)           # delta_2 = g_out * sigmoid'(out), from the caller
+            P.op(K_LD_T, P.t('D%d_2' % h), P.row(r2), r2.rows)           # delta_2 = g_out * sigmoid'(out), from the caller
             keep = [rGZ] if rGZ else []
             # z-part of the last layer's input: GZ (+)= W2[w1:, :] delta_2
             if rGZ is None:

@@ -35,63 +35,103 @@ def _f2i(x):
 
 
 class Region:
-    def __init__(self, row0, feats, alloc_rows):
-        self.row0, self.feats, self.alloc_rows = row0, feats, alloc_rows
+    """`feats` features of a 32-point tile in LDS rows [row0, row0 + alloc_rows); row0 is assigned by Program.finalize()."""
+
+    def __init__(self, feats, alloc_rows):
+        self.row0, self.feats, self.alloc_rows = None, feats, alloc_rows
         self.rows = (feats + 7) // 8
 
 
+class _Row:          # placeholder inside an op: "row0 of this region", resolved when the program is finalized
+    def __init__(self, region):
+        self.region = region
+
+
 class Program:
-    """Op list + first-fit LDS row allocation + the weight gathers its GEMMs need."""
+    """Op list + the weight gathers its GEMMs need.  LDS rows are assigned at finalize() by an exact depth-first search over
+    the allocation requests (each new region must not overlap the regions live at that point), minimising the row count --
+    staying under 80 rows keeps two workgroups resident per CU."""
 
     def __init__(self, tensor_names, seed=None):
         self.tn = {n: i for i, n in enumerate(tensor_names)}
         assert len(self.tn) <= MAX_TENSORS
         self.ops, self.gathers, self.total_rows = [], [], 0
-        self.rng = None if seed is None else np.random.default_rng(seed)
-        self.ends = {0}
+        self.requests = []          # (region, live regions) in program order
 
     def t(self, name):
         return -1 if name is None else self.tn[name]
 
     def alloc(self, feats, live, tiles=None, high=False):
-        """Rows for a new region that overlaps none of `live`.  Deterministic first-fit when the program was made without
-        a seed; with a seed, a random valid candidate (the engine keeps the tightest of many seeded builds)."""
         rows = 4 * tiles if tiles is not None else (feats + 7) // 8
-        free = lambda r0: not any(r0 < r.row0 + r.alloc_rows and r.row0 < r0 + rows for r in live)
-        cands = sorted(c for c in (self.ends | {r.row0 + r.alloc_rows for r in live}) if free(c))
-        if self.rng is None or len(cands) == 1:
-            row0 = cands[0]
-        else:
-            cands = cands[:4]
-            row0 = cands[int(self.rng.choice(len(cands), p=np.array([0.55, 0.25, 0.12, 0.08][:len(cands)]) / sum([0.55, 0.25, 0.12, 0.08][:len(cands)])))]
-        self.ends.add(row0 + rows)
-        self.total_rows = max(self.total_rows, row0 + rows)
-        return Region(row0, feats, rows)
+        r = Region(feats, rows)
+        self.requests.append((r, [x for x in live if x is not None]))
+        return r
 
     def gemm(self, key, M_shape, segs, col_fns, out_feats, live, epi=EPI_ACT, act=ACT_NONE, bias_key=None, aux1=None, aux2=None,
              store=None, store2=None, dst=None, accumulate=False, want_dst=True, high=False):
         """segs: Regions forming K; col_fns[i](f) -> column of M for local feature f of segs[i] (or -1)."""
         tiles = (out_feats + 31) // 32
         if dst is None and want_dst:
-            dst = self.alloc(out_feats, list(segs) + list(live), tiles=tiles, high=high)
+            dst = self.alloc(out_feats, list(segs) + list(live), tiles=tiles)
         seg_desc = [(s.rows, fn) for s, fn in zip(segs, col_fns)]
         self.gathers.append((key, (M_shape[0], M_shape[1], seg_desc), bias_key, out_feats if bias_key else None, len(self.ops)))
         kA, kB = segs[0], (segs[1] if len(segs) > 1 else None)
-        self.ops.append([K_GEMM, tiles, kA.row0, kA.rows, kB.row0 if kB else 0, kB.rows if kB else 0, -1, -1,
-                         dst.row0 if dst is not None else -1, epi, act, self.t(aux1), self.t(aux2), self.t(store), self.t(store2),
+        self.ops.append([K_GEMM, tiles, _Row(kA), kA.rows, _Row(kB) if kB else 0, kB.rows if kB else 0, -1, -1,
+                         _Row(dst) if dst is not None else -1, epi, act, self.t(aux1), self.t(aux2), self.t(store), self.t(store2),
                          1 if accumulate else 0])
         return dst
 
     def op(self, kind, *p):
         self.ops.append([kind] + list(p) + [0] * (15 - len(p)))
 
+    def row(self, region):
+        return _Row(region)
+
     def materialize(self):
-        """build the (large) gather index arrays -- only for the program build that is kept"""
+        """build the (large) gather index arrays"""
         self.gathers = [(key, gemm_index(*spec), bkey, None if bo is None else bias_index(bo), oi)
                         for key, spec, bkey, bo, oi in self.gathers]
         return self
 
+    def _solve_rows(self, node_limit=400000):
+        reqs = self.requests
+        n = len(reqs)
+        best = {'top': None, 'pos': None}
+        nodes = [0]
+        placed = []
+
+        def rec(i, top, pos):
+            if best['top'] is not None and top >= best['top']:
+                return
+            if i == n:
+                best['top'], best['pos'] = top, list(pos)
+                return
+            nodes[0] += 1
+            if nodes[0] > node_limit and best['pos'] is not None:
+                return
+            reg, live = reqs[i]
+            need = reg.alloc_rows
+            cands = sorted({0} | {r.row0 + r.alloc_rows for r in placed})
+            for c in cands:
+                if any(c < r.row0 + r.alloc_rows and r.row0 < c + need for r in live):
+                    continue
+                reg.row0 = c
+                placed.append(reg)
+                rec(i + 1, max(top, c + need), pos + [c])
+                placed.pop()
+                reg.row0 = None
+                if best['top'] is not None and nodes[0] > node_limit:
+                    return
+
+        rec(0, 0, [])
+        assert best['pos'] is not None
+        for (reg, _), c in zip(reqs, best['pos']):
+            reg.row0 = c
+        return best['top']
+
     def finalize(self, n_waves=None):
+        self.total_rows = self._solve_rows()
+        self.ops = [[(e.region.row0 if isinstance(e, _Row) else e) for e in op] for op in self.ops]
         lds = self.total_rows * 1024
         self.n_waves = n_waves or (4 if 2 * lds <= 160 * 1024 else 8)
         assert len(self.ops) <= MAX_OPS, len(self.ops)
@@ -185,12 +225,6 @@ class NeusTrainEngine:
         for name, build in (('prog_fwd', self._build_forward), ('prog_cbwd', self._build_colour_backward),
                             ('prog_sbwd', self._build_sdf_backward)):
             best = build(None)
-            for seed in range(200):                           # LDS row packing: keep the tightest of many seeded builds
-                if best.total_rows <= 79:
-                    break
-                cand = build(seed)
-                if cand.total_rows < best.total_rows:
-                    best = cand
             assert best.total_rows * 1024 <= 160 * 1024, f'{name}: {best.total_rows} KB of LDS'
             setattr(self, name, best.materialize())
         self._dev = {}
@@ -230,7 +264,7 @@ class NeusTrainEngine:
         P = Program(self._names(), seed)
         nL, nC = self.nL, self.nC
         rE = P.alloc(self.E, [])
-        P.op(K_LD_POSENC, P.t('X'), rE.row0, self.mr, self.E, P.t('E'), _f2i(self.scale))
+        P.op(K_LD_POSENC, P.t('X'), P.row(rE), self.mr, self.E, P.t('E'), _f2i(self.scale))
         prev = None
         for l in range(nL):
             segs, cols = self._sdf_fwd_cols(l, prev, rE)
@@ -238,11 +272,11 @@ class NeusTrainEngine:
                           bias_key=('b', l), store='U%d' % (l + 1))
         rU = prev
         rOUT = P.gemm(('W', nL), (self.F, self.inn[nL]), [rU], [_ident(self.inn[nL])], self.F, live=[], bias_key=('b', nL), store='OUTF')
-        P.op(K_ST_VEC, rOUT.row0, 0, 1, P.t('SDF'), ACT_NONE, _f2i(1.0 / self.scale))
+        P.op(K_ST_VEC, P.row(rOUT), 0, 1, P.t('SDF'), ACT_NONE, _f2i(1.0 / self.scale))
         # reverse sweep for n = d sdf / dx.  rOUT is NOT kept in LDS meanwhile (it is re-read from OUTF for the colour net):
         # that keeps the program under 80 KB, i.e. two workgroups per CU.
         rONE = P.alloc(1, [])
-        P.op(K_LD_VEC, P.t('ONES'), rONE.row0, 1, _f2i(1.0), -1, 0)
+        P.op(K_LD_VEC, P.t('ONES'), P.row(rONE), 1, _f2i(1.0), -1, 0)
         g = P.gemm(('WT_sdfrow',), (self.out[nL - 1], 1), [rONE], [_ident(1)], self.out[nL - 1], live=[],
                    epi=EPI_MUL_DACT, act=ACT_SOFTPLUS, aux1='U%d' % nL, store='GH%d' % (nL - 1))
         rEB, have_eb = None, False
@@ -258,12 +292,12 @@ class NeusTrainEngine:
             P.gemm(('WT_e', 0), (self.E, self.out[0]), [g], [_ident(self.out[0])], self.E, live=[], dst=rEB, accumulate=True)
         else:
             rEB = P.gemm(('WT_e', 0), (self.E, self.out[0]), [g], [_ident(self.out[0])], self.E, live=[g])
-        P.op(K_POSENC_VJP, rEB.row0, P.t('X'), P.t('N'), self.mr, _f2i(self.scale))
+        P.op(K_POSENC_VJP, P.row(rEB), P.t('X'), P.t('N'), self.mr, _f2i(self.scale))
         # colour network on [pts, posenc(view), normals, feat]
         rOUT = P.alloc(self.F, [], tiles=self._tiles(self.F))
-        P.op(K_LD_T, P.t('OUTF'), rOUT.row0, rOUT.rows)
+        P.op(K_LD_T, P.t('OUTF'), P.row(rOUT), rOUT.rows)
         rEX = P.alloc(self.X, [rOUT])
-        P.op(K_LD_EXTRAS, P.t('X'), P.t('DIRS'), P.t('N'), rEX.row0, self.mrv, P.t('EXTR'), self.X)
+        P.op(K_LD_EXTRAS, P.t('X'), P.t('DIRS'), P.t('N'), P.row(rEX), self.mrv, P.t('EXTR'), self.X)
         prev = P.gemm(('Wc', 0), (self.cout[0], self.cin[0]), [rOUT, rEX], [_shift(1, self.F, self.X), _ident(self.X)], self.cout[0],
                       live=[], act=ACT_RELU, bias_key=('bc', 0), store='C1')
         for l in range(1, nC):
@@ -271,28 +305,28 @@ class NeusTrainEngine:
                           bias_key=('bc', l), store='C%d' % (l + 1))
         rRGB = P.gemm(('Wc', nC), (3, self.cin[nC]), [prev], [_ident(self.cin[nC])], 3, live=[],
                       act=ACT_SIGMOID if self.squeeze else ACT_NONE, bias_key=('bc', nC))
-        P.op(K_ST_VEC, rRGB.row0, 0, 3, P.t('RGB'), ACT_NONE, _f2i(1.0))
+        P.op(K_ST_VEC, P.row(rRGB), 0, 3, P.t('RGB'), ACT_NONE, _f2i(1.0))
         return P.finalize()
 
     def _build_colour_backward(self, seed):
         P = Program(self._names(), seed)
         nC = self.nC
         rD = P.alloc(3, [], tiles=1)
-        P.op(K_LD_VEC, P.t('DOUT'), rD.row0, 3, _f2i(1.0), P.t('DC%d' % nC), 0)
+        P.op(K_LD_VEC, P.t('DOUT'), P.row(rD), 3, _f2i(1.0), P.t('DC%d' % nC), 0)
         for l in range(nC, 0, -1):                            # delta_{l-1} = (Wc_l^T delta_l) * relu'(c_l)
             rD = P.gemm(('WcT', l), (self.cin[l], self.cout[l]), [rD], [_ident(self.cout[l])], self.cin[l], live=[],
                         epi=EPI_MUL_DACT, act=ACT_RELU, aux1='C%d' % l, store='DC%d' % (l - 1))
         # adjoints of the colour-net inputs: [sdf(=0) ; feat] in OUTF feature order, and the extras (normals at X-3..X-1)
         P.gemm(('WcT0_feat',), (self.F, self.cout[0]), [rD], [_ident(self.cout[0])], self.F, live=[rD], store='GOUTF', want_dst=False)
         rGX = P.gemm(('WcT0_extra',), (self.X, self.cout[0]), [rD], [_ident(self.cout[0])], self.X, live=[rD])
-        P.op(K_ST_VEC, rGX.row0, self.X - 3, 3, P.t('GNCOL'), ACT_NONE, _f2i(1.0))
+        P.op(K_ST_VEC, P.row(rGX), self.X - 3, 3, P.t('GNCOL'), ACT_NONE, _f2i(1.0))
         return P.finalize()
 
     def _build_sdf_backward(self, seed):
         P = Program(self._names(), seed)
         nL = self.nL
         rED = P.alloc(self.E, [])
-        P.op(K_LD_POSENC_JVP, P.t('X'), P.t('V'), rED.row0, self.mr, self.E, P.t('ED'), _f2i(self.scale))
+        P.op(K_LD_POSENC_JVP, P.t('X'), P.t('V'), P.row(rED), self.mr, self.E, P.t('ED'), _f2i(self.scale))
         prev = None
         for l in range(nL):                                   # tangent pass (no bias)
             segs, cols = self._sdf_fwd_cols(l, prev, rED)
@@ -300,9 +334,9 @@ class NeusTrainEngine:
                           aux1='U%d' % (l + 1), aux2='GH%d' % l, store='UD%d' % (l + 1), store2='S%d' % l)
         # adjoint of u_L from the final layer: W_L[1:]^T g_feat + W_L[0]^T g_sdf / scale
         rGO = P.alloc(self.F, [])
-        P.op(K_LD_T, P.t('GOUTF'), rGO.row0, rGO.rows)
+        P.op(K_LD_T, P.t('GOUTF'), P.row(rGO), rGO.rows)
         rGS = P.alloc(1, [rGO])
-        P.op(K_LD_VEC, P.t('GS'), rGS.row0, 1, _f2i(1.0 / self.scale), -1, 0)
+        P.op(K_LD_VEC, P.t('GS'), P.row(rGS), 1, _f2i(1.0 / self.scale), -1, 0)
         ab = P.gemm(('WT_last',), (self.out[nL - 1], self.F), [rGO, rGS], [_shift(1, self.F, 1), _ident(1)], self.out[nL - 1], live=[],
                     epi=EPI_BWD2, act=ACT_SOFTPLUS, aux1='U%d' % nL, aux2='S%d' % (nL - 1), store='AB%d' % (nL - 1))
         for l in range(nL - 1, 0, -1):
