@@ -39,7 +39,10 @@ int vqn_vq_assign(const float* x, int64_t N, int D, const float* codebook, int K
  *   counts[k] = #{n : idx[n] == k}   (as float),   dw[d,k] = sum_n x[n,d] [idx[n] == k].
  * counts [K], dw [D,K] are overwritten. */
 int vqn_vq_ema_stats(const float* x, const int64_t* idx, int64_t N, int D, int K, float* counts, float* dw,
-                     void* stream);
+                     float* ws, int64_t ws_bytes, void* stream);
+/* Bytes of device scratch `ws` that make vqn_vq_ema_stats use its deterministic two-pass form (per-wave LDS images,
+ * fixed-order reduction; K*D <= 4096); 0 = not applicable.  With ws == NULL the single-pass LDS-atomic form runs. */
+int64_t vqn_vq_ema_stats_ws_bytes(int64_t N, int D, int K);
 
 /* ---- reflectance MLP stacks + shading (decomp/nerfvq_nfr3/nerfactor) ------------------------- */
 

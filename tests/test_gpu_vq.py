@@ -131,3 +131,23 @@ def test_full_size_properties():
     perm = torch.randperm(N, device='cuda', generator=g)
     idx_p, _, _ = _C.vq_assign(x[perm].contiguous(), C, want_quant=False)
     assert torch.equal(idx_p, idx[perm])                              # row-order independence
+
+
+def test_ema_stats_two_pass_is_deterministic_and_matches_atomic_form():
+    """K*D <= 4096 takes the two-pass form (per-wave LDS images, fixed-order reduction): bit-identical across runs;
+    larger codebooks take the LDS-atomic form; both agree with the fp64-accumulated oracle."""
+    import torch
+    from oracle import vq_strict
+    from vqnerf_release_amd import _C
+    rng = np.random.default_rng(3)
+    for K in (15, 64):
+        x = rng.uniform(0, 1, (50001, 256)).astype(np.float32)
+        idx = rng.integers(0, K, 50001)
+        xt, it = torch.tensor(x).cuda(), torch.tensor(idx).cuda()
+        c1, d1 = _C.vq_ema_stats(xt, it, K)
+        c2, d2 = _C.vq_ema_stats(xt, it, K)
+        rc, rd = vq_strict.ema_stats(x, idx, K)
+        np.testing.assert_array_equal(c1.cpu().numpy(), rc)
+        np.testing.assert_allclose(d1.cpu().numpy(), rd, rtol=2e-5, atol=1e-3)
+        if K * 256 <= 4096:
+            assert torch.equal(d1, d2) and torch.equal(c1, c2)

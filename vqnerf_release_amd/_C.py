@@ -131,9 +131,13 @@ def vq_ema_stats(x, idx, K):
     assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() == N
     counts = torch.empty((K,), dtype=torch.float32, device=x.device)
     dw = torch.empty((D, K), dtype=torch.float32, device=x.device)
+    L = lib()
+    L.vqn_vq_ema_stats_ws_bytes.restype = ctypes.c_int64
+    need = int(L.vqn_vq_ema_stats_ws_bytes(ctypes.c_int64(N), ctypes.c_int(D), ctypes.c_int(K)))
+    ws = torch.empty((need // 4,), dtype=torch.float32, device=x.device) if need > 0 else None
     with _clock('vqn_vq_ema_stats'):
-        rc = lib().vqn_vq_ema_stats(_ptr(x), _ptr(idx), ctypes.c_int64(N), ctypes.c_int(D), ctypes.c_int(K),
-                                    _ptr(counts), _ptr(dw), _stream())
+        rc = L.vqn_vq_ema_stats(_ptr(x), _ptr(idx), ctypes.c_int64(N), ctypes.c_int(D), ctypes.c_int(K),
+                                _ptr(counts), _ptr(dw), _ptr(ws), ctypes.c_int64(need), _stream())
     _check(rc, 'vqn_vq_ema_stats')
     return counts, dw
 

@@ -24,9 +24,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ float clip01(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
 __device__ __forceinline__ float div_no_nan(float a, float b) { return b == 0.f ? 0.f : a / b; }
 // tf.linalg.l2_normalize: x * rsqrt(max(sum(x^2), eps))   (util/math.py:63-64, eps = 1e-6)
+// v_rsq_f32 (1 ulp): the per-light loop is VALU-bound, an IEEE 1/sqrt costs ~20 instructions
 __device__ __forceinline__ float inv_norm(float x, float y, float z) {
-  return 1.0f / sqrtf(fmaxf(x * x + y * y + z * z, 1e-6f));
+  return __builtin_amdgcn_rsqf(fmaxf(x * x + y * y + z * z, 1e-6f));
 }
+// a / b with tf.math.divide_no_nan semantics on the 1-ulp hardware reciprocal
+__device__ __forceinline__ float fdiv_no_nan(float a, float b) { return b == 0.f ? 0.f : a * __builtin_amdgcn_rcpf(b); }
 
 struct ShadeArgs {
   const float *xyz, *normal, *rayo, *lvis, *lxyz, *lareas, *light, *gamma;
@@ -118,21 +121,22 @@ __global__ __launch_bounds__(256) void brdf_shade_kernel(const ShadeArgs a) {
       const float l_dot_n = wx * mx + wy * my + wz * mz;
       const float cl = clip01(l_dot_n);
       const float den = 4.f * fabsf(l_dot_n) * fabsf(v_dot_n);
+      const float inv_den = den == 0.f ? 0.f : __builtin_amdgcn_rcpf(den);
       const float lr = vis * Lr[k], lg = vis * Lg[k], lb = vis * Lb[k];
 #pragma unroll
       for (int s = 0; s < 2; ++s)
         if (s < a.n_sets) {
           const float a2 = M[s].a2;
           const float t = cos_m * cos_m * (a2 - 1.f) + 1.f;
-          const float D = div_no_nan(a2, PI_F * t * t);
-          const float G = div_no_nan(2.f * cl, cl + sqrtf(fabsf(a2 + (1.f - a2) * cl * cl))) * M[s].g1v;
+          const float D = fdiv_no_nan(a2, PI_F * t * t);
+          const float G = fdiv_no_nan(2.f * cl, cl + __builtin_amdgcn_sqrtf(fabsf(a2 + (1.f - a2) * cl * cl))) * M[s].g1v;
           const float gd = G * D;
           float gl[3], df[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const float F = M[s].f0[c] + (1.f - M[s].f0[c]) * om5;
-            gl[c] = div_no_nan(F * gd, den);
-            df[c] = M[s].a[c] / PI_F;
+            gl[c] = F * gd * inv_den;
+            df[c] = M[s].a[c] * (1.f / PI_F);
           }
           acc[s][0] += (gl[0] + df[0]) * lr * cosl * area[k];
           acc[s][1] += (gl[1] + df[1]) * lg * cosl * area[k];
@@ -176,12 +180,13 @@ struct ShadeBwdArgs {
 // d/d a2 of G1(c) = 2c / (c + sqrt|a2 + (1 - a2) c^2|), with divide_no_nan semantics
 __device__ __forceinline__ void g1_and_da2(float c, float a2, float* g1, float* dg1) {
   const float q = a2 + (1.f - a2) * c * c;
-  const float s = sqrtf(fabsf(q));
+  const float s = __builtin_amdgcn_sqrtf(fabsf(q));
   const float den = c + s;
   if (den == 0.f) { *g1 = 0.f; *dg1 = 0.f; return; }
-  *g1 = 2.f * c / den;
-  const float ds = s > 0.f ? (q >= 0.f ? 1.f : -1.f) * (1.f - c * c) / (2.f * s) : 0.f;
-  *dg1 = -2.f * c / (den * den) * ds;
+  const float rden = __builtin_amdgcn_rcpf(den);
+  *g1 = 2.f * c * rden;
+  const float ds = s > 0.f ? (q >= 0.f ? 1.f : -1.f) * (1.f - c * c) * 0.5f * __builtin_amdgcn_rcpf(s) : 0.f;
+  *dg1 = -2.f * c * rden * rden * ds;
 }
 
 template <int LQ>
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(256) void brdf_shade_bwd_kernel(const ShadeBwdArgs 
       const float l_dot_n = wx * mx + wy * my + wz * mz;
       const float cl = clip01(l_dot_n);
       const float den = 4.f * fabsf(l_dot_n) * fabsf(v_dot_n);
-      const float inv_den = den == 0.f ? 0.f : 1.f / den;
+      const float inv_den = den == 0.f ? 0.f : __builtin_amdgcn_rcpf(den);
       const float wgt = vis * cosl * area[k];                       // geometry weight of this light (without radiance)
       const float Lc[3] = {Lr[k], Lg[k], Lb[k]};
 #pragma unroll
@@ -261,8 +266,9 @@ __global__ __launch_bounds__(256) void brdf_shade_bwd_kernel(const ShadeBwdArgs 
           const float pd = PI_F * t * t;
           float D = 0.f, dD = 0.f;
           if (pd != 0.f) {
-            D = a2[s] / pd;
-            dD = (t - 2.f * a2[s] * cos_m * cos_m) / (PI_F * t * t * t);
+            const float rpd = __builtin_amdgcn_rcpf(pd);
+            D = a2[s] * rpd;
+            dD = (t - 2.f * a2[s] * cos_m * cos_m) * rpd * __builtin_amdgcn_rcpf(t);
           }
           float g1l, dg1l;
           g1_and_da2(cl, a2[s], &g1l, &dg1l);

@@ -178,6 +178,72 @@ __global__ void vq_ema_stats_kernel(const float* __restrict__ x, const long long
     if (cnt[i]) atomicAdd(&counts[i], (float)cnt[i]);
 }
 
+
+// ---- EMA statistics, deterministic two-pass form (K * D <= 4096) ---------------------------------------------------
+// pass 1: every wave owns a private [K][D] accumulator image in LDS (no atomics): for each of its rows it adds the row
+//         (one float4 per lane and 256 features) into the slice of the row's code; 4 rows are in flight per wave.
+//         The per-wave images go to the workspace.
+// pass 2: counts[k], dw[d][k] = sums over the wave images in index order  -> bit-reproducible.
+template <int RU>
+__global__ __launch_bounds__(256) void vq_ema_partial_kernel(const float* __restrict__ x, const long long* __restrict__ idx,
+                                                             long N, int D, int K, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int KD = K * D;
+  float* acc = smem + (size_t)wave * (KD + K);         // [K][D] then [K] counts
+  for (int i = lane; i < KD + K; i += 64) acc[i] = 0.f;
+  __builtin_amdgcn_wave_barrier();
+  const long wid = (long)blockIdx.x * 4 + wave, nw = (long)gridDim.x * 4;
+  const int D4 = D >> 2;
+  for (long r0 = wid * RU; r0 < N; r0 += nw * RU) {
+    int k[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) k[u] = (r0 + u < N) ? (int)idx[r0 + u] : -1;
+    for (int c = lane; c < D4; c += 64) {
+      f32x4 v[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u)
+        if (k[u] >= 0 && k[u] < K) v[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(r0 + u) * D + 4 * c);
+#pragma unroll
+      for (int u = 0; u < RU; ++u)
+        if (k[u] >= 0 && k[u] < K) {
+          f32x4* a = reinterpret_cast<f32x4*>(acc + (size_t)k[u] * D + 4 * c);
+          f32x4 t = *a;
+          t[0] += v[u][0]; t[1] += v[u][1]; t[2] += v[u][2]; t[3] += v[u][3];
+          *a = t;
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int u = 0; u < RU; ++u)
+        if (k[u] >= 0 && k[u] < K) acc[KD + k[u]] += 1.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  float* out = part + (size_t)wid * (KD + K);
+  for (int i = lane; i < KD + K; i += 64) out[i] = acc[i];
+}
+
+__global__ void vq_ema_reduce_kernel(const float* __restrict__ part, long n_part, int D, int K, float* __restrict__ counts,
+                                     float* __restrict__ dw) {
+  const int KD = K * D;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= KD + K) return;
+  float s = 0.f;
+  for (long w = 0; w < n_part; ++w) s += part[(size_t)w * (KD + K) + i];
+  if (i < KD) { const int k = i / D, d = i - k * D; dw[(size_t)d * K + k] = s; }
+  else counts[i - KD] = s;
+}
+
+static long ema_grid(long N, int D, int K) {
+  const size_t lds = (size_t)4 * (K * D + K) * sizeof(float);
+  const long per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+  long blocks = (N + 63) / 64;
+  const long cap = (long)vqn_num_cus() * per_cu;
+  if (blocks > cap) blocks = cap;
+  return blocks < 1 ? 1 : blocks;
+}
+
 template <int KT>
 int launch_assign(const float* x, long N, int D, const float* C, int K, const float* sel, float* ws, long long* idx,
                   float* quant, float* dist, hipStream_t s) {
@@ -229,11 +295,32 @@ extern "C" int vqn_vq_assign(const float* x, int64_t N, int D, const float* code
   }
 }
 
+extern "C" int64_t vqn_vq_ema_stats_ws_bytes(int64_t N, int D, int K) {
+  if (N <= 0 || D <= 0 || K <= 0 || (long)K * D > 4096 || (D & 3)) return 0;       // 0: the single-pass (LDS-atomic) form is used
+  return ema_grid(N, D, K) * 4 * (int64_t)(K * D + K) * (int64_t)sizeof(float);
+}
+
 extern "C" int vqn_vq_ema_stats(const float* x, const int64_t* idx, int64_t N, int D, int K, float* counts, float* dw,
-                                void* stream) {
+                                float* ws, int64_t ws_bytes, void* stream) {
   VQN_CHECK_ARG(N >= 0 && D > 0 && K > 0, "N >= 0, D > 0, K > 0 required");
   VQN_CHECK_ARG(counts && dw, "counts and dw must be non-null");
   hipStream_t s = (hipStream_t)stream;
+  const int64_t need = vqn_vq_ema_stats_ws_bytes(N, D, K);
+  if (N > 0 && need > 0 && ws != nullptr && ws_bytes >= need) {
+    VQN_CHECK_ARG(x && idx, "x and idx must be non-null");
+    VQN_CHECK_SHAPE(((uintptr_t)x % 16) == 0, "x must be 16-byte aligned");
+    const long blocks = ema_grid(N, D, K);
+    const size_t lds = (size_t)4 * (K * D + K) * sizeof(float);
+    if (lds > 64 * 1024)
+      VQN_HIP(hipFuncSetAttribute((const void*)vq_ema_partial_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(vq_ema_partial_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, s, x,
+                       reinterpret_cast<const long long*>(idx), (long)N, D, K, ws);
+    VQN_LAUNCH_CHECK();
+    const int tot = K * D + K;
+    hipLaunchKernelGGL(vq_ema_reduce_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, ws, blocks * 4, D, K, counts, dw);
+    VQN_LAUNCH_CHECK();
+    return VQN_OK;
+  }
   VQN_HIP(hipMemsetAsync(counts, 0, sizeof(float) * K, s));
   VQN_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)D * K, s));
   if (N == 0) return VQN_OK;
