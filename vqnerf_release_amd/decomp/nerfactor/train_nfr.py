@@ -130,3 +130,21 @@ def outer_sample(batch, config, data_type, alpha_thres=0.9, generator=None):
         else:
             out.append([t[int(i)] for i in flat.tolist()] if isinstance(t, (list, tuple)) else t)
     return tuple(out)
+
+
+@torch.no_grad()
+def z_cluster(model, init_batch_vis, init_z_path, num_embed, device='cuda', n_samples=None, seed=1):
+    """Codebook initialisation (train_nfr.py:471-488): k-means over the encoder's latents of the training views; writes the
+    `[num_embed, z_dim]` centres to `init_z_path` (the `cluster_center_path` that vq_nfr.Model.get_codebook loads)."""
+    import numpy as np
+    from vqnerf_release_amd.decomp.nerfactor.util.torch_kmeans import kmeans
+    zs = torch.cat([torch.as_tensor(z) for z in init_batch_vis], 0).to(device)
+    if n_samples is not None:
+        index = np.array(range(zs.shape[0]))
+        np.random.shuffle(index)
+        zs = zs[torch.as_tensor(index[:int(n_samples)], device=zs.device)]
+    _, centers = kmeans(X=zs, num_clusters=num_embed, distance='euclidean', device=device, seed=seed)
+    z_centers = centers.detach().cpu().numpy()
+    if init_z_path:
+        np.save(init_z_path, z_centers)
+    return z_centers
