@@ -65,12 +65,15 @@ int vqn_mlp_chain_fwd(const int32_t* desc, const float* wbuf, const float* in, i
  *   albedo_s, spec_s [N,3], rough_s [N]; gamma: device [2] = (bias, index) or NULL (data_type nerf);
  *   normal_out [N,3] or NULL; rgb_s [N,3]; rgb0_diff / rgb0_spec [N,3] or both NULL (vali mode,
  *   vq_nfr.py:605-610).  L in {256, 512, 1024}.  raw != 0: rgb_s receive the plain sums over lights
- *   (no gamma, no clip): the training path applies those in the host framework so that autograd sees them. */
+ *   (no gamma, no clip): the training path applies those in the host framework so that autograd sees them.
+ *   probes [P,L,3] (or NULL): material set 0 is additionally re-lit by every probe in the same pass
+ *   (vq_nfr.py:724-733, the per-probe Python loop of the reference) -> rgb0_probes [N,P,3]. */
 int vqn_brdf_shade_fwd(const float* xyz, const float* normal, const float* rayo, const float* lvis,
                        const float* lxyz, const float* lareas, const float* light, int64_t N, int L, int n_sets,
                        const float* albedo0, const float* spec0, const float* rough0, const float* albedo1,
                        const float* spec1, const float* rough1, const float* gamma, float* normal_out, float* rgb0,
-                       float* rgb1, float* rgb0_diff, float* rgb0_spec, int raw, void* stream);
+                       float* rgb1, float* rgb0_diff, float* rgb0_spec, int raw, const float* probes, int n_probes,
+                       float* rgb0_probes, void* stream);
 
 /* Reverse of vqn_brdf_shade_fwd(raw = 1) (autograd in the reference: tape.gradient through microfacet.py:9-89 and
  * vq_nfr.py:694-723): given g_sum_s = d loss / d (plain sum over lights) [N,3] per material set, returns

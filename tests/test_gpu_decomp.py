@@ -233,3 +233,36 @@ def test_full_image_properties(setup):
         b3 = tuple(t[:100001] if torch.is_tensor(t) else t[:100001] for t in batch)
         pred3, _, _, _ = model.call(b3, mode='vali')
         assert torch.equal(pred3['vq_rgb'], pred['vq_rgb'][:100001])
+
+
+def test_relight_16_probes_single_pass(setup):
+    """fast_render(relight_probes=True) (test.py:254-266 -> vq_nfr.py:724-733): all 16 probes in ONE shading pass must equal
+    16 separate passes bit for bit (same per-light weights, same reduction order) and the oracle within the shading tolerance."""
+    od, model, pt, specs = setup['od'], setup['model'], setup['pt'], setup['specs']
+    rng = np.random.default_rng(2)
+    model.novel_probes = {f'probe{i:02d}': torch.tensor(rng.uniform(0, 2, (16, 32, 3)).astype(np.float32)).cuda() for i in range(16)}
+    N = 300
+    pts = od.make_points(N, seed=12)
+    batch = make_batch(pts, 'cuda', bg_every=5)
+    with torch.no_grad():
+        pred, gt, lk, to_vis = model.fast_render(batch, mode='test', relight_probes=True)
+        assert pred['rgb_probes'].shape == (N, 16, 3)
+        keep = np.ones(N, bool); keep[::5] = False
+        m = torch.tensor(keep).cuda()
+        assert float(pred['rgb_probes'][~m].abs().max()) == 0.0
+        # one probe at a time through dst_env
+        for i, name in enumerate(list(model.novel_probes)[:4]):
+            one, _, _, _ = model.fast_render(batch, mode='test', dst_env=name)
+            assert torch.equal(one['rgb'][m], pred['rgb_probes'][m][:, i])
+    # oracle
+    T = od.T
+    ob = {k: T(v[keep]) for k, v in pts.items()}
+    surf2l = od.calc_ldir(setup['lxyz'], ob['xyz']); surf2c = od.calc_vdir(ob['rayo'], ob['xyz'])
+    n_pred = od.normal_correct(ob['normal'], surf2c)
+    z = od.pred_enc(pt, specs, ob['xyz'])
+    base, ks, rough = od.heads(pt, specs, z, False)
+    brdf, _, _ = od.get_brdf(surf2l, surf2c, n_pred, (1 - ks) * base, rough, ks * base)
+    for i, lp in enumerate(list(model.novel_probes.values())[:3]):
+        want = od.linear2srgb(od.render_integrate(brdf, surf2l, n_pred, setup['lareas'], lp.cpu(), ob['lvis']))
+        np.testing.assert_allclose(_np(pred['rgb_probes'][m][:, i]), want.numpy(), rtol=0, atol=2e-4)
+    model.novel_probes = {}

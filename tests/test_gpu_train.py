@@ -143,10 +143,10 @@ def test_empty_and_degenerate_inputs():
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     assert lib.vqn_neus_composite_bwd(p(one), p(one), p(one), p(one), p(one), p(one), p(one), p(one), z, ctypes.c_int64(0), 8,
                                       ctypes.c_float(2.0), ctypes.c_float(1.0), p(one), z, z, z, z, p(one), p(one), p(one), p(one), z) == 0
-    assert lib.vqn_brdf_shade_fwd(z, z, z, z, z, z, z, ctypes.c_int64(0), 512, 1, z, z, z, z, z, z, z, z, z, z, z, z, 0, z) == 0
+    assert lib.vqn_brdf_shade_fwd(z, z, z, z, z, z, z, ctypes.c_int64(0), 512, 1, z, z, z, z, z, z, z, z, z, z, z, z, 0, z, 0, z, z) == 0
     assert lib.vqn_mlp_chain_fwd(p(one), p(one), z, ctypes.c_int64(0), z, 0, z, 0, z, 0, z, 0, z) == 0
     rc = lib.vqn_wgrad_partials(p(one), 1, 0, 9, p(one), 1, 0, 1, ctypes.c_int64(1), 4, p(one), z)
     assert rc == -2 and b'feature tiles' in lib.vqn_last_error()
     rc = lib.vqn_brdf_shade_fwd(p(one), p(one), p(one), z, p(one), p(one), p(one), ctypes.c_int64(4), 100, 1, p(one), p(one), p(one),
-                                z, z, z, z, z, p(one), z, z, z, 0, z)
+                                z, z, z, z, z, p(one), z, z, z, 0, z, 0, z, z)
     assert rc == -2 and b'256, 512 or 1024' in lib.vqn_last_error()

@@ -302,7 +302,7 @@ def mlp_chain_fwd(desc, wbuf, x, out_widths):
 
 
 def brdf_shade_fwd(xyz, normal, rayo, lvis, lxyz, lareas, light, materials, gamma=None, want_normal=True,
-                   want_split=False, raw=False):
+                   want_split=False, raw=False, probes=None):
     """materials: [(albedo [N,3], spec [N,3], rough [N,1])] (1 or 2 sets).
     -> dict(rgb=[...per set], normal=..., rgb_diff=..., rgb_spec=...)."""
     for n_, t in (('xyz', xyz), ('normal', normal), ('rayo', rayo), ('lxyz', lxyz), ('lareas', lareas), ('light', light)):
@@ -327,14 +327,19 @@ def brdf_shade_fwd(xyz, normal, rayo, lvis, lxyz, lareas, light, materials, gamm
     rd, rs = (f(N, 3), f(N, 3)) if want_split else (None, None)
     if gamma is not None:
         gamma = _f32c(gamma.reshape(-1).contiguous(), 'gamma')
+    n_probes, rgb_probes = 0, None
+    if probes is not None:
+        probes = _f32c(probes.reshape(-1, L, 3).contiguous(), 'probes')
+        n_probes = probes.shape[0]
+        rgb_probes = f(N, n_probes, 3)
     with _clock('vqn_brdf_shade_fwd'):
         rc = lib().vqn_brdf_shade_fwd(_ptr(xyz), _ptr(normal), _ptr(rayo), _ptr(lvis), _ptr(lxyz), _ptr(lareas),
                                       _ptr(light), ctypes.c_int64(N), ctypes.c_int(L), ctypes.c_int(len(materials)),
                                       *[_ptr(m) for m in mats], _ptr(gamma), _ptr(nout), _ptr(rgb[0]),
                                       _ptr(rgb[1] if len(rgb) > 1 else None), _ptr(rd), _ptr(rs), ctypes.c_int(1 if raw else 0),
-                                      _stream())
+                                      _ptr(probes), ctypes.c_int(n_probes), _ptr(rgb_probes), _stream())
     _check(rc, 'vqn_brdf_shade_fwd')
-    return dict(rgb=rgb, normal=nout, rgb_diff=rd, rgb_spec=rs)
+    return dict(rgb=rgb, normal=nout, rgb_diff=rd, rgb_spec=rs, rgb_probes=rgb_probes)
 
 
 def neus_composite_bwd(rays_o, rays_d, mid_z, dists, sdf, grad, rgb, inv_s, background_rgb, radius, cos_anneal_ratio,

@@ -38,6 +38,9 @@ struct ShadeArgs {
   long N;
   int n_sets;
   int raw;                     // 1: write the plain sums over lights (no gamma, no [0,1] clip) -- the training path applies those in torch
+  const float* probes;         // [P][L][3] novel light probes (vq_nfr.py:724-733) or null
+  float* rgb_probes;           // [N][P][3]: material set 0 re-lit by every probe in the same pass
+  int n_probes;
 };
 
 struct Material {
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(256) void brdf_shade_kernel(const ShadeArgs a) {
       }
     float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     float accd[3] = {0.f, 0.f, 0.f}, accs[3] = {0.f, 0.f, 0.f};
+    float wbr[LP][3];                                // set 0: brdf_c * vis * cos * area per light = contribution per unit radiance
 #pragma unroll
     for (int k = 0; k < LP; ++k) {
       // light direction (shape.py:103-110)
@@ -141,6 +145,10 @@ __global__ __launch_bounds__(256) void brdf_shade_kernel(const ShadeArgs a) {
           acc[s][0] += (gl[0] + df[0]) * lr * cosl * area[k];
           acc[s][1] += (gl[1] + df[1]) * lg * cosl * area[k];
           acc[s][2] += (gl[2] + df[2]) * lb * cosl * area[k];
+          if (s == 0 && a.probes != nullptr) {
+            const float gw = vis * cosl * area[k];
+            wbr[k][0] = (gl[0] + df[0]) * gw; wbr[k][1] = (gl[1] + df[1]) * gw; wbr[k][2] = (gl[2] + df[2]) * gw;
+          }
           if (split && s == 0) {
             accd[0] += df[0] * lr * cosl * area[k]; accd[1] += df[1] * lg * cosl * area[k]; accd[2] += df[2] * lb * cosl * area[k];
             accs[0] += gl[0] * lr * cosl * area[k]; accs[1] += gl[1] * lg * cosl * area[k]; accs[2] += gl[2] * lb * cosl * area[k];
@@ -159,6 +167,24 @@ __global__ __launch_bounds__(256) void brdf_shade_kernel(const ShadeArgs a) {
         const float r = finish(acc[s][0]), g = finish(acc[s][1]), b = finish(acc[s][2]);
         if (lane < 3) a.rgb[s][n * 3 + lane] = lane == 0 ? r : (lane == 1 ? g : b);
       }
+    if (a.probes != nullptr) {
+      // all probes against the SAME per-light weights: the [N,L] x [L,3P] contraction of the relighting loop
+      for (int pr = 0; pr < a.n_probes; ++pr) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < LQ; ++g) {
+          const f32x4* pp = reinterpret_cast<const f32x4*>(a.probes + ((size_t)pr * L + 256 * g + 4 * lane) * 3);
+          const f32x4 q0 = pp[0], q1 = pp[1], q2 = pp[2];      // 4 lights x rgb, interleaved
+          const float rad[12] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3], q2[0], q2[1], q2[2], q2[3]};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s0 += wbr[4 * g + e][0] * rad[3 * e]; s1 += wbr[4 * g + e][1] * rad[3 * e + 1]; s2 += wbr[4 * g + e][2] * rad[3 * e + 2];
+          }
+        }
+        const float r = finish(s0), gg = finish(s1), b = finish(s2);
+        if (lane < 3) a.rgb_probes[((size_t)n * a.n_probes + pr) * 3 + lane] = lane == 0 ? r : (lane == 1 ? gg : b);
+      }
+    }
     if (split) {
       const float r = finish(accd[0]), g = finish(accd[1]), b = finish(accd[2]);
       if (lane < 3) a.rgb_diff[n * 3 + lane] = lane == 0 ? r : (lane == 1 ? g : b);
@@ -315,7 +341,7 @@ extern "C" int vqn_brdf_shade_fwd(const float* xyz, const float* normal, const f
                                   int n_sets, const float* albedo0, const float* spec0, const float* rough0,
                                   const float* albedo1, const float* spec1, const float* rough1, const float* gamma,
                                   float* normal_out, float* rgb0, float* rgb1, float* rgb0_diff, float* rgb0_spec,
-                                  int raw, void* stream) {
+                                  int raw, const float* probes, int n_probes, float* rgb0_probes, void* stream) {
   VQN_CHECK_ARG(N >= 0, "N >= 0");
   if (N == 0) return VQN_OK;
   VQN_CHECK_ARG(xyz && normal && rayo && lxyz && lareas && light, "null geometry / light pointer");
@@ -332,6 +358,9 @@ extern "C" int vqn_brdf_shade_fwd(const float* xyz, const float* normal, const f
   a.albedo[1] = albedo1; a.spec[1] = spec1; a.rough[1] = rough1;
   a.normal_out = normal_out; a.rgb[0] = rgb0; a.rgb[1] = rgb1; a.rgb_diff = rgb0_diff; a.rgb_spec = rgb0_spec;
   a.N = N; a.n_sets = n_sets; a.raw = raw;
+  VQN_CHECK_ARG(probes == nullptr || (n_probes >= 1 && rgb0_probes != nullptr), "probes need n_probes >= 1 and rgb0_probes");
+  VQN_CHECK_SHAPE(probes == nullptr || ((uintptr_t)probes & 15) == 0, "probes must be 16-byte aligned");
+  a.probes = probes; a.n_probes = probes ? n_probes : 0; a.rgb_probes = rgb0_probes;
   long blocks = (N + 3) / 4;
   const long cap = (long)vqn_num_cus() * 8;
   if (blocks > cap) blocks = cap;

@@ -279,7 +279,7 @@ class BrdfModel(ShapeModel):
             rgb_probes = torch.stack([self._integrate(brdf, vis, cos, lp) for lp in self.novel_probes.values()], 1)
         return rgb, None, rgb_probes
 
-    def _shade(self, xyz, normal, rayo, lvis, materials, split=False, light=None):
+    def _shade(self, xyz, normal, rayo, lvis, materials, split=False, light=None, probes=None):
         """Fused directions + BRDF + integral for 1-2 material sets (no graph).  Returns the dict of _C.brdf_shade_fwd."""
         light = self.light if light is None else light
         gamma = None if self.data_type == 'nerf' else self.gamma.detach()
@@ -290,7 +290,7 @@ class BrdfModel(ShapeModel):
                                  None if lvis is None else lvis.detach().float().contiguous(),
                                  self.lxyz.reshape(-1, 3).contiguous(), self.lareas.reshape(-1).contiguous(),
                                  light.detach().float().reshape(-1, 3).contiguous(), mats, gamma=gamma,
-                                 want_normal=True, want_split=split)
+                                 want_normal=True, want_split=split, probes=probes)
 
     def _shade_train(self, xyz, normal, rayo, lvis, materials, light=None):
         """Shading with gradients (albedo / spec / rough / light) through the fused forward + backward kernels."""

@@ -122,11 +122,11 @@ class Model(BrdfModel):
     def _shade_or_render(self, xyz, normal, rayo, lvis, materials, split=False, light=None, probes=False):
         """dict(rgb=[per set], normal, rgb_diff, rgb_spec[, rgb_probes]) -- fused kernel without a graph, torch with."""
         if self._fused(xyz, *[t for m in materials for t in m]):
-            out = self._shade(xyz, normal, rayo, lvis, materials, split=split, light=light)
-            if probes:
-                out['rgb_probes'] = torch.stack(
-                    [self._shade(xyz, normal, rayo, lvis, materials[:1], light=lp)['rgb'][0] for lp in self.novel_probes.values()], 1)
-            return out
+            pr = None
+            if probes and len(self.novel_probes) > 0:
+                pr = torch.stack([torch.as_tensor(lp, dtype=torch.float32, device=xyz.device).reshape(-1, 3)
+                                  for lp in self.novel_probes.values()], 0)
+            return self._shade(xyz, normal, rayo, lvis, materials, split=split, light=light, probes=pr)
         if self.train_backend == 'hip' and xyz.is_cuda and not split and not probes:
             return self._shade_train(xyz, normal, rayo, lvis, materials, light=light)
         surf2l = self._calc_ldir(xyz)
