@@ -237,7 +237,7 @@ def test_full_image_properties(setup):
 
 def test_relight_16_probes_single_pass(setup):
     """fast_render(relight_probes=True) (test.py:254-266 -> vq_nfr.py:724-733): all 16 probes in ONE shading pass must equal
-    16 separate passes bit for bit (same per-light weights, same reduction order) and the oracle within the shading tolerance."""
+    16 separate passes (to rounding: the radiance is multiplied in last instead of first) and the oracle within the shading tolerance."""
     od, model, pt, specs = setup['od'], setup['model'], setup['pt'], setup['specs']
     rng = np.random.default_rng(2)
     model.novel_probes = {f'probe{i:02d}': torch.tensor(rng.uniform(0, 2, (16, 32, 3)).astype(np.float32)).cuda() for i in range(16)}
