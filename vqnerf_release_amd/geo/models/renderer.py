@@ -159,13 +159,34 @@ class NeuSRenderer:
             z_vals, sdf = self.cat_z_vals(rays_o, rays_d, z_vals, new_z, sdf, last=(i + 1 == self.up_sample_steps))
         return z_vals
 
+    # ---- NeRF++ background (renderer.py:93-129).  Dead code in every shipped conf (n_outside = 0); kept for API
+    # completeness as torch ops on the GPU -- not a HIP path (SURVEY 8a9').
+    def render_core_outside(self, rays_o, rays_d, z_vals, sample_dist, nerf, background_rgb=None):
+        B, n = z_vals.shape
+        dists = z_vals[..., 1:] - z_vals[..., :-1]
+        dists = torch.cat([dists, torch.full_like(dists[..., :1], float(sample_dist))], -1)
+        mid = z_vals + dists * 0.5
+        pts = rays_o[:, None, :] + rays_d[:, None, :] * mid[..., :, None]
+        r = torch.linalg.norm(pts, ord=2, dim=-1, keepdim=True).clip(1.0, 1e10)
+        pts = torch.cat([pts / r, 1.0 / r], dim=-1).reshape(-1, 4)
+        dirs = rays_d[:, None, :].expand(B, n, 3).reshape(-1, 3)
+        density, col = nerf(pts, dirs)
+        alpha = 1.0 - torch.exp(-F.softplus(density.reshape(B, n)) * dists)
+        weights = alpha * torch.cumprod(torch.cat([torch.ones([B, 1], device=alpha.device), 1. - alpha + 1e-7], -1), -1)[:, :-1]
+        col = col.reshape(B, n, 3)
+        color = (weights[:, :, None] * col).sum(dim=1)
+        if background_rgb is not None:
+            color = color + background_rgb * (1.0 - weights.sum(dim=-1, keepdim=True))
+        return {'color': color, 'sampled_color': col, 'alpha': alpha, 'weights': weights}
+
     # ---- render_core ----------------------------------------------------------------------------
     def render_core(self, rays_o, rays_d, z_vals, sample_dist, radius, sdf_network, deviation_network, color_network,
                     background_alpha=None, background_sampled_color=None, background_rgb=None,
                     cos_anneal_ratio=0.0, to_light=False):
         if background_alpha is not None:
-            raise NotImplementedError('n_outside > 0 (NeRF++ background) is not on the MI355X hot path; '
-                                      'every shipped conf sets n_outside = 0')
+            return self._render_core_autograd(rays_o, rays_d, z_vals, sample_dist, radius, sdf_network, deviation_network,
+                                              color_network, background_rgb, cos_anneal_ratio, to_light,
+                                              background_alpha=background_alpha, background_sampled_color=background_sampled_color)
         if _needs_graph(sdf_network, rays_o) or any(p.requires_grad and torch.is_grad_enabled()
                                                     for m in (deviation_network, color_network) for p in m.parameters()):
             if self.train_backend == 'hip' and rays_o.is_cuda and self._train_engine(sdf_network, color_network) is not None:
@@ -235,7 +256,8 @@ class NeuSRenderer:
         }
 
     def _render_core_autograd(self, rays_o, rays_d, z_vals, sample_dist, radius, sdf_network, deviation_network,
-                              color_network, background_rgb, cos_anneal_ratio, to_light):
+                              color_network, background_rgb, cos_anneal_ratio, to_light, background_alpha=None,
+                              background_sampled_color=None):
         """torch-op statement of renderer.py:207-297 for when autograd needs the graph."""
         B, n = z_vals.shape
         dists = z_vals[..., 1:] - z_vals[..., :-1]
@@ -258,11 +280,16 @@ class NeuSRenderer:
         pts_r = torch.linalg.norm(pts, ord=2, dim=-1).reshape(B, n)
         inside = (pts_r < radius).float().detach()
         relax = (pts_r < radius * 1.1).float().detach()
+        if background_alpha is not None:                      # renderer.py:254-261
+            alpha = alpha * inside + background_alpha[:, :n] * (1.0 - inside)
+            alpha = torch.cat([alpha, background_alpha[:, n:]], dim=-1)
+            rgb = rgb * inside[:, :, None] + background_sampled_color[:, :n] * (1.0 - inside)[:, :, None]
+            rgb = torch.cat([rgb, background_sampled_color[:, n:]], dim=1)
         trans = torch.cumprod(torch.cat([torch.ones([B, 1], device=alpha.device), 1.0 - alpha + 1e-7], -1), -1)[:, :-1]
         weights = alpha * trans
         wsum = weights.sum(-1, keepdim=True)
         color = (rgb * weights[:, :, None]).sum(1)
-        surf = (pts.reshape(B, n, 3) * weights[:, :, None]).sum(1)
+        surf = (pts.reshape(B, n, 3) * weights[:, :n, None]).sum(1)
         depth = torch.linalg.norm(surf - rays_o, ord=2, dim=-1, keepdim=True)
         if background_rgb is not None:
             color = color + background_rgb * (1.0 - wsum)
@@ -279,9 +306,6 @@ class NeuSRenderer:
     # ---- render ---------------------------------------------------------------------------------
     def render(self, rays_o, rays_d, near, far, radius, perturb_overwrite=-1, background_rgb=None,
                cos_anneal_ratio=0.0, to_light=False, t_rand=None):
-        if self.n_outside > 0:
-            raise NotImplementedError('n_outside > 0 (NeRF++ background) is not on the MI355X hot path; '
-                                      'every shipped conf sets n_outside = 0')
         rays_o = rays_o.float().contiguous()
         rays_d = rays_d.float().contiguous()
         dev = rays_o.device
@@ -295,17 +319,30 @@ class NeuSRenderer:
                 t_rand = torch.rand([B, 1], device=dev) - 0.5
             z_vals = z_vals + t_rand * 2.0 * radius / self.n_samples
         z_vals = z_vals.float().contiguous()
+        z_vals_outside = None
+        if self.n_outside > 0:                                   # renderer.py:309-331 (torch ops; never reached by shipped confs)
+            zo = torch.linspace(1e-3, 1.0 - 1.0 / (self.n_outside + 1.0), self.n_outside, device=dev)
+            if perturb > 0:
+                mids = .5 * (zo[..., 1:] + zo[..., :-1])
+                upper, lower = torch.cat([mids, zo[..., -1:]], -1), torch.cat([zo[..., :1], mids], -1)
+                zo = lower[None, :] + (upper - lower)[None, :] * torch.rand([B, zo.shape[-1]], device=dev)
+            z_vals_outside = far / torch.flip(zo, dims=[-1]) + 1.0 / self.n_samples
         n = self.n_samples
         if self.n_importance > 0:
             z_vals = self._importance_z(rays_o, rays_d, z_vals, radius)
             n = self.n_samples + self.n_importance
+        bg_alpha = bg_color = None
+        if self.n_outside > 0:
+            z_feed, _ = torch.sort(torch.cat([z_vals, z_vals_outside.expand(B, -1)], dim=-1), dim=-1)
+            ro = self.render_core_outside(rays_o, rays_d, z_feed, sample_dist, self.nerf)
+            bg_color, bg_alpha = ro['sampled_color'], ro['alpha']
         rc = self.render_core(rays_o, rays_d, z_vals, sample_dist, radius, self.sdf_network, self.deviation_network,
-                              self.color_network, background_rgb=background_rgb, cos_anneal_ratio=cos_anneal_ratio,
-                              to_light=to_light)
+                              self.color_network, background_alpha=bg_alpha, background_sampled_color=bg_color,
+                              background_rgb=background_rgb, cos_anneal_ratio=cos_anneal_ratio, to_light=to_light)
         weights = rc['weights']
         return {
             'color_fine': rc['color'],
-            's_val': rc['s_val'].reshape(B, n).mean(dim=-1, keepdim=True),
+            's_val': rc['s_val'].reshape(B, -1).mean(dim=-1, keepdim=True),
             'cdf_fine': rc['cdf'],
             'weight_sum': rc['weight_sum'],
             'weight_max': rc['weight_max'],
