@@ -266,3 +266,30 @@ def test_relight_16_probes_single_pass(setup):
         want = od.linear2srgb(od.render_integrate(brdf, surf2l, n_pred, setup['lareas'], lp.cpu(), ob['lvis']))
         np.testing.assert_allclose(_np(pred['rgb_probes'][m][:, i]), want.numpy(), rtol=0, atol=2e-4)
     model.novel_probes = {}
+
+
+def test_ref_nfr_stage3_model(setup):
+    """Stage-3 model (ref_nfr): fused inference == its own torch statements; frozen stage-2 parts get no gradient."""
+    od, p = setup['od'], setup['p']
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    m = get_model_class('ref_nfr')(make_config(model='ref_nfr'))
+    m.build_nets(device='cuda', seed=3).to('cuda')
+    m.load_stage2(setup['model'])
+    N = 400
+    pts = od.make_points(N, seed=21)
+    b = make_batch(pts, 'cuda', bg_every=9)
+    ref = torch.rand(N, 3, device='cuda')
+    batch = b[:9] + (ref,) + b[9:]
+    with torch.no_grad():
+        pred, gt, lk, _ = m.call(batch, mode='vali')                           # fused kernels
+    m.train_backend = 'torch'
+    pred_t, _, lk_t, _ = m.call(batch, mode='vali')                            # torch statements (graph path)
+    for k in ('rgb', 'albedo', 'spec', 'rough', 'rgb_diff', 'rgb_spec', 'normal'):
+        np.testing.assert_allclose(_np(pred[k]), _np(pred_t[k]), rtol=0, atol=1e-4, err_msg=k)
+    m.train_backend = 'hip'
+    pred_h, gt_h, lk_h, _ = m.call(batch, mode='train')
+    loss, ld = m.compute_loss(pred_h, gt_h, **dict(lk_h))
+    loss.mean().backward()
+    assert m.net['rgb_enc'].layers[0].kernel.grad.abs().sum() > 0 and m.net['diff_out'].layers[2].kernel.grad.abs().sum() > 0
+    assert m.net['fine_enc'].layers[0].kernel.grad is None and m.net['spec_out'].layers[0].kernel.grad is None
+    assert m._light.grad.abs().sum() > 0

@@ -156,10 +156,11 @@ class BrdfModel(ShapeModel):
             self._plans['enc'] = b.build()
         return self._plans['enc']
 
-    def _head_program(self, names):
-        key = 'heads:' + ','.join(names)
+    def _head_program(self, names, in_dim=None):
+        in_dim = in_dim or self.z_dim
+        key = 'heads:%d:' % in_dim + ','.join(names)
         if key not in self._plans:
-            b = packing.ChainBuilder('raw', self.z_dim)
+            b = packing.ChainBuilder('raw', in_dim)
             for slot, name in enumerate(names):
                 net = self.net[name]
                 b.mlp(name, net.widths, net.act, net.skip_at, b.input, keep=[b.input], out_slot=slot)
@@ -181,8 +182,8 @@ class BrdfModel(ShapeModel):
         return _C.mlp_chain_fwd(desc, wbuf, pts.detach().float().contiguous(), [self.z_dim])[0]
 
     def _fused_heads(self, z, names):
-        plan = self._head_program(names)
-        wbuf, desc = self._program_pack('heads:' + ','.join(names), plan, names)
+        plan = self._head_program(names, z.shape[1])
+        wbuf, desc = self._program_pack('heads:%d:' % z.shape[1] + ','.join(names), plan, names)
         widths = [self.net[n].widths[-1] for n in names]
         return _C.mlp_chain_fwd(desc, wbuf, z.detach().float().contiguous(), widths)
 
@@ -217,6 +218,11 @@ class BrdfModel(ShapeModel):
     def _head(self, name, z):
         if self._fused(z):
             return self._fused_heads(z, [name])[0]
+        if self._train_hip(z) and z.shape[1] == self.z_dim and any(p.requires_grad for p in self.net[name].parameters()):
+            from vqnerf_release_amd.decomp.train_programs import HeadsFunction
+            net = self.net[name]
+            return HeadsFunction.apply(self._heads_engine([name], z.device), z, *[l.kernel for l in net.layers],
+                                       *[l.bias for l in net.layers])[0]
         return self.net[name](z)
 
     def _albedo_affine(self, albedo):

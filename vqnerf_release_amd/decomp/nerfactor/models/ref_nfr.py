@@ -1,0 +1,120 @@
+"""Stage-3 residual-baking model: mirror of decomp/nerfvq_nfr3/nerfactor/models/ref_nfr.py (nets :137-159, call :176-300,
+_pred_ref_at :487-496, compute_loss :584-610; fast_render / vis / HTML are out of scope).
+
+The encoder (`fine_enc`, `bottleneck`) and the specular head come frozen from the stage-2 vq_nfr model; a new `rgb_enc`
+(3 -> 256 -> 256 -> 256) embeds the per-point reference colour and the diffuse / roughness heads read [z_xyz ; z_ref]
+(512 wide).  Same kernels as the other stages: `vqn_mlp_chain_fwd` programs (incl. a 512-wide head program and a
+3-feature raw-input program) and the fused shading forward / backward."""
+import torch
+
+from vqnerf_release_amd.decomp import packing
+from vqnerf_release_amd import _C
+from vqnerf_release_amd.decomp.nerfactor.models.nfr_unit import BrdfModel, scatter_rows
+from vqnerf_release_amd.decomp.nerfactor.networks import mlp
+from vqnerf_release_amd.decomp.nerfactor.util import img as imgutil
+
+
+class Model(BrdfModel):
+    def __init__(self, config, debug=False):
+        self.no_brdf_chunk = config.getboolean('DEFAULT', 'no_brdf_chunk', fallback=True)
+        self.vqnfr_ckpt = config.get('DEFAULT', 'vqnfr_model_ckpt', fallback='')
+        super().__init__(config, debug=debug)
+
+    def _init_net(self):
+        z = self.z_dim
+        net = self._encoder_nets()
+        net['spec_out'] = mlp.Network([z, z // 2, 1], act=['relu'] * 2 + ['sigmoid'], skip_at=[1])
+        net['rgb_enc'] = mlp.Network([z, z, z], act=[None, 'relu', 'sigmoid'])
+        net['diff_out'] = mlp.Network([z, z // 2, 3], act=['relu'] * 2 + ['sigmoid'], skip_at=[1])
+        net['rough_out'] = mlp.Network([z, z // 2, 1], act=['relu'] * 2 + ['sigmoid'], skip_at=[1])
+        return net
+
+    def build_nets(self, device=None, seed=None):
+        gen = torch.Generator().manual_seed(int(seed)) if seed is not None else None
+        d_xyz = getattr(self.embedder['xyz'], 'out_dims', 3)
+        d_in = {'fine_enc': d_xyz, 'bottleneck': self.config.getint('DEFAULT', 'mlp_width'), 'spec_out': self.z_dim, 'rgb_enc': 3,
+                'diff_out': 2 * self.z_dim, 'rough_out': 2 * self.z_dim}
+        for name, net in self.net.items():
+            net.build(d_in[name], device=device, generator=gen)
+        self.register_trainable()
+        return self
+
+    def load_stage2(self, vq_model):
+        """Stage hand-off (ref_nfr.py:141-146): frozen encoder + specular head of the vq_nfr model, and its light."""
+        for dst, src in (('fine_enc', 'fine_enc'), ('bottleneck', 'bottleneck'), ('spec_out', 'spec_main')):
+            self.net[dst].load_state_dict(vq_model.net[src].state_dict())
+            for p in self.net[dst].parameters():
+                p.requires_grad_(False)
+        if vq_model._light is not None:
+            self.set_light(vq_model._light.detach().clone())
+
+    def _pred_ref_at(self, ref):
+        if self._fused(ref):
+            if 'ref' not in self._plans:
+                b = packing.ChainBuilder('raw', 3)
+                net = self.net['rgb_enc']
+                b.mlp('rgb_enc', net.widths, net.act, net.skip_at, b.input, out_slot=0, small_last=False)
+                self._plans['ref'] = b.build()
+            wbuf, desc = self._program_pack('ref', self._plans['ref'], ['rgb_enc'])
+            return _C.mlp_chain_fwd(desc, wbuf, ref.detach().float().contiguous(), [self.z_dim])[0]
+        return self.net['rgb_enc'](ref)
+
+    def call(self, batch, mode='train', relight_olat=False, relight_probes=False, save_z=False, opt_scale=None, bias_weight=None):
+        self._validate_mode(mode)
+        id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz, normal, ref = batch[:10]
+        lvis = batch[10] if self.data_type == 'nerf' else None
+        mask = alpha[:, 0] > 0
+        n = alpha.shape[0]
+        rayo, rgb_m, xyz_m, normal_m, ref_m = rayo[mask], rgb[mask], xyz[mask], normal[mask], ref[mask]
+        lvis_m = lvis[mask] if lvis is not None else None
+        z_xyz = self._pred_bias_at(xyz_m)
+        ks = self._head('spec_out', z_xyz)
+        z_bias = torch.cat([z_xyz, self._pred_ref_at(ref_m)], -1)
+        basecolor = self._albedo_affine(self._head('diff_out', z_bias))
+        rough = self._head('rough_out', z_bias)
+        spec, albedo = ks * basecolor, (1 - ks) * basecolor
+        if (opt_scale is not None) and (mode == 'test'):
+            albedo, spec = albedo * opt_scale, spec * opt_scale
+        if self._fused(xyz_m, albedo, spec, rough):
+            pr = None
+            if relight_probes and len(self.novel_probes) > 0:
+                pr = torch.stack([torch.as_tensor(lp, dtype=torch.float32, device=xyz_m.device).reshape(-1, 3)
+                                  for lp in self.novel_probes.values()], 0)
+            sh = self._shade(xyz_m, normal_m, rayo, lvis_m, [(albedo, spec, rough)], split=(mode != 'train'), probes=pr)
+        elif self.train_backend == 'hip' and xyz_m.is_cuda and mode == 'train':
+            sh = self._shade_train(xyz_m, normal_m, rayo, lvis_m, [(albedo, spec, rough)])
+        else:
+            surf2l, surf2c = self._calc_ldir(xyz_m), self._calc_vdir(rayo, xyz_m)
+            n_pred = self._normal_correct(normal_m, surf2c)
+            brdf, brdf_s, brdf_d = self._eval_brdf_at(surf2l, surf2c, n_pred, albedo, spec, rough)
+            r0, _, rp = self._render(brdf, surf2l, n_pred, lvis_m, relight_probes=relight_probes)
+            sh = {'rgb': [r0], 'normal': n_pred, 'rgb_probes': rp, 'rgb_diff': None, 'rgb_spec': None}
+            if mode != 'train':
+                sh['rgb_diff'] = self._render(brdf_d, surf2l, n_pred, lvis_m)[0]
+                sh['rgb_spec'] = self._render(brdf_s, surf2l, n_pred, lvis_m)[0]
+        rgb_pred, normal_pred = sh['rgb'][0], sh['normal']
+        loss_kwargs = {'mode': mode, 'env': self._light, 'gtc': rgb_m, 'rgb': rgb_pred}
+        srgb = (lambda t: imgutil.linear2srgb(t)) if self.data_type == 'nerf' else (lambda t: t)
+        pred = {'rgb': scatter_rows(mask, srgb(rgb_pred), n), 'normal': scatter_rows(mask, normal_pred, n),
+                'albedo': scatter_rows(mask, albedo, n), 'alpha': pred_alpha, 'spec': scatter_rows(mask, spec, n),
+                'rough': scatter_rows(mask, rough, n), 'ks': scatter_rows(mask, ks, n), 'basecolor': scatter_rows(mask, basecolor, n)}
+        if mode != 'train':
+            pred['rgb_spec'], pred['rgb_diff'] = scatter_rows(mask, sh['rgb_spec'], n), scatter_rows(mask, sh['rgb_diff'], n)
+        if relight_probes and sh.get('rgb_probes') is not None:
+            pred['rgb_probes'] = scatter_rows(mask, srgb(sh['rgb_probes']), n)
+        gt = {'rgb': scatter_rows(mask, rgb_m, n), 'normal': scatter_rows(mask, normal_m, n), 'alpha': alpha}
+        to_vis = {'id': id_, 'hw': hw}
+        for k, v in pred.items():
+            to_vis['pred_' + k] = v
+        for k, v in gt.items():
+            to_vis['gt_' + k] = v
+        return pred, gt, loss_kwargs, to_vis
+
+    def compute_loss(self, pred, gt, **kwargs):
+        mode = kwargs.pop('mode')
+        rgb_gt, rgb_pred = kwargs.pop('gtc'), kwargs.pop('rgb')
+        linear_gt = imgutil.srgb2linear(rgb_gt) if self.data_type == 'nerf' else rgb_gt
+        loss = ((linear_gt - rgb_pred) ** 2).mean(-1)
+        if mode != 'train':
+            return loss                                     # ref_nfr.py:606 returns the bare tensor in vali mode
+        return loss, {'rgb': loss, 'loss': loss}
