@@ -86,6 +86,53 @@ __device__ __forceinline__ void gemm_tiles(const f32x4* __restrict__ lds, const 
   }
 }
 
+// gemm_tiles for a chain of layers: `pre` holds the first four weight fragments of this wave's FIRST tile (loaded by the
+// previous layer before its epilogue and barrier, so their L2 latency is not paid after the barrier); before the epilogue
+// of its LAST tile the function refills `pre` from `next_wp` (the same fragments of the next layer; nullptr = none).
+template <int NW = 4, class Init, class Epi>
+__device__ __forceinline__ void gemm_tiles_chain(const f32x4* __restrict__ lds, const KSegs ks,
+                                                 const f32x4* __restrict__ w, const int n_out_tiles, const int wave,
+                                                 const int lane, f32x4 (&pre)[4], const f32x4* __restrict__ next_wp,
+                                                 Init init, Epi epi) {
+  const int ng = ks.nA + ks.nB;
+  for (int ot = wave; ot < n_out_tiles; ot += NW) {
+    f32x16 acc;
+    init(ot, acc);
+    const f32x4* __restrict__ wp = w + (size_t)ot * ng * 64 + lane;
+    auto brow = [&](int g) { return ((g < ks.nA) ? (ks.rowA + g) : (ks.rowB + (g - ks.nA))) * 64 + lane; };
+    f32x4 a0[4], b0[4], a1[4], b1[4];
+    const bool first = ot == wave;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < ng) { if (first) a0[i] = pre[i]; else a0[i] = wp[i * 64]; b0[i] = lds[brow(i)]; }
+    for (int g = 0; g < ng; g += 8) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (g + 4 + i < ng) { a1[i] = wp[(g + 4 + i) * 64]; b1[i] = lds[brow(g + 4 + i)]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (g + i < ng) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][j], b0[i][j], acc, 0, 0, 0);
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (g + 8 + i < ng) { a0[i] = wp[(g + 8 + i) * 64]; b0[i] = lds[brow(g + 8 + i)]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (g + 4 + i < ng) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], b1[i][j], acc, 0, 0, 0);
+        }
+    }
+    if (ot + NW >= n_out_tiles && next_wp != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pre[i] = next_wp[i * 64];
+    }
+    epi(ot, acc);
+  }
+}
+
 __device__ __forceinline__ f32x4 acc_quad(const f32x16& acc, int rq) {
   // static rq only (callers unroll)
   return (f32x4){acc[4 * rq + 0], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]};

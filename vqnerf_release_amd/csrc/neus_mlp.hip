@@ -80,15 +80,24 @@ __global__ __launch_bounds__(256, 2) void neus_points_kernel(
 
     // ---------------- SDF hidden layers ----------------
     int cur = X0, oth = Y0;
+    f32x4 pre[4];                                  // first weight fragments of the next layer's first tile of this wave
+    {
+      const f32x4* wp0 = wsdf + sd.layers[0].w_off + (size_t)wave * sd.emb_rows * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pre[i] = wp0[i * 64];
+    }
     for (int l = 0; l < n_lin - 1; ++l) {
       const LayerDesc L = sd.layers[l];
+      const f32x4* next_wp = nullptr;              // layer l + 1 has K rows = this layer's outputs (+ embedding at the skip)
+      if (l + 1 < n_lin - 1)
+        next_wp = wsdf + sd.layers[l + 1].w_off + (size_t)wave * (4 * L.n_out_tiles + ((l + 1 == sd.skip) ? sd.emb_rows : 0)) * 64 + lane;
       const KSegs ks = (l == 0) ? KSegs{E0, sd.emb_rows, 0, 0}
                                 : KSegs{cur, 4 * sd.layers[l - 1].n_out_tiles, E0, (l == sd.skip) ? sd.emb_rows : 0};
       const int dst = (l == 0) ? X0 : oth;
       const bool do_save = FINE && (l < n_lin - 2);
       const f32x4* bp = wsdf + L.b_off;
       f32x4* sv = save + (size_t)l * 4 * MT * 64;
-      gemm_tiles(lds, ks, wsdf + L.w_off, L.n_out_tiles, wave, lane,
+      gemm_tiles_chain(lds, ks, wsdf + L.w_off, L.n_out_tiles, wave, lane, pre, next_wp,
                  [&](int ot, f32x16& acc) { init_bias(bp, ot, lane, acc); },
                  [&](int ot, const f32x16& acc) {
 #pragma unroll
