@@ -1,21 +1,20 @@
 """Dev probe: time the fused NeuS kernels alone (not the bench contract)."""
-import sys, os, time
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import geo as og
+import bench
 from vqnerf_release_amd import _C
-from vqnerf_release_amd.geo import packing as pk
+from vqnerf_release_amd.geo.models.fields import SDFNetwork, RenderingNetwork, SingleVarianceNetwork
+from vqnerf_release_amd.geo.models.renderer import NeuSRenderer
 
-cfg = og.FULL_CFG
-c, cc = cfg['sdf'], cfg['color']
-sp = pk.SdfPackPlan(og.sdf_dims(cfg), c['skip_in'], c['multires'], c['scale'], max_tiles=8)
-cp = pk.ColPackPlan(cc['d_feature'], cc['mode'], cc['d_hidden'], cc['n_layers'], cc['d_out'], cc['multires_view'], cc['squeeze_out'], feat_tiles=sp.tiles[-1])
-p_sdf = og.to_torch(og.make_sdf_params(cfg, 0)); p_col = og.to_torch(og.make_color_params(cfg, 1))
-Ws = [og.wn_weight(p_sdf, l).cuda() for l in range(sp.n_lin)]; bs = [p_sdf[f'lin{l}.bias'].cuda() for l in range(sp.n_lin)]
-Wc = [og.wn_weight(p_col, l).cuda() for l in range(cp.n_lin)]; bc = [p_col[f'lin{l}.bias'].cuda() for l in range(cp.n_lin)]
-wb_s, d_s = sp.pack(Ws, bs); wb_c, d_c = cp.pack(Wc, bc)
+torch.manual_seed(0)
+sdf, col, var = SDFNetwork(**bench.FULL['sdf']).cuda(), RenderingNetwork(**bench.FULL['color']).cuda(), SingleVarianceNetwork(0.3).cuda()
+ren = NeuSRenderer(None, sdf, var, col, **bench.FULL['renderer'])
+wb_s, d_s, wb_c, d_c = ren._packs()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-o, d, near, far = map(lambda a: torch.tensor(a).cuda(), og.make_rays(B, 2))
+o_np, d_np = bench.image_rays(np.arange((B + 799) // 800))
+o, d = torch.tensor(o_np[:B]).cuda(), torch.tensor(d_np[:B]).cuda()
+near, far = torch.full((B, 1), 2.0).cuda(), torch.full((B, 1), 6.0).cuda()
 for S, fine in ((64, False), (128, True)):
     z = (near + (far - near) * torch.linspace(0, 1, S, device='cuda')[None, :]).contiguous()
     f = (lambda: _C.neus_fine_points(d_s, wb_s, d_c, wb_c, rays_o=o, rays_d=d, z=z)) if fine else (lambda: _C.neus_sdf_points(d_s, wb_s, rays_o=o, rays_d=d, z=z))
