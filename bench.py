@@ -166,8 +166,7 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
                        'ms': t_shade * 1e3, 'note': 'two material sets + diffuse/specular split per pass'},
         'kernel_launches_per_call': launches_per_call}
     small = points(2048)
-    opt2 = torch.optim.Adam(model.trainable_variables, lr=5e-4, eps=1e-7, amsgrad=True)
-    model.get_codebook(); _ = model.light
+    model.get_codebook(); _ = model.light            # lazily created variables must exist before the optimiser is built
     opt2 = torch.optim.Adam(model.trainable_variables, lr=5e-4, eps=1e-7, amsgrad=True)
     tr = train_nfr.Trainer(model, opt2)
     dt = _time_gpu(lambda: tr.train_iter(small, global_bs=1024), 5, warm=2)

@@ -38,9 +38,9 @@ class _Engine:
 
     def _finish(self, progs):
         for name, build in progs:
-            best = build(None)
-            assert best.total_rows * 1024 <= 160 * 1024
-            setattr(self, name, best.materialize())
+            prog = build()
+            assert prog.total_rows * 1024 <= 160 * 1024, f'{name}: {prog.total_rows} KB of LDS'
+            setattr(self, name, prog.materialize())
         self._dev = {}
 
     def _static(self, names):
@@ -118,8 +118,8 @@ class EncoderEngine(_Engine):
             self.specs['D%d' % k] = ('t', (L['out'] + 31) // 32)
         self._finish([('prog_fwd', self._build_fwd), ('prog_bwd', self._build_bwd)])
 
-    def _build_fwd(self, seed):
-        P = Program(list(self.specs.keys()), seed)
+    def _build_fwd(self):
+        P = Program(list(self.specs.keys()))
         rE = P.alloc(self.E, [])
         P.op(K_LD_POSENC, P.t('X'), P.row(rE), self.mr, self.E, P.t('E'), _f2i(1.0))
         prev = rE
@@ -131,8 +131,8 @@ class EncoderEngine(_Engine):
             prev = P.gemm(('Wt', k), shape, segs, cols, L['out'], live=[rE], act=L['act'], bias_key=('b', k), store='Y%d' % k)
         return P.finalize()
 
-    def _build_bwd(self, seed):
-        P = Program(list(self.specs.keys()), seed)
+    def _build_bwd(self):
+        P = Program(list(self.specs.keys()))
         top = self.nl - 1
         r = P.alloc(self.layers[top]['out'], [], tiles=(self.layers[top]['out'] + 31) // 32)
         P.op(K_LD_T, P.t('GZ'), P.row(r), r.rows)                       # = delta_top (act' of the top layer applied by the caller)
@@ -232,8 +232,8 @@ class HeadsEngine(_Engine):
                 self.specs['D%d_%d' % (h, k)] = ('t', (w + 31) // 32)
         self._finish([('prog_fwd', self._build_fwd), ('prog_bwd', self._build_bwd)])
 
-    def _build_fwd(self, seed):
-        P = Program(list(self.specs.keys()), seed)
+    def _build_fwd(self):
+        P = Program(list(self.specs.keys()))
         rZ = P.alloc(self.Z, [])
         P.op(K_LD_T, P.t('Z'), P.row(rZ), rZ.rows)
         for h, net in enumerate(self.nets):
@@ -244,8 +244,8 @@ class HeadsEngine(_Engine):
                    bias_key=('b', h, 2), store='Y%d_2' % h, want_dst=False)
         return P.finalize()
 
-    def _build_bwd(self, seed):
-        P = Program(list(self.specs.keys()), seed)
+    def _build_bwd(self):
+        P = Program(list(self.specs.keys()))
         rGZ = None
         last = len(self.nets) - 1
         for h, net in enumerate(self.nets):

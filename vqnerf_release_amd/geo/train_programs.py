@@ -52,7 +52,7 @@ class Program:
     the allocation requests (each new region must not overlap the regions live at that point), minimising the row count --
     staying under 80 rows keeps two workgroups resident per CU."""
 
-    def __init__(self, tensor_names, seed=None):
+    def __init__(self, tensor_names):
         self.tn = {n: i for i, n in enumerate(tensor_names)}
         assert len(self.tn) <= MAX_TENSORS
         self.ops, self.gathers, self.total_rows = [], [], 0
@@ -61,14 +61,14 @@ class Program:
     def t(self, name):
         return -1 if name is None else self.tn[name]
 
-    def alloc(self, feats, live, tiles=None, high=False):
+    def alloc(self, feats, live, tiles=None):
         rows = 4 * tiles if tiles is not None else (feats + 7) // 8
         r = Region(feats, rows)
         self.requests.append((r, [x for x in live if x is not None]))
         return r
 
     def gemm(self, key, M_shape, segs, col_fns, out_feats, live, epi=EPI_ACT, act=ACT_NONE, bias_key=None, aux1=None, aux2=None,
-             store=None, store2=None, dst=None, accumulate=False, want_dst=True, high=False):
+             store=None, store2=None, dst=None, accumulate=False, want_dst=True):
         """segs: Regions forming K; col_fns[i](f) -> column of M for local feature f of segs[i] (or -1)."""
         tiles = (out_feats + 31) // 32
         if dst is None and want_dst:
@@ -224,11 +224,10 @@ class NeusTrainEngine:
         self.n_split = n_split
         for name, build in (('prog_fwd', self._build_forward), ('prog_cbwd', self._build_colour_backward),
                             ('prog_sbwd', self._build_sdf_backward)):
-            best = build(None)
-            assert best.total_rows * 1024 <= 160 * 1024, f'{name}: {best.total_rows} KB of LDS'
-            setattr(self, name, best.materialize())
+            prog = build()
+            assert prog.total_rows * 1024 <= 160 * 1024, f'{name}: {prog.total_rows} KB of LDS'
+            setattr(self, name, prog.materialize())
         self._dev = {}
-        self._desc_dev = {}
 
     # tensor tables -------------------------------------------------------------------------------
     def _tiles(self, f):
@@ -260,8 +259,8 @@ class NeusTrainEngine:
             return [prev, emb], [_ident(self.out[l - 1]), _ident(self.E, base=self.out[l - 1])]
         return [prev], [_ident(self.inn[l])]
 
-    def _build_forward(self, seed):
-        P = Program(self._names(), seed)
+    def _build_forward(self):
+        P = Program(self._names())
         nL, nC = self.nL, self.nC
         rE = P.alloc(self.E, [])
         P.op(K_LD_POSENC, P.t('X'), P.row(rE), self.mr, self.E, P.t('E'), _f2i(self.scale))
@@ -308,8 +307,8 @@ class NeusTrainEngine:
         P.op(K_ST_VEC, P.row(rRGB), 0, 3, P.t('RGB'), ACT_NONE, _f2i(1.0))
         return P.finalize()
 
-    def _build_colour_backward(self, seed):
-        P = Program(self._names(), seed)
+    def _build_colour_backward(self):
+        P = Program(self._names())
         nC = self.nC
         rD = P.alloc(3, [], tiles=1)
         P.op(K_LD_VEC, P.t('DOUT'), P.row(rD), 3, _f2i(1.0), P.t('DC%d' % nC), 0)
@@ -322,8 +321,8 @@ class NeusTrainEngine:
         P.op(K_ST_VEC, P.row(rGX), self.X - 3, 3, P.t('GNCOL'), ACT_NONE, _f2i(1.0))
         return P.finalize()
 
-    def _build_sdf_backward(self, seed):
-        P = Program(self._names(), seed)
+    def _build_sdf_backward(self):
+        P = Program(self._names())
         nL = self.nL
         rED = P.alloc(self.E, [])
         P.op(K_LD_POSENC_JVP, P.t('X'), P.t('V'), P.row(rED), self.mr, self.E, P.t('ED'), _f2i(self.scale))
