@@ -132,3 +132,22 @@ def test_fine_points_fp64_error_budget():
     ec_hip = (rgb.cpu().double() - c64o).abs().max().item()
     print(f'max|err| vs fp64: sdf hip {e_hip:.2e} cpu32 {e_cpu:.2e}; grad hip {eg_hip:.2e} cpu32 {eg_cpu:.2e}; rgb hip {ec_hip:.2e}')
     assert e_hip < 1e-5 and eg_hip < 2e-4 and ec_hip < 1e-4
+
+
+def test_narrow_layers_fewer_tiles_than_waves():
+    """A layer with fewer 32-feature tiles than waves (here the 25-wide layer before the skip of a 64-wide net) leaves some
+    waves idle in that layer; they must still hand the next layer its prefetched weight fragments."""
+    import torch
+    from vqnerf_release_amd.geo.models.fields import SDFNetwork
+    torch.manual_seed(1)
+    sdf = SDFNetwork(d_in=3, d_out=65, d_hidden=64, n_layers=4, skip_in=(2,), multires=6).cuda()
+    with torch.no_grad():
+        for p in sdf.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    pts = torch.tensor(np.random.default_rng(0).uniform(-1, 1, (333, 3)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        got, ref = sdf.sdf(pts), sdf.forward(pts)[:, :1]
+        g_hip = sdf.gradient(pts)
+    g_ref = sdf.gradient(pts.clone().requires_grad_(True))
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(g_hip.cpu().numpy(), g_ref.detach().cpu().numpy(), rtol=0, atol=3e-4)

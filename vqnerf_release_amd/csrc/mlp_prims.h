@@ -131,6 +131,10 @@ __device__ __forceinline__ void gemm_tiles_chain(const f32x4* __restrict__ lds, 
     }
     epi(ot, acc);
   }
+  if (wave >= n_out_tiles && next_wp != nullptr) {      // a wave without a tile in this layer still owes the next layer its fragments
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pre[i] = next_wp[i * 64];
+  }
 }
 
 __device__ __forceinline__ f32x4 acc_quad(const f32x16& acc, int rq) {

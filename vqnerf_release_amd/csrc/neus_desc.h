@@ -27,8 +27,10 @@ struct SdfDesc {                       // 12 + 12*8 = 108 ints
   int max_tiles;                       // LDS buffer capacity in 32-feature tiles (>= every layer of both nets)
   float scale;
   int last_w_off;                      // sdf row of the last layer as a rowdot image [rows][2] float4
-  float last_bias;
-  int reserved0, reserved1, reserved2;
+  float last_bias;                     // used when last_b_off == 0
+  int last_b_off;                      // > 0: the sdf row's bias lives in the pack at this float4 offset (component 0):
+                                       // re-packing after an optimiser step then needs no device -> host copy
+  int reserved1, reserved2;
   LayerDesc layers[VQN_MAX_SDF_LAYERS];  // layers[n_lin-1] = the FEATURE rows of the last layer (n_out_tiles = 0 if none)
 };
 
@@ -41,7 +43,8 @@ struct ColDesc {                       // 16 + 8*8 = 80 ints
   int d_out;                           // 3
   int squeeze_out;
   int last_w_off;                      // rowdot image [3][rows][2] float4
-  float last_bias[4];
-  int reserved0, reserved1, reserved2, reserved3;
+  float last_bias[4];                  // used when last_b_off == 0
+  int last_b_off;                      // > 0: [b0, b1, b2, 0] in the pack at this float4 offset
+  int reserved1, reserved2, reserved3;
   LayerDesc layers[VQN_MAX_COL_LAYERS];
 };

@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256, 2) void neus_points_kernel(
     }
     __syncthreads();
     if (tid < 32 && p0 + tid < P) {
-      const float s = ((sm->part[tid] + sm->part[32 + tid]) + (sm->part[64 + tid] + sm->part[96 + tid])) + sd.last_bias;
+      const float s = ((sm->part[tid] + sm->part[32 + tid]) + (sm->part[64 + tid] + sm->part[96 + tid])) +
+                      (sd.last_b_off > 0 ? wsdf[sd.last_b_off][0] : sd.last_bias);
       out_sdf[p0 + tid] = s / sd.scale;
     }
     if (!FINE) { __syncthreads(); continue; }
@@ -259,7 +260,8 @@ __global__ __launch_bounds__(256, 2) void neus_points_kernel(
       if (tid < 96) {
         const int pp = tid & 31, o = tid >> 5;
         float v = ((sm->part[(0 * 32 + pp) * 3 + o] + sm->part[(1 * 32 + pp) * 3 + o]) +
-                   (sm->part[(2 * 32 + pp) * 3 + o] + sm->part[(3 * 32 + pp) * 3 + o])) + cd.last_bias[o];
+                   (sm->part[(2 * 32 + pp) * 3 + o] + sm->part[(3 * 32 + pp) * 3 + o])) +
+                  (cd.last_b_off > 0 ? wcol[cd.last_b_off][o] : cd.last_bias[o]);
         if (cd.squeeze_out) v = 1.f / (1.f + expf(-v));
         if (p0 + pp < P) out_rgb[(p0 + pp) * 3 + o] = v;
       }

@@ -143,14 +143,17 @@ class NeuSRenderer:
         if last:
             z, _ = _C.neus_merge(z_vals.contiguous(), None, new_z_vals.contiguous(), None)
             return z, sdf
-        wb_s, d_s, _, _ = self._packs()
+        wb_s, d_s = self._sdf_pack()
         new_sdf = _C.neus_sdf_points(d_s, wb_s, rays_o=rays_o.contiguous(), rays_d=rays_d.contiguous(),
                                      z=new_z_vals.contiguous()).reshape(new_z_vals.shape)
         return _C.neus_merge(z_vals.contiguous(), sdf.reshape(z_vals.shape).contiguous(), new_z_vals.contiguous(), new_sdf)
 
+    def _sdf_pack(self):
+        return self.sdf_network.packs(max_tiles=self.color_network.max_tiles())
+
     @torch.no_grad()
     def _importance_z(self, rays_o, rays_d, z_vals, radius):
-        wb_s, d_s, _, _ = self._packs()
+        wb_s, d_s = self._sdf_pack()
         B = rays_o.shape[0]
         sdf = _C.neus_sdf_points(d_s, wb_s, rays_o=rays_o, rays_d=rays_d, z=z_vals).reshape(B, self.n_samples)
         m = self.n_importance // self.up_sample_steps

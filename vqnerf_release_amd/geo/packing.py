@@ -84,6 +84,10 @@ def _take(mat, idx_dev):
     return torch.take(flat, idx_dev).reshape(-1)
 
 
+def wbuf_zero3(like):
+    return like.new_zeros(3, dtype=torch.float32)
+
+
 def emb_rows_for(n_feats):
     return (((n_feats + 1) // 2) + 3) // 4
 
@@ -199,13 +203,16 @@ class SdfPackPlan:
                 layer[l]['wTE'] = o4
             chunks.append(c)
             off += c.numel()
+        # the sdf row's bias rides in the pack (component 0 of one float4): no device -> host copy per re-pack
+        last_b_off = off // 4
+        chunks.append(torch.cat([biases[self.n_lin - 1][:1].reshape(1).float(), wbuf_zero3(weights[0])]))
+        off += 4
         wbuf = torch.cat(chunks).contiguous()
         desc = np.zeros(SDF_DESC_INTS, np.int32)
         desc[0:6] = [self.n_lin, self.skip, self.multires, self.emb, self.emb_rows, self.max_tiles]
         desc[6] = np.float32(self.scale).view(np.int32)
         desc[7] = last_w_off
-        self._last_bias_src = biases[self.n_lin - 1][0]
-        desc[8] = np.float32(float(self._last_bias_src)).view(np.int32)      # one scalar D2H per re-pack
+        desc[9] = last_b_off
         for l in range(self.n_lin):
             d = layer[l]
             desc[12 + 8 * l: 12 + 8 * l + 8] = [d['n_out_tiles'], d['kA'], d['kB'], d['w'], d['b'], d['wT'], d['wTE'], 0]
@@ -264,11 +271,13 @@ class ColPackPlan:
                 last_w_off = o4
             chunks.append(c)
             off += c.numel()
+        last_b_off = off // 4
+        chunks.append(torch.cat([biases[self.n_lin - 1][:3].reshape(3).float(), wbuf_zero3(weights[0])[:1]]))
+        off += 4
         wbuf = torch.cat(chunks).contiguous()
         desc = np.zeros(COL_DESC_INTS, np.int32)
         desc[0:8] = [self.n_lin, self.n_view, self.has_normal, self.extra, self.extra_rows, 3, self.squeeze_out, last_w_off]
-        lb = biases[self.n_lin - 1].detach().float().cpu().numpy()
-        desc[8:11] = lb.astype(np.float32).view(np.int32)
+        desc[12] = last_b_off
         for l in range(self.n_lin):
             d = layer[l]
             desc[16 + 8 * l: 16 + 8 * l + 8] = [d['n_out_tiles'], 0, 0, d['w'], d['b'], -1, -1, 0]
