@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 SHAPES = [
     dict(d_hidden=64, n_layers=2, skip_in=(), multires=6, mv=4),
     dict(d_hidden=100, n_layers=3, skip_in=(2,), multires=4, mv=2),
-    dict(d_hidden=32, n_layers=5, skip_in=(3,), multires=6, mv=4),
+    dict(d_hidden=48, n_layers=5, skip_in=(3,), multires=6, mv=4),      # the layer before the skip is 48 - 39 = 9 wide
     dict(d_hidden=160, n_layers=4, skip_in=(1,), multires=8, mv=4),
     dict(d_hidden=256, n_layers=8, skip_in=(4,), multires=6, mv=4),
 ]
@@ -101,7 +101,7 @@ def test_reflectance_model_shapes(width, z, nf):
     cb = rng.uniform(0, 1, (8, z)).astype(np.float32)
     m.set_codebook(cb)
     m.set_light(rng.uniform(0, 1, (16, 32, 3)).astype(np.float32))
-    batch = make_batch(od.make_points(193, seed=3), 'cuda', bg_every=11)
+    batch = make_batch(od.make_points(192, seed=3), 'cuda')     # training batches are [p, p_neighbour] pairs: even count
     with torch.no_grad():
         p_f, _, lk_f, _ = m.call(batch, mode='vali')
     grads = {}
