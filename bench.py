@@ -211,11 +211,16 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback)'
+    local_rank %= torch.cuda.device_count()        # (rehearsals put several ranks on one card; the driver gives one GPU per rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    backend = os.environ.get('VQN_BENCH_BACKEND', 'nccl')      # 'gloo' only to rehearse the multi-rank path on a 1-GPU box
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from vqnerf_release_amd import _C
     from vqnerf_release_amd.geo.models.fields import SDFNetwork, RenderingNetwork, SingleVarianceNetwork
@@ -265,7 +270,7 @@ def main():
     clock = _C.KernelClock.summary()
     _C.KernelClock.reset(False)
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(out['color_fine']).all()
