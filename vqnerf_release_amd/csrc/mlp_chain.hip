@@ -45,45 +45,50 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_kernel(con
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long p0 = tile << 5;
     const long pt = (p0 + p < N) ? p0 + p : N - 1;
-    // ---------------- input image ----------------
-    if (d.in_mode == 1) {                       // positional encoding of a 3-vector (embedder.py:23-47)
-      const float x0 = in[pt * d.in_stride + 0], x1 = in[pt * d.in_stride + 1], x2 = in[pt * d.in_stride + 2];
-      for (int r = wave; r < d.in_rows; r += NW) {
-        f32x4 v;
+    // ---------------- input image (also re-loadable later in the program: kind 2) ----------------
+    auto load_input = [&](const int row0) {
+      if (d.in_mode == 1) {                       // positional encoding of a 3-vector (embedder.py:23-47)
+        const float x0 = in[pt * d.in_stride + 0], x1 = in[pt * d.in_stride + 1], x2 = in[pt * d.in_stride + 2];
+        for (int r = wave; r < d.in_rows; r += NW) {
+          f32x4 v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int f = row_feat(r, h, j);
-          v[j] = f < d.in_feats ? posenc_feat(f, x0, x1, x2) : 0.f;
+          for (int j = 0; j < 4; ++j) {
+            const int f = row_feat(r, h, j);
+            v[j] = f < d.in_feats ? posenc_feat(f, x0, x1, x2) : 0.f;
+          }
+          lds[(row0 + r) * 64 + lane] = v;
         }
-        lds[(d.in_row0 + r) * 64 + lane] = v;
-      }
-    } else {                                     // raw features [N, in_feats], row stride in_stride
-      const float* xr = in + pt * (long)d.in_stride;
-      const bool vec_ok = (d.in_stride & 3) == 0;
-      for (int r = wave; r < d.in_rows; r += NW) {
-        const int f0 = 32 * (r >> 2) + 8 * (r & 3) + 4 * h;
-        f32x4 v;
-        if (vec_ok && f0 + 3 < d.in_feats) v = *reinterpret_cast<const f32x4*>(xr + f0);
-        else {
+      } else {                                     // raw features [N, in_feats], row stride in_stride
+        const float* xr = in + pt * (long)d.in_stride;
+        const bool vec_ok = (d.in_stride & 3) == 0;
+        for (int r = wave; r < d.in_rows; r += NW) {
+          const int f0 = 32 * (r >> 2) + 8 * (r & 3) + 4 * h;
+          f32x4 v;
+          if (vec_ok && f0 + 3 < d.in_feats) v = *reinterpret_cast<const f32x4*>(xr + f0);
+          else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = (f0 + j < d.in_feats) ? xr[f0 + j] : 0.f;
+            for (int j = 0; j < 4; ++j) v[j] = (f0 + j < d.in_feats) ? xr[f0 + j] : 0.f;
+          }
+          // lanes (p,0) and (p,1) hold features f..f+3 and f+4..f+7; the image wants even / odd features
+          const float s0 = h ? v[0] : v[1], s1 = h ? v[2] : v[3];
+          const float r0 = __shfl_xor(s0, 32), r1 = __shfl_xor(s1, 32);
+          f32x4 w;
+          if (h == 0) { w[0] = v[0]; w[1] = v[2]; w[2] = r0; w[3] = r1; }
+          else { w[0] = r0; w[1] = r1; w[2] = v[1]; w[3] = v[3]; }
+          lds[(row0 + r) * 64 + lane] = w;
         }
-        // lanes (p,0) and (p,1) hold features f..f+3 and f+4..f+7; the image wants even / odd features
-        const float s0 = h ? v[0] : v[1], s1 = h ? v[2] : v[3];
-        const float r0 = __shfl_xor(s0, 32), r1 = __shfl_xor(s1, 32);
-        f32x4 w;
-        if (h == 0) { w[0] = v[0]; w[1] = v[2]; w[2] = r0; w[3] = r1; }
-        else { w[0] = r0; w[1] = r1; w[2] = v[1]; w[3] = v[3]; }
-        lds[(d.in_row0 + r) * 64 + lane] = w;
       }
-    }
-    __syncthreads();
+      __syncthreads();
+    };
+    load_input(d.in_row0);
 
     // ---------------- layer program ----------------
     for (int l = 0; l < d.n_layers; ++l) {
       const ChainLayer L = d.layers[l];
       const KSegs ks{L.kA_row0, L.kA_rows, L.kB_row0, L.kB_rows};
-      if (L.kind == 0) {
+      if (L.kind == 2) {                            // input image again (it was not kept resident: LDS rows are the scarce resource)
+        load_input(L.dst_row0);
+      } else if (L.kind == 0) {
         const f32x4* bp = wbuf + L.b_off;
         const int act = L.act, dst = L.dst_row0;
         gemm_tiles<NW>(lds, ks, wbuf + L.w_off, L.n_out_tiles, wave, lane,
@@ -170,6 +175,10 @@ int check_desc(const ChainDesc& d) {
   if (d.in_feats < 1 || d.in_feats > 8 * d.in_rows || d.in_stride < 1) return 6;
   for (int l = 0; l < d.n_layers; ++l) {
     const ChainLayer& L = d.layers[l];
+    if (L.kind == 2) {
+      if (L.dst_row0 < 0 || L.dst_row0 + d.in_rows > d.total_rows) return 20;
+      continue;
+    }
     if (L.kA_rows < 0 || L.kB_rows < 0 || L.kA_rows + L.kB_rows < 1) return 10;
     if (L.kA_row0 < 0 || L.kA_row0 + L.kA_rows > d.total_rows) return 11;
     if (L.kB_rows > 0 && (L.kB_row0 < 0 || L.kB_row0 + L.kB_rows > d.total_rows)) return 12;

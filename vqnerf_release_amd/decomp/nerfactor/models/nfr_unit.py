@@ -161,11 +161,29 @@ class BrdfModel(ShapeModel):
         key = 'heads:%d:' % in_dim + ','.join(names)
         if key not in self._plans:
             b = packing.ChainBuilder('raw', in_dim)
+            x = b.input
             for slot, name in enumerate(names):
                 net = self.net[name]
-                b.mlp(name, net.widths, net.act, net.skip_at, b.input, keep=[b.input], out_slot=slot)
+                if self._is_std_head(net):
+                    # [w0, w1, c] with the input concatenated into the last layer: the input image is NOT kept in LDS while
+                    # the two wide activations are live -- it is fetched again (L2) for the last layer, and for the next head.
+                    # That keeps the program at 64 rows, i.e. two workgroups per CU instead of one.
+                    if x is None:
+                        x = b.reload_input()
+                    y0 = b.dense(f'{name}/0', [x], net.widths[0], net.act[0])
+                    y1 = b.dense(f'{name}/1', [y0], net.widths[1], net.act[1])
+                    x = b.reload_input(keep=[y1])
+                    b.dense_small(f'{name}/2', [y1, x], net.widths[2], net.act[2], slot)
+                else:
+                    if x is None:
+                        x = b.reload_input()
+                    b.mlp(name, net.widths, net.act, net.skip_at, x, keep=[x], out_slot=slot)
             self._plans[key] = b.build()
         return self._plans[key]
+
+    @staticmethod
+    def _is_std_head(net):
+        return len(net.widths) == 3 and net.skip_at == [1] and net.widths[2] <= 4
 
     def _program_pack(self, key, plan, nets):
         cache = self._packs.setdefault(key, _PackCache())

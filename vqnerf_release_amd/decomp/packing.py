@@ -72,6 +72,13 @@ class ChainBuilder:
             self.n_slots = max(self.n_slots, out_slot + 1)
         return dst
 
+    def reload_input(self, keep=()):
+        """The input image again, in fresh rows: lets a program drop the input while wide activations are live and fetch it
+        back (from L2) where a later layer concatenates it."""
+        r = Region(None, self.in_feats)
+        self.layers.append(dict(kind=2, key=None, segs=[], out=0, act=0, dst=r, tiles=0, live=list(keep), out_slot=-1))
+        return r
+
     def dense_small(self, key, segs, n_out, act, out_slot):
         assert 1 <= n_out <= 4 and 1 <= len(segs) <= 2
         self.layers.append(dict(kind=1, key=key, segs=list(segs), out=n_out, act=ACT[act], dst=None, tiles=n_out,
@@ -97,7 +104,7 @@ class ChainBuilder:
     def _assign_rows(self):
         """Place every GEMM output so that it overlaps none of its layer's live regions, minimising the LDS rows
         used (small depth-first search over 'row 0 or right after an already placed region')."""
-        gemm = [L for L in self.layers if L['kind'] == 0]
+        gemm = [L for L in self.layers if L['kind'] in (0, 2)]
         best = {'rows': None, 'pos': None}
         placed = [self.input]
 
@@ -119,6 +126,7 @@ class ChainBuilder:
                 placed.pop()
                 L['dst'].row0 = None
 
+        self.input.row0 = 0
         rec(0, self.input.alloc_rows, [])
         assert best['pos'] is not None
         for L, c in zip(gemm, best['pos']):
@@ -142,6 +150,10 @@ class ChainPlan:
         self.gather = []
         for L in self.layers:
             in_feats = sum(s.feats for s in L['segs'])
+            if L['kind'] == 2:
+                L['k_rows'], L['in_feats'] = [], 0
+                self.gather.append((None, None))
+                continue
             if L['kind'] == 0:
                 segs, base = [], 0
                 for s in L['segs']:
@@ -162,7 +174,7 @@ class ChainPlan:
     def _indices(self, device):
         k = str(device)
         if k not in self._dev:
-            self._dev[k] = [(torch.from_numpy(w).to(device), None if bi is None else torch.from_numpy(bi).to(device))
+            self._dev[k] = [(None if w is None else torch.from_numpy(w).to(device), None if bi is None else torch.from_numpy(bi).to(device))
                             for w, bi in self.gather]
         return self._dev[k]
 
@@ -172,13 +184,17 @@ class ChainPlan:
     def pack(self, params):
         """params[key] = (kernel [in, out], bias [out]) device tensors.  -> (wbuf, desc int32 numpy)."""
         b = self.b
-        dev = params[self.layers[0]['key']][0].device
+        dev = params[next(L['key'] for L in self.layers if L['kind'] != 2)][0].device
         chunks, off = [], 0
         desc = np.zeros(DESC_INTS, np.int32)
         desc[0:9] = [len(self.layers), 1 if b.in_mode == 'posenc' else 0, b.in_feats, b.input.rows, b.input.row0,
                      b.n_freqs, self.total_rows, self.n_waves, b.in_stride]
         small_bias = []
         for li, (L, (wi, bi)) in enumerate(zip(self.layers, self._indices(dev))):
+            if L['kind'] == 2:
+                base = 16 + LAYER_INTS * li
+                desc[base:base + 12] = [2, 0, 0, 0, 0, 0, 0, L['dst'].row0, 0, -1, -1, 0]
+                continue
             W, bias = params[L['key']]
             assert tuple(W.shape) == (L['in_feats'], L['out']), (L['key'], tuple(W.shape), (L['in_feats'], L['out']))
             M = W.t().contiguous()                                  # [out, in]
