@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libvqnerf_hip.so')
+LIB_PATH = os.environ.get('VQN_LIB', os.path.join(_HERE, 'lib', 'libvqnerf_hip.so'))     # VQN_LIB: diagnostic builds only
 _lib = None
 
 

@@ -62,6 +62,7 @@ __device__ __forceinline__ void gemm_tiles(const f32x4* __restrict__ lds, const 
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       if (i < ng) { a0[i] = wp[i * 64]; b0[i] = lds[brow(i)]; }
+    __builtin_amdgcn_s_setprio(1);
     for (int g = 0; g < ng; g += 8) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -82,6 +83,7 @@ __device__ __forceinline__ void gemm_tiles(const f32x4* __restrict__ lds, const 
           for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], b1[i][j], acc, 0, 0, 0);
         }
     }
+    __builtin_amdgcn_s_setprio(0);
     epi(ot, acc);
   }
 }
@@ -105,6 +107,7 @@ __device__ __forceinline__ void gemm_tiles_chain(const f32x4* __restrict__ lds, 
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       if (i < ng) { if (first) a0[i] = pre[i]; else a0[i] = wp[i * 64]; b0[i] = lds[brow(i)]; }
+    __builtin_amdgcn_s_setprio(1);
     for (int g = 0; g < ng; g += 8) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -125,6 +128,7 @@ __device__ __forceinline__ void gemm_tiles_chain(const f32x4* __restrict__ lds, 
           for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], b1[i][j], acc, 0, 0, 0);
         }
     }
+    __builtin_amdgcn_s_setprio(0);
     if (ot + NW >= n_out_tiles && next_wp != nullptr) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) pre[i] = next_wp[i * 64];

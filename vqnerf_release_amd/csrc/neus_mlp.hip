@@ -15,6 +15,26 @@
 
 using namespace eng;
 
+// In-kernel phase stamps (cdna_hip_programming.md section 7): a DIAGNOSTIC build only (make stamps -> lib/libvqnerf_hip_stamps.so,
+// -DVQN_STAMPS); the shipped library contains none of this.  Wave 0 of every workgroup accumulates shader-clock cycles per
+// phase and adds them to g_stamps at exit: [0] tile set-up (points, posenc), [1] GEMM main loops (operand waits included),
+// [2] epilogues, [3] barrier waits, [4] everything else, [5] total, [6] workgroups.
+#ifdef VQN_STAMPS
+__device__ unsigned long long g_stamps[8];
+#define VQN_STAMP_DECL unsigned long long st_[6] = {0, 0, 0, 0, 0, 0}; unsigned long long st_prev = __builtin_amdgcn_s_memtime(); const unsigned long long st_begin = st_prev;
+#define VQN_STAMP(i) { const unsigned long long st_now = __builtin_amdgcn_s_memtime(); st_[i] += st_now - st_prev; st_prev = st_now; }
+#define VQN_STAMP_FLUSH if (threadIdx.x == 0) { st_[5] = __builtin_amdgcn_s_memtime() - st_begin; for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&g_stamps[i_], st_[i_]); atomicAdd(&g_stamps[6], 1ull); }
+extern "C" int vqn_debug_read_stamps(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return -3;
+  if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -3; }
+  return 0;
+}
+#else
+#define VQN_STAMP_DECL
+#define VQN_STAMP(i)
+#define VQN_STAMP_FLUSH
+#endif
+
 namespace {
 
 constexpr int E0 = 0;        // LDS rows [0,8): embedding / colour-net extras / d sdf / d embedding
@@ -42,8 +62,10 @@ __global__ __launch_bounds__(256, 2) void neus_points_kernel(
   f32x4* save = FINE ? scratch + (size_t)blockIdx.x * (size_t)(n_lin - 1) * 4 * MT * 64 : nullptr;
   const int feat_slot = (n_lin - 2) * 4 * MT;
 
+  VQN_STAMP_DECL
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long p0 = tile << 5;
+    VQN_STAMP(4)
     // ---------------- points of this tile ----------------
     if (tid < 32) {
       long pt = p0 + tid;
@@ -78,6 +100,7 @@ __global__ __launch_bounds__(256, 2) void neus_points_kernel(
     }
     __syncthreads();
 
+    VQN_STAMP(0)
     // ---------------- SDF hidden layers ----------------
     int cur = X0, oth = Y0;
     f32x4 pre[4];                                  // first weight fragments of the next layer's first tile of this wave
@@ -98,8 +121,9 @@ __global__ __launch_bounds__(256, 2) void neus_points_kernel(
       const f32x4* bp = wsdf + L.b_off;
       f32x4* sv = save + (size_t)l * 4 * MT * 64;
       gemm_tiles_chain(lds, ks, wsdf + L.w_off, L.n_out_tiles, wave, lane, pre, next_wp,
-                 [&](int ot, f32x16& acc) { init_bias(bp, ot, lane, acc); },
+                 [&](int ot, f32x16& acc) { VQN_STAMP(2) init_bias(bp, ot, lane, acc); },
                  [&](int ot, const f32x16& acc) {
+                   VQN_STAMP(1)
 #pragma unroll
                    for (int rq = 0; rq < 4; ++rq) {
                      f32x4 v = acc_quad(acc, rq);
@@ -109,7 +133,9 @@ __global__ __launch_bounds__(256, 2) void neus_points_kernel(
                      if (do_save) sv[(ot * 4 + rq) * 64 + lane] = v;
                    }
                  });
+      VQN_STAMP(2)
       __syncthreads();
+      VQN_STAMP(3)
       if (l == 0) { cur = X0; oth = Y0; } else { const int t = cur; cur = oth; oth = t; }
     }
     const int hid_rows = 4 * sd.layers[n_lin - 2].n_out_tiles;
@@ -268,6 +294,8 @@ __global__ __launch_bounds__(256, 2) void neus_points_kernel(
     }
     __syncthreads();
   }
+  VQN_STAMP(4)
+  VQN_STAMP_FLUSH
 }
 
 int check_sdf_desc(const SdfDesc& d) {
