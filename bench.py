@@ -125,6 +125,26 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
                                 'a tangent pass), weight-gradient contraction, compositing fwd/bwd; torch only for Adam, the '
                                 'weight-norm chain rule and small reductions'}
 
+    # ---- light-visibility extraction (gen_geo.py compute_vis): secondary rays surface -> light, occupancy only ----
+    from vqnerf_release_amd.geo.gen_geo import GeoExtractor
+    ex = GeoExtractor(ren, max_radius=2.0, light_h=16, max_rays=1 << 20)
+    npts = 4096
+    u = torch.randn(npts, 3, device=dev)
+    nrm = u / u.norm(dim=-1, keepdim=True)
+    surf = 0.5 * nrm                                            # points on the 0.5-sphere the geometric init approximates
+    msk = torch.ones(npts, 1, device=dev)
+    with torch.no_grad():
+        ex.compute_vis(surf[:256], nrm[:256], msk[:256], perturb_overwrite=0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lv = ex.compute_vis(surf, nrm, msk, perturb_overwrite=0)
+        torch.cuda.synchronize()
+        dtv = time.perf_counter() - t0
+    n_sec = int((torch.einsum('ijk,ik->ij', torch.nn.functional.normalize(ex.lxyz.to(dev) - surf[:, None, :], dim=-1), nrm) > 0).sum())
+    out['compute_vis'] = {'secondary_rays_per_s': n_sec / dtv, 'surface_points': npts, 'secondary_rays': n_sec, 'ms': dtv * 1e3,
+                          'note': 'all front-lit (point, light) pairs of a chunk in one batch; colour network skipped (weights_only); '
+                                  'the reference walks 512 lights one by one with a host sync each (gen_geo.py:202-242)'}
+
     # ---- reflectance model (vq_nfr): full-view inference and one training step ----
     model = get_model_class('vq_nfr')(config_from_dict(DECOMP_INI))
     model.build_nets(device=dev, seed=0).to(dev)
