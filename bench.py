@@ -199,6 +199,15 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     dt = _time_gpu(lambda: tr.train_iter(big_tr, global_bs=262144), 3, warm=1)
     out['decomp_train_256k'] = {'points_per_s': 262144 / dt, 'ms_per_step': dt * 1e3, 'batch_points': 262144,
                                 'note': 'same step on a 128x larger batch (what a data-parallel / large-batch run would use)'}
+    # the same reference-size step captured once into a HIP graph and replayed (Trainer(graph=True)); last, as it switches
+    # the model to its all-foreground statement
+    opt3, _, clip3 = train_nfr.make_optimizer(config_from_dict(DECOMP_INI), model.trainable_variables, capturable=True)
+    tr_g = train_nfr.Trainer(model, opt3, clip=clip3, graph=True)
+    dt = _time_gpu(lambda: tr_g.train_iter(small, global_bs=1024), 20, warm=train_nfr.Trainer.GRAPH_WARMUP + 2)
+    out['decomp_train_graph'] = {'points_per_s': 2048 / dt, 'ms_per_step': dt * 1e3, 'batch_points': 2048,
+                                 'captured': tr_g._captured is not None,
+                                 'note': 'decomp_train with the whole step (forward, loss, backward, EMA codebook move, Adam) '
+                                         'replayed from one captured HIP graph'}
 
     # ---- standalone VQ nearest-code assignment + EMA statistics (HBM-bound) ----
     Nv, D, K = 1 << 20, 256, 15

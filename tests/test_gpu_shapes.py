@@ -114,7 +114,6 @@ def test_reflectance_model_shapes(width, z, nf):
             m._codebook.copy_(cb0)                              # undo the EMA move so that both passes see the same codebook
         m.vq_layer.ema_cluster_size.hidden.zero_(); m.vq_layer.ema_dw.hidden.zero_()
         m.vq_layer.ema_cluster_size.counter.zero_(); m.vq_layer.ema_dw.counter.zero_()
-        m.vq_layer.ema_cluster_size._steps = m.vq_layer.ema_dw._steps = 0
         loss, _ = m.compute_loss(p, g, **dict(lk))
         loss.mean().backward()
         grads[backend] = {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}

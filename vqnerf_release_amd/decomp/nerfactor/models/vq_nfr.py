@@ -12,7 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from vqnerf_release_amd.decomp.nerfactor.models.nfr_unit import BrdfModel, scatter_rows
+from vqnerf_release_amd.decomp.nerfactor.models.nfr_unit import BrdfModel, scatter_rows, take_rows
 from vqnerf_release_amd.decomp.nerfactor.networks import mlp
 from vqnerf_release_amd.decomp.nerfactor.networks.vq_layers import VectorQuantizerEMA
 from vqnerf_release_amd.decomp.nerfactor.util import img as imgutil, math as mathutil
@@ -147,10 +147,11 @@ class Model(BrdfModel):
     def call(self, batch, mode='train', thres=None, full_vis=False, roll=None):
         self._validate_mode(mode)
         id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz, normal, lvis = self._unpack(batch)
-        mask = alpha[:, 0] > 0
+        # `assume_foreground`: the caller guarantees alpha > 0 on every row (outer_sample's batches are), so no boolean
+        # gather / scatter -- and no host sync -- is needed
+        mask = None if self.assume_foreground else alpha[:, 0] > 0
         n = alpha.shape[0]
-        rayo, rgb_m, xyz_m, normal_m = rayo[mask], rgb[mask], xyz[mask], normal[mask]
-        lvis_m = lvis[mask] if lvis is not None else None
+        rayo, rgb_m, xyz_m, normal_m, lvis_m = take_rows(mask, rayo, rgb, xyz, normal, lvis)
 
         z_enc = self._pred_enc_at(xyz_m)
         vq, z_vq, vq_loss, embed_ind = self._quantise(z_enc, mode, thres, roll=roll)

@@ -23,7 +23,6 @@ class ExponentialMovingAverage(torch.nn.Module):
         self.register_buffer('hidden', torch.zeros(shape, dtype=dtype))
         self.register_buffer('average', torch.zeros(shape, dtype=dtype))
         self.register_buffer('counter', torch.zeros((), dtype=torch.int64))
-        self._steps = 0     # host copy of `counter`, avoids a device sync per update
 
     def initialize(self, value):
         self.hidden = torch.zeros_like(value)
@@ -31,12 +30,13 @@ class ExponentialMovingAverage(torch.nn.Module):
 
     @torch.no_grad()
     def update(self, value):
-        if self._steps == 0 and int(self.counter) != 0:     # restored from a checkpoint
-            self._steps = int(self.counter)
-        self._steps += 1
+        """hidden -= (hidden - v) (1 - decay); counter += 1; average = hidden / (1 - decay^counter).  Everything stays on the
+        device (no host copy of the counter: the update can live inside a captured HIP graph); the zero-debias factor is taken
+        in float64 so that 1 - 0.999^k keeps its digits."""
         self.counter += 1
         self.hidden -= (self.hidden - value) * (1.0 - self.decay)
-        self.average = self.hidden / (1.0 - self.decay ** self._steps)
+        debias = 1.0 - torch.pow(torch.full((), self.decay, dtype=torch.float64, device=self.counter.device), self.counter.double())
+        self.average = (self.hidden.double() / debias).to(self.hidden.dtype)
 
     @property
     def value(self):

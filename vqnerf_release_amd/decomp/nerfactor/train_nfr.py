@@ -10,11 +10,16 @@ import torch
 from vqnerf_release_amd import parallel
 
 
-def make_optimizer(config, params):
+def make_optimizer(config, params, capturable=False):
     """Keras Adam(lr, amsgrad=True) (train_nfr.py:121-139): epsilon 1e-7 (Keras default, torch's is 1e-8), optional
-    ExponentialDecay(lr_decay_steps, lr_decay_rate) -> returned as a LambdaLR, clipnorm / clipvalue as a closure."""
+    ExponentialDecay(lr_decay_steps, lr_decay_rate) -> returned as a LambdaLR, clipnorm / clipvalue as a closure.
+    `capturable`: step counters and lr live on the device, as `Trainer(graph=True)` needs (and the update is torch's fused
+    multi-tensor kernel: one launch instead of a dozen foreach passes)."""
     lr = config.getfloat('DEFAULT', 'lr')
-    opt = torch.optim.Adam(params, lr=lr, eps=1e-7, amsgrad=True)
+    params = list(params)
+    if capturable:
+        lr = torch.tensor(lr, dtype=torch.float32, device=params[0].device)
+    opt = torch.optim.Adam(params, lr=lr, eps=1e-7, amsgrad=True, capturable=capturable, fused=bool(capturable))
     decay_steps = config.getint('DEFAULT', 'lr_decay_steps', fallback=-1)
     sched = None
     if decay_steps > 0:
@@ -32,12 +37,31 @@ def compute_average_loss(per_example_loss, global_batch_size):
 
 
 class Trainer:
-    """Holds the DP plumbing of one model: flat gradient bucket + VQ statistics reducer."""
+    """Holds the DP plumbing of one model: flat gradient bucket + VQ statistics reducer.
 
-    def __init__(self, model, optimizer, clip=(-1, -1), sched=None):
+    `graph=True` (single rank): the step at the reference's batch size (n_rays_per_step = 1024 pairs) is ~150 short
+    launches, i.e. launch-bound; the whole of it -- forward, loss, backward, EMA codebook move, Adam -- is captured once
+    into a HIP graph and replayed on static buffers.  Conditions, all checked: batches of a fixed shape whose rows are all
+    foreground (`outer_sample` only yields such rows; sets `model.assume_foreground`), no `thres` / `roll`, a `capturable`
+    optimiser (make_optimizer(..., capturable=True)).  The first `GRAPH_WARMUP` calls run eagerly (they are real steps);
+    the tensors returned by later calls are the graph's static outputs, overwritten by the next call."""
+
+    GRAPH_WARMUP = 2
+
+    def __init__(self, model, optimizer, clip=(-1, -1), sched=None, graph=False):
         assert model.trainable_registered, 'Register the trainable layers before using `trainable_variables`'
         self.model, self.optimizer, self.clip, self.sched = model, optimizer, clip, sched
         self.bucket = None
+        self.graph = bool(graph)
+        self._calls, self._captured, self._static_in, self._static_out = 0, None, None, None
+        if self.graph:
+            if parallel.is_dist():
+                raise RuntimeError('Trainer(graph=True) is single-rank: the captured step holds no collective')
+            if not all(g.get('capturable', False) for g in optimizer.param_groups):
+                raise ValueError('Trainer(graph=True) needs a capturable optimiser (make_optimizer(..., capturable=True))')
+            if sched is not None and not all(torch.is_tensor(g['lr']) for g in optimizer.param_groups):
+                raise ValueError('a scheduler under Trainer(graph=True) needs a tensor learning rate')
+            model.assume_foreground = True
         # lazily created variables (light, gamma, codebook) must exist before the gradient bucket is laid out
         _ = model.light
         if getattr(model, 'data_type', 'nerf') != 'nerf':
@@ -49,6 +73,35 @@ class Trainer:
     def train_iter(self, batch, global_bs, thres=None, roll=None):
         """One step (train_nfr.py:562-576).  `global_bs` is the reference's normaliser (n_rays_per_step, :571-572) times
         the number of ranks when each rank draws its own rays.  Returns (weighted_loss summed over ranks, to_vis, loss_dict)."""
+        if self.graph:
+            if thres is not None or roll is not None:
+                raise ValueError('code dropout (`thres` / `roll`) is drawn on the host: not available under graph=True')
+            self._calls += 1
+            if self._calls > self.GRAPH_WARMUP:
+                return self._replay(batch, global_bs)
+        return self._step(batch, global_bs, thres, roll)
+
+    def _replay(self, batch, global_bs):
+        if self._captured is None:
+            self._static_in = [t.clone() if torch.is_tensor(t) else t for t in batch]
+            self._global_bs = global_bs
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._static_out = self._step(tuple(self._static_in), global_bs, None, None, sched=False)
+            self._captured = g
+        if global_bs != self._global_bs:
+            raise ValueError('global_bs is baked into the captured step')
+        for dst, src in zip(self._static_in, batch):
+            if torch.is_tensor(dst):
+                if dst.shape != src.shape:
+                    raise ValueError(f'captured step takes batches of shape {tuple(dst.shape)}, got {tuple(src.shape)}')
+                dst.copy_(src)
+        self._captured.replay()
+        if self.sched is not None:
+            self.sched.step()
+        return self._static_out
+
+    def _step(self, batch, global_bs, thres, roll, sched=True):
         model = self.model
         if self.bucket is None:
             self.bucket = parallel.FlatBucket(model.trainable_variables, n_extra=1)
@@ -74,9 +127,12 @@ class Trainer:
         if clipvalue > 0:
             self.bucket.flat[:self.bucket.n_grad].clamp_(-clipvalue, clipvalue)
         self.optimizer.step()
-        if self.sched is not None:
+        if sched and self.sched is not None:
             self.sched.step()
-        return extra[0], to_vis, loss_dict
+        # hand back values, not autograd history: a caller holding on to the loss would keep this step's AccumulateGrad nodes
+        # (and their stream) alive into the next one, which is what breaks a later capture
+        det = lambda d: {k: (v.detach() if torch.is_tensor(v) else v) for k, v in d.items()}
+        return extra[0], det(to_vis), det(loss_dict)
 
 
 def train_iter(model, batch, optimizer, global_bs, thres=None, _trainers={}):
