@@ -225,6 +225,57 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     return out
 
 
+def decomp_cpu_leg(dev, cores, N=16384):
+    """CPU-baseline leg of the reflectance model (R_dec,render next to its CPU figure, PSNR(build, oracle) on rgb and
+    albedo, VQ index match %): one vali-mode call of vq_nfr.Model on N synthetic surface points, the oracle (oracle/decomp.py,
+    test infrastructure) on the same points and weights on the host cores."""
+    from oracle import decomp as od
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    from vqnerf_release_amd.decomp.nerfactor.util.io import config_from_dict
+    p, specs = od.make_model_params(seed=0, K=15)
+    model = get_model_class('vq_nfr')(config_from_dict(DECOMP_INI))
+    model.build_nets(device=dev, seed=0)
+    with torch.no_grad():
+        for name, net in model.net.items():
+            for layer, (W, b) in zip(net.layers, p[name]):
+                layer.kernel.copy_(torch.as_tensor(np.asarray(W)))
+                layer.bias.copy_(torch.as_tensor(np.asarray(b)))
+    model.to(dev)
+    model.set_codebook(np.asarray(p['codebook_raw']).T)
+    model.set_light(np.asarray(p['light']))
+    pts = od.make_points(N, seed=3)
+    T = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32, device=dev)
+    one = torch.ones(N, 1, device=dev)
+    batch = (['v'], torch.zeros(N, 2, device=dev), T(pts['rayo']), torch.zeros(N, 3, device=dev), T(pts['rgb']), one, one.clone(),
+             T(pts['xyz']), T(pts['normal']), T(pts['lvis']))
+    with torch.no_grad():
+        model.call(batch, mode='vali')
+        gdt = _time_gpu(lambda: model.call(batch, mode='vali'), 5)
+        pred, _, lk, _ = model.call(batch, mode='vali')
+    pt = {k: ([(od.T(W), od.T(b)) for W, b in v] if isinstance(v, list) else od.T(v)) for k, v in p.items()}
+    lxyz, lareas = od.gen_light_xyz(16, 32)
+    lxyz, lareas = od.T(lxyz.reshape(-1, 3)), od.T(lareas.reshape(-1))
+    ob = {k: od.T(v) for k, v in pts.items()}
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        od.model_call(pt, specs, {k: v[:256] for k, v in ob.items()}, lxyz, lareas, od.EMA(0.999, (15,)), od.EMA(0.999, (256, 15)), mode='vali')
+        t0 = time.perf_counter()
+        want = od.model_call(pt, specs, ob, lxyz, lareas, od.EMA(0.999, (15,)), od.EMA(0.999, (256, 15)), mode='vali')
+        cdt = time.perf_counter() - t0
+    psnr = lambda a, b: -10.0 * math.log10(float(((a.cpu() - b) ** 2).mean()) + 1e-20)
+    # nearest-code indices must agree wherever the fp64 top-2 distance gap is not a rounding tie
+    d64 = od.vq_distances(want['z_norm'].double(), want['codebook'].double())
+    top2 = torch.topk(-d64, 2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-6
+    same = pred['embed'][:, 0].cpu() == want['embed']
+    return {'value': N / cdt, 'unit': 'points/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{N} surface points (512 lights, visibility rows), one oracle.decomp.model_call(vali), {cdt:.1f} s',
+            'gpu_points_per_s_same_sample': N / gdt, 'psnr_rgb_vs_oracle_db': psnr(lk['rgb'], want['rgb']),
+            'psnr_albedo_vs_oracle_db': psnr(pred['albedo'], want['albedo']),
+            'vq_idx_match_pct': 100.0 * float(same[clear].float().mean()), 'vq_idx_match_pct_all_rows': 100.0 * float(same.float().mean()),
+            'near_tie_fraction': 1.0 - float(clear.float().mean())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -377,6 +428,8 @@ def main():
                                             f'{cpu_dt:.1f} s, torch {torch.__version__} CPU fp32'}
         result['psnr_vs_oracle_db'] = -10.0 * math.log10(mse + 1e-20)
         result['speedup_vs_cpu'] = value / (n_cpu / cpu_dt)
+        if not args.no_extras:
+            result['cpu_baseline_decomp'] = decomp_cpu_leg(dev, cores)
     if world == 1 and not args.no_extras:
         result['extra'] = secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col)
     print(json.dumps(result))

@@ -1,0 +1,215 @@
+"""Per-view geometry-buffer loader of the reflectance stages: mirror of
+decomp/nerfvq_nfr3/nerfactor/datasets/shape_unit.py (`_glob` :46-92, `_load_data` :149-262, `_gen_rays` :265-293,
+`_sample_rays` :112-131, `_process_example_postcache` :95-110) and of base.py's `build_pipeline` (:83-122).
+
+On-disk contract (kept): `<data_root>/{train,val}_???/{metadata.json, rgba.png}` and
+`<data_nerf_root>/<id>/{xyz.npy, normal.npy [H,W,3], alpha.png, lvis.npy [H,W,L]}` -- what `geo/gen_geo.py` writes.
+
+MI355X-first differences: a view is decoded once on the host (numpy + Pillow; no tf.data / py_function), flattened to
+rays-major rows and parked in HBM (`cache`: a 512x512 view with 512-light visibility is 0.5 GB; a 100-view set fits in
+288 GB several times over), so an epoch is pointer hand-offs and the pair sampler (`train_nfr.outer_sample`) gathers
+on the device.  `id_` is a one-element list instead of a per-ray tiled string tensor (the tiling exists "to make
+distributed strategy happy", shape_unit.py:106-108).  Resizing follows xiuminglib's rule (area when shrinking, bilinear
+when growing) with torch kernels instead of cv2: identical for integer shrink factors, ~1e-3 apart otherwise.
+"""
+import json
+import os
+from glob import glob
+from os.path import basename, dirname, join
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def resize_hw(arr, new_h):
+    """xm.img.resize(arr, new_h=...) (xiuminglib img.py:77-116): aspect kept, INTER_AREA down / INTER_LINEAR up."""
+    h, w = arr.shape[:2]
+    new_w = int(w / h * new_h)
+    t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))
+    t = t[None, None] if t.ndim == 2 else t.permute(2, 0, 1)[None]
+    if new_h > h:
+        t = F.interpolate(t, size=(new_h, new_w), mode='bilinear', align_corners=False)
+    else:
+        t = F.interpolate(t, size=(new_h, new_w), mode='area')
+    out = t[0, 0] if arr.ndim == 2 else t[0].permute(1, 2, 0)
+    return out.numpy().astype(arr.dtype if arr.dtype.kind == 'f' else np.float64)
+
+
+def read_image_normalized(path):
+    """xm.io.img.load + xm.img.normalize_uint: Pillow decode, uint8 -> /255, uint16 -> /65535, float64."""
+    from PIL import Image
+    a = np.asarray(Image.open(path))
+    if a.dtype not in (np.uint8, np.uint16):
+        if a.dtype == np.int32:                       # Pillow's 'I' mode for 16-bit greys
+            a = a.astype(np.uint16)
+        else:
+            raise TypeError(a.dtype)
+    return a.astype(float) / np.iinfo(a.dtype).max
+
+
+class Dataset:
+    def __init__(self, config, mode, debug=False, device='cuda'):
+        assert mode in ('train', 'vali', 'test', 'render'), \
+            "Accepted dataset modes: 'train', 'vali', 'test', 'render', but input is %s" % mode
+        self.config, self.mode, self.debug = config, mode, debug
+        self.device = torch.device(device)
+        self.meta2buf = {}
+        self._cache = {}
+        self.files = self._glob()
+        assert self.files, 'No file to process into a dataset'
+        self.bs = self._get_batch_size()
+
+    # ------------------------------------------------------------------ file discovery
+    def _glob(self):
+        cfg = self.config
+        root = cfg.get('DEFAULT', 'data_root')
+        nerf_root = cfg.get('DEFAULT', 'data_nerf_root')
+        self.data_type = cfg.get('DEFAULT', 'data_type')
+        self.model_name = cfg.get('DEFAULT', 'model', fallback='')
+        mode_str = 'train' if self.mode in ('train', 'render') else 'val'
+        pattern = join(root, '%s_002' % mode_str) if self.debug else join(root, '%s_???' % mode_str)
+        metadata_paths, self.incomplete_paths = [], []
+        for metadata_path in sorted(glob(join(pattern, 'metadata.json'))):
+            id_ = self._parse_id(metadata_path)
+            paths = {'xyz': join(nerf_root, id_, 'xyz.npy'), 'normal': join(nerf_root, id_, 'normal.npy'),
+                     'alpha': join(nerf_root, id_, 'alpha.png'), 'rgba': join(dirname(metadata_path), 'rgba.png')}
+            if self.data_type == 'nerf':
+                paths['lvis'] = join(nerf_root, id_, 'lvis.npy')
+            if all(os.path.exists(p) for p in paths.values()):
+                metadata_paths.append(metadata_path)
+                self.meta2buf[metadata_path] = paths
+            else:
+                self.incomplete_paths.append(metadata_path)       # skipped, as shape_unit.py:86-90
+        return metadata_paths
+
+    @staticmethod
+    def _parse_id(metadata_path):
+        return basename(dirname(metadata_path))
+
+    def get_n_views(self):
+        return len(self.files)
+
+    def _get_batch_size(self):
+        if self.mode == 'train':
+            return self.config.getint('DEFAULT', 'n_rays_per_step')
+        ret = self._load_data(self.files[0])
+        return int(np.prod(ret[-1].shape[:2]))
+
+    # ------------------------------------------------------------------ one view, host side
+    def _load_data(self, metadata_path):
+        """-> (id, rayo, rayd, rgb, alpha, pred_alpha, xyz, normal[, lvis]) as [H,W,...] float32 arrays."""
+        cfg = self.config
+        imh = cfg.getint('DEFAULT', 'imh')
+        white_bg = cfg.getboolean('DEFAULT', 'white_bg')
+        id_ = self._parse_id(metadata_path)
+        with open(metadata_path) as f:
+            metadata = json.load(f)
+        if self.data_type == 'dtu':
+            k = imh / metadata['imh']
+            imw = int(k * metadata['imw'])
+            proj = (np.array(metadata['world_mat']) @ np.array(metadata['scale_mat']))[0:3, 0:4]
+            intrinsic, cam_to_world = self.decompose_projection_matrix(proj)
+            intrinsic[:2, :3] = intrinsic[:2, :3] * k
+            rayo, rayd = self._gen_rays(cam_to_world, np.linalg.inv(intrinsic), imh, imw)
+        else:
+            imw = int(metadata['imw'] * imh / metadata['imh'])
+            cam_to_world = np.array([float(x) for x in metadata['cam_transform_mat'].split(',')]).reshape(4, 4)
+            cx = cy = None
+            if 'cx' in metadata:
+                cx, cy = imh / metadata['imh'] * metadata['cx'], imh / metadata['imh'] * metadata['cy']
+            rayo, rayd = self._gen_rays(cam_to_world, metadata['cam_angle_x'], imh, imw, cx, cy)
+        rayo, rayd = rayo.astype(np.float32), rayd.astype(np.float32)
+
+        paths = self.meta2buf[metadata_path]
+        xyz = np.load(paths['xyz'])
+        normal = np.load(paths['normal'])
+        pred_alpha = read_image_normalized(paths['alpha'])
+        rgba = read_image_normalized(paths['rgba'])
+        assert rgba.ndim == 3 and rgba.shape[2] == 4, 'Input image is not RGBA'
+        rgb = rgba[:, :, :3]
+        alpha = pred_alpha if self.mode == 'test' else rgba[:, :, 3]
+        fit = lambda a: resize_hw(a, imh) if a.shape[0] != imh else a
+        xyz, normal, alpha, pred_alpha, rgb = fit(xyz), fit(normal), fit(alpha), fit(pred_alpha), fit(rgb)
+
+        # occupancy accumulated to 0: the "surface" sits on the camera -> push it 0.1 along the ray (:232-234)
+        zero_bg = np.linalg.norm(xyz - rayo, axis=-1) == 0.0
+        xyz = xyz.copy()
+        xyz[zero_bg] = rayo[zero_bg] + rayd[zero_bg] * 0.1
+        zero_bg = np.mean(normal, axis=-1) == 0.0
+        normal = normal.copy()
+        normal[zero_bg] = np.array([0.0, 1.0, 0.0])
+        normal = normal / np.linalg.norm(normal, axis=2, keepdims=True)
+        bg = np.ones_like(rgb) if white_bg else np.zeros_like(rgb)
+        rgb = (rgb * alpha[..., None] + bg * (1.0 - alpha[..., None])).astype(np.float32)
+        out = (id_, rayo, rayd, rgb, alpha.astype(np.float32), pred_alpha.astype(np.float32), xyz.astype(np.float32),
+               normal.astype(np.float32))
+        if self.data_type == 'nerf':
+            lvis = fit(np.load(paths['lvis']))
+            out = out + (np.clip(lvis, 0, 1).astype(np.float32),)
+        return out
+
+    def _gen_rays(self, to_world, intrinsic, imh, imw, cx=None, cy=None):
+        """Pixel-corner rays, NOT normalised for the pin-hole branch (shape_unit.py:265-293)."""
+        rayo = np.tile(to_world[:3, 3][None, None, :], (imh, imw, 1))
+        xs, ys = np.meshgrid(np.linspace(0, imw, imw, endpoint=False), np.linspace(0, imh, imh, endpoint=False))
+        if self.data_type == 'dtu':
+            p = np.stack((xs, ys, np.ones_like(xs)), axis=-1)
+            p = (intrinsic[None, None, :3, :3] @ p[..., None])[..., 0]
+            rayd = p / np.linalg.norm(p, ord=2, axis=-1, keepdims=True)
+            rayd = (to_world[None, None, :3, :3] @ rayd[..., None])[..., 0]
+        else:
+            fl = 0.5 * imw / np.tan(0.5 * intrinsic)
+            cx = 0.5 * imw if cx is None else cx
+            cy = 0.5 * imh if cy is None else cy
+            rayd = np.stack(((xs - cx) / fl, -(ys - cy) / fl, -np.ones_like(xs)), axis=-1)
+            rayd = np.sum(rayd[:, :, np.newaxis, :] * to_world[:3, :3], axis=-1)
+        return rayo, rayd
+
+    @staticmethod
+    def decompose_projection_matrix(P):
+        """P = K [R | -R c] -> (4x4 intrinsics with K[2,2] = 1, camera-to-world pose) (shape_unit.py:295-312; the reference
+        calls cv2.decomposeProjectionMatrix, here an RQ factorisation with the same sign conventions)."""
+        from scipy.linalg import rq
+        K, R = rq(P[:3, :3])
+        S = np.diag(np.sign(np.diag(K)))
+        K, R = K @ S, S @ R
+        if np.linalg.det(R) < 0:
+            R = -R
+        c = -np.linalg.solve(P[:3, :3], P[:3, 3])
+        intrinsics = np.eye(4)
+        intrinsics[:3, :3] = K / K[2, 2]
+        pose = np.eye(4, dtype=np.float32)
+        pose[:3, :3] = R.transpose()
+        pose[:3, 3] = c
+        return intrinsics, pose
+
+    # ------------------------------------------------------------------ one view, device side
+    def view(self, which):
+        """The element the reference's pipeline yields with no_batch=True: (id_, hw [N,2], rayo, rayd, rgb [N,3], alpha,
+        pred_alpha [N,1], xyz, normal [N,3][, lvis [N,L]]), N = H*W rows in row-major pixel order, resident on the device."""
+        path = self.files[which] if isinstance(which, int) else which
+        if path in self._cache:
+            return self._cache[path]
+        rec = self._load_data(path)
+        id_, maps = rec[0], rec[1:]
+        H, W = maps[2].shape[:2]
+        flat = [torch.from_numpy(np.ascontiguousarray(m)).reshape(H * W, -1).to(self.device) for m in maps]
+        hw = torch.tensor([[H, W]], dtype=torch.int32, device=self.device).expand(H * W, 2)
+        batch = ([id_], hw) + tuple(flat)
+        if self.config.getboolean('DEFAULT', 'cache', fallback=True):
+            self._cache[path] = batch
+        return batch
+
+    def build_pipeline(self, filter_predicate=None, seed=None, no_batch=True, no_shuffle=False, pretrain=False, sort=True):
+        """One pass over the views (base.py:83-122 with no_batch=True, which is how the VQ-stage trainer consumes it,
+        train_nfr.py:235-243); training mode shuffles the view order."""
+        assert no_batch, 'views are handed over whole; the pair sampler (train_nfr.outer_sample) makes the ray batches'
+        files = sorted(self.files) if sort else list(self.files)
+        if filter_predicate is not None:
+            files = [f for f in files if filter_predicate(f)]
+        if self.mode == 'train' and not no_shuffle:
+            order = np.random.default_rng(seed).permutation(len(files))
+            files = [files[i] for i in order]
+        for f in files:
+            yield self.view(f)

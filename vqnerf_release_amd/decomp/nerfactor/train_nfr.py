@@ -3,7 +3,7 @@
 classes, with rank-sharded data parallelism added (the reference's VQ stage is single-device; its only DP site is
 trainvali.py:436-486 for stages 1/3, which `train_iter` covers as well since the step contract is the same).
 
-Out of scope here: tf.data view loaders, checkpoint managers, TensorBoard, the k-means codebook init.
+The view loader is datasets/shape_unit.py; out of scope here: checkpoint managers, TensorBoard.
 """
 import torch
 
@@ -184,7 +184,8 @@ def outer_sample(batch, config, data_type, alpha_thres=0.9, generator=None):
         if torch.is_tensor(t):
             out.append(t[flat])
         else:
-            out.append([t[int(i)] for i in flat.tolist()] if isinstance(t, (list, tuple)) else t)
+            # ids: a per-ray list is gathered (host), a per-view id (one element, what datasets.shape_unit yields) passes through
+            out.append([t[int(i)] for i in flat.tolist()] if isinstance(t, (list, tuple)) and len(t) > 1 else t)
     return tuple(out)
 
 

@@ -2,9 +2,10 @@
 `train` :99-175, cosine LR with warm-up :186-195, cos-anneal :180-184, checkpoint keys :210-232) on the MI355X
 classes, plus rank-sharded data parallelism (the reference trains on one GPU).
 
-Out of scope here: image/pose loading, TensorBoard, mesh export.  The dataset is any object with
-the reference's dataset contract -- `n_images`, `max_radius`, `gen_random_rays_at(img_idx, batch_size) -> [B,10]`
-(o, d, rgb, mask) and `near_far_from_sphere(rays_o, rays_d)`; `SyntheticDataset` provides it for tests and bench.
+Out of scope here: TensorBoard, mesh export.  The dataset is any object with the reference's
+dataset contract -- `n_images`, `max_radius`, `gen_random_rays_at(img_idx, batch_size) -> [B,10]` (o, d, rgb, mask) and
+`near_far_from_sphere(rays_o, rays_d)`: `models.nerfset.Dataset` when the conf's `dataset.data_dir` holds a Blender-format
+image set (as nerf_runner.py:36 does), `SyntheticDataset` (tests, bench) otherwise.
 """
 import math
 import os
@@ -74,7 +75,15 @@ class Runner:
         self.conf_path = conf_path
         self.conf = hocon.parse_string(conf_text.replace('CASE_NAME', case))
         self.base_exp_dir = self.conf['general.base_exp_dir']
-        self.dataset = dataset if dataset is not None else SyntheticDataset(self.conf.get('dataset'), device=self.device)
+        if dataset is None:
+            dconf = self.conf.get('dataset')
+            data_dir = dconf.get('data_dir') if dconf is not None else None
+            if data_dir and os.path.isfile(os.path.join(data_dir, 'transforms_train.json')):
+                from vqnerf_release_amd.geo.models.nerfset import Dataset
+                dataset = Dataset(dconf, is_train=(mode == 'train'), device=self.device)
+            else:
+                dataset = SyntheticDataset(dconf, device=self.device)
+        self.dataset = dataset
         self.iter_step = 0
         t = self.conf['train']
         self.end_iter, self.save_freq, self.report_freq = t.get_int('end_iter'), t.get_int('save_freq'), t.get_int('report_freq')
