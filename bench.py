@@ -186,6 +186,31 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
                        'unit': 'GB/s', 'frac': N * SHADE_BYTES / t_shade / 1e9 / 8000.0, 'bytes_per_point': SHADE_BYTES,
                        'ms': t_shade * 1e3, 'note': 'two material sets + diffuse/specular split per pass'},
         'kernel_launches_per_call': launches_per_call}
+    # ---- the same view on the split-precision MLP kernels (matrix_mode 'f16s': f16 hi/lo operands, 3 f16 MFMAs per product) ----
+    with torch.no_grad():
+        ref_pred = model.call(big, mode='vali')[0]
+        model.matrix_mode = 'f16s'
+        try:
+            got_pred = model.call(big, mode='vali')[0]
+            _C.KernelClock.reset(True)
+            dt16 = _time_gpu(lambda: model.call(big, mode='vali'), 3, warm=0)
+            clk16 = _C.KernelClock.summary()
+        finally:
+            model.matrix_mode = 'f32'
+            _C.KernelClock.reset(False)
+    t_chain16 = sum(v[1] for k, v in clk16.items() if k == 'vqn_mlp_chain_fwd_f16s') / 3 * 1e-3
+    F16_MFMA_PEAK_TFLOPS = 2516.6
+    eff = 2.0 * (enc_macs + head_macs) * N / t_chain16 / 1e12
+    same_code = (got_pred['embed'] == ref_pred['embed']).float().mean()
+    out['decomp_render_f16s'] = {
+        'points_per_s': N / dt16, 'ms_per_view': dt16 * 1e3, 'points': N,
+        'mlp_chain': {'bound': 'mfma', 'achieved': eff, 'unit': 'TFLOP/s (algorithmic f32 FLOPs)', 'ms': t_chain16 * 1e3,
+                      'issued_f16_tflops': 3.0 * eff, 'peak': F16_MFMA_PEAK_TFLOPS, 'frac': 3.0 * eff / F16_MFMA_PEAK_TFLOPS,
+                      'frac_note': 'issued f16 MFMA FLOPs (3 per algorithmic FLOP) over the dense f16 peak',
+                      'speedup_vs_f32_kernel': t_chain / t_chain16},
+        'max_abs_diff_vs_f32': {k: float((got_pred[k] - ref_pred[k]).abs().max()) for k in ('rgb', 'albedo', 'rough', 'vq_rgb')},
+        'vq_idx_match_vs_f32_pct': 100.0 * float(same_code),
+        'note': 'opt-in precision mode (model.matrix_mode = "f16s"); `value` and every other line are the f32 path'}
     small = points(2048)
     model.get_codebook(); _ = model.light            # lazily created variables must exist before the optimiser is built
     opt2 = torch.optim.Adam(model.trainable_variables, lr=5e-4, eps=1e-7, amsgrad=True)

@@ -56,6 +56,13 @@ int64_t vqn_vq_ema_stats_ws_bytes(int64_t N, int D, int K);
 int vqn_mlp_chain_fwd(const int32_t* desc, const float* wbuf, const float* in, int64_t N, float* out0, int ld0,
                       float* out1, int ld1, float* out2, int ld2, float* out3, int ld3, void* stream);
 
+/* The same evaluator on the split-precision engine ("fp16 MFMA path"): every f32 value is carried as an f16 hi/lo
+ * pair and every product as hi*hi + 2^-11 (hi*lo + lo*hi) on v_mfma_f32_32x32x16_f16 with f32 accumulation.  Same
+ * arguments; `desc` / `wbuf` must be built for it (ChainBuilder(mode='f16s'): even row counts, f16 hi/lo weight
+ * fragments).  Opt-in: agrees with vqn_mlp_chain_fwd to ~1e-6 relative, not bitwise; |weights| < 6e4. */
+int vqn_mlp_chain_fwd_f16s(const int32_t* desc, const float* wbuf, const float* in, int64_t N, float* out0, int ld0,
+                           float* out1, int ld1, float* out2, int ld2, float* out3, int ld3, void* stream);
+
 /* Fused shading: light / view directions (models/shape.py:103-119), camera-facing normal
  * (models/vq_nfr.py:830-833), GGX microfacet BRDF (util/microfacet.py:9-89) and the rendering-equation
  * sum over L lights with front-lit test, visibility, optional gamma and the [0,1] clip

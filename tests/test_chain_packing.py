@@ -2,6 +2,7 @@
 of csrc/mlp_chain.hip's data movement (activation image, A-fragment packs, MFMA 32x32x2 operand maps), reproduce the
 oracle's Dense stacks.  This pins the host logic (row allocation, gather indices, descriptor fields) without a GPU."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import decomp as od
@@ -128,3 +129,112 @@ def test_regions_never_overlap_live_data():
     disjoint = lambda a, c: a.row0 >= c.row0 + c.alloc_rows or a.row0 + a.alloc_rows <= c.row0
     assert disjoint(y0, x) and disjoint(y1, x) and disjoint(y1, y0) and disjoint(y2, y1) and disjoint(y2, x)
     assert plan.total_rows == 32 + 32 + 16                       # y2 fits into y0's rows
+
+
+# ------------------------------------------------------------------ split-precision (f16 hi/lo) programs
+def step_feat(sl, h, jj):
+    return 16 * sl + 8 * (jj >> 2) + 4 * h + (jj & 3)
+
+
+def _split(x):
+    hi = x.astype(np.float16)
+    lo = ((x - hi.astype(np.float64)) * 2048.0).astype(np.float16)
+    return hi, lo
+
+
+def emulate_f16s(desc, wbuf, x, out_widths):
+    """numpy emulator of csrc/mlp_chain_f16s.hip: split activation image (row pairs hi / lo), f16 hi/lo A-fragment packs,
+    v_mfma_f32_32x32x16_f16 operand maps, three products per step; products and sums in float64."""
+    d = np.asarray(desc)
+    wb = np.ascontiguousarray(np.asarray(wbuf, np.float32))
+    w16 = wb.view(np.float16).astype(np.float64).reshape(-1, 8)          # one 16-byte lane fragment per row
+    w4 = wb.astype(np.float64).reshape(-1, 4)
+    n_layers, in_mode, in_feats, in_rows, in_row0, n_freqs, total_rows = [int(v) for v in d[:7]]
+    assert in_rows % 2 == 0
+    P = x.shape[0]
+    lds = np.full((total_rows, 64, 8), np.nan)                           # halves, as float64
+    feats = od.posenc(torch.tensor(x, dtype=torch.float64), n_freqs).numpy() if in_mode == 1 else x.astype(np.float64)
+
+    def store(row, lane, vals):
+        hi, lo = _split(np.asarray(vals, np.float64))
+        lds[row, lane], lds[row + 1, lane] = hi, lo
+
+    for sl in range(in_rows // 2):
+        for lane in range(64):
+            p, h = lane & 31, lane >> 5
+            v = [feats[p, step_feat(sl, h, jj)] if (p < P and step_feat(sl, h, jj) < in_feats) else 0.0 for jj in range(8)]
+            store(in_row0 + 2 * sl, lane, v)
+    outs = [np.zeros((P, w)) for w in out_widths]
+    for l in range(n_layers):
+        L = d[16 + 16 * l: 32 + 16 * l]
+        kind, a, tiles, kA0, kA, kB0, kB, dst0, w_off, b_off, slot, out_feats = [int(v) for v in L[:12]]
+        assert kA % 2 == 0 and kB % 2 == 0
+        rows = [kA0 + i for i in range(kA)] + [kB0 + i for i in range(kB)]
+        nr, ns = len(rows), len(rows) // 2
+        B = np.stack([lds[r] for r in rows]).reshape(ns, 2, 2, 32, 8)                                 # [step, part, h, n, jj]
+        if kind == 0:
+            for ot in range(tiles):
+                nrp = 8 * ((nr + 7) // 8)                                                               # packs hold whole 4-step blocks
+                A = w16[w_off + ot * nrp * 64: w_off + (ot + 1) * nrp * 64].reshape(nrp // 2, 2, 2, 32, 8)
+                assert not A[ns:].any()                                                                # zero padding
+                A = A[:ns]                                                                              # [step, part, h, i, jj]
+                acc1 = np.einsum('shij,shnj->in', A[:, 0], B[:, 0])
+                acc2 = np.einsum('shij,shnj->in', A[:, 0], B[:, 1]) + np.einsum('shij,shnj->in', A[:, 1], B[:, 0])
+                bias = w4[b_off + ot * 8: b_off + (ot + 1) * 8].reshape(2, 16)
+                for lane in range(64):
+                    n_, h = lane & 31, lane >> 5
+                    for s in range(2):
+                        v = []
+                        for jj in range(8):
+                            reg = 8 * s + jj
+                            i = (reg & 3) + 8 * (reg >> 2) + 4 * h
+                            assert i == step_feat(s, h, jj)                                           # registers ARE the half-slots
+                            v.append(act(a, acc1[i, n_] + bias[h, reg] + acc2[i, n_] / 2048.0))
+                        store(dst0 + ot * 4 + 2 * s, lane, v)
+                        if slot >= 0 and n_ < P:
+                            for jj in range(8):
+                                f = 32 * ot + step_feat(s, h, jj)
+                                if f < out_feats:
+                                    outs[slot][n_, f] = v[jj]
+        elif kind == 1:
+            img = w4[w_off: w_off + tiles * ns * 2 * 2].reshape(tiles, ns, 2, 8)
+            X = B[:, 0] + B[:, 1] / 2048.0                                                             # [step, h, n, jj]
+            bias4 = d[16 + 16 * l + 12: 16 + 16 * l + 16].view(np.float32).astype(np.float64)
+            val = np.einsum('oshj,shnj->no', img, X)
+            outs[slot][:, :tiles] = act(a, val[:P] + bias4[None, :tiles])
+    return outs
+
+
+def test_split_precision_programs_match_oracle():
+    p, specs = od.make_model_params(seed=3, K=15)
+    fe, bn = specs['fine_enc'], specs['bottleneck']
+    b = pk.ChainBuilder('posenc', 63, n_freqs=10, mode='f16s')
+    y = b.mlp('fine_enc', fe['widths'], fe['act'], fe['skip_at'], b.input)
+    b.mlp('bottleneck', bn['widths'], bn['act'], bn['skip_at'], y, out_slot=0, small_last=False)
+    plan = b.build()
+    assert plan.macs_per_point() == 179968 and plan.total_rows <= 72
+    wbuf, desc = plan.pack(_params(['fine_enc', 'bottleneck'], p))
+    xyz = od.make_points(20, seed=5)['xyz']
+    got = emulate_f16s(desc, wbuf.numpy(), xyz, [256])[0]
+    pt = {k: [(torch.tensor(W, dtype=torch.float64), torch.tensor(bb, dtype=torch.float64)) for W, bb in v]
+          for k, v in p.items() if isinstance(v, list)}
+    want = od.pred_enc(pt, specs, torch.tensor(xyz, dtype=torch.float64)).numpy()
+    # hi + lo carries ~22 bits, the lo*lo products are dropped: ~1e-6 of the layer's magnitude, not bitwise
+    np.testing.assert_allclose(got, want, rtol=0, atol=3e-6 * np.abs(want).max())
+    assert np.abs(got - want).max() > 0                              # (and it is not the f32 path in disguise)
+
+    names = ['diff_vq', 'spec_vq', 'rough_vq']
+    b = pk.ChainBuilder('raw', 256, mode='f16s')
+    for slot, n in enumerate(names):
+        s = specs[n]
+        b.mlp(n, s['widths'], s['act'], s['skip_at'], b.input, keep=[b.input], out_slot=slot)
+    plan = b.build()
+    wbuf, desc = plan.pack(_params(names, p))
+    z = np.random.default_rng(0).uniform(0, 1, (32, 256)).astype(np.float32)
+    got = emulate_f16s(desc, wbuf.numpy(), z, [3, 3, 1])
+    for g, n in zip(got, names):
+        ptn = [(torch.tensor(W, dtype=torch.float64), torch.tensor(bb, dtype=torch.float64)) for W, bb in p[n]]
+        want = od.mlp_forward(ptn, specs[n], torch.tensor(z, dtype=torch.float64)).numpy()
+        np.testing.assert_allclose(g, want, rtol=0, atol=3e-6 * max(1.0, np.abs(want).max()))
+    with pytest.raises(ValueError):
+        pk.split_pack(torch.full((1, 1, 64, 8), 7.0e4))

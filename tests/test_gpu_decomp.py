@@ -55,6 +55,40 @@ def test_chain_ragged_sizes(setup, n):
     np.testing.assert_allclose(_np(z), od.pred_enc(pt, specs, od.T(pts['xyz'])).numpy(), rtol=0, atol=3e-6)
 
 
+@pytest.mark.parametrize('n', [1, 33, 1000])
+def test_split_precision_chain_vs_fp64_oracle(setup, n):
+    """matrix_mode = 'f16s' (vqn_mlp_chain_fwd_f16s: f16 hi/lo operands, three f16 MFMAs per product, f32 accumulate) is an
+    opt-in mode with a STATED tolerance instead of bitwise agreement: against the oracle in float64 its error must stay
+    within 4x the f32 kernel's own error + 2e-6 of the output scale (measured: about 1-2x)."""
+    od, model, p, specs = setup['od'], setup['model'], setup['p'], setup['specs']
+    pts = od.make_points(n, seed=40 + n)
+    xyz = torch.tensor(pts['xyz']).cuda()
+    p64 = {k: [(torch.tensor(W, dtype=torch.float64), torch.tensor(b, dtype=torch.float64)) for W, b in v]
+           for k, v in p.items() if isinstance(v, list)}
+    z64 = od.pred_enc(p64, specs, torch.tensor(pts['xyz'], dtype=torch.float64))
+    try:
+        with torch.no_grad():
+            z32 = model._pred_enc_at(xyz)
+            h32 = model._all_heads(z32, 'main') + model._all_heads(z32, 'vq')
+            model.matrix_mode = 'f16s'
+            z16 = model._pred_enc_at(xyz)
+            h16 = model._all_heads(z32, 'main') + model._all_heads(z32, 'vq')
+            one = model._pred_rough_at(z32, vq=True)
+    finally:
+        model.matrix_mode = 'f32'
+    scale = float(z64.abs().max())
+    e32, e16 = np.abs(_np(z32) - z64.numpy()).max(), np.abs(_np(z16) - z64.numpy()).max()
+    assert e16 <= 4 * e32 + 2e-6 * scale, (e16, e32, scale)
+    assert not torch.equal(z16, z32)                                  # it really is the other kernel
+    want = od.heads(p64, specs, torch.tensor(_np(z32), dtype=torch.float64), False) + \
+        od.heads(p64, specs, torch.tensor(_np(z32), dtype=torch.float64), True)
+    for g32, g16, w in zip(h32, h16, want):
+        assert g16.shape == w.shape
+        a32, a16 = np.abs(_np(g32) - w.numpy()).max(), np.abs(_np(g16) - w.numpy()).max()
+        assert a16 <= 4 * a32 + 2e-6, (a16, a32)
+    assert torch.equal(one, h16[5])                                   # one head per launch == three per launch, here too
+
+
 def _oracle_shade(od, setup, pts, mats, light, with_lvis, dtype, gamma=None):
     T = lambda a: od.T(a, dtype)
     xyz, normal, rayo = T(pts['xyz']), T(pts['normal']), T(pts['rayo'])

@@ -282,8 +282,11 @@ def neus_composite_fwd(rays_o, rays_d, mid_z, dists, sdf, grad, rgb, inv_s, back
 
 # --------------------------------------------------------------------------------------
 # reflectance path (csrc/mlp_chain.hip, csrc/brdf_shade.hip)
-def mlp_chain_fwd(desc, wbuf, x, out_widths):
-    """Run a layer program (decomp/packing.py) over x [N, in_stride]; returns one [N, w] tensor per output slot."""
+def mlp_chain_fwd(desc, wbuf, x, out_widths, mode='f32'):
+    """Run a layer program (decomp/packing.py) over x [N, in_stride]; returns one [N, w] tensor per output slot.
+    mode 'f16s': the split-precision kernel (program and pack must come from ChainBuilder(mode='f16s'))."""
+    assert mode in ('f32', 'f16s')
+    entry = 'vqn_mlp_chain_fwd' if mode == 'f32' else 'vqn_mlp_chain_fwd_f16s'
     _f32c(wbuf, 'wbuf'); _f32c(x, 'x')
     d, dp = _i32(desc)
     N = x.shape[0]
@@ -295,9 +298,9 @@ def mlp_chain_fwd(desc, wbuf, x, out_widths):
             args += [_ptr(outs[i]), ctypes.c_int(out_widths[i])]
         else:
             args += [ctypes.c_void_p(0), ctypes.c_int(0)]
-    with _clock('vqn_mlp_chain_fwd'):
-        rc = lib().vqn_mlp_chain_fwd(dp, _ptr(wbuf), _ptr(x), ctypes.c_int64(N), *args, _stream())
-    _check(rc, 'vqn_mlp_chain_fwd')
+    with _clock(entry):
+        rc = getattr(lib(), entry)(dp, _ptr(wbuf), _ptr(x), ctypes.c_int64(N), *args, _stream())
+    _check(rc, entry)
     return outs
 
 

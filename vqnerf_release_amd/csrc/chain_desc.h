@@ -14,7 +14,7 @@ struct ChainLayer {            // 16 ints
   int n_out_tiles;             // kind 0: ceil(out/32);  kind 1: number of outputs (1..4)
   int kA_row0, kA_rows;        // K segment A: LDS rows
   int kB_row0, kB_rows;        // K segment B (skip-concat input), kB_rows = 0 if none
-  int dst_row0;
+  int dst_row0;                // kind 1: offset (float4 units) of this layer's weight image in the workgroup's LDS copy
   int w_off;                   // kind 0: A-fragment pack [n_out_tiles][kA+kB][64] float4;  kind 1: [n_out][kA+kB][2] float4
   int b_off;                   // kind 0: bias pack [n_out_tiles][2][4] float4
   int out_slot;                // >= 0: leaves for HBM output `out_slot` (kind 0: first out_feats features of dst)
@@ -32,6 +32,7 @@ struct ChainDesc {             // 16 + 16*16 = 272 ints
   int total_rows;              // LDS rows (1 KB each) the program uses
   int n_waves;                 // 4 (two workgroups per CU when LDS allows) or 8 (one 512-thread workgroup per CU)
   int in_stride;               // floats between consecutive input rows
-  int reserved[7];
+  int small_w4;                // float4 count of all kind-1 weight images (copied to LDS once per workgroup, after the rows)
+  int reserved[6];
   ChainLayer layers[VQN_CHAIN_MAX_LAYERS];
 };

@@ -39,8 +39,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_kernel(con
                                                                              const OutPtrs outs) {
   extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
   ChainSmalls* sm = reinterpret_cast<ChainSmalls*>(lds + (size_t)d.total_rows * 64);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+  f32x4* smallw = lds + (size_t)d.total_rows * 64 + sizeof(ChainSmalls) / sizeof(f32x4);
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: let the compiler know
   const long n_tiles = (N + 31) >> 5;
+  // the <= 4-output layers' weight images are tiny and the same for every point tile: one LDS copy per workgroup (their
+  // VALU dots would otherwise wait on an L2 round trip per row)
+  for (int l = 0; l < d.n_layers; ++l)
+    if (d.layers[l].kind == 1) {
+      const int n4 = d.layers[l].n_out_tiles * (d.layers[l].kA_rows + d.layers[l].kB_rows) * 2;
+      for (int i = tid; i < n4; i += NW * 64) smallw[d.layers[l].dst_row0 + i] = wbuf[d.layers[l].w_off + i];
+    }
+  __syncthreads();
 
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long p0 = tile << 5;
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_kernel(con
       } else {                                    // <= 4 outputs: VALU row-dots, fixed-order combine
         const int nout = L.n_out_tiles;
         const int n_rows = L.kA_rows + L.kB_rows;
-        const f32x4* wimg = wbuf + L.w_off;
+        const f32x4* wimg = smallw + L.dst_row0;
         float s[4] = {0.f, 0.f, 0.f, 0.f};
         for (int r = wave; r < n_rows; r += NW) {
           const int row = r < L.kA_rows ? L.kA_row0 + r : L.kB_row0 + (r - L.kA_rows);
@@ -156,7 +166,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_kernel(con
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) v += sm->part[(w * 32 + pp) * 4 + o];
-            v = act_rt(L.act, v + L.bias4[o]);
+            // (constant indices only: a dynamically indexed member would push the whole layer record, and with it every
+            // loop bound and row number, out of scalar registers into scratch)
+            const float b4 = o == 0 ? L.bias4[0] : (o == 1 ? L.bias4[1] : (o == 2 ? L.bias4[2] : L.bias4[3]));
+            v = act_rt(L.act, v + b4);
             outs.p[L.out_slot][(p0 + pp) * (long)outs.ld[L.out_slot] + o] = v;
           }
         }
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_kernel(con
 int check_desc(const ChainDesc& d) {
   if (d.n_layers < 1 || d.n_layers > VQN_CHAIN_MAX_LAYERS) return 1;
   if (d.n_waves != 4 && d.n_waves != 8) return 2;
-  if (d.total_rows < 1 || (size_t)d.total_rows * 1024 + sizeof(ChainSmalls) > 160 * 1024) return 3;
+  if (d.total_rows < 1 || d.small_w4 < 0 || (size_t)d.total_rows * 1024 + sizeof(ChainSmalls) + (size_t)d.small_w4 * 16 > 160 * 1024) return 3;
   if (d.in_rows < 1 || d.in_row0 < 0 || d.in_row0 + d.in_rows > d.total_rows) return 4;
   if (d.in_mode == 1 && (d.in_feats != 3 + 6 * d.n_freqs || d.n_freqs > 16)) return 5;
   if (d.in_feats < 1 || d.in_feats > 8 * d.in_rows || d.in_stride < 1) return 6;
@@ -192,6 +205,7 @@ int check_desc(const ChainDesc& d) {
       if (L.kB_rows > 0 && d0 < L.kB_row0 + L.kB_rows && L.kB_row0 < d1) return 17;
     } else if (L.kind == 1) {
       if (L.n_out_tiles < 1 || L.n_out_tiles > 4 || L.out_slot < 0) return 18;
+      if (L.dst_row0 < 0 || L.dst_row0 + L.n_out_tiles * (L.kA_rows + L.kB_rows) * 2 > d.small_w4) return 21;
     } else return 19;
   }
   return 0;
@@ -227,7 +241,7 @@ extern "C" int vqn_mlp_chain_fwd(const int32_t* desc, const float* wbuf, const f
     }
   }
   if (d.in_mode == 0 && (d.in_stride & 3) == 0) VQN_CHECK_ARG(((uintptr_t)in & 15) == 0, "in must be 16-byte aligned");
-  const size_t lds = (size_t)d.total_rows * 1024 + sizeof(ChainSmalls);
+  const size_t lds = (size_t)d.total_rows * 1024 + sizeof(ChainSmalls) + (size_t)d.small_w4 * 16;
   const long n_tiles = (N + 31) / 32;
   hipStream_t s = (hipStream_t)stream;
   if (d.n_waves == 4) {

@@ -59,14 +59,18 @@ __device__ __forceinline__ void gemm_tiles(const f32x4* __restrict__ lds, const 
     const f32x4* __restrict__ wp = w + (size_t)ot * ng * 64 + lane;
     auto brow = [&](int g) { return ((g < ks.nA) ? (ks.rowA + g) : (ks.rowB + (g - ks.nA))) * 64 + lane; };
     f32x4 a0[4], b0[4], a1[4], b1[4];
+    // Operand fetches are UNCONDITIONAL (group index clamped to the last one; a clamped fetch is never multiplied) and the
+    // vector-memory counter is drained once before the loop: every path through the loop then carries the same number of
+    // outstanding loads, and the compiler's s_waitcnt before a block's MFMAs is the exact distance to that block's
+    // operands.  With guarded fetches it falls back to vmcnt(0) lgkmcnt(0) after issuing the NEXT block's fetches, i.e.
+    // no overlap of fetch and matrix work inside a wave at all.
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (i < ng) { a0[i] = wp[i * 64]; b0[i] = lds[brow(i)]; }
+    for (int i = 0; i < 4; ++i) { const int q = min(i, ng - 1); a0[i] = wp[q * 64]; b0[i] = lds[brow(q)]; }
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) only
     __builtin_amdgcn_s_setprio(1);
     for (int g = 0; g < ng; g += 8) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (g + 4 + i < ng) { a1[i] = wp[(g + 4 + i) * 64]; b1[i] = lds[brow(g + 4 + i)]; }
+      for (int i = 0; i < 4; ++i) { const int q = min(g + 4 + i, ng - 1); a1[i] = wp[q * 64]; b1[i] = lds[brow(q)]; }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (g + i < ng) {
@@ -74,8 +78,7 @@ __device__ __forceinline__ void gemm_tiles(const f32x4* __restrict__ lds, const 
           for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][j], b0[i][j], acc, 0, 0, 0);
         }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (g + 8 + i < ng) { a0[i] = wp[(g + 8 + i) * 64]; b0[i] = lds[brow(g + 8 + i)]; }
+      for (int i = 0; i < 4; ++i) { const int q = min(g + 8 + i, ng - 1); a0[i] = wp[q * 64]; b0[i] = lds[brow(q)]; }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (g + 4 + i < ng) {
@@ -104,14 +107,18 @@ __device__ __forceinline__ void gemm_tiles_chain(const f32x4* __restrict__ lds, 
     auto brow = [&](int g) { return ((g < ks.nA) ? (ks.rowA + g) : (ks.rowB + (g - ks.nA))) * 64 + lane; };
     f32x4 a0[4], b0[4], a1[4], b1[4];
     const bool first = ot == wave;
+    // (unconditional, clamped operand fetches + one drain per tile: see gemm_tiles)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (i < ng) { if (first) a0[i] = pre[i]; else a0[i] = wp[i * 64]; b0[i] = lds[brow(i)]; }
+    for (int i = 0; i < 4; ++i) {
+      const int q = min(i, ng - 1);
+      if (first) a0[i] = pre[i]; else a0[i] = wp[q * 64];
+      b0[i] = lds[brow(q)];
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) only
     __builtin_amdgcn_s_setprio(1);
     for (int g = 0; g < ng; g += 8) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (g + 4 + i < ng) { a1[i] = wp[(g + 4 + i) * 64]; b1[i] = lds[brow(g + 4 + i)]; }
+      for (int i = 0; i < 4; ++i) { const int q = min(g + 4 + i, ng - 1); a1[i] = wp[q * 64]; b1[i] = lds[brow(q)]; }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (g + i < ng) {
@@ -119,8 +126,7 @@ __device__ __forceinline__ void gemm_tiles_chain(const f32x4* __restrict__ lds, 
           for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][j], b0[i][j], acc, 0, 0, 0);
         }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (g + 8 + i < ng) { a0[i] = wp[(g + 8 + i) * 64]; b0[i] = lds[brow(g + 8 + i)]; }
+      for (int i = 0; i < 4; ++i) { const int q = min(g + 8 + i, ng - 1); a0[i] = wp[q * 64]; b0[i] = lds[brow(q)]; }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (g + 4 + i < ng) {

@@ -1,0 +1,198 @@
+// Split-precision variant of the fused small-MLP engine (gfx950): every f32 value x travels as two f16 numbers
+//   hi = f16(x) (round toward zero),  lo = f16((x - hi) * 2^11)      =>  x = hi + lo * 2^-11  to ~2^-22 |x|
+// and a product a*w is taken as  a_hi*w_hi + 2^-11 (a_hi*w_lo + a_lo*w_hi)  on v_mfma_f32_32x32x16_f16 (f32 accumulate;
+// the dropped a_lo*w_lo term is 2^-22 relative).  Three f16 MFMAs (3 x 32 cycles) cover what sixteen f32 MFMAs
+// (8 x 64 cycles) cover in mlp_prims.h -- 5.3x less matrix-pipe time -- at 2^-21 instead of 2^-24 relative accuracy
+// per product.  NOT bit-compatible with the f32 engine: an opt-in mode (results within ~1e-6 relative of it).
+//
+// Data layout ("split activation image").  Same geometry as mlp_prims.h -- a workgroup owns 32 points, activations
+// live in LDS as rows of 64 x 16 B (1 KB), four rows per 32 features -- but a 16-feature K-step `sl` of a segment
+// is the row PAIR (2 sl, 2 sl + 1) = (hi, lo): lane (p = lane & 31, h = lane >> 5), half jj = 0..7 of either row holds
+// feature  16 sl + 8 (jj >> 2) + 4 h + (jj & 3)  of point p.  That is
+//   * the B operand of v_mfma_f32_32x32x16_f16 (lane (n, h) supplies B[k = 8 h + jj][n]) under a fixed permutation of
+//     the 16 features of the step, the same on the weight side, and
+//   * the accumulator layout of the 32x32 MFMA: register reg of lane (n, h) is output row
+//     (reg & 3) + 8 (reg >> 2) + 4 h, so registers 8 s .. 8 s + 7 ARE half-slots jj = 0..7 of step s of the output tile:
+//     an output tile is split and written back with four ds_write_b128, no shuffles, no row permutation.
+// Weights: pack[out_tile][2 step + part][lane][8 halfs] = part(W[out = 32 ot + (lane & 31)][in = feature(step, lane >> 5, jj)]),
+// the same 4 KB per 32x32 block as the f32 packs, so descriptors (offsets in float4 units) keep their meaning.
+#pragma once
+#include "mlp_prims.h"
+
+namespace eng {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
+
+__device__ __forceinline__ f16x8 as_h8(const f32x4 v) { return __builtin_bit_cast(f16x8, v); }
+
+__device__ __forceinline__ float pack_rtz(float a, float b) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+
+// 8 values -> (hi, lo) fragments
+__device__ __forceinline__ void split8(const float (&x)[8], f32x4& hi, f32x4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const auto hh = __builtin_amdgcn_cvt_pkrtz(x[2 * i], x[2 * i + 1]);
+    const float r0 = (x[2 * i] - (float)hh[0]) * LO_SCALE, r1 = (x[2 * i + 1] - (float)hh[1]) * LO_SCALE;
+    hi[i] = __builtin_bit_cast(float, hh);
+    lo[i] = pack_rtz(r0, r1);
+  }
+}
+
+__device__ __forceinline__ void join8(const f32x4 hi, const f32x4 lo, float (&x)[8]) {
+  const f16x8 h = as_h8(hi), l = as_h8(lo);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = fmaf((float)l[i], LO_INV, (float)h[i]);
+}
+
+// feature held by half-slot jj of lane half h in local K-step sl of a segment
+__device__ __forceinline__ int step_feat(int sl, int h, int jj) { return 16 * sl + 8 * (jj >> 2) + 4 * h + (jj & 3); }
+
+// out[32 x 32-point tile `ot`] over the K row pairs of `ks` (row counts even); wave w owns tiles w, w + NW, ...
+// acc1 collects hi*hi (+ the bias from init), acc2 the two cross terms (scaled 2^11).
+template <int NW = 4, class Init, class Epi>
+__device__ __forceinline__ void gemm_tiles_f16s(const f32x4* __restrict__ lds, const KSegs ks,
+                                                const f32x4* __restrict__ w, const int n_out_tiles, const int wave,
+                                                const int lane, Init init, Epi epi) {
+  const int nr = ks.nA + ks.nB, ns = nr >> 1;
+  for (int ot = wave; ot < n_out_tiles; ot += NW) {
+    f32x16 acc1, acc2;
+    init(ot, acc1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
+    const f32x4* __restrict__ wp = w + (size_t)ot * nr * 64 + lane;
+    auto brow = [&](int r) { return ((r < ks.nA) ? (ks.rowA + r) : (ks.rowB + (r - ks.nA))) * 64 + lane; };
+    f32x4 a0[8], b0[8], a1[8], b1[8];                 // 4 steps each: [2 i] = hi, [2 i + 1] = lo
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < nr) { a0[i] = wp[i * 64]; b0[i] = lds[brow(i)]; }
+    __builtin_amdgcn_s_setprio(1);
+    for (int s = 0; s < ns; s += 8) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (2 * s + 8 + i < nr) { a1[i] = wp[(2 * s + 8 + i) * 64]; b1[i] = lds[brow(2 * s + 8 + i)]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (s + i < ns) {
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(a0[2 * i]), as_h8(b0[2 * i]), acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(a0[2 * i]), as_h8(b0[2 * i + 1]), acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(a0[2 * i + 1]), as_h8(b0[2 * i]), acc2, 0, 0, 0);
+        }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (2 * s + 16 + i < nr) { a0[i] = wp[(2 * s + 16 + i) * 64]; b0[i] = lds[brow(2 * s + 16 + i)]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (s + 4 + i < ns) {
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(a1[2 * i]), as_h8(b1[2 * i]), acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(a1[2 * i]), as_h8(b1[2 * i + 1]), acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(a1[2 * i + 1]), as_h8(b1[2 * i]), acc2, 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    epi(ot, acc1, acc2);
+  }
+}
+
+// The same product with the weight stream decoupled from the layer structure.  On this engine a K = 256 tile is only
+// 16 x 96 matrix-pipe cycles, less than two L2 round trips, so weight fragments must be in flight long before they are
+// used: `A` is a ring of R 4-step blocks (R = 2: 128 features of K) that lives across tiles, layers and barriers.  After a
+// block is consumed its slot is refilled with the block R positions further down the wave's stream: the same tile,
+// then the wave's next tile of this layer, then (`next_wp`, `next_nb`) the wave's first tile of the next GEMM layer --
+// issued before this layer's epilogue and barrier.  Everything that touches a memory counter is unconditional and the
+// same on every path (eight global loads per block, two LDS reads per step), so the compiler's waitcnt bookkeeping stays
+// exact across the loop: only the MFMAs of a padding block are skipped, by a scalar branch.  That needs
+//   * packs padded with zero rows to whole blocks per tile (8 rows; a padded step multiplies a clamped, finite activation
+//     row by zeros), and
+//   * tiles padded to whole groups of R blocks in the ring's slot numbering, so block q of any tile always sits in slot
+//     q % R (all register indices static); the refill of a padding position is a dummy re-load of the tile's last block.
+// On entry the ring holds the first R blocks of this call's first tile (ring_prime once per kernel, then the chain keeps
+// itself primed: the stream wraps to the next point tile).  `wave` must be wave-uniform (readfirstlane).
+template <int R>
+__device__ __forceinline__ void ring_prime(f32x4 (&A)[R][8], const f32x4* __restrict__ wp, const int nb) {
+#pragma unroll
+  for (int u = 0; u < R; ++u)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) A[u][i] = wp[(min(u, nb - 1) * 8 + i) * 64];
+}
+
+template <int NW = 4, int R = 2, class Init, class Epi>
+__device__ __forceinline__ void gemm_tiles_f16s_ring(const f32x4* __restrict__ lds, const KSegs ks,
+                                                     const f32x4* __restrict__ w, const int n_out_tiles, const int wave,
+                                                     const int lane, f32x4 (&A)[R][8],
+                                                     const f32x4* __restrict__ next_wp, const int next_nb, Init init, Epi epi) {
+  const int nr = ks.nA + ks.nB, ns = nr >> 1, nb = (nr + 7) >> 3, nbp = ((nb + R - 1) / R) * R;
+  auto bstep = [&](int st) {                                  // LDS index of the hi row of K-step st (clamped to the last one)
+    const int r = 2 * min(st, ns - 1);
+    return ((r < ks.nA) ? (ks.rowA + r) : (ks.rowB + (r - ks.nA))) * 64 + lane;
+  };
+  for (int ot = wave; ot < n_out_tiles; ot += NW) {
+    const f32x4* __restrict__ wp = w + (size_t)ot * nb * 512 + lane;
+    const bool more = ot + NW < n_out_tiles;
+    const f32x4* __restrict__ nwp = more ? wp + (size_t)NW * nb * 512 : next_wp;
+    const int nnb = more ? nb : next_nb;
+    f32x16 acc1, acc2;
+    init(ot, acc1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
+    f32x4 Bh[4], Bl[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int a = bstep(j); Bh[j] = lds[a]; Bl[j] = lds[a + 64]; }
+    // drain the vector-memory counter once per tile (the ring was filled at least a whole epilogue + barrier ago: nothing
+    // to wait for in practice).  With nothing pending on loop entry the compiler's in-loop waits are the exact distances
+    // of the ring (vmcnt(8 R - 1 - 2 j ...)) instead of the vmcnt(0) it falls back to when entry and back-edge disagree.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_setprio(1);
+    for (int bi = 0; bi < nbp; bi += R) {
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int blk = bi + u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int a = bstep(blk * 4 + j + 2);
+          Bh[(j + 2) & 3] = lds[a];
+          Bl[(j + 2) & 3] = lds[a + 64];
+          if (blk < nb) {
+#ifdef VQN_DIAG_NO_MFMA      // timing only: the operand loads stay (their registers are "used"), the matrix work goes
+            asm volatile("" ::"v"(A[u][2 * j]), "v"(A[u][2 * j + 1]), "v"(Bh[j]), "v"(Bl[j]));
+#else
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(A[u][2 * j]), as_h8(Bh[j]), acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(A[u][2 * j]), as_h8(Bl[j]), acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(A[u][2 * j + 1]), as_h8(Bh[j]), acc2, 0, 0, 0);
+#endif
+          }
+        }
+        // refill slot u: own block blk + R, else block u of the wave's next tile, else (padding position) a dummy re-load
+        const int pos = blk + R;
+        const bool own = pos < nb, nxt = pos >= nbp;
+        const f32x4* __restrict__ src = nxt ? nwp : wp;
+        const int sb = own ? pos : (nxt ? min(u, nnb - 1) : nb - 1);
+#ifdef VQN_DIAG_W_L1         // timing only: every weight fragment from the same L1-resident 8 KB
+#pragma unroll
+        for (int i = 0; i < 8; ++i) A[u][i] = w[i * 64 + lane];
+#else
+#pragma unroll
+        for (int i = 0; i < 8; ++i) A[u][i] = src[(sb * 8 + i) * 64];
+#endif
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    epi(ot, acc1, acc2);
+  }
+}
+
+// acc init from a packed bias: bpack[ot][h][16], register order
+__device__ __forceinline__ void init_bias_f16s(const f32x4* __restrict__ bpack, int ot, int lane, f32x16& acc) {
+  const f32x4* b = bpack + (ot * 2 + (lane >> 5)) * 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 v = b[q];
+    acc[4 * q + 0] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
+  }
+}
+
+}  // namespace eng

@@ -88,6 +88,7 @@ class BrdfModel(ShapeModel):
         self._light = None
         self._gamma_index, self._gamma_bias = None, None
         self._plans, self._packs, self._engines = {}, {}, {}
+        self.matrix_mode = 'f32'         # 'f16s': inference MLP stacks on the split-precision (f16 hi/lo MFMA) kernel, ~1e-6 relative
         self.assume_foreground = False   # True: callers promise alpha > 0 everywhere (vq_nfr.Model.call skips the boolean gathers)
         self.train_backend = 'hip'       # 'hip': fused shading fwd/bwd kernels under autograd; 'torch': torch statements
         self.novel_probes = {}
@@ -157,25 +158,32 @@ class BrdfModel(ShapeModel):
 
     # ------------------------------------------------------------------ fused layer programs
     def _enc_program(self):
-        if 'enc' not in self._plans:
+        pkey = 'enc:' + self.matrix_mode
+        if pkey not in self._plans:
             emb = self.embedder['xyz']
-            b = packing.ChainBuilder('posenc', emb.out_dims, n_freqs=emb.n_freqs)
+            b = packing.ChainBuilder('posenc', emb.out_dims, n_freqs=emb.n_freqs, mode=self.matrix_mode)
             fe, bn = self.net['fine_enc'], self.net['bottleneck']
             y = b.mlp('fine_enc', fe.widths, fe.act, fe.skip_at, b.input)
             assert not isinstance(y, list)
             b.mlp('bottleneck', bn.widths, bn.act, bn.skip_at, y, out_slot=0, small_last=False)
-            self._plans['enc'] = b.build()
-        return self._plans['enc']
+            self._plans[pkey] = b.build()
+        return self._plans[pkey]
 
     def _head_program(self, names, in_dim=None):
         in_dim = in_dim or self.z_dim
-        key = 'heads:%d:' % in_dim + ','.join(names)
+        key = 'heads:%s:%d:' % (self.matrix_mode, in_dim) + ','.join(names)
         if key not in self._plans:
-            b = packing.ChainBuilder('raw', in_dim)
+            b = packing.ChainBuilder('raw', in_dim, mode=self.matrix_mode)
             x = b.input
             for slot, name in enumerate(names):
                 net = self.net[name]
-                if self._is_std_head(net):
+                if self._is_std_head(net) and self.matrix_mode == 'f16s' and not os.environ.get('VQN_F16S_RELOAD'):
+                    # on the split-precision engine the matrix work is ~5x shorter and the extra passes over z (6 KB per point
+                    # per program with reloads) would dominate: keep the input resident (80 rows, one 8-wave workgroup per CU)
+                    y0 = b.dense(f'{name}/0', [x], net.widths[0], net.act[0], keep=[x])
+                    y1 = b.dense(f'{name}/1', [y0], net.widths[1], net.act[1], keep=[x])
+                    b.dense_small(f'{name}/2', [y1, x], net.widths[2], net.act[2], slot)
+                elif self._is_std_head(net):
                     # [w0, w1, c] with the input concatenated into the last layer: the input image is NOT kept in LDS while
                     # the two wide activations are live -- it is fetched again (L2) for the last layer, and for the next head.
                     # That keeps the program at 64 rows, i.e. two workgroups per CU instead of one.
@@ -207,14 +215,14 @@ class BrdfModel(ShapeModel):
 
     def _fused_enc(self, pts):
         plan = self._enc_program()
-        wbuf, desc = self._program_pack('enc', plan, ['fine_enc', 'bottleneck'])
-        return _C.mlp_chain_fwd(desc, wbuf, pts.detach().float().contiguous(), [self.z_dim])[0]
+        wbuf, desc = self._program_pack('enc:' + self.matrix_mode, plan, ['fine_enc', 'bottleneck'])
+        return _C.mlp_chain_fwd(desc, wbuf, pts.detach().float().contiguous(), [self.z_dim], mode=self.matrix_mode)[0]
 
     def _fused_heads(self, z, names):
         plan = self._head_program(names, z.shape[1])
-        wbuf, desc = self._program_pack('heads:%d:' % z.shape[1] + ','.join(names), plan, names)
+        wbuf, desc = self._program_pack('heads:%s:%d:' % (self.matrix_mode, z.shape[1]) + ','.join(names), plan, names)
         widths = [self.net[n].widths[-1] for n in names]
-        return _C.mlp_chain_fwd(desc, wbuf, z.detach().float().contiguous(), widths)
+        return _C.mlp_chain_fwd(desc, wbuf, z.detach().float().contiguous(), widths, mode=self.matrix_mode)
 
     # ------------------------------------------------------------------ training engines (tile programs)
     def _train_hip(self, x):

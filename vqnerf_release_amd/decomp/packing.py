@@ -1,6 +1,10 @@
 """Host-side layer programs + weight packs for the generic fused Dense-stack kernel (csrc/mlp_chain.hip,
 descriptor layout csrc/chain_desc.h).  Activation-image / A-fragment layouts are those of geo/packing.py.
 
+`ChainBuilder(mode='f16s')` builds the same programs for the split-precision kernel (csrc/mlp_chain_f16s.hip, layouts in
+csrc/mlp_prims_f16s.h): K segments advance in 16-feature steps (row pairs hi / lo), weights are packed as f16 hi / lo
+fragments (same bytes, same offsets), biases in accumulator-register order.
+
 A program is built once per network shape with `ChainBuilder`; `ChainPlan.pack(params)` then gathers the
 current Keras-layout weights (`kernel [in, out]`, `bias [out]`) into one flat device buffer -- a pure index
 gather, cheap enough to redo after every optimiser step.
@@ -21,9 +25,9 @@ class Region:
     """`feats` features of 32 points held in LDS rows [row0, row0 + rows) (8 features per row); a GEMM output
     occupies whole 32-feature tiles (`alloc_rows`), of which only the first `rows` need to be read as K."""
 
-    def __init__(self, row0, feats, alloc_rows=None):
+    def __init__(self, row0, feats, alloc_rows=None, mode='f32'):
         self.row0, self.feats = row0, feats
-        self.rows = (feats + 7) // 8
+        self.rows = (feats + 7) // 8 if mode == 'f32' else 2 * ((feats + 15) // 16)
         self.alloc_rows = alloc_rows if alloc_rows is not None else self.rows
 
     @property
@@ -46,16 +50,80 @@ def _rowdot_index_segs(n_out, n_cols, segs):
     return np.where(colb >= 0, o * n_cols + colb, n_out * n_cols).astype(np.int64)
 
 
+def _step_feat(n_rows):
+    """[n_rows/2, 64, 8] local feature held by (step, lane, half-slot) of the split image (mlp_prims_f16s.h step_feat)."""
+    sl = np.arange(n_rows // 2)[:, None, None]
+    h = (np.arange(64) >> 5)[None, :, None]
+    jj = np.arange(8)[None, None, :]
+    return 16 * sl + 8 * (jj >> 2) + 4 * h + (jj & 3)
+
+
+def gemm_index_f16s(n_out, n_cols, segs):
+    """Gather index [n_out_tiles, n_steps, 64, 8] into M[n_out, n_cols].flatten() ++ [0]; segs = [(rows, feats, col_base)].
+    A operand of v_mfma_f32_32x32x16_f16: lane (r, h) holds W[32 ot + r][feature(step, h, jj)]."""
+    n_tiles = (n_out + 31) // 32
+    cols = []
+    for rows, feats, base in segs:
+        f = _step_feat(rows)
+        cols.append(np.where(f < feats, f + base, -1))
+    col = np.concatenate(cols, 0)                                     # [S,64,8]
+    pad = (-col.shape[0]) % 4                                         # whole 4-step blocks per tile: zero rows (gemm_tiles_f16s_ring)
+    if pad:
+        col = np.concatenate([col, np.full((pad, 64, 8), -1, col.dtype)], 0)
+    row = 32 * np.arange(n_tiles)[:, None, None, None] + (np.arange(64) & 31)[None, None, :, None]
+    row = np.broadcast_to(row, (n_tiles,) + col.shape)
+    colb = np.broadcast_to(col[None], row.shape)
+    return np.where((row < n_out) & (colb >= 0), row * n_cols + colb, n_out * n_cols).astype(np.int64)
+
+
+def bias_index_f16s(n_out):
+    """[n_tiles, 2, 16]: accumulator register reg of lane half h is output row (reg & 3) + 8 (reg >> 2) + 4 h."""
+    n_tiles = (n_out + 31) // 32
+    ot = np.arange(n_tiles)[:, None, None]
+    h = np.arange(2)[None, :, None]
+    reg = np.arange(16)[None, None, :]
+    f = 32 * ot + (reg & 3) + 8 * (reg >> 2) + 4 * h
+    return np.where(f < n_out, f, n_out).astype(np.int64)
+
+
+def _rowdot_index_segs_f16s(n_out, n_cols, segs):
+    """[n_out, n_steps, 2, 8] f32 image of M's rows in split-image order."""
+    cols = []
+    for rows, feats, base in segs:
+        f = _step_feat(rows)[:, ::32, :]                              # lanes 0 and 32 -> h = 0, 1
+        cols.append(np.where(f < feats, f + base, -1))
+    col = np.concatenate(cols, 0)                                     # [S,2,8]
+    o = np.arange(n_out)[:, None, None, None]
+    colb = np.broadcast_to(col[None], (n_out,) + col.shape)
+    return np.where(colb >= 0, o * n_cols + colb, n_out * n_cols).astype(np.int64)
+
+
+def split_f16(g):
+    """f32 tensor [..., 8] -> [..., 2 (hi, lo), ..., 8] halves packed as float32 words: see split_pack."""
+    hi = g.to(torch.float16)
+    lo = ((g - hi.float()) * 2048.0).to(torch.float16)
+    return hi, lo
+
+
+def split_pack(g):
+    """g [T, S, 64, 8] f32 (gemm_index_f16s order) -> flat float32 view of [T, S, 2, 64, 8] f16 (hi rows, lo rows)."""
+    if float(g.abs().max()) > 6.0e4:
+        raise ValueError('split-precision packs hold weights as f16 hi/lo: |w| must stay below 6e4')
+    hi, lo = split_f16(g)
+    return torch.stack([hi, lo], 2).contiguous().view(torch.float32).reshape(-1)
+
+
 class ChainBuilder:
     """Builds the layer program; LDS rows are assigned first-fit against the regions still needed."""
 
-    def __init__(self, in_mode, in_feats, n_freqs=0, in_stride=None):
-        assert in_mode in ('raw', 'posenc')
+    def __init__(self, in_mode, in_feats, n_freqs=0, in_stride=None, mode='f32'):
+        assert in_mode in ('raw', 'posenc') and mode in ('f32', 'f16s')
+        self.mode = mode
         if in_mode == 'posenc':
             assert in_feats == 3 + 6 * n_freqs
         self.in_mode, self.in_feats, self.n_freqs = in_mode, in_feats, n_freqs
         self.in_stride = in_stride if in_stride is not None else (3 if in_mode == 'posenc' else in_feats)
-        self.input = Region(0, in_feats)
+        self.input = Region(0, in_feats, mode=mode)
         self.layers = []           # dicts
         self.total_rows = self.input.rows
         self.n_slots = 0
@@ -65,7 +133,7 @@ class ChainBuilder:
         `keep`: regions that later layers still read (must not be overwritten).  Rows are assigned in build()."""
         assert 1 <= len(segs) <= 2
         tiles = (out_feats + 31) // 32
-        dst = Region(None, out_feats, alloc_rows=4 * tiles)
+        dst = Region(None, out_feats, alloc_rows=4 * tiles, mode=self.mode)
         self.layers.append(dict(kind=0, key=key, segs=list(segs), out=out_feats, act=ACT[act], dst=dst, tiles=tiles,
                                 live=list(segs) + list(keep), out_slot=-1 if out_slot is None else out_slot))
         if out_slot is not None:
@@ -75,7 +143,7 @@ class ChainBuilder:
     def reload_input(self, keep=()):
         """The input image again, in fresh rows: lets a program drop the input while wide activations are live and fetch it
         back (from L2) where a later layer concatenates it."""
-        r = Region(None, self.in_feats)
+        r = Region(None, self.in_feats, mode=self.mode)
         self.layers.append(dict(kind=2, key=None, segs=[], out=0, act=0, dst=r, tiles=0, live=list(keep), out_slot=-1))
         return r
 
@@ -144,7 +212,14 @@ class ChainPlan:
         self.b = b
         self.layers = b.layers
         self.total_rows = b.total_rows
-        lds = self.total_rows * 1024 + 8 * 32 * 4 * 4
+        # <= 4-output layers keep their weight images in LDS (16 B x 2 lane halves per K row and output)
+        self.small_w4, off4 = 0, 0
+        for L in self.layers:
+            if L['kind'] == 1:
+                L['lds_w_off'] = off4
+                off4 += L['out'] * sum(s.rows for s in L['segs']) * 2
+        self.small_w4 = off4
+        lds = self.total_rows * 1024 + 8 * 32 * 4 * 4 + 16 * self.small_w4
         assert lds <= 160 * 1024, f'program needs {lds} B of LDS'
         self.n_waves = 4 if 2 * lds <= 160 * 1024 else 8
         self.gather = []
@@ -154,7 +229,7 @@ class ChainPlan:
                 L['k_rows'], L['in_feats'] = [], 0
                 self.gather.append((None, None))
                 continue
-            if L['kind'] == 0:
+            if L['kind'] == 0 and b.mode == 'f32':
                 segs, base = [], 0
                 for s in L['segs']:
                     segs.append((s.rows, ident_cols(s.feats, base=base)))
@@ -167,7 +242,12 @@ class ChainPlan:
                     segs.append((s.rows, s.feats, base))
                     base += s.feats
                 L['k_rows'] = [sg[0] for sg in segs]
-                self.gather.append((_rowdot_index_segs(L['out'], in_feats, segs), None))
+                if L['kind'] == 0:
+                    self.gather.append((gemm_index_f16s(L['out'], in_feats, segs), bias_index_f16s(L['out'])))
+                elif b.mode == 'f16s':
+                    self.gather.append((_rowdot_index_segs_f16s(L['out'], in_feats, segs), None))
+                else:
+                    self.gather.append((_rowdot_index_segs(L['out'], in_feats, segs), None))
             L['in_feats'] = in_feats
         self._dev = {}
 
@@ -187,8 +267,8 @@ class ChainPlan:
         dev = params[next(L['key'] for L in self.layers if L['kind'] != 2)][0].device
         chunks, off = [], 0
         desc = np.zeros(DESC_INTS, np.int32)
-        desc[0:9] = [len(self.layers), 1 if b.in_mode == 'posenc' else 0, b.in_feats, b.input.rows, b.input.row0,
-                     b.n_freqs, self.total_rows, self.n_waves, b.in_stride]
+        desc[0:10] = [len(self.layers), 1 if b.in_mode == 'posenc' else 0, b.in_feats, b.input.rows, b.input.row0,
+                      b.n_freqs, self.total_rows, self.n_waves, b.in_stride, self.small_w4]
         small_bias = []
         for li, (L, (wi, bi)) in enumerate(zip(self.layers, self._indices(dev))):
             if L['kind'] == 2:
@@ -199,6 +279,8 @@ class ChainPlan:
             assert tuple(W.shape) == (L['in_feats'], L['out']), (L['key'], tuple(W.shape), (L['in_feats'], L['out']))
             M = W.t().contiguous()                                  # [out, in]
             c = _take(M, wi)
+            if b.mode == 'f16s' and L['kind'] == 0:
+                c = split_pack(c.reshape(wi.shape))
             w_off = off // 4
             chunks.append(c); off += c.numel()
             b_off = -1
@@ -209,7 +291,7 @@ class ChainPlan:
             segs = L['segs']
             kA0, kA = segs[0].row0, L['k_rows'][0]
             kB0, kB = (segs[1].row0, L['k_rows'][1]) if len(segs) == 2 else (0, 0)
-            dst0 = L['dst'].row0 if L['dst'] is not None else 0
+            dst0 = L['dst'].row0 if L['dst'] is not None else L['lds_w_off']
             base = 16 + LAYER_INTS * li
             desc[base:base + 12] = [L['kind'], L['act'], L['tiles'], kA0, kA, kB0, kB, dst0, w_off, b_off, L['out_slot'],
                                     L['out'] if L['kind'] == 0 else 0]
