@@ -125,6 +125,38 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
                                 'a tangent pass), weight-gradient contraction, compositing fwd/bwd; torch only for Adam, the '
                                 'weight-norm chain rule and small reductions'}
 
+    # ---- the headline render on the split-precision kernels (renderer.matrix_mode = 'f16s'), opt-in mode ----
+    Bq = 80000
+    o_np, d_np = image_rays(np.arange(Bq // 800))
+    oq, dq = torch.tensor(o_np, device=dev), torch.tensor(d_np, device=dev)
+    nq, fq = torch.full((Bq, 1), 2.0, device=dev), torch.full((Bq, 1), 6.0, device=dev)
+    bgq = torch.ones(1, 3, device=dev)
+    rend = lambda: ren.render(oq, dq, nq, fq, 2.0, perturb_overwrite=0, background_rgb=bgq, cos_anneal_ratio=1.0)
+    with torch.no_grad():
+        ref_img = rend()['color_fine']
+        ren.matrix_mode = 'f16s'
+        try:
+            got_img = rend()['color_fine']
+            _C.KernelClock.reset(True)
+            dt16 = _time_gpu(rend, 3, warm=0)
+            clk16 = _C.KernelClock.summary()
+        finally:
+            ren.matrix_mode = 'f32'
+            _C.KernelClock.reset(False)
+    t_fine16 = clk16['vqn_neus_fine_points_f16s'][1] / clk16['vqn_neus_fine_points_f16s'][0] * 1e-3
+    flop_fine = 2.0 * (2 * m_sdf + m_col) * Bq * 128
+    mse16 = float(((got_img - ref_img) ** 2).mean())
+    out['geo_render_f16s'] = {
+        'rays_per_s': Bq / dt16, 'ms_per_step': dt16 * 1e3, 'rays': Bq,
+        'psnr_vs_f32_render_db': -10.0 * math.log10(mse16 + 1e-30), 'max_abs_diff_vs_f32': float((got_img - ref_img).abs().max()),
+        'fine_kernel': {'ms': t_fine16 * 1e3, 'achieved': flop_fine / t_fine16 / 1e12, 'unit': 'TFLOP/s (algorithmic f32 FLOPs)',
+                        'issued_f16_tflops': 3.0 * flop_fine / t_fine16 / 1e12, 'peak': 2516.6,
+                        'frac': 3.0 * flop_fine / t_fine16 / 1e12 / 2516.6,
+                        'frac_note': 'issued f16 MFMA FLOPs (3 per algorithmic FLOP) over the dense f16 peak'},
+        'kernel_ms_per_step': {k: v[1] / 3 for k, v in sorted(clk16.items())},
+        'note': 'opt-in precision mode (renderer.matrix_mode = "f16s": f16 hi/lo operands, 3 f16 MFMAs per product, f32 accumulate); '
+                '`value` is the f32 path'}
+
     # ---- light-visibility extraction (gen_geo.py compute_vis): secondary rays surface -> light, occupancy only ----
     from vqnerf_release_amd.geo.gen_geo import GeoExtractor
     ex = GeoExtractor(ren, max_radius=2.0, light_h=16, max_rays=1 << 20)

@@ -121,6 +121,18 @@ int vqn_neus_fine_points(const int32_t* sdf_desc, const float* wbuf_sdf, const i
                          const float* pts, const float* dirs, int64_t P, int S, void* scratch,
                          int64_t scratch_bytes, float* out_sdf, float* out_grad, float* out_rgb, void* stream);
 
+/* Split-precision twins of vqn_neus_sdf_points / vqn_neus_fine_points ("fp16 MFMA path"): same arguments, same outputs,
+ * every product taken as hi*hi + 2^-11 (hi*lo + lo*hi) over f16 hi/lo operand pairs on v_mfma_f32_32x32x16_f16 with f32
+ * accumulation.  Descriptors and packs must be built for it (SdfPackPlan(mode='f16s'), ColPackPlan(matrix_mode='f16s'):
+ * even row counts, f16 hi/lo weight fragments padded to whole 64-feature blocks).  Opt-in: agrees with the f32 entry
+ * points to ~1e-6 relative, not bitwise; |weights| < 6e4.  Scratch size: vqn_neus_fine_scratch_bytes. */
+int vqn_neus_sdf_points_f16s(const int32_t* sdf_desc, const float* wbuf_sdf, const float* rays_o, const float* rays_d,
+                             const float* z, const float* pts, int64_t P, int S, float* out_sdf, void* stream);
+int vqn_neus_fine_points_f16s(const int32_t* sdf_desc, const float* wbuf_sdf, const int32_t* col_desc,
+                              const float* wbuf_col, const float* rays_o, const float* rays_d, const float* z,
+                              const float* pts, const float* dirs, int64_t P, int S, void* scratch,
+                              int64_t scratch_bytes, float* out_sdf, float* out_grad, float* out_rgb, void* stream);
+
 /* ---- per-ray NeuS kernels (geo/NeuS-ours2/models/renderer.py) ------------------------------ */
 
 /* Replaces NeuSRenderer.up_sample (renderer.py:131-175) incl. sample_pdf(det=True) (:39-69):

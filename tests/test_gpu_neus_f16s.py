@@ -1,0 +1,118 @@
+"""GPU: the split-precision NeuS kernels (vqn_neus_sdf_points_f16s / vqn_neus_fine_points_f16s; f16 hi/lo operands, three f16
+MFMAs per product, f32 accumulate) -- an OPT-IN mode with a stated tolerance instead of bitwise agreement.
+
+Stated tolerance: the same bounds the f32 kernels are held to against the reference goldens and the oracle (sdf 2e-5 abs,
+gradients 2e-4, rgb 2e-4), and against the f32 kernels themselves sdf 5e-6, gradients 1e-4 relative to the gradient scale,
+rgb 5e-5; a rendered image within 80 dB PSNR of the f32 render."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(name):
+    from oracle import geo as og
+    return og.FULL_CFG if name == 'full' else og.SMALL_CFG
+
+
+def _packed(cfg, mode, dev='cuda'):
+    from oracle import geo as og
+    from vqnerf_release_amd.geo import packing as pk
+    c, cc = cfg['sdf'], cfg['color']
+    sp = pk.SdfPackPlan(og.sdf_dims(cfg), c['skip_in'], c['multires'], c['scale'], max_tiles=(cc['d_hidden'] + 31) // 32, mode=mode)
+    cp = pk.ColPackPlan(cc['d_feature'], cc['mode'], cc['d_hidden'], cc['n_layers'], cc['d_out'], cc['multires_view'],
+                        cc['squeeze_out'], feat_tiles=sp.tiles[-1], matrix_mode=mode)
+    p_sdf = og.to_torch(og.make_sdf_params(cfg, 0))
+    p_col = og.to_torch(og.make_color_params(cfg, 1))
+    Ws = [og.wn_weight(p_sdf, l).to(dev) for l in range(sp.n_lin)]
+    bs = [p_sdf[f'lin{l}.bias'].to(dev) for l in range(sp.n_lin)]
+    Wc = [og.wn_weight(p_col, l).to(dev) for l in range(cp.n_lin)]
+    bc = [p_col[f'lin{l}.bias'].to(dev) for l in range(cp.n_lin)]
+    return (p_sdf, p_col) + sp.pack(Ws, bs) + cp.pack(Wc, bc)
+
+
+@pytest.mark.parametrize('name', ['full', 'small'])
+@pytest.mark.parametrize('P', [1, 33, 4099])
+def test_sdf_points_f16s(name, P):
+    from oracle import geo as og
+    from vqnerf_release_amd import _C
+    cfg = _cfg(name)
+    p_sdf, _, wb32, d32, _, _ = _packed(cfg, 'f32')
+    _, _, wb16, d16, _, _ = _packed(cfg, 'f16s')
+    pts = torch.tensor(np.random.default_rng(3).uniform(-1.2, 1.2, (P, 3)).astype(np.float32))
+    a = _C.neus_sdf_points(d32, wb32, pts=pts.cuda())
+    b = _C.neus_sdf_points(d16, wb16, pts=pts.cuda(), mode='f16s')
+    with torch.no_grad():
+        ref = og.sdf_only(p_sdf, cfg, pts)[:, 0]
+    np.testing.assert_allclose(b.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=5e-6)
+    # ray form (o + z d) = point form
+    o = torch.zeros(P, 3).cuda()
+    d = pts.cuda() / pts.cuda().norm(dim=-1, keepdim=True)
+    z = pts.cuda().norm(dim=-1, keepdim=True).contiguous()
+    c = _C.neus_sdf_points(d16, wb16, rays_o=o, rays_d=d.contiguous(), z=z, mode='f16s')
+    np.testing.assert_allclose(c.cpu().numpy(), _C.neus_sdf_points(d32, wb32, rays_o=o, rays_d=d.contiguous(), z=z).cpu().numpy(), rtol=0, atol=5e-6)
+
+
+@pytest.mark.parametrize('name', ['full', 'small'])
+def test_fine_points_f16s_vs_golden_and_f32(name, golden_dir):
+    from vqnerf_release_amd import _C
+    cfg = _cfg(name)
+    g = dict(np.load(os.path.join(golden_dir, f'geo_{name}.npz')))
+    _, _, wb_s, d_s, wb_c, d_c = _packed(cfg, 'f16s')
+    _, _, wb_s32, d_s32, wb_c32, d_c32 = _packed(cfg, 'f32')
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-1.2, 1.2, (96, 3)).astype(np.float32)
+    dirs = rng.normal(size=(96, 3)).astype(np.float32)
+    dirs = dirs / np.linalg.norm(dirs, axis=1, keepdims=True)
+    P, D = torch.tensor(pts).cuda(), torch.tensor(dirs).cuda()
+    sdf, grad, rgb = _C.neus_fine_points(d_s, wb_s, d_c, wb_c, pts=P, dirs=D, mode='f16s')
+    # the reference's own outputs on these points
+    np.testing.assert_allclose(sdf.cpu().numpy(), g['net_sdf_out'][:, 0], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(grad.cpu().numpy(), g['net_sdf_grad'], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(rgb.cpu().numpy(), g['net_color'], rtol=0, atol=2e-4)
+    # the f32 kernels
+    s32, g32, c32 = _C.neus_fine_points(d_s32, wb_s32, d_c32, wb_c32, pts=P, dirs=D)
+    np.testing.assert_allclose(sdf.cpu().numpy(), s32.cpu().numpy(), rtol=0, atol=5e-6)
+    np.testing.assert_allclose(grad.cpu().numpy(), g32.cpu().numpy(), rtol=0, atol=1e-4 * float(g32.abs().max()))
+    np.testing.assert_allclose(rgb.cpu().numpy(), c32.cpu().numpy(), rtol=0, atol=5e-5)
+    assert not torch.equal(sdf, s32)                                 # (it is the other kernel)
+    # gradient-only form (SDFNetwork.gradient) and ragged sizes
+    zero_col = np.zeros_like(d_c)
+    for n in (1, 31, 65):
+        s2, g2, _ = _C.neus_fine_points(d_s, wb_s, zero_col, wb_c, pts=P[:n].contiguous(), dirs=D[:n].contiguous(), mode='f16s')
+        assert torch.equal(s2, sdf[:n]) and torch.equal(g2, grad[:n])
+
+
+def test_render_f16s_matches_f32_render():
+    """matrix_mode='f16s' through NeuSRenderer.render (up-sampling on the f16s SDF kernel, fine pass on the f16s fine kernel)."""
+    from oracle import geo as og
+    from vqnerf_release_amd.geo.models.fields import SDFNetwork, RenderingNetwork, SingleVarianceNetwork
+    from vqnerf_release_amd.geo.models.renderer import NeuSRenderer
+    cfg = og.FULL_CFG
+    torch.manual_seed(0)
+    sdf = SDFNetwork(**cfg['sdf']).cuda()
+    col = RenderingNetwork(**cfg['color']).cuda()
+    var = SingleVarianceNetwork(0.3).cuda()
+    ren = NeuSRenderer(None, sdf, var, col, n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4, perturb=0.0)
+    B = 600
+    rng = np.random.default_rng(5)
+    d = rng.normal(size=(B, 3)).astype(np.float32) * 0.15 + np.array([0, 0, -1], np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o = np.tile(np.array([[0, 0, 4.0]], np.float32), (B, 1))
+    O, D = torch.tensor(o).cuda(), torch.tensor(d).cuda()
+    near, far = torch.full((B, 1), 2.0).cuda(), torch.full((B, 1), 6.0).cuda()
+    with torch.no_grad():
+        a = ren.render(O, D, near, far, 2.0, perturb_overwrite=0, background_rgb=torch.ones(1, 3).cuda(), cos_anneal_ratio=1.0)
+        ren.matrix_mode = 'f16s'
+        b = ren.render(O, D, near, far, 2.0, perturb_overwrite=0, background_rgb=torch.ones(1, 3).cuda(), cos_anneal_ratio=1.0)
+    mse = float(((a['color_fine'] - b['color_fine']) ** 2).mean())
+    assert -10 * np.log10(mse + 1e-30) > 80.0, mse
+    assert float(a['weight_sum'].max()) > 0.5                        # rays do hit the surface
+    np.testing.assert_allclose(b['weight_sum'].cpu().numpy(), a['weight_sum'].cpu().numpy(), rtol=0, atol=2e-4)
+    # per-sample gradients: the sample positions themselves move by ~1e-6 (importance sampling on the other SDF kernel)
+    dg = (b['gradients'] - a['gradients']).abs().cpu().numpy()
+    assert np.quantile(dg, 0.999) < 1e-3 and dg.max() < 2e-2, (np.quantile(dg, 0.999), dg.max())

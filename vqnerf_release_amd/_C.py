@@ -153,7 +153,7 @@ def _i32(desc):
     return d, d.ctypes.data_as(ctypes.c_void_p)
 
 
-def neus_sdf_points(sdf_desc, wbuf_sdf, rays_o=None, rays_d=None, z=None, pts=None):
+def neus_sdf_points(sdf_desc, wbuf_sdf, rays_o=None, rays_d=None, z=None, pts=None, mode='f32'):
     """SDF value at ray samples (rays_o/rays_d [B,3], z [B,S]) or at explicit pts [P,3] -> [P]."""
     _f32c(wbuf_sdf, 'wbuf_sdf')
     d, dp = _i32(sdf_desc)
@@ -166,14 +166,16 @@ def neus_sdf_points(sdf_desc, wbuf_sdf, rays_o=None, rays_d=None, z=None, pts=No
         P = B * S
         dev = z.device
     out = torch.empty((P,), dtype=torch.float32, device=dev)
-    with _clock('vqn_neus_sdf_points'):
-        rc = lib().vqn_neus_sdf_points(dp, _ptr(wbuf_sdf), _ptr(rays_o), _ptr(rays_d), _ptr(z), _ptr(pts),
-                                       ctypes.c_int64(P), ctypes.c_int(S), _ptr(out), _stream())
-    _check(rc, 'vqn_neus_sdf_points')
+    assert mode in ('f32', 'f16s')
+    entry = 'vqn_neus_sdf_points' if mode == 'f32' else 'vqn_neus_sdf_points_f16s'
+    with _clock(entry):
+        rc = getattr(lib(), entry)(dp, _ptr(wbuf_sdf), _ptr(rays_o), _ptr(rays_d), _ptr(z), _ptr(pts),
+                                   ctypes.c_int64(P), ctypes.c_int(S), _ptr(out), _stream())
+    _check(rc, entry)
     return out
 
 
-def neus_fine_points(sdf_desc, wbuf_sdf, col_desc, wbuf_col, rays_o=None, rays_d=None, z=None, pts=None, dirs=None):
+def neus_fine_points(sdf_desc, wbuf_sdf, col_desc, wbuf_col, rays_o=None, rays_d=None, z=None, pts=None, dirs=None, mode='f32'):
     """sdf [P], d sdf/d x [P,3], rgb [P,3] at ray samples or explicit (pts, dirs)."""
     _f32c(wbuf_sdf, 'wbuf_sdf'); _f32c(wbuf_col, 'wbuf_col')
     sd, sdp = _i32(sdf_desc)
@@ -199,11 +201,13 @@ def neus_fine_points(sdf_desc, wbuf_sdf, col_desc, wbuf_col, rays_o=None, rays_d
     sdf = torch.empty((P,), dtype=torch.float32, device=dev)
     grad = torch.empty((P, 3), dtype=torch.float32, device=dev)
     rgb = torch.empty((P, 3), dtype=torch.float32, device=dev)
-    with _clock('vqn_neus_fine_points'):
-        rc = L.vqn_neus_fine_points(sdp, _ptr(wbuf_sdf), cdp, _ptr(wbuf_col), _ptr(rays_o), _ptr(rays_d), _ptr(z),
-                                    _ptr(pts), _ptr(dirs), ctypes.c_int64(P), ctypes.c_int(S), _ptr(buf),
-                                    ctypes.c_int64(buf.numel()), _ptr(sdf), _ptr(grad), _ptr(rgb), _stream())
-    _check(rc, 'vqn_neus_fine_points')
+    assert mode in ('f32', 'f16s')
+    entry = 'vqn_neus_fine_points' if mode == 'f32' else 'vqn_neus_fine_points_f16s'
+    with _clock(entry):
+        rc = getattr(L, entry)(sdp, _ptr(wbuf_sdf), cdp, _ptr(wbuf_col), _ptr(rays_o), _ptr(rays_d), _ptr(z),
+                               _ptr(pts), _ptr(dirs), ctypes.c_int64(P), ctypes.c_int(S), _ptr(buf),
+                               ctypes.c_int64(buf.numel()), _ptr(sdf), _ptr(grad), _ptr(rgb), _stream())
+    _check(rc, entry)
     return sdf, grad, rgb
 
 

@@ -55,7 +55,6 @@ __device__ __forceinline__ void gemm_tiles(const f32x4* __restrict__ lds, const 
   const int ng = ks.nA + ks.nB;
   for (int ot = wave; ot < n_out_tiles; ot += NW) {
     f32x16 acc;
-    init(ot, acc);
     const f32x4* __restrict__ wp = w + (size_t)ot * ng * 64 + lane;
     auto brow = [&](int g) { return ((g < ks.nA) ? (ks.rowA + g) : (ks.rowB + (g - ks.nA))) * 64 + lane; };
     f32x4 a0[4], b0[4], a1[4], b1[4];
@@ -67,6 +66,7 @@ __device__ __forceinline__ void gemm_tiles(const f32x4* __restrict__ lds, const 
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int q = min(i, ng - 1); a0[i] = wp[q * 64]; b0[i] = lds[brow(q)]; }
     __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) only
+    init(ot, acc);                             // after the drain: loads issued here (stashed activations ...) land under the K loop
     __builtin_amdgcn_s_setprio(1);
     for (int g = 0; g < ng; g += 8) {
 #pragma unroll
@@ -102,7 +102,6 @@ __device__ __forceinline__ void gemm_tiles_chain(const f32x4* __restrict__ lds, 
   const int ng = ks.nA + ks.nB;
   for (int ot = wave; ot < n_out_tiles; ot += NW) {
     f32x16 acc;
-    init(ot, acc);
     const f32x4* __restrict__ wp = w + (size_t)ot * ng * 64 + lane;
     auto brow = [&](int g) { return ((g < ks.nA) ? (ks.rowA + g) : (ks.rowB + (g - ks.nA))) * 64 + lane; };
     f32x4 a0[4], b0[4], a1[4], b1[4];
@@ -115,6 +114,7 @@ __device__ __forceinline__ void gemm_tiles_chain(const f32x4* __restrict__ lds, 
       b0[i] = lds[brow(q)];
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) only
+    init(ot, acc);                             // after the drain: loads issued here (stashed activations ...) land under the K loop
     __builtin_amdgcn_s_setprio(1);
     for (int g = 0; g < ng; g += 8) {
 #pragma unroll
@@ -152,13 +152,17 @@ __device__ __forceinline__ f32x4 acc_quad(const f32x16& acc, int rq) {
   return (f32x4){acc[4 * rq + 0], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]};
 }
 
-// acc init from a packed bias: bpack[ot][h][16]
+// acc init from a packed bias: bpack[ot][h][16].  `ot` is wave-uniform (callers take `wave` through readfirstlane), so both
+// halves are fetched at uniform addresses -- scalar loads: short latency, and nothing enters the vector-memory counter that
+// paces the K loop -- and each lane keeps its half.
 __device__ __forceinline__ void init_bias(const f32x4* __restrict__ bpack, int ot, int lane, f32x16& acc) {
-  const f32x4* b = bpack + (ot * 2 + (lane >> 5)) * 4;
+  const f32x4* b = bpack + ot * 8;
+  const bool hi = lane >= 32;
 #pragma unroll
   for (int rq = 0; rq < 4; ++rq) {
-    f32x4 v = b[rq];
-    acc[4 * rq + 0] = v[0]; acc[4 * rq + 1] = v[1]; acc[4 * rq + 2] = v[2]; acc[4 * rq + 3] = v[3];
+    const f32x4 v0 = b[rq], v1 = b[4 + rq];
+    acc[4 * rq + 0] = hi ? v1[0] : v0[0]; acc[4 * rq + 1] = hi ? v1[1] : v0[1];
+    acc[4 * rq + 2] = hi ? v1[2] : v0[2]; acc[4 * rq + 3] = hi ? v1[3] : v0[3];
   }
 }
 
@@ -197,23 +201,36 @@ __device__ __forceinline__ float posenc_jac(int f, float x0, float x1, float x2,
 __device__ __forceinline__ int row_feat(int r, int h, int j) { return 32 * (r >> 2) + 2 * (4 * (r & 3) + j) + h; }
 
 // part[(wave*32 + p)*NOUT + o] = this wave's share of sum_f wimg[o][f] * act[f][p] over rows
-// [row0, row0+n_rows); the caller adds the four partials in a fixed order (deterministic)
+// [row0, row0+n_rows); the caller adds the four partials in a fixed order (deterministic).
+// The weight rows come from L2: they are fetched a chunk of rows at a time, all fetches of a chunk (unconditional, clamped)
+// before its first use, so a chunk pays one round trip instead of one per row; the sum order is the plain row order.
 template <int NOUT, int NW = 4>
 __device__ __forceinline__ void rowdot(const f32x4* __restrict__ lds, int row0, int n_rows,
                                        const f32x4* __restrict__ wimg /* [NOUT][n_rows][2] float4 */, float* out_s,
                                        int wave, int lane) {
+  constexpr int CH = NOUT == 1 ? 8 : (NOUT <= 2 ? 4 : 3);
   float s[NOUT];
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) s[o] = 0.f;
   const int h = lane >> 5;
-  for (int r = wave; r < n_rows; r += NW) {
-    const f32x4 b = lds[(row0 + r) * 64 + lane];
+  for (int r0 = wave; r0 < n_rows; r0 += NW * CH) {
+    f32x4 b[CH], wv[CH][NOUT];
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o) {
-      const f32x4 wv = wimg[(o * n_rows + r) * 2 + h];
-      s[o] = fmaf(b[0], wv[0], s[o]); s[o] = fmaf(b[1], wv[1], s[o]);
-      s[o] = fmaf(b[2], wv[2], s[o]); s[o] = fmaf(b[3], wv[3], s[o]);
+    for (int c = 0; c < CH; ++c) {
+      const int r = min(r0 + NW * c, n_rows - 1);
+      b[c] = lds[(row0 + r) * 64 + lane];
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) wv[c][o] = wimg[(o * n_rows + r) * 2 + h];
     }
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (r0 + NW * c < n_rows) {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+          s[o] = fmaf(b[c][0], wv[c][o][0], s[o]); s[o] = fmaf(b[c][1], wv[c][o][1], s[o]);
+          s[o] = fmaf(b[c][2], wv[c][o][2], s[o]); s[o] = fmaf(b[c][3], wv[c][o][3], s[o]);
+        }
+      }
   }
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) {

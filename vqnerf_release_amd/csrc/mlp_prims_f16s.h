@@ -136,7 +136,6 @@ __device__ __forceinline__ void gemm_tiles_f16s_ring(const f32x4* __restrict__ l
     const f32x4* __restrict__ nwp = more ? wp + (size_t)NW * nb * 512 : next_wp;
     const int nnb = more ? nb : next_nb;
     f32x16 acc1, acc2;
-    init(ot, acc1);
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
     f32x4 Bh[4], Bl[4];
@@ -146,6 +145,7 @@ __device__ __forceinline__ void gemm_tiles_f16s_ring(const f32x4* __restrict__ l
     // to wait for in practice).  With nothing pending on loop entry the compiler's in-loop waits are the exact distances
     // of the ring (vmcnt(8 R - 1 - 2 j ...)) instead of the vmcnt(0) it falls back to when entry and back-edge disagree.
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    init(ot, acc1);                            // after the drain: vector loads issued here land under the K loop
     __builtin_amdgcn_s_setprio(1);
     for (int bi = 0; bi < nbp; bi += R) {
 #pragma unroll
@@ -185,13 +185,90 @@ __device__ __forceinline__ void gemm_tiles_f16s_ring(const f32x4* __restrict__ l
   }
 }
 
+// an output tile (16 values per lane in accumulator-register order) -> the four split rows of tile base row `row0`
+__device__ __forceinline__ void store_tile_f16s(f32x4* __restrict__ lds, const int row0, const int lane, const float (&v)[16]) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const float x[8] = {v[8 * s], v[8 * s + 1], v[8 * s + 2], v[8 * s + 3], v[8 * s + 4], v[8 * s + 5], v[8 * s + 6], v[8 * s + 7]};
+    f32x4 hi, lo;
+    split8(x, hi, lo);
+    lds[(row0 + 2 * s) * 64 + lane] = hi;
+    lds[(row0 + 2 * s + 1) * 64 + lane] = lo;
+  }
+}
+
+// the four split rows of a tile -> 16 register-order values (e.g. as an accumulator init)
+__device__ __forceinline__ void load_tile_f16s(const f32x4* __restrict__ lds, const int row0, const int lane, float (&v)[16]) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    float x[8];
+    join8(lds[(row0 + 2 * s) * 64 + lane], lds[(row0 + 2 * s + 1) * 64 + lane], x);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[8 * s + i] = x[i];
+  }
+}
+
+// value of feature f (region starting at row0) of point pp, read half by half
+__device__ __forceinline__ float lds_feat_f16s(const f32x4* __restrict__ lds, const int row0, const int f, const int pp) {
+  const int sl = f >> 4, fi = f & 15, hh = (fi >> 2) & 1, jj = 4 * (fi >> 3) + (fi & 3);
+  const _Float16* hi = reinterpret_cast<const _Float16*>(lds + (row0 + 2 * sl) * 64 + pp + 32 * hh);
+  const _Float16* lo = reinterpret_cast<const _Float16*>(lds + (row0 + 2 * sl + 1) * 64 + pp + 32 * hh);
+  return fmaf((float)lo[jj], LO_INV, (float)hi[jj]);
+}
+
+// part[(wave*32 + p)*NOUT + o] = this wave's share of sum_f wimg[o][f] * act[f][p] over the row pairs of [row0, row0+n_rows);
+// wimg is the f32 image [NOUT][n_rows/2][2][8]; weight fetches of a chunk of steps are issued together (one L2 round trip).
+template <int NOUT, int NW = 4>
+__device__ __forceinline__ void rowdot_f16s(const f32x4* __restrict__ lds, int row0, int n_rows,
+                                            const f32x4* __restrict__ wimg, float* out_s, int wave, int lane) {
+  constexpr int CH = NOUT == 1 ? 4 : 2;
+  const int ns = n_rows >> 1, h = lane >> 5;
+  float s[NOUT];
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) s[o] = 0.f;
+  for (int q0 = wave; q0 < ns; q0 += NW * CH) {
+    f32x4 bh[CH], bl[CH], wv[CH][NOUT][2];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int q = min(q0 + NW * c, ns - 1);
+      bh[c] = lds[(row0 + 2 * q) * 64 + lane];
+      bl[c] = lds[(row0 + 2 * q + 1) * 64 + lane];
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) {
+        wv[c][o][0] = wimg[((o * ns + q) * 2 + h) * 2];
+        wv[c][o][1] = wimg[((o * ns + q) * 2 + h) * 2 + 1];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (q0 + NW * c < ns) {
+        float x[8];
+        join8(bh[c], bl[c], x);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+          s[o] = fmaf(x[0], wv[c][o][0][0], s[o]); s[o] = fmaf(x[1], wv[c][o][0][1], s[o]);
+          s[o] = fmaf(x[2], wv[c][o][0][2], s[o]); s[o] = fmaf(x[3], wv[c][o][0][3], s[o]);
+          s[o] = fmaf(x[4], wv[c][o][1][0], s[o]); s[o] = fmaf(x[5], wv[c][o][1][1], s[o]);
+          s[o] = fmaf(x[6], wv[c][o][1][2], s[o]); s[o] = fmaf(x[7], wv[c][o][1][3], s[o]);
+        }
+      }
+  }
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) {
+    s[o] += __shfl_xor(s[o], 32);
+    if (h == 0) out_s[(wave * 32 + (lane & 31)) * NOUT + o] = s[o];
+  }
+}
+
 // acc init from a packed bias: bpack[ot][h][16], register order
 __device__ __forceinline__ void init_bias_f16s(const f32x4* __restrict__ bpack, int ot, int lane, f32x16& acc) {
-  const f32x4* b = bpack + (ot * 2 + (lane >> 5)) * 4;
+  const f32x4* b = bpack + ot * 8;               // ot is wave-uniform: both halves by scalar loads, each lane keeps its own
+  const bool hi = lane >= 32;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const f32x4 v = b[q];
-    acc[4 * q + 0] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
+    const f32x4 v0 = b[q], v1 = b[4 + q];
+    acc[4 * q + 0] = hi ? v1[0] : v0[0]; acc[4 * q + 1] = hi ? v1[1] : v0[1];
+    acc[4 * q + 2] = hi ? v1[2] : v0[2]; acc[4 * q + 3] = hi ? v1[3] : v0[3];
   }
 }
 

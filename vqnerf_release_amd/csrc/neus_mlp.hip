@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256, 2) void neus_points_kernel(
   const int MT = sd.max_tiles;
   const int X0 = E_ROWS, Y0 = E_ROWS + 4 * MT;
   Smalls* sm = reinterpret_cast<Smalls*>(lds + (size_t)(E_ROWS + 8 * MT) * 64);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: let the compiler know
   const int n_lin = sd.n_lin;
   const int emb_tiles = (sd.emb_feats + 31) >> 5;
   const long n_tiles = (P + 31) >> 5;
@@ -163,12 +164,21 @@ __global__ __launch_bounds__(256, 2) void neus_points_kernel(
 
     // ---------------- reverse sweep: d sdf / d x ----------------
     // G_pre(last hidden) = w_sdf_row (.) act'(h), in place
-    for (int r = wave; r < hid_rows; r += 4) {
-      f32x4 v = lds[(cur + r) * 64 + lane];
-      const f32x4 wv = wsdf[sd.last_w_off + r * 2 + h];
+    for (int r0 = wave; r0 < hid_rows; r0 += 32) {            // 8 rows per pass: all fetches first (one L2 round trip per pass)
+      f32x4 v[8], wv[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = wv[j] * act_bwd_from_out<ACT_SOFTPLUS100>(v[j]);
-      lds[(cur + r) * 64 + lane] = v;
+      for (int c = 0; c < 8; ++c) {
+        const int r = min(r0 + 4 * c, hid_rows - 1);
+        v[c] = lds[(cur + r) * 64 + lane];
+        wv[c] = wsdf[sd.last_w_off + r * 2 + h];
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (r0 + 4 * c < hid_rows) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[c][j] = wv[c][j] * act_bwd_from_out<ACT_SOFTPLUS100>(v[c][j]);
+          lds[(cur + r0 + 4 * c) * 64 + lane] = v[c];
+        }
     }
     __syncthreads();
     for (int l = n_lin - 2; l >= 1; --l) {
@@ -257,7 +267,14 @@ __global__ __launch_bounds__(256, 2) void neus_points_kernel(
       }
       const f32x4* sv = save + (size_t)feat_slot * 64;
       const int feat_rows = 4 * sd.layers[n_lin - 1].n_out_tiles;
-      for (int r = wave; r < feat_rows; r += 4) lds[(X0 + r) * 64 + lane] = sv[r * 64 + lane];
+      for (int r0 = wave; r0 < feat_rows; r0 += 32) {          // feature rows back from the stash: 8 fetches in flight per pass
+        f32x4 v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = sv[min(r0 + 4 * c, feat_rows - 1) * 64 + lane];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (r0 + 4 * c < feat_rows) lds[(X0 + r0 + 4 * c) * 64 + lane] = v[c];
+      }
       __syncthreads();
       cur = X0; oth = Y0;
       int in_rows = feat_rows;

@@ -57,7 +57,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void tile_vm_kernel(const
                                                                            const f32x4* __restrict__ wbuf,
                                                                            const VmTable tab, const long N) {
   extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: let the compiler know
   const long n_tiles = (N + 31) >> 5;
   const int n_ops = dp->n_ops;
   float* ldsf = reinterpret_cast<float*>(lds);

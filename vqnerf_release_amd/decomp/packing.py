@@ -12,6 +12,7 @@ gather, cheap enough to redo after every optimiser step.
 import numpy as np
 import torch
 
+from vqnerf_release_amd.geo import packing as geo_packing
 from vqnerf_release_amd.geo.packing import gemm_index, bias_index, ident_cols, _take
 
 MAX_LAYERS = 16
@@ -51,39 +52,16 @@ def _rowdot_index_segs(n_out, n_cols, segs):
 
 
 def _step_feat(n_rows):
-    """[n_rows/2, 64, 8] local feature held by (step, lane, half-slot) of the split image (mlp_prims_f16s.h step_feat)."""
-    sl = np.arange(n_rows // 2)[:, None, None]
-    h = (np.arange(64) >> 5)[None, :, None]
-    jj = np.arange(8)[None, None, :]
-    return 16 * sl + 8 * (jj >> 2) + 4 * h + (jj & 3)
+    return geo_packing.step_features(n_rows)
 
 
 def gemm_index_f16s(n_out, n_cols, segs):
-    """Gather index [n_out_tiles, n_steps, 64, 8] into M[n_out, n_cols].flatten() ++ [0]; segs = [(rows, feats, col_base)].
-    A operand of v_mfma_f32_32x32x16_f16: lane (r, h) holds W[32 ot + r][feature(step, h, jj)]."""
-    n_tiles = (n_out + 31) // 32
-    cols = []
-    for rows, feats, base in segs:
-        f = _step_feat(rows)
-        cols.append(np.where(f < feats, f + base, -1))
-    col = np.concatenate(cols, 0)                                     # [S,64,8]
-    pad = (-col.shape[0]) % 4                                         # whole 4-step blocks per tile: zero rows (gemm_tiles_f16s_ring)
-    if pad:
-        col = np.concatenate([col, np.full((pad, 64, 8), -1, col.dtype)], 0)
-    row = 32 * np.arange(n_tiles)[:, None, None, None] + (np.arange(64) & 31)[None, None, :, None]
-    row = np.broadcast_to(row, (n_tiles,) + col.shape)
-    colb = np.broadcast_to(col[None], row.shape)
-    return np.where((row < n_out) & (colb >= 0), row * n_cols + colb, n_out * n_cols).astype(np.int64)
+    """segs = [(rows, feats, col_base)] -> geo.packing.gemm_index_f16s (A operand of v_mfma_f32_32x32x16_f16, whole 4-step blocks)."""
+    return geo_packing.gemm_index_f16s(n_out, n_cols, [(rows, ident_cols(feats, base=base)) for rows, feats, base in segs])
 
 
-def bias_index_f16s(n_out):
-    """[n_tiles, 2, 16]: accumulator register reg of lane half h is output row (reg & 3) + 8 (reg >> 2) + 4 h."""
-    n_tiles = (n_out + 31) // 32
-    ot = np.arange(n_tiles)[:, None, None]
-    h = np.arange(2)[None, :, None]
-    reg = np.arange(16)[None, None, :]
-    f = 32 * ot + (reg & 3) + 8 * (reg >> 2) + 4 * h
-    return np.where(f < n_out, f, n_out).astype(np.int64)
+bias_index_f16s = geo_packing.bias_index_f16s
+split_pack = geo_packing.split_pack
 
 
 def _rowdot_index_segs_f16s(n_out, n_cols, segs):
@@ -96,21 +74,6 @@ def _rowdot_index_segs_f16s(n_out, n_cols, segs):
     o = np.arange(n_out)[:, None, None, None]
     colb = np.broadcast_to(col[None], (n_out,) + col.shape)
     return np.where(colb >= 0, o * n_cols + colb, n_out * n_cols).astype(np.int64)
-
-
-def split_f16(g):
-    """f32 tensor [..., 8] -> [..., 2 (hi, lo), ..., 8] halves packed as float32 words: see split_pack."""
-    hi = g.to(torch.float16)
-    lo = ((g - hi.float()) * 2048.0).to(torch.float16)
-    return hi, lo
-
-
-def split_pack(g):
-    """g [T, S, 64, 8] f32 (gemm_index_f16s order) -> flat float32 view of [T, S, 2, 64, 8] f16 (hi rows, lo rows)."""
-    if float(g.abs().max()) > 6.0e4:
-        raise ValueError('split-precision packs hold weights as f16 hi/lo: |w| must stay below 6e4')
-    hi, lo = split_f16(g)
-    return torch.stack([hi, lo], 2).contiguous().view(torch.float32).reshape(-1)
 
 
 class ChainBuilder:

@@ -94,6 +94,7 @@ class SDFNetwork(nn.Module):
         self.activation = nn.Softplus(beta=100)
         self._plan = None
         self._cache = _PackCache()
+        self._alt = {}                    # other matrix modes: mode -> (plan, pack cache)
 
     def _geometric_init(self, lin, l, dims, out_dim, bias, inside_outside):
         # sphere initialisation of IDR/NeuS (fields.py:45-63)
@@ -118,18 +119,26 @@ class SDFNetwork(nn.Module):
     def _hip_supported(self):
         return self.d_in == 3 and self.multires > 0 and len([s for s in self.skip_in if 0 < s < self.num_layers - 1]) <= 1
 
-    def plan(self, max_tiles=None):
-        if self._plan is None or (max_tiles and self._plan.max_tiles < max_tiles):
-            self._plan = packing.SdfPackPlan(self.dims, self.skip_in, self.multires, self.scale, max_tiles=max_tiles)
-            self._cache = _PackCache()
-        return self._plan
+    def plan(self, max_tiles=None, mode='f32'):
+        """Pack plan; mode 'f16s' = packs of the split-precision kernels (csrc/neus_mlp_f16s.hip), cached beside the f32 ones."""
+        if mode == 'f32':
+            if self._plan is None or (max_tiles and self._plan.max_tiles < max_tiles):
+                self._plan = packing.SdfPackPlan(self.dims, self.skip_in, self.multires, self.scale, max_tiles=max_tiles)
+                self._cache = _PackCache()
+            return self._plan
+        cur = self._alt.get(mode)
+        if cur is None or (max_tiles and cur[0].max_tiles < max_tiles):
+            cur = (packing.SdfPackPlan(self.dims, self.skip_in, self.multires, self.scale, max_tiles=max_tiles, mode=mode), _PackCache())
+            self._alt[mode] = cur
+        return cur[0]
 
-    def packs(self, max_tiles=None):
-        plan = self.plan(max_tiles)
+    def packs(self, max_tiles=None, mode='f32'):
+        plan = self.plan(max_tiles, mode)
+        cache = self._cache if mode == 'f32' else self._alt[mode][1]
         lins = [getattr(self, 'lin' + str(l)) for l in range(self.num_layers - 1)]
         params = list(self.parameters())
-        return self._cache.get(params, params[0].device,
-                               lambda: plan.pack([m.effective_weight() for m in lins], [m.bias for m in lins]))
+        return cache.get(params, params[0].device,
+                         lambda: plan.pack([m.effective_weight() for m in lins], [m.bias for m in lins]))
 
     # ---- reference API --------------------------------------------------------------------
     def forward(self, inputs):
@@ -196,6 +205,7 @@ class RenderingNetwork(nn.Module):
         self.relu = nn.ReLU()
         self._plan = None
         self._cache = _PackCache()
+        self._alt = {}                    # other matrix modes: mode -> (plan, pack cache)
 
     def max_tiles(self):
         return max((d + 31) // 32 for d in self.dims[1:-1])
@@ -205,16 +215,24 @@ class RenderingNetwork(nn.Module):
             + (3 if self.mode in ('idr', 'no_view_dir') else 0) + self.d_feature
         return self.dims[-1] == 3 and self.multires_view > 0 and self.dims[0] == want
 
-    def packs(self, feat_tiles):
-        if self._plan is None or self._plan.feat_tiles != feat_tiles:
-            self._plan = packing.ColPackPlan(self.d_feature, self.mode, self.dims[1], self.num_layers - 2, self.dims[-1],
-                                             self.multires_view, self.squeeze_out, feat_tiles)
-            self._cache = _PackCache()
+    def packs(self, feat_tiles, mode='f32'):
+        if mode == 'f32':
+            if self._plan is None or self._plan.feat_tiles != feat_tiles:
+                self._plan = packing.ColPackPlan(self.d_feature, self.mode, self.dims[1], self.num_layers - 2, self.dims[-1],
+                                                 self.multires_view, self.squeeze_out, feat_tiles)
+                self._cache = _PackCache()
+            plan, cache = self._plan, self._cache
+        else:
+            cur = self._alt.get(mode)
+            if cur is None or cur[0].feat_tiles != feat_tiles:
+                cur = (packing.ColPackPlan(self.d_feature, self.mode, self.dims[1], self.num_layers - 2, self.dims[-1],
+                                           self.multires_view, self.squeeze_out, feat_tiles, matrix_mode=mode), _PackCache())
+                self._alt[mode] = cur
+            plan, cache = cur
         lins = [getattr(self, 'lin' + str(l)) for l in range(self.num_layers - 1)]
         params = list(self.parameters())
-        plan = self._plan
-        return self._cache.get(params, params[0].device,
-                               lambda: plan.pack([m.effective_weight() for m in lins], [m.bias for m in lins]))
+        return cache.get(params, params[0].device,
+                         lambda: plan.pack([m.effective_weight() for m in lins], [m.bias for m in lins]))
 
     def forward(self, points, normals, view_dirs, feature_vectors):
         if self.embedview_fn is not None:

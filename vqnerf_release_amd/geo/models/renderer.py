@@ -117,13 +117,14 @@ class NeuSRenderer:
         self._u = {}
         self._engines = {}
         self.weights_only = False         # True: no-graph renders skip the colour net (weights / weight_sum / surf stay exact)
+        self.matrix_mode = 'f32'          # 'f16s': no-graph renders on the split-precision kernels (f16 hi/lo MFMA; ~1e-6 relative, opt-in)
         self.train_backend = 'hip'        # 'hip': tile programs of geo/train_programs.py; 'torch': autograd over torch ops
 
     # ---- packs shared by all kernels --------------------------------------------------------
     def _packs(self):
-        mt = self.color_network.max_tiles()
-        wb_s, d_s = self.sdf_network.packs(max_tiles=mt)
-        wb_c, d_c = self.color_network.packs(feat_tiles=self.sdf_network.plan().tiles[-1])
+        mt, mode = self.color_network.max_tiles(), self.matrix_mode
+        wb_s, d_s = self.sdf_network.packs(max_tiles=mt, mode=mode)
+        wb_c, d_c = self.color_network.packs(feat_tiles=self.sdf_network.plan(mode=mode).tiles[-1], mode=mode)
         return wb_s, d_s, wb_c, d_c
 
     def _quantiles(self, m, device):
@@ -145,17 +146,17 @@ class NeuSRenderer:
             return z, sdf
         wb_s, d_s = self._sdf_pack()
         new_sdf = _C.neus_sdf_points(d_s, wb_s, rays_o=rays_o.contiguous(), rays_d=rays_d.contiguous(),
-                                     z=new_z_vals.contiguous()).reshape(new_z_vals.shape)
+                                     z=new_z_vals.contiguous(), mode=self.matrix_mode).reshape(new_z_vals.shape)
         return _C.neus_merge(z_vals.contiguous(), sdf.reshape(z_vals.shape).contiguous(), new_z_vals.contiguous(), new_sdf)
 
     def _sdf_pack(self):
-        return self.sdf_network.packs(max_tiles=self.color_network.max_tiles())
+        return self.sdf_network.packs(max_tiles=self.color_network.max_tiles(), mode=self.matrix_mode)
 
     @torch.no_grad()
     def _importance_z(self, rays_o, rays_d, z_vals, radius):
         wb_s, d_s = self._sdf_pack()
         B = rays_o.shape[0]
-        sdf = _C.neus_sdf_points(d_s, wb_s, rays_o=rays_o, rays_d=rays_d, z=z_vals).reshape(B, self.n_samples)
+        sdf = _C.neus_sdf_points(d_s, wb_s, rays_o=rays_o, rays_d=rays_d, z=z_vals, mode=self.matrix_mode).reshape(B, self.n_samples)
         m = self.n_importance // self.up_sample_steps
         for i in range(self.up_sample_steps):
             new_z = self.up_sample(rays_o, rays_d, z_vals, sdf, radius, m, 64 * 2 ** i)
@@ -204,10 +205,10 @@ class NeuSRenderer:
         if self.weights_only:
             # occupancy queries (gen_geo.py:231-242 uses nothing but weight_sum): the colour network is skipped
             no_col = np.zeros(packing.COL_DESC_INTS, np.int32)
-            sdf, grad, _ = _C.neus_fine_points(d_s, wb_s, no_col, wb_s, rays_o=rays_o, rays_d=rays_d, z=mid_z)
+            sdf, grad, _ = _C.neus_fine_points(d_s, wb_s, no_col, wb_s, rays_o=rays_o, rays_d=rays_d, z=mid_z, mode=self.matrix_mode)
             rgb = torch.zeros_like(grad)
         else:
-            sdf, grad, rgb = _C.neus_fine_points(d_s, wb_s, d_c, wb_c, rays_o=rays_o, rays_d=rays_d, z=mid_z)
+            sdf, grad, rgb = _C.neus_fine_points(d_s, wb_s, d_c, wb_c, rays_o=rays_o, rays_d=rays_d, z=mid_z, mode=self.matrix_mode)
         inv_s = torch.exp(deviation_network.variance.detach().float() * 10.0).reshape(1).contiguous()
         bg = None if background_rgb is None else background_rgb.detach().float().to(z_vals.device)
         o = _C.neus_composite_fwd(rays_o, rays_d, mid_z, dists, sdf, grad, rgb, inv_s, bg, radius, cos_anneal_ratio)

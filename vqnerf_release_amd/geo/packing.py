@@ -79,6 +79,62 @@ def rowdot_index(n_out, n_rows, n_cols, col_fn=None):
     return np.where(valid, o * n_cols + colb, n_out * n_cols).astype(np.int64)
 
 
+# ---- split-precision engine (csrc/mlp_prims_f16s.h): K advances in 16-feature steps = row pairs (hi, lo) ----
+def step_features(n_rows):
+    """[n_rows/2, 64, 8] -> local feature held by (step, lane, half-slot): 16 sl + 8 (jj >> 2) + 4 h + (jj & 3)."""
+    sl = np.arange(n_rows // 2)[:, None, None]
+    h = (np.arange(64) >> 5)[None, :, None]
+    jj = np.arange(8)[None, None, :]
+    return 16 * sl + 8 * (jj >> 2) + 4 * h + (jj & 3)
+
+
+def emb_rows_for_f16s(n_feats):
+    return 2 * ((n_feats + 15) // 16)
+
+
+def gemm_index_f16s(n_rows_out, n_cols, segs):
+    """[n_out_tiles, n_steps (padded to whole 4-step blocks), 64, 8] gather index into M.flatten() ++ [0]: the A operand of
+    v_mfma_f32_32x32x16_f16 -- lane (r, h) holds M[32 ot + r][col(step, h, jj)]; segs as in gemm_index."""
+    n_tiles = (n_rows_out + 31) // 32
+    col = np.concatenate([col_fn(step_features(n_rows)) for n_rows, col_fn in segs], 0)      # [S,64,8]
+    pad = (-col.shape[0]) % 4
+    if pad:
+        col = np.concatenate([col, np.full((pad, 64, 8), -1, col.dtype)], 0)
+    row = 32 * np.arange(n_tiles)[:, None, None, None] + (np.arange(64) & 31)[None, None, :, None]
+    row = np.broadcast_to(row, (n_tiles,) + col.shape)
+    colb = np.broadcast_to(col[None], row.shape)
+    return np.where((row < n_rows_out) & (colb >= 0), row * n_cols + colb, n_rows_out * n_cols).astype(np.int64)
+
+
+def bias_index_f16s(n_out):
+    """[n_tiles, 2, 16]: accumulator register reg of lane half h is output row (reg & 3) + 8 (reg >> 2) + 4 h."""
+    n_tiles = (n_out + 31) // 32
+    ot = np.arange(n_tiles)[:, None, None]
+    h = np.arange(2)[None, :, None]
+    reg = np.arange(16)[None, None, :]
+    f = 32 * ot + (reg & 3) + 8 * (reg >> 2) + 4 * h
+    return np.where(f < n_out, f, n_out).astype(np.int64)
+
+
+def rowdot_index_f16s(n_out, n_rows, n_cols, col_fn=None):
+    """[n_out, n_rows/2, 2, 8] f32 image of the rows of M [n_out, n_cols] in split-image order."""
+    f = step_features(n_rows)[:, ::32, :]
+    col = f if col_fn is None else col_fn(f)
+    o = np.arange(n_out)[:, None, None, None]
+    colb = np.broadcast_to(col[None], (n_out,) + col.shape)
+    valid = (colb >= 0) & (colb < n_cols)
+    return np.where(valid, o * n_cols + colb, n_out * n_cols).astype(np.int64)
+
+
+def split_pack(g):
+    """g [T, S, 64, 8] f32 (gemm_index_f16s order) -> flat float32 view of [T, S, 2, 64, 8] f16: hi = f16(w), lo = f16((w - hi) 2^11)."""
+    if float(g.abs().max()) > 6.0e4:
+        raise ValueError('split-precision packs hold weights as f16 hi/lo: |w| must stay below 6e4')
+    hi = g.to(torch.float16)
+    lo = ((g - hi.float()) * 2048.0).to(torch.float16)
+    return torch.stack([hi, lo], 2).contiguous().view(torch.float32).reshape(-1)
+
+
 def _take(mat, idx_dev):
     flat = torch.cat([mat.reshape(-1), mat.new_zeros(1)])
     return torch.take(flat, idx_dev).reshape(-1)
@@ -99,8 +155,10 @@ def ident_cols(n_valid, base=0):
 class SdfPackPlan:
     """Index tensors + descriptor for an SDFNetwork-shaped MLP (fields.py:9-107)."""
 
-    def __init__(self, dims, skip_in, multires, scale, max_tiles=None, with_reverse=True):
+    def __init__(self, dims, skip_in, multires, scale, max_tiles=None, with_reverse=True, mode='f32'):
         # dims: [d0, hidden..., d_out] as in fields.py:24 (d0 = embedded input width)
+        assert mode in ('f32', 'f16s')
+        self.mode = mode                    # 'f16s': packs for csrc/neus_mlp_f16s.hip (split-precision engine)
         self.dims = list(dims)
         self.n_lin = len(dims) - 1
         assert 2 <= self.n_lin <= MAX_SDF_LAYERS
@@ -111,7 +169,7 @@ class SdfPackPlan:
         self.multires = multires
         self.emb = dims[0]
         assert self.emb == 3 + 6 * multires and self.emb <= 64
-        self.emb_rows = emb_rows_for(self.emb)
+        self.emb_rows = emb_rows_for(self.emb) if mode == 'f32' else emb_rows_for_f16s(self.emb)
         self.scale = float(scale)
         # true output width of every linear layer (fields.py:38-41)
         self.out_dims = []
@@ -128,6 +186,9 @@ class SdfPackPlan:
 
     def _build(self):
         E, er = self.emb, self.emb_rows
+        f32 = self.mode == 'f32'
+        gemm_index, bias_index, rowdot_index = ((globals()['gemm_index'], globals()['bias_index'], globals()['rowdot_index']) if f32
+                                                else (gemm_index_f16s, bias_index_f16s, rowdot_index_f16s))
         plan = []          # (kind, layer, index array)
         for l in range(self.n_lin):
             rows_prev = 4 * self.tiles[l - 1] if l > 0 else 0
@@ -189,6 +250,8 @@ class SdfPackPlan:
             elif kind == 'wTE':
                 src = W[:, self.out_dims[l - 1]:].t() if l == self.skip else W.t()
             c = _take(src.contiguous(), ix)
+            if self.mode == 'f16s' and kind in ('w', 'wfeat', 'wT', 'wTE'):
+                c = split_pack(c.reshape(ix.shape))
             assert c.numel() % 4 == 0
             o4 = off // 4
             if kind in ('w', 'wfeat'):
@@ -222,12 +285,17 @@ class SdfPackPlan:
 class ColPackPlan:
     """RenderingNetwork-shaped MLP (fields.py:111-172); input order [pts, view_embed, normals, feat]."""
 
-    def __init__(self, d_feature, mode, d_hidden, n_layers, d_out, multires_view, squeeze_out, feat_tiles):
+    def __init__(self, d_feature, mode, d_hidden, n_layers, d_out, multires_view, squeeze_out, feat_tiles, matrix_mode='f32'):
+        assert matrix_mode in ('f32', 'f16s')
+        self.matrix_mode = matrix_mode
+        f32 = matrix_mode == 'f32'
+        gemm_index, bias_index, rowdot_index = ((globals()['gemm_index'], globals()['bias_index'], globals()['rowdot_index']) if f32
+                                                else (gemm_index_f16s, bias_index_f16s, rowdot_index_f16s))
         self.mode = mode
         self.n_view = (3 + 6 * multires_view) if mode in ('idr', 'no_normal') else 0
         self.has_normal = 1 if mode in ('idr', 'no_view_dir') else 0
         self.extra = 3 + self.n_view + 3 * self.has_normal
-        self.extra_rows = emb_rows_for(self.extra)
+        self.extra_rows = emb_rows_for(self.extra) if f32 else emb_rows_for_f16s(self.extra)
         self.d_feature = d_feature
         self.dims = [self.extra + d_feature] + [d_hidden] * n_layers + [d_out]
         self.n_lin = len(self.dims) - 1
@@ -262,6 +330,8 @@ class ColPackPlan:
         for (kind, l, _), ix in zip(self.plan, self._indices(dev)):
             src = weights[l] if kind in ('w', 'wrow') else biases[l]
             c = _take(src.contiguous(), ix)
+            if self.matrix_mode == 'f16s' and kind == 'w':
+                c = split_pack(c.reshape(ix.shape))
             o4 = off // 4
             if kind == 'w':
                 layer[l]['w'] = o4
