@@ -485,6 +485,15 @@ def main():
                                             f'{cpu_dt:.1f} s, torch {torch.__version__} CPU fp32'}
         result['psnr_vs_oracle_db'] = -10.0 * math.log10(mse + 1e-20)
         result['speedup_vs_cpu'] = value / (n_cpu / cpu_dt)
+        # the same check for the opt-in split-precision mode (reported under extra.geo_render_f16s)
+        ren.matrix_mode = 'f16s'
+        try:
+            with torch.no_grad():
+                got16 = step()['color_fine'][torch.tensor(sel, device=dev)].cpu()
+        finally:
+            ren.matrix_mode = 'f32'
+        mse16 = float(((got16 - ref['color_fine'].detach()) ** 2).mean())
+        result['psnr_f16s_vs_oracle_db'] = -10.0 * math.log10(mse16 + 1e-20)
         if not args.no_extras:
             result['cpu_baseline_decomp'] = decomp_cpu_leg(dev, cores)
     if world == 1 and not args.no_extras:
