@@ -32,3 +32,24 @@ for S, fine in ((64, False), (128, True)):
     print('fine' if fine else 'sdf ', f'P={B*S}  wave-0 cycles per workgroup: total {v[5] / max(v[6], 1):.3e} over {v[6]} workgroups')
     for i in range(5):
         print(f'    {names[i]:72s} {100.0 * v[i] / max(v[5], 1):5.1f} %')
+
+# ---- split-precision kernels (16 phases) ----
+if hasattr(lib, 'vqn_debug_read_stamps16'):
+    names16 = ['set-up (points, posenc)', 'forward K loops', 'forward epilogues (softplus, act\', split, stash)', 'forward barrier waits',
+               'sdf row + feature layer + sdf out', 'G_pre', 'reverse K loops (+ wTE)', 'reverse epilogues', 'reverse barrier waits',
+               'embedding chain rule', 'colour set-up (extras, features from stash)', 'colour layers', 'colour out / tile turn-around']
+    wb_s16, d_s16 = sdf.packs(max_tiles=col.max_tiles(), mode='f16s')
+    wb_c16, d_c16 = col.packs(feat_tiles=sdf.plan(mode='f16s').tiles[-1], mode='f16s')
+    for S, fine in ((64, False), (128, True)):
+        z = (near + (far - near) * torch.linspace(0, 1, S, device='cuda')[None, :]).contiguous()
+        f = (lambda: _C.neus_fine_points(d_s16, wb_s16, d_c16, wb_c16, rays_o=o, rays_d=d, z=z, mode='f16s')) if fine \
+            else (lambda: _C.neus_sdf_points(d_s16, wb_s16, rays_o=o, rays_d=d, z=z, mode='f16s'))
+        f(); torch.cuda.synchronize()
+        buf = (ctypes.c_ulonglong * 16)()
+        lib.vqn_debug_read_stamps16(buf, 1)
+        f(); torch.cuda.synchronize()
+        lib.vqn_debug_read_stamps16(buf, 1)
+        v = [int(x) for x in buf]
+        print('f16s fine' if fine else 'f16s sdf ', f'P={B*S}  wave-0 cycles per workgroup: total {v[14] / max(v[15], 1):.3e} over {v[15]} workgroups')
+        for i in range(13):
+            print(f'    {names16[i]:72s} {100.0 * v[i] / max(v[14], 1):5.1f} %')

@@ -116,3 +116,26 @@ def test_render_f16s_matches_f32_render():
     # per-sample gradients: the sample positions themselves move by ~1e-6 (importance sampling on the other SDF kernel)
     dg = (b['gradients'] - a['gradients']).abs().cpu().numpy()
     assert np.quantile(dg, 0.999) < 1e-3 and dg.max() < 2e-2, (np.quantile(dg, 0.999), dg.max())
+
+
+def test_wide_network_takes_the_one_image_kernel():
+    """d_hidden = 320 (10 tiles): two 32-point images no longer fit in LDS, the entry points fall back to the one-image
+    workgroup form -- same results against the f32 kernels."""
+    from vqnerf_release_amd import _C
+    from vqnerf_release_amd.geo.models.fields import SDFNetwork, RenderingNetwork
+    torch.manual_seed(1)
+    sdf = SDFNetwork(d_in=3, d_out=257, d_hidden=320, n_layers=4, skip_in=(2,), multires=6, bias=0.5, scale=1.0,
+                     geometric_init=True, weight_norm=True).cuda()
+    col = RenderingNetwork(d_feature=256, mode='idr', d_in=9, d_out=3, d_hidden=320, n_layers=2, weight_norm=True,
+                           multires_view=4, squeeze_out=True).cuda()
+    rng = np.random.default_rng(9)
+    P = torch.tensor(rng.uniform(-1, 1, (77, 3)).astype(np.float32)).cuda()
+    D = torch.nn.functional.normalize(torch.tensor(rng.normal(size=(77, 3)).astype(np.float32)), dim=-1).cuda()
+    out = {}
+    for mode in ('f32', 'f16s'):
+        wb_s, d_s = sdf.packs(max_tiles=col.max_tiles(), mode=mode)
+        wb_c, d_c = col.packs(feat_tiles=sdf.plan(mode=mode).tiles[-1], mode=mode)
+        out[mode] = _C.neus_fine_points(d_s, wb_s, d_c, wb_c, pts=P, dirs=D, mode=mode) + (_C.neus_sdf_points(d_s, wb_s, pts=P, mode=mode),)
+    for a, b, tol in zip(out['f16s'], out['f32'], (5e-6, None, 5e-5, 5e-6)):
+        tol = tol if tol is not None else 1e-4 * float(b.abs().max())
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=tol)
