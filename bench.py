@@ -172,8 +172,20 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
         lv = ex.compute_vis(surf, nrm, msk, perturb_overwrite=0)
         torch.cuda.synchronize()
         dtv = time.perf_counter() - t0
+    ren.matrix_mode = 'f16s'
+    try:
+        with torch.no_grad():
+            ex.compute_vis(surf[:256], nrm[:256], msk[:256], perturb_overwrite=0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            lv16 = ex.compute_vis(surf, nrm, msk, perturb_overwrite=0)
+            torch.cuda.synchronize()
+            dtv16 = time.perf_counter() - t0
+    finally:
+        ren.matrix_mode = 'f32'
     n_sec = int((torch.einsum('ijk,ik->ij', torch.nn.functional.normalize(ex.lxyz.to(dev) - surf[:, None, :], dim=-1), nrm) > 0).sum())
     out['compute_vis'] = {'secondary_rays_per_s': n_sec / dtv, 'surface_points': npts, 'secondary_rays': n_sec, 'ms': dtv * 1e3,
+                          'secondary_rays_per_s_f16s': n_sec / dtv16, 'max_abs_diff_f16s_vs_f32': float((lv16 - lv).abs().max()),
                           'note': 'all front-lit (point, light) pairs of a chunk in one batch; colour network skipped (weights_only); '
                                   'the reference walks 512 lights one by one with a host sync each (gen_geo.py:202-242)'}
 
@@ -243,6 +255,25 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
         'max_abs_diff_vs_f32': {k: float((got_pred[k] - ref_pred[k]).abs().max()) for k in ('rgb', 'albedo', 'rough', 'vq_rgb')},
         'vq_idx_match_vs_f32_pct': 100.0 * float(same_code),
         'note': 'opt-in precision mode (model.matrix_mode = "f16s"); `value` and every other line are the f32 path'}
+    # ---- BASELINE.json configs[4]: relighting one view under 16 probes (test.py pd_relit pass), f32 and split-precision MLP stacks ----
+    model.novel_probes = {f'probe{i:02d}': torch.tensor(rng.uniform(0, 2, (16, 32, 3)).astype(np.float32), device=dev) for i in range(16)}
+    rel = {}
+    with torch.no_grad():
+        for mm in ('f32', 'f16s'):
+            model.matrix_mode = mm
+            try:
+                pr = model.fast_render(big, mode='test', relight_probes=True)[0]
+                rel[mm] = (_time_gpu(lambda: model.fast_render(big, mode='test', relight_probes=True), 3, warm=0), pr['rgb_probes'])
+            finally:
+                model.matrix_mode = 'f32'
+    model.novel_probes = {}
+    out['decomp_relight16'] = {
+        'points': N, 'probes': 16, 'ms_per_view_f32': rel['f32'][0] * 1e3, 'ms_per_view_f16s': rel['f16s'][0] * 1e3,
+        'relit_pixels_per_s_f32': 16 * N / rel['f32'][0], 'relit_pixels_per_s_f16s': 16 * N / rel['f16s'][0],
+        'max_abs_diff_f16s_vs_f32': float((rel['f16s'][1] - rel['f32'][1]).abs().max()),
+        'note': 'fast_render(relight_probes=True): encoder + main heads + ONE shading pass against all 16 probes (the reference loops '
+                'over probes, vq_nfr.py:724-733); f16s = the fp16-MFMA path of BASELINE.json configs[4] (opt-in)'}
+    del rel
     small = points(2048)
     model.get_codebook(); _ = model.light            # lazily created variables must exist before the optimiser is built
     opt2 = torch.optim.Adam(model.trainable_variables, lr=5e-4, eps=1e-7, amsgrad=True)
