@@ -197,6 +197,10 @@ int vqn_tile_program(const void* desc_dev, const int32_t* desc_host, const float
 int vqn_wgrad_partials(const float* A, int a_tiles, int a_t0, int a_nt, const float* B, int b_tiles, int b_t0, int b_nt,
                        int64_t n_point_tiles, int n_split, float* ws, void* stream);
 
+/* The ordered sum of those partial blocks: out[r][c] (+)= sum_s ws[s][r][c], s = 0 .. n-1 (fixed order: deterministic),
+ * written into a [rows, cols] window of a matrix with row stride out_ld.  cols, out_ld multiples of 4. */
+int vqn_reduce_partials(const float* ws, int n, int rows, int cols, float* out, int64_t out_ld, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

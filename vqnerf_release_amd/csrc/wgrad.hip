@@ -70,7 +70,46 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
   }
 }
 
+// out[r][c] (+)= sum_s ws[s][r][c] in a fixed order.  A block owns 16 consecutive float4 of the output; its 16 thread groups
+// each sum a contiguous share of the n partial blocks (all loads independent: bandwidth-, not latency-bound), then thread
+// group 0 adds the 16 group sums in group order (LDS): the same order for every launch, hence deterministic.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const f32x4* __restrict__ ws, const int n, const long numel4,
+                                                              const int cols4, float* __restrict__ out, const long out_ld,
+                                                              const int accumulate) {
+  __shared__ f32x4 part[16][16];
+  const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + o;
+  const int per = (n + 15) >> 4, s0 = g * per, s1 = min(n, s0 + per);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (i < numel4)
+    for (int s = s0; s < s1; ++s) acc += ws[(size_t)s * numel4 + i];
+  part[g][o] = acc;
+  __syncthreads();
+  if (g == 0 && i < numel4) {
+    f32x4 t = part[0][o];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += part[k][o];
+    const long r = i / cols4, c4 = i - r * cols4;
+    f32x4* op = reinterpret_cast<f32x4*>(out + r * out_ld + 4 * c4);
+    if (accumulate) t += *op;
+    *op = t;
+  }
+}
+
 }  // namespace
+
+extern "C" int vqn_reduce_partials(const float* ws, int n, int rows, int cols, float* out, int64_t out_ld, int accumulate,
+                                   void* stream) {
+  VQN_CHECK_ARG(ws && out, "null pointer");
+  VQN_CHECK_ARG(n >= 1 && rows >= 1 && cols >= 4, "n >= 1, rows >= 1, cols >= 4");
+  VQN_CHECK_SHAPE((cols & 3) == 0 && (out_ld & 3) == 0 && out_ld >= cols, "cols and out_ld multiples of 4, out_ld >= cols");
+  VQN_CHECK_SHAPE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)out & 15) == 0, "ws and out must be 16-byte aligned");
+  const long numel4 = (long)rows * (cols / 4);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((numel4 + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const f32x4*>(ws), n, numel4, cols / 4, out, (long)out_ld, accumulate);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
 
 extern "C" int vqn_wgrad_partials(const float* A, int a_tiles, int a_t0, int a_nt, const float* B, int b_tiles, int b_t0,
                                   int b_nt, int64_t n_point_tiles, int n_split, float* ws, void* stream) {

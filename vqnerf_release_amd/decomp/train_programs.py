@@ -80,7 +80,12 @@ class _Engine:
                                             _C._ptr(ws), _C._stream())
         if n <= 0:
             _C._check(n if n < 0 else -3, 'vqn_wgrad_partials')
-        return ws[: n * an * 32 * bn * 32].view(n, an * 32, bn * 32).sum(0)[:a_rows, :b_cols]
+        out = torch.empty((an * 32, bn * 32), dtype=torch.float32, device=A.device)
+        with _C._clock('vqn_reduce_partials'):                        # ordered sum of the split-over-points partial blocks
+            rc = _C.lib().vqn_reduce_partials(_C._ptr(ws), ctypes.c_int(n), ctypes.c_int(an * 32), ctypes.c_int(bn * 32), _C._ptr(out),
+                                              ctypes.c_int64(bn * 32), ctypes.c_int(0), _C._stream())
+        _C._check(rc, 'vqn_reduce_partials')
+        return out[:a_rows, :b_cols]
 
     @staticmethod
     def alloc(specs, N, device, only=None):

@@ -426,23 +426,32 @@ class NeusTrainEngine:
                                            ctypes.c_int64(P), _C._stream())
         _C._check(rc, 'vqn_tile_program')
 
-    def wgrad(self, A, B, a_rows, b_cols, ws):
-        """sum_p A[o][p] B[i][p] -> [a_rows, b_cols] (A, B: TFMT tensors [tiles, ft, 32, 32])."""
+    def wgrad(self, A, B, a_rows, b_cols, ws, A2=None, B2=None):
+        """sum_p A[o][p] B[i][p] (+ sum_p A2[o][p] B2[i][p]) -> [a_rows, b_cols] (TFMT tensors [tiles, ft, 32, 32]); the partial
+        blocks of the split over points are summed in a fixed order by vqn_reduce_partials (deterministic)."""
         nt, at, bt = A.shape[0], A.shape[1], B.shape[1]
         a_nt_all, b_nt_all = (a_rows + 31) // 32, (b_cols + 31) // 32
         out = torch.empty((a_nt_all * 32, b_nt_all * 32), dtype=torch.float32, device=A.device)
-        for a0 in range(0, a_nt_all, 8):
-            an = min(8, a_nt_all - a0)
-            for b0 in range(0, b_nt_all, 8):
-                bn = min(8, b_nt_all - b0)
-                with _C._clock('vqn_wgrad_partials'):
-                    n = _C.lib().vqn_wgrad_partials(_C._ptr(A), ctypes.c_int(at), ctypes.c_int(a0), ctypes.c_int(an), _C._ptr(B),
-                                                    ctypes.c_int(bt), ctypes.c_int(b0), ctypes.c_int(bn), ctypes.c_int64(nt),
-                                                    ctypes.c_int(self.n_split), _C._ptr(ws), _C._stream())
-                if n <= 0:
-                    _C._check(n if n < 0 else -3, 'vqn_wgrad_partials')
-                part = ws[: n * an * 32 * bn * 32].view(n, an * 32, bn * 32)
-                out[a0 * 32:(a0 + an) * 32, b0 * 32:(b0 + bn) * 32] = part.sum(0)
+        lib = _C.lib()
+        for pi, (A_, B_) in enumerate(((A, B), (A2, B2))):
+            if A_ is None:
+                continue
+            for a0 in range(0, a_nt_all, 8):
+                an = min(8, a_nt_all - a0)
+                for b0 in range(0, b_nt_all, 8):
+                    bn = min(8, b_nt_all - b0)
+                    with _C._clock('vqn_wgrad_partials'):
+                        n = lib.vqn_wgrad_partials(_C._ptr(A_), ctypes.c_int(at), ctypes.c_int(a0), ctypes.c_int(an), _C._ptr(B_),
+                                                   ctypes.c_int(bt), ctypes.c_int(b0), ctypes.c_int(bn), ctypes.c_int64(nt),
+                                                   ctypes.c_int(self.n_split), _C._ptr(ws), _C._stream())
+                    if n <= 0:
+                        _C._check(n if n < 0 else -3, 'vqn_wgrad_partials')
+                    blk = out[a0 * 32:(a0 + an) * 32, b0 * 32:(b0 + bn) * 32]
+                    with _C._clock('vqn_reduce_partials'):
+                        rc = lib.vqn_reduce_partials(_C._ptr(ws), ctypes.c_int(n), ctypes.c_int(an * 32), ctypes.c_int(bn * 32),
+                                                     ctypes.c_void_p(blk.data_ptr()), ctypes.c_int64(out.stride(0)), ctypes.c_int(pi),
+                                                     _C._stream())
+                    _C._check(rc, 'vqn_reduce_partials')
         return out[:a_rows, :b_cols]
 
     def weight_grads(self, T, g_sdf):
@@ -455,12 +464,12 @@ class NeusTrainEngine:
         for l in range(nL):
             ab, gh = T['AB%d' % l], T['GH%d' % l]
             if l == 0:
-                g = self.wgrad(ab, T['E'], self.out[0], self.E, ws) + self.wgrad(gh, T['ED'], self.out[0], self.E, ws)
+                g = self.wgrad(ab, T['E'], self.out[0], self.E, ws, gh, T['ED'])
             else:
                 pu = self.out[l - 1]
-                g = self.wgrad(ab, T['U%d' % l], self.out[l], pu, ws) + self.wgrad(gh, T['UD%d' % l], self.out[l], pu, ws)
+                g = self.wgrad(ab, T['U%d' % l], self.out[l], pu, ws, gh, T['UD%d' % l])
                 if l == self.skip:
-                    ge = self.wgrad(ab, T['E'], self.out[l], self.E, ws) + self.wgrad(gh, T['ED'], self.out[l], self.E, ws)
+                    ge = self.wgrad(ab, T['E'], self.out[l], self.E, ws, gh, T['ED'])
                     g = torch.cat([g, ge], 1) * s2
             dW[l], db[l] = g, tsum(ab, self.out[l])
         # final layer: rows 1.. from the feature adjoints, row 0 = (g_sdf/scale) (x) u_L + u'_L
