@@ -238,3 +238,71 @@ def test_split_precision_programs_match_oracle():
         np.testing.assert_allclose(g, want, rtol=0, atol=3e-6 * max(1.0, np.abs(want).max()))
     with pytest.raises(ValueError):
         pk.split_pack(torch.full((1, 1, 64, 8), 7.0e4))
+
+
+# ------------------------------------------------------------------ NeuS pack plans in split-precision mode
+def test_sdf_pack_plan_f16s_forward_matches_oracle():
+    """SdfPackPlan(mode='f16s'): the forward packs (f16 hi/lo A fragments in whole 64-feature blocks, register-order biases, the
+    skip layer's two K segments, the sdf row image) run through a numpy model of csrc/neus_mlp_f16s.hip's forward reproduce
+    oracle.geo.sdf_only to the split-precision tolerance."""
+    from oracle import geo as og
+    from vqnerf_release_amd.geo import packing as gp
+    cfg = og.SMALL_CFG
+    c = cfg['sdf']
+    plan = gp.SdfPackPlan(og.sdf_dims(cfg), c['skip_in'], c['multires'], c['scale'], mode='f16s')
+    p = og.to_torch(og.make_sdf_params(cfg, 0))
+    W = [og.wn_weight(p, l) for l in range(plan.n_lin)]
+    b = [p[f'lin{l}.bias'] for l in range(plan.n_lin)]
+    wbuf, desc = plan.pack(W, b)
+    wb = np.ascontiguousarray(wbuf.numpy())
+    w16 = wb.view(np.float16).astype(np.float64).reshape(-1, 8)
+    w4 = wb.astype(np.float64).reshape(-1, 4)
+    n_lin, skip, multires, emb, emb_rows = [int(v) for v in desc[:5]]
+    assert emb_rows % 2 == 0 and emb_rows == 2 * ((emb + 15) // 16)
+    P = 20
+    pts = np.random.default_rng(2).uniform(-1, 1, (P, 3))
+    E = od.posenc(torch.tensor(pts * c['scale'], dtype=torch.float64), multires).numpy()          # [P, emb]
+
+    def image(feats, n_rows):
+        """[n_steps, part, h, n, jj] halves of a region holding `feats` [P, F]."""
+        ns = n_rows // 2
+        out = np.zeros((ns, 2, 2, 32, 8))
+        for sl in range(ns):
+            for h in range(2):
+                for jj in range(8):
+                    f = step_feat(sl, h, jj)
+                    if f < feats.shape[1]:
+                        hi, lo = _split(feats[:, f])
+                        out[sl, 0, h, :P, jj], out[sl, 1, h, :P, jj] = hi, lo
+        return out
+
+    emb_img = image(E, emb_rows)
+    cur = None
+    for l in range(n_lin - 1):
+        tiles, _, _, w_off, b_off = [int(v) for v in desc[12 + 8 * l: 12 + 8 * l + 5]]
+        B = emb_img if l == 0 else (np.concatenate([cur, emb_img], 0) if l == skip else cur)
+        ns = B.shape[0]
+        nbr = 8 * ((2 * ns + 7) // 8)                                                            # pack rows per tile: whole blocks
+        out = np.zeros((P, 32 * tiles))
+        for ot in range(tiles):
+            A = w16[w_off + ot * nbr * 64: w_off + (ot + 1) * nbr * 64].reshape(nbr // 2, 2, 2, 32, 8)
+            assert not A[ns:].any()
+            A = A[:ns]
+            acc = np.einsum('shij,shnj->in', A[:, 0], B[:, 0]) + (np.einsum('shij,shnj->in', A[:, 0], B[:, 1]) +
+                                                                 np.einsum('shij,shnj->in', A[:, 1], B[:, 0])) / 2048.0
+            bias = w4[b_off + ot * 8: b_off + (ot + 1) * 8].reshape(2, 16)
+            for h in range(2):
+                for reg in range(16):
+                    i = (reg & 3) + 8 * (reg >> 2) + 4 * h
+                    x = acc[i, :P] + bias[h, reg]
+                    out[:, 32 * ot + i] = np.where(100 * x > 20, x, np.log1p(np.exp(np.minimum(100 * x, 50))) / 100)
+        cur = image(out[:, :32 * tiles], 4 * tiles)
+    # sdf row: f32 image [1][n_steps][2][8]
+    last_w = int(desc[7])
+    ns = cur.shape[0]
+    img = w4[last_w: last_w + ns * 4].reshape(ns, 2, 8)
+    X = cur[:, 0] + cur[:, 1] / 2048.0                                                           # [step, h, n, jj]
+    sdf = np.einsum('shj,shnj->n', img, X)[:P] + float(w4[int(desc[9])][0])
+    with torch.no_grad():
+        want = og.sdf_only({k: v.double() for k, v in p.items()}, cfg, torch.tensor(pts, dtype=torch.float64))[:, 0].numpy()
+    np.testing.assert_allclose(sdf / c['scale'], want, rtol=0, atol=5e-6)
