@@ -1,0 +1,29 @@
+"""Dev probe: torch-op level profile of one full-view vq_nfr.call(mode='vali') (which torch ops make up the glue)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+from vqnerf_release_amd.decomp.nerfactor.util.io import config_from_dict
+dev = torch.device('cuda:0')
+rng = np.random.default_rng(1)
+model = get_model_class('vq_nfr')(config_from_dict(bench.DECOMP_INI))
+model.build_nets(device=dev, seed=0).to(dev)
+cb = rng.uniform(0, 1, (15, 256)).astype(np.float32)
+model.set_codebook(cb / np.linalg.norm(cb, axis=1, keepdims=True))
+model.set_light(rng.uniform(0, 1, (16, 32, 3)).astype(np.float32))
+n = 640000
+xyz = torch.nn.functional.normalize(torch.randn(n, 3, device=dev), dim=-1)
+nrm = torch.nn.functional.normalize(xyz + 0.1 * torch.randn(n, 3, device=dev), dim=-1)
+one = torch.ones(n, 1, device=dev)
+batch = (['v'], torch.zeros(n, 2, device=dev), torch.tensor([[0, 0, 4.0]], device=dev).repeat(n, 1), torch.zeros(n, 3, device=dev),
+         torch.rand(n, 3, device=dev), one, one.clone(), xyz, nrm, (torch.rand(n, 512, device=dev) < 0.7).float())
+with torch.no_grad():
+    for _ in range(2):
+        model.call(batch, mode='vali')
+    torch.cuda.synchronize()
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA]) as prof:
+        for _ in range(3):
+            model.call(batch, mode='vali')
+        torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by='self_cuda_time_total', row_limit=25, max_name_column_width=60))

@@ -20,6 +20,13 @@ from vqnerf_release_amd.decomp.nerfactor.networks import mlp
 from vqnerf_release_amd.decomp.nerfactor.util import img as imgutil, math as mathutil, microfacet as micro_util
 
 
+def fg_rows(alpha):
+    """Row indices of the foreground rays (alpha > 0), ascending -- what `tf.where(mask)` / `tf.boolean_mask` select.  Taken
+    ONCE per call and reused for every gather and scatter: a boolean-mask index costs a `nonzero` (a host sync) each time,
+    twenty of them per rendered view."""
+    return (alpha[:, 0] > 0).nonzero(as_tuple=False).squeeze(1)
+
+
 def scatter_rows(mask, x, n):
     """tf.scatter_nd(tf.where(mask), x, (n, c)): rows of x back to their ray slots, zeros elsewhere.  mask None = every
     row is foreground (see `take_rows`)."""
@@ -372,7 +379,7 @@ class Model(BrdfModel):
         self._validate_mode(mode)
         id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz, normal, lvis = self._unpack(batch)
         gt = {'rgb': rgb, 'normal': normal, 'alpha': alpha, 'xyz': xyz}
-        mask = alpha[:, 0] > 0
+        mask = fg_rows(alpha)
         n = alpha.shape[0]
         rayo, rgb_m, xyz_m, normal_m = rayo[mask], rgb[mask], xyz[mask], normal[mask]
         lvis_m = lvis[mask] if lvis is not None else None

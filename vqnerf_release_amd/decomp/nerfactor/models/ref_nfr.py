@@ -9,7 +9,7 @@ import torch
 
 from vqnerf_release_amd.decomp import packing
 from vqnerf_release_amd import _C
-from vqnerf_release_amd.decomp.nerfactor.models.nfr_unit import BrdfModel, scatter_rows
+from vqnerf_release_amd.decomp.nerfactor.models.nfr_unit import BrdfModel, fg_rows, scatter_rows
 from vqnerf_release_amd.decomp.nerfactor.networks import mlp
 from vqnerf_release_amd.decomp.nerfactor.util import img as imgutil
 
@@ -63,7 +63,7 @@ class Model(BrdfModel):
         self._validate_mode(mode)
         id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz, normal, ref = batch[:10]
         lvis = batch[10] if self.data_type == 'nerf' else None
-        mask = alpha[:, 0] > 0
+        mask = fg_rows(alpha)
         n = alpha.shape[0]
         rayo, rgb_m, xyz_m, normal_m, ref_m = rayo[mask], rgb[mask], xyz[mask], normal[mask], ref[mask]
         lvis_m = lvis[mask] if lvis is not None else None

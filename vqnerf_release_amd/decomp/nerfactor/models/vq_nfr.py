@@ -12,7 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from vqnerf_release_amd.decomp.nerfactor.models.nfr_unit import BrdfModel, scatter_rows, take_rows
+from vqnerf_release_amd.decomp.nerfactor.models.nfr_unit import BrdfModel, fg_rows, scatter_rows, take_rows
 from vqnerf_release_amd.decomp.nerfactor.networks import mlp
 from vqnerf_release_amd.decomp.nerfactor.networks.vq_layers import VectorQuantizerEMA
 from vqnerf_release_amd.decomp.nerfactor.util import img as imgutil, math as mathutil
@@ -88,7 +88,7 @@ class Model(BrdfModel):
     # ------------------------------------------------------------------ entry points
     def init_z(self, batch):
         id_, hw, _, _, _, alpha, pred_alpha, xyz = batch[:8]
-        mask = alpha[:, 0] > 0
+        mask = fg_rows(alpha)
         return {'id': id_, 'hw': hw, 'z_pred': self._pred_enc_at(xyz[mask])}
 
     def init_mat(self, z_pred):
@@ -98,7 +98,7 @@ class Model(BrdfModel):
     def fast_embed(self, batch, mode='train', thres=None, ref_batch=True):
         self._validate_mode(mode)
         id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz = batch[:8]
-        mask = alpha[:, 0] > 0
+        mask = fg_rows(alpha)
         n = alpha.shape[0]
         xyz_m = xyz[mask]
         _, _, _, embed_ind = self._quantise(self._pred_enc_at(xyz_m), mode, thres)
@@ -109,7 +109,7 @@ class Model(BrdfModel):
 
     def vq_test(self, batch, mode='vali', thres=None):
         id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz, normal, lvis = self._unpack(batch)
-        mask = alpha[:, 0] > 0
+        mask = fg_rows(alpha)
         rayo, rgb_m, xyz_m, normal_m = rayo[mask], rgb[mask], xyz[mask], normal[mask]
         lvis_m = lvis[mask] if lvis is not None else None
         vq, z_vq, vq_loss, _ = self._quantise(self._pred_enc_at(xyz_m), mode, thres)
@@ -149,7 +149,7 @@ class Model(BrdfModel):
         id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz, normal, lvis = self._unpack(batch)
         # `assume_foreground`: the caller guarantees alpha > 0 on every row (outer_sample's batches are), so no boolean
         # gather / scatter -- and no host sync -- is needed
-        mask = None if self.assume_foreground else alpha[:, 0] > 0
+        mask = None if self.assume_foreground else fg_rows(alpha)
         n = alpha.shape[0]
         rayo, rgb_m, xyz_m, normal_m, lvis_m = take_rows(mask, rayo, rgb, xyz, normal, lvis)
 
@@ -197,7 +197,7 @@ class Model(BrdfModel):
         self._validate_mode(mode)
         id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz, normal = batch[:9]
         lvis = batch[-1] if self.data_type == 'nerf' else None
-        mask = alpha[:, 0] > 0
+        mask = fg_rows(alpha)
         n = alpha.shape[0]
         rayo, rgb_m, xyz_m, normal_m = rayo[mask], rgb[mask], xyz[mask], normal[mask]
         lvis_m = lvis[mask] if lvis is not None else None
@@ -246,7 +246,7 @@ class Model(BrdfModel):
     def vis_mat(self, batch, mode='train', opt_scale=None, ref_batch=False, thres=None):
         self._validate_mode(mode)
         id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz = batch[:8]
-        mask = alpha[:, 0] > 0
+        mask = fg_rows(alpha)
         n = alpha.shape[0]
         z_enc = self._pred_enc_at(xyz[mask])
         _, _, _, embed_ind = self._quantise(z_enc, mode, thres)

@@ -87,7 +87,7 @@ class VectorQuantizerEMA(torch.nn.Module):
         encodings = torch.nn.functional.one_hot(idx, K).to(flat.dtype)
         encoding_indices = idx.reshape(inputs.shape[:-1])
         quantized = quant.reshape(inputs.shape)
-        e_latent_loss = torch.mean((quantized - inputs) ** 2)
+        e_latent_loss = torch.nn.functional.mse_loss(quantized, inputs)          # = mean((quantized - inputs)^2), one pass
         ret = {}
         if is_training:
             counts, dw = _C.vq_ema_stats(x, idx, K)
