@@ -133,10 +133,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_f16s_kerne
                             [&](int ot, f32x16& acc) { init_bias_f16s(bp, ot, lane, acc); },
                             [&](int ot, const f32x16& acc1, const f32x16& acc2) {
 #pragma unroll
-#ifdef VQN_DIAG_NO_EPI
-                              if (acc1[0] == 123.456f) lds[lane] = (f32x4){acc1[1], acc2[2], acc1[3], acc2[4]};
-                              if (true) return;
-#endif
                               for (int s = 0; s < 2; ++s) {
                                 float x[8];
 #pragma unroll
@@ -166,9 +162,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_f16s_kerne
                             });
         __syncthreads();
       } else {                                    // <= 4 outputs: VALU dots over the re-joined values, fixed-order combine
-#ifdef VQN_DIAG_NO_SMALL
-        if (tile >= 0) continue;
-#endif
         const int nout = L.n_out_tiles;
         const int n_steps = (L.kA_rows + L.kB_rows) >> 1, sA = L.kA_rows >> 1;
         const f32x4* wimg = smallw + L.dst_row0;        // [nout][n_steps][2][8] f32

@@ -52,53 +52,10 @@ __device__ __forceinline__ void join8(const f32x4 hi, const f32x4 lo, float (&x)
 // feature held by half-slot jj of lane half h in local K-step sl of a segment
 __device__ __forceinline__ int step_feat(int sl, int h, int jj) { return 16 * sl + 8 * (jj >> 2) + 4 * h + (jj & 3); }
 
-// out[32 x 32-point tile `ot`] over the K row pairs of `ks` (row counts even); wave w owns tiles w, w + NW, ...
-// acc1 collects hi*hi (+ the bias from init), acc2 the two cross terms (scaled 2^11).
-template <int NW = 4, class Init, class Epi>
-__device__ __forceinline__ void gemm_tiles_f16s(const f32x4* __restrict__ lds, const KSegs ks,
-                                                const f32x4* __restrict__ w, const int n_out_tiles, const int wave,
-                                                const int lane, Init init, Epi epi) {
-  const int nr = ks.nA + ks.nB, ns = nr >> 1;
-  for (int ot = wave; ot < n_out_tiles; ot += NW) {
-    f32x16 acc1, acc2;
-    init(ot, acc1);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
-    const f32x4* __restrict__ wp = w + (size_t)ot * nr * 64 + lane;
-    auto brow = [&](int r) { return ((r < ks.nA) ? (ks.rowA + r) : (ks.rowB + (r - ks.nA))) * 64 + lane; };
-    f32x4 a0[8], b0[8], a1[8], b1[8];                 // 4 steps each: [2 i] = hi, [2 i + 1] = lo
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (i < nr) { a0[i] = wp[i * 64]; b0[i] = lds[brow(i)]; }
-    __builtin_amdgcn_s_setprio(1);
-    for (int s = 0; s < ns; s += 8) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (2 * s + 8 + i < nr) { a1[i] = wp[(2 * s + 8 + i) * 64]; b1[i] = lds[brow(2 * s + 8 + i)]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (s + i < ns) {
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(a0[2 * i]), as_h8(b0[2 * i]), acc1, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(a0[2 * i]), as_h8(b0[2 * i + 1]), acc2, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(a0[2 * i + 1]), as_h8(b0[2 * i]), acc2, 0, 0, 0);
-        }
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (2 * s + 16 + i < nr) { a0[i] = wp[(2 * s + 16 + i) * 64]; b0[i] = lds[brow(2 * s + 16 + i)]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (s + 4 + i < ns) {
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(a1[2 * i]), as_h8(b1[2 * i]), acc1, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(a1[2 * i]), as_h8(b1[2 * i + 1]), acc2, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(a1[2 * i + 1]), as_h8(b1[2 * i]), acc2, 0, 0, 0);
-        }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    epi(ot, acc1, acc2);
-  }
-}
-
-// The same product with the weight stream decoupled from the layer structure.  On this engine a K = 256 tile is only
+// GEMM of the engine: out[32 x 32-point tile `ot`] over the K row pairs of `ks` (row counts even); wave w owns tiles w, w + NW,
+// ...; acc1 collects hi*hi (+ the init, e.g. the bias), acc2 the two cross terms (scaled 2^11).
+//
+// The weight stream is decoupled from the layer structure.  On this engine a K = 256 tile is only
 // 16 x 96 matrix-pipe cycles, less than two L2 round trips, so weight fragments must be in flight long before they are
 // used: `A` is a ring of R 4-step blocks (R = 2: 128 features of K) that lives across tiles, layers and barriers.  After a
 // block is consumed its slot is refilled with the block R positions further down the wave's stream: the same tile,
