@@ -52,6 +52,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_kernel(con
     }
   __syncthreads();
 
+  f32x4 pre[4];                    // first weight fragments of this wave's next GEMM tile (see the GEMM layers)
+  int pre_for = -1;                // layer they belong to
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long p0 = tile << 5;
     const long pt = (p0 + p < N) ? p0 + p : N - 1;
@@ -101,7 +103,23 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_kernel(con
       } else if (L.kind == 0) {
         const f32x4* bp = wbuf + L.b_off;
         const int act = L.act, dst = L.dst_row0;
-        gemm_tiles<NW>(lds, ks, wbuf + L.w_off, L.n_out_tiles, wave, lane,
+        // weight fragments run one GEMM layer ahead: the first four of this wave's first tile of the NEXT GEMM layer in which
+        // it owns a tile (program order, wrapping into the next point tile) are requested before this layer's epilogue + barrier
+        int nl = -1;
+        for (int k = 1; k <= d.n_layers && nl < 0; ++k) {
+          const int m = (l + k) % d.n_layers;
+          if (d.layers[m].kind == 0 && wave < d.layers[m].n_out_tiles && d.layers[m].kA_rows + d.layers[m].kB_rows >= 4) nl = m;
+        }
+        const f32x4* next_wp = nl < 0 ? nullptr
+                                      : wbuf + d.layers[nl].w_off + (size_t)wave * (d.layers[nl].kA_rows + d.layers[nl].kB_rows) * 64 + lane;
+        if (wave < L.n_out_tiles && pre_for != l) {             // nothing in flight for this layer yet (first layer of the launch)
+          const int ng = L.kA_rows + L.kB_rows;
+          const f32x4* wp = wbuf + L.w_off + (size_t)wave * ng * 64 + lane;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pre[i] = wp[min(i, ng - 1) * 64];
+        }
+        if (next_wp != nullptr) pre_for = nl;
+        gemm_tiles_chain<NW>(lds, ks, wbuf + L.w_off, L.n_out_tiles, wave, lane, pre, next_wp,
                        [&](int ot, f32x16& acc) { init_bias(bp, ot, lane, acc); },
                        [&](int ot, const f32x16& acc) {
 #pragma unroll

@@ -184,13 +184,7 @@ class BrdfModel(ShapeModel):
             x = b.input
             for slot, name in enumerate(names):
                 net = self.net[name]
-                if self._is_std_head(net) and self.matrix_mode == 'f16s' and not os.environ.get('VQN_F16S_RELOAD'):
-                    # on the split-precision engine the matrix work is ~5x shorter and the extra passes over z (6 KB per point
-                    # per program with reloads) would dominate: keep the input resident (80 rows, one 8-wave workgroup per CU)
-                    y0 = b.dense(f'{name}/0', [x], net.widths[0], net.act[0], keep=[x])
-                    y1 = b.dense(f'{name}/1', [y0], net.widths[1], net.act[1], keep=[x])
-                    b.dense_small(f'{name}/2', [y1, x], net.widths[2], net.act[2], slot)
-                elif self._is_std_head(net):
+                if self._is_std_head(net):
                     # [w0, w1, c] with the input concatenated into the last layer: the input image is NOT kept in LDS while
                     # the two wide activations are live -- it is fetched again (L2) for the last layer, and for the next head.
                     # That keeps the program at 64 rows, i.e. two workgroups per CU instead of one.
