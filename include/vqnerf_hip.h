@@ -193,9 +193,10 @@ int vqn_tile_program(const void* desc_dev, const int32_t* desc_host, const float
 /* Weight-gradient contraction over points (autograd's grad_weight GEMMs): partial blocks
  * ws[s][a_nt*32][b_nt*32] = sum over the point tiles of split s of A[o][p] * B[i][p], A/B in TFMT with
  * a_tiles/b_tiles feature tiles of which [t0, t0+nt) are used.  Returns the number of partial blocks written
- * (> 0; the caller sums them in order) or a negative error code. */
+ * (> 0; the caller sums them in order) or a negative error code.  rowsum_ws (optional): [n_split][a_nt*32] partial sums over
+ * points of A itself -- the bias gradients, for free while A streams through the registers. */
 int vqn_wgrad_partials(const float* A, int a_tiles, int a_t0, int a_nt, const float* B, int b_tiles, int b_t0, int b_nt,
-                       int64_t n_point_tiles, int n_split, float* ws, void* stream);
+                       int64_t n_point_tiles, int n_split, float* ws, float* rowsum_ws, void* stream);
 
 /* The ordered sum of those partial blocks: out[r][c] (+)= sum_s ws[s][r][c], s = 0 .. n-1 (fixed order: deterministic),
  * written into a [rows, cols] window of a matrix with row stride out_ld.  cols, out_ld multiples of 4. */

@@ -16,8 +16,9 @@ namespace {
 template <int NOT /* ot per wave */>
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__ A, int a_tiles, int a_t0, int a_nt,
                                                        const float* __restrict__ B, int b_tiles, int b_t0, int b_nt,
-                                                       long n_ptiles, float* __restrict__ ws) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                                       long n_ptiles, float* __restrict__ ws, float* __restrict__ rowsum_ws) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: scalar guards around the MFMA groups
   const int fi = lane & 31, kk = lane >> 5;
   f32x16 acc[NOT][8];
 #pragma unroll
@@ -26,30 +27,45 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
     for (int b = 0; b < 8; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  f32x4 rs[NOT];                                 // running sum over points of this lane's A values (-> bias gradients)
+#pragma unroll
+  for (int a = 0; a < NOT; ++a) rs[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (long t = blockIdx.x; t < n_ptiles; t += gridDim.x) {
-    const float* At = A + ((t * a_tiles + a_t0) * 32 + fi) * 32 + 4 * kk;
-    const float* Bt = B + ((t * b_tiles + b_t0) * 32 + fi) * 32 + 4 * kk;
+  // One register-resident wave per SIMD: nothing else hides the HBM latency of the operand fetches, so they are double
+  // buffered by hand -- step q = (point tile, quarter u) is fetched while step q - 1 multiplies.  The fetches are
+  // UNCONDITIONAL (tile indices clamped; an out-of-range tile is fetched and never multiplied): with guarded fetches the
+  // compiler falls back to s_waitcnt vmcnt(0) right after issuing them (mlp_prims.h, gemm_tiles).
+  const long my_tiles = (n_ptiles - blockIdx.x + gridDim.x - 1) / gridDim.x, n_q = 4 * my_tiles;
+  auto fetch = [&](long q, f32x4 (&af)[NOT], f32x4 (&bf)[8]) {
+    long t = blockIdx.x + (q >> 2) * (long)gridDim.x;
+    if (t >= n_ptiles) t = n_ptiles - 1;
+    const int u = (int)(q & 3);
+    const float* At = A + ((t * a_tiles + a_t0) * 32 + fi) * 32 + 4 * kk + 8 * u;
+    const float* Bt = B + ((t * b_tiles + b_t0) * 32 + fi) * 32 + 4 * kk + 8 * u;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      f32x4 af[NOT], bf[8];
+    for (int a = 0; a < NOT; ++a) af[a] = *reinterpret_cast<const f32x4*>(At + (long)min(wave + 4 * a, a_nt - 1) * 1024);
 #pragma unroll
-      for (int a = 0; a < NOT; ++a) {
-        const int ot = wave + 4 * a;
-        af[a] = ot < a_nt ? *reinterpret_cast<const f32x4*>(At + (long)ot * 1024 + 8 * u) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
+    for (int b = 0; b < 8; ++b) bf[b] = *reinterpret_cast<const f32x4*>(Bt + (long)min(b, b_nt - 1) * 1024);
+  };
+  auto multiply = [&](const f32x4 (&af)[NOT], const f32x4 (&bf)[8]) {
+#pragma unroll
+    for (int a = 0; a < NOT; ++a) {
+      rs[a] += af[a];
 #pragma unroll
       for (int b = 0; b < 8; ++b)
-        bf[b] = b < b_nt ? *reinterpret_cast<const f32x4*>(Bt + (long)b * 1024 + 8 * u) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (wave + 4 * a < a_nt && b < b_nt) {
 #pragma unroll
-      for (int a = 0; a < NOT; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b)
-          if (wave + 4 * a < a_nt && b < b_nt) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
-          }
+          for (int j = 0; j < 4; ++j) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+        }
     }
+  };
+  f32x4 af0[NOT], bf0[8], af1[NOT], bf1[8];
+  fetch(0, af0, bf0);
+  for (long q = 0; q < n_q; q += 2) {            // n_q is a multiple of 4
+    fetch(q + 1, af1, bf1);
+    multiply(af0, bf0);
+    fetch(q + 2, af0, bf0);
+    multiply(af1, bf1);
   }
   // partial block of this workgroup: ws[blockIdx][a_nt*32][b_nt*32]; accumulator reg e of lane (n, hh): row (e&3) + 8 (e>>2) + 4 hh, col n
   const int cols = b_nt * 32;
@@ -66,6 +82,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
         const int row = (e & 3) + 8 * (e >> 2) + 4 * kk;
         w[(size_t)(ot * 32 + row) * cols + b * 32 + fi] = acc[a][b][e];
       }
+    }
+    if (rowsum_ws != nullptr) {                  // sum over this workgroup's points of A[ot*32 + fi][.]: lanes (fi, 0) and (fi, 1) in a fixed order
+      float r = (rs[a][0] + rs[a][1]) + (rs[a][2] + rs[a][3]);
+      r += __shfl_xor(r, 32);
+      if (kk == 0) rowsum_ws[(size_t)blockIdx.x * (a_nt * 32) + ot * 32 + fi] = r;
     }
   }
 }
@@ -112,7 +133,7 @@ extern "C" int vqn_reduce_partials(const float* ws, int n, int rows, int cols, f
 }
 
 extern "C" int vqn_wgrad_partials(const float* A, int a_tiles, int a_t0, int a_nt, const float* B, int b_tiles, int b_t0,
-                                  int b_nt, int64_t n_point_tiles, int n_split, float* ws, void* stream) {
+                                  int b_nt, int64_t n_point_tiles, int n_split, float* ws, float* rowsum_ws, void* stream) {
   VQN_CHECK_ARG(A && B && ws, "null pointer");
   VQN_CHECK_ARG(n_point_tiles >= 1 && n_split >= 1, "n_point_tiles >= 1, n_split >= 1");
   VQN_CHECK_SHAPE(a_nt >= 1 && a_nt <= 8 && b_nt >= 1 && b_nt <= 8, "1..8 feature tiles per operand and call");
@@ -123,10 +144,10 @@ extern "C" int vqn_wgrad_partials(const float* A, int a_tiles, int a_t0, int a_n
   hipStream_t s = (hipStream_t)stream;
   if (a_nt <= 4)
     hipLaunchKernelGGL(wgrad_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, A, a_tiles, a_t0, a_nt, B, b_tiles, b_t0, b_nt,
-                       (long)n_point_tiles, ws);
+                       (long)n_point_tiles, ws, rowsum_ws);
   else
     hipLaunchKernelGGL(wgrad_kernel<2>, dim3((unsigned)grid), dim3(256), 0, s, A, a_tiles, a_t0, a_nt, B, b_tiles, b_t0, b_nt,
-                       (long)n_point_tiles, ws);
+                       (long)n_point_tiles, ws, rowsum_ws);
   VQN_LAUNCH_CHECK();
   return (int)grid;      // number of partial blocks written (>= 1)
 }

@@ -70,21 +70,31 @@ class _Engine:
                                            _C._stream())
         _C._check(rc, 'vqn_tile_program')
 
-    def wgrad(self, A, B, a_rows, b_cols, ws):
+    def wgrad(self, A, B, a_rows, b_cols, ws, rowsum=False):
+        """sum_p A[o][p] B[i][p] -> [a_rows, b_cols]; rowsum=True: also sum_p A[o][p] (bias gradient) from the same pass."""
         nt, at, bt = A.shape[0], A.shape[1], B.shape[1]
         an, bn = (a_rows + 31) // 32, (b_cols + 31) // 32
         assert an <= 8 and bn <= 8
+        if rowsum and (getattr(self, '_rs_ws', None) is None or self._rs_ws.device != A.device):
+            self._rs_ws = torch.empty(self.n_split * 256, dtype=torch.float32, device=A.device)
+        lib = _C.lib()
         with _C._clock('vqn_wgrad_partials'):
-            n = _C.lib().vqn_wgrad_partials(_C._ptr(A), ctypes.c_int(at), ctypes.c_int(0), ctypes.c_int(an), _C._ptr(B), ctypes.c_int(bt),
-                                            ctypes.c_int(0), ctypes.c_int(bn), ctypes.c_int64(nt), ctypes.c_int(self.n_split),
-                                            _C._ptr(ws), _C._stream())
+            n = lib.vqn_wgrad_partials(_C._ptr(A), ctypes.c_int(at), ctypes.c_int(0), ctypes.c_int(an), _C._ptr(B), ctypes.c_int(bt),
+                                       ctypes.c_int(0), ctypes.c_int(bn), ctypes.c_int64(nt), ctypes.c_int(self.n_split),
+                                       _C._ptr(ws), _C._ptr(self._rs_ws if rowsum else None), _C._stream())
         if n <= 0:
             _C._check(n if n < 0 else -3, 'vqn_wgrad_partials')
         out = torch.empty((an * 32, bn * 32), dtype=torch.float32, device=A.device)
         with _C._clock('vqn_reduce_partials'):                        # ordered sum of the split-over-points partial blocks
-            rc = _C.lib().vqn_reduce_partials(_C._ptr(ws), ctypes.c_int(n), ctypes.c_int(an * 32), ctypes.c_int(bn * 32), _C._ptr(out),
-                                              ctypes.c_int64(bn * 32), ctypes.c_int(0), _C._stream())
-        _C._check(rc, 'vqn_reduce_partials')
+            rc = lib.vqn_reduce_partials(_C._ptr(ws), ctypes.c_int(n), ctypes.c_int(an * 32), ctypes.c_int(bn * 32), _C._ptr(out),
+                                         ctypes.c_int64(bn * 32), ctypes.c_int(0), _C._stream())
+            _C._check(rc, 'vqn_reduce_partials')
+            if rowsum:
+                rs = torch.empty((an * 32,), dtype=torch.float32, device=A.device)
+                rc = lib.vqn_reduce_partials(_C._ptr(self._rs_ws), ctypes.c_int(n), ctypes.c_int(1), ctypes.c_int(an * 32), _C._ptr(rs),
+                                             ctypes.c_int64(an * 32), ctypes.c_int(0), _C._stream())
+                _C._check(rc, 'vqn_reduce_partials')
+                return out[:a_rows, :b_cols], rs[:a_rows]
         return out[:a_rows, :b_cols]
 
     @staticmethod
@@ -195,11 +205,11 @@ class EncoderEngine(_Engine):
         for k, L in enumerate(self.layers):
             D = T['D%d' % k]
             src = T['E'] if k == 0 else T['Y%d' % (k - 1)]
-            g = self.wgrad(D, src, L['out'], L['in_y'], ws)
+            g, bsum = self.wgrad(D, src, L['out'], L['in_y'], ws, rowsum=True)
             if L['skip']:
                 g = torch.cat([g, self.wgrad(D, T['E'], L['out'], self.E, ws)], 1)
             dW.append(g.t().contiguous())                              # Keras layout [in, out]
-            db.append(D.sum((0, 3)).reshape(-1)[:L['out']])
+            db.append(bsum)
         return dW, db
 
 
@@ -320,11 +330,13 @@ class HeadsEngine(_Engine):
         for h, net in enumerate(self.nets):
             w0, w1, c = net.widths
             D0, D1, D2 = T['D%d_0' % h], T['D%d_1' % h], T['D%d_2' % h]
-            g0 = self.wgrad(D0, T['Z'], w0, self.Z, ws).t().contiguous()
-            g1 = self.wgrad(D1, T['Y%d_0' % h], w1, w0, ws).t().contiguous()
-            g2 = torch.cat([self.wgrad(D2, T['Y%d_1' % h], c, w1, ws), self.wgrad(D2, T['Z'], c, self.Z, ws)], 1).t().contiguous()
+            g0, b0 = self.wgrad(D0, T['Z'], w0, self.Z, ws, rowsum=True)
+            g1, b1 = self.wgrad(D1, T['Y%d_0' % h], w1, w0, ws, rowsum=True)
+            g2a, b2 = self.wgrad(D2, T['Y%d_1' % h], c, w1, ws, rowsum=True)
+            g0, g1 = g0.t().contiguous(), g1.t().contiguous()
+            g2 = torch.cat([g2a, self.wgrad(D2, T['Z'], c, self.Z, ws)], 1).t().contiguous()
             dW += [g0, g1, g2]
-            db += [D0.sum((0, 3)).reshape(-1)[:w0], D1.sum((0, 3)).reshape(-1)[:w1], D2.sum((0, 3)).reshape(-1)[:c]]
+            db += [b0, b1, b2]
         return from_tfmt(T['GZ'], N, self.Z), dW, db
 
 

@@ -222,6 +222,7 @@ class NeusTrainEngine:
         self.cin = [c.dims[l] for l in range(self.nC + 1)]
         self.squeeze = bool(c.squeeze_out)
         self.n_split = n_split
+        self._rs_ws = None             # workspace of the fused bias-gradient partial sums
         for name, build in (('prog_fwd', self._build_forward), ('prog_cbwd', self._build_colour_backward),
                             ('prog_sbwd', self._build_sdf_backward)):
             prog = build()
@@ -426,12 +427,16 @@ class NeusTrainEngine:
                                            ctypes.c_int64(P), _C._stream())
         _C._check(rc, 'vqn_tile_program')
 
-    def wgrad(self, A, B, a_rows, b_cols, ws, A2=None, B2=None):
+    def wgrad(self, A, B, a_rows, b_cols, ws, A2=None, B2=None, rowsum=False):
         """sum_p A[o][p] B[i][p] (+ sum_p A2[o][p] B2[i][p]) -> [a_rows, b_cols] (TFMT tensors [tiles, ft, 32, 32]); the partial
-        blocks of the split over points are summed in a fixed order by vqn_reduce_partials (deterministic)."""
+        blocks of the split over points are summed in a fixed order by vqn_reduce_partials (deterministic).
+        rowsum=True: also sum_p A[o][p] -> [a_rows] (the bias gradient), accumulated by the same kernel pass."""
         nt, at, bt = A.shape[0], A.shape[1], B.shape[1]
         a_nt_all, b_nt_all = (a_rows + 31) // 32, (b_cols + 31) // 32
         out = torch.empty((a_nt_all * 32, b_nt_all * 32), dtype=torch.float32, device=A.device)
+        rs_out = torch.empty((1, a_nt_all * 32), dtype=torch.float32, device=A.device) if rowsum else None
+        if rowsum and (self._rs_ws is None or self._rs_ws.device != A.device):
+            self._rs_ws = torch.empty(self.n_split * 256, dtype=torch.float32, device=A.device)
         lib = _C.lib()
         for pi, (A_, B_) in enumerate(((A, B), (A2, B2))):
             if A_ is None:
@@ -440,10 +445,12 @@ class NeusTrainEngine:
                 an = min(8, a_nt_all - a0)
                 for b0 in range(0, b_nt_all, 8):
                     bn = min(8, b_nt_all - b0)
+                    want_rs = rowsum and pi == 0 and b0 == 0
                     with _C._clock('vqn_wgrad_partials'):
                         n = lib.vqn_wgrad_partials(_C._ptr(A_), ctypes.c_int(at), ctypes.c_int(a0), ctypes.c_int(an), _C._ptr(B_),
                                                    ctypes.c_int(bt), ctypes.c_int(b0), ctypes.c_int(bn), ctypes.c_int64(nt),
-                                                   ctypes.c_int(self.n_split), _C._ptr(ws), _C._stream())
+                                                   ctypes.c_int(self.n_split), _C._ptr(ws), _C._ptr(self._rs_ws if want_rs else None),
+                                                   _C._stream())
                     if n <= 0:
                         _C._check(n if n < 0 else -3, 'vqn_wgrad_partials')
                     blk = out[a0 * 32:(a0 + an) * 32, b0 * 32:(b0 + bn) * 32]
@@ -451,7 +458,14 @@ class NeusTrainEngine:
                         rc = lib.vqn_reduce_partials(_C._ptr(ws), ctypes.c_int(n), ctypes.c_int(an * 32), ctypes.c_int(bn * 32),
                                                      ctypes.c_void_p(blk.data_ptr()), ctypes.c_int64(out.stride(0)), ctypes.c_int(pi),
                                                      _C._stream())
-                    _C._check(rc, 'vqn_reduce_partials')
+                        _C._check(rc, 'vqn_reduce_partials')
+                        if want_rs:
+                            rc = lib.vqn_reduce_partials(_C._ptr(self._rs_ws), ctypes.c_int(n), ctypes.c_int(1), ctypes.c_int(an * 32),
+                                                         ctypes.c_void_p(rs_out[:, a0 * 32:].data_ptr()), ctypes.c_int64(a_nt_all * 32),
+                                                         ctypes.c_int(0), _C._stream())
+                            _C._check(rc, 'vqn_reduce_partials')
+        if rowsum:
+            return out[:a_rows, :b_cols], rs_out[0, :a_rows]
         return out[:a_rows, :b_cols]
 
     def weight_grads(self, T, g_sdf):
@@ -464,33 +478,33 @@ class NeusTrainEngine:
         for l in range(nL):
             ab, gh = T['AB%d' % l], T['GH%d' % l]
             if l == 0:
-                g = self.wgrad(ab, T['E'], self.out[0], self.E, ws, gh, T['ED'])
+                g, bsum = self.wgrad(ab, T['E'], self.out[0], self.E, ws, gh, T['ED'], rowsum=True)
             else:
                 pu = self.out[l - 1]
-                g = self.wgrad(ab, T['U%d' % l], self.out[l], pu, ws, gh, T['UD%d' % l])
+                g, bsum = self.wgrad(ab, T['U%d' % l], self.out[l], pu, ws, gh, T['UD%d' % l], rowsum=True)
                 if l == self.skip:
                     ge = self.wgrad(ab, T['E'], self.out[l], self.E, ws, gh, T['ED'])
                     g = torch.cat([g, ge], 1) * s2
-            dW[l], db[l] = g, tsum(ab, self.out[l])
+            dW[l], db[l] = g, bsum
         # final layer: rows 1.. from the feature adjoints, row 0 = (g_sdf/scale) (x) u_L + u'_L
-        gl = self.wgrad(T['GOUTF'], T['U%d' % nL], self.F, self.out[nL - 1], ws)
+        gl, bl = self.wgrad(T['GOUTF'], T['U%d' % nL], self.F, self.out[nL - 1], ws, rowsum=True)
         uL, udL = T['U%d' % nL], T['UD%d' % nL]
         nt = uL.shape[0]
         gs = torch.zeros(nt * 32, dtype=torch.float32, device=dev)
         gs[:g_sdf.numel()] = g_sdf.reshape(-1) / self.scale
         row0 = (uL * gs.view(nt, 1, 1, 32)).sum((0, 3)).reshape(-1)[:self.out[nL - 1]] + tsum(udL, self.out[nL - 1])
         gl = torch.cat([row0[None], gl[1:]], 0)
-        bl = tsum(T['GOUTF'], self.F).clone()
+        bl = bl.clone()
         bl[0] = gs.sum()
         dW[nL], db[nL] = gl, bl
         # colour net
         d0 = T['DC0']
-        g_feat = self.wgrad(d0, T['OUTF'], self.cout[0], self.F, ws)[:, 1:]
+        g_feat, b0 = self.wgrad(d0, T['OUTF'], self.cout[0], self.F, ws, rowsum=True)
         g_ext = self.wgrad(d0, T['EXTR'], self.cout[0], self.X, ws)
-        dWc[0], dbc[0] = torch.cat([g_ext, g_feat], 1), tsum(d0, self.cout[0])
+        dWc[0], dbc[0] = torch.cat([g_ext, g_feat[:, 1:]], 1), b0
         for l in range(1, nC + 1):
             dl = T['DC%d' % l]
-            dWc[l], dbc[l] = self.wgrad(dl, T['C%d' % l], self.cout[l], self.cin[l], ws), tsum(dl, self.cout[l])
+            dWc[l], dbc[l] = self.wgrad(dl, T['C%d' % l], self.cout[l], self.cin[l], ws, rowsum=True)
         return dW, db, dWc, dbc
 
 
