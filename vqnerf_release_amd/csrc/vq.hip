@@ -63,21 +63,35 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
   for (long rg = (long)blockIdx.x * 4 + wave; rg < n_groups; rg += (long)gridDim.x * 4) {
     const long row0 = rg << 4;
     const bool rvalid = (row0 + col) < N;
-    const float* xr = x + (size_t)(row0 + col) * D + 4 * q;
+    const float* xr = x + (size_t)(rvalid ? row0 + col : N - 1) * D;          // clamped: every fetch below is in bounds
     f32x4 acc[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) acc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float p = 0.f;
-#pragma unroll 4
-    for (int t = 0; t < D16; ++t) {
-      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (rvalid && (16 * t + 4 * q) < D) a = *reinterpret_cast<const f32x4*>(xr + 16 * t);
-      p = fmaf(a[0], a[0], p); p = fmaf(a[1], a[1], p); p = fmaf(a[2], a[2], p); p = fmaf(a[3], a[3], p);
+    // the row's fragments are requested 16 K-steps (one 256-feature row) at a time, all of them before the first use and
+    // unconditionally (clamped offsets, zeroed afterwards where out of range): the stream is HBM-bound, so what matters is how
+    // many fetches are in flight -- a guarded fetch per step makes the compiler wait for each one before the next is issued
+    for (int t0 = 0; t0 < D16; t0 += 16) {
+      f32x4 av[16];
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        f32x4 b = Bf[((size_t)kt * D16 + t) * 64 + lane];
+      for (int i = 0; i < 16; ++i) {
+        const int off = min(16 * (t0 + i) + 4 * q, D - 4);
+        av[i] = *reinterpret_cast<const f32x4*>(xr + off);
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc[kt], 0, 0, 0);
+      for (int i = 0; i < 16; ++i) {
+        const int t = t0 + i;
+        if (t < D16) {
+          f32x4 a = av[i];
+          if (!(rvalid && (16 * t + 4 * q) < D)) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+          p = fmaf(a[0], a[0], p); p = fmaf(a[1], a[1], p); p = fmaf(a[2], a[2], p); p = fmaf(a[3], a[3], p);
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) {
+            f32x4 b = Bf[((size_t)kt * D16 + t) * 64 + lane];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc[kt], 0, 0, 0);
+          }
+        }
       }
     }
     // x2 for row (lane&15): (p0+p1)+(p2+p3)
@@ -195,15 +209,23 @@ __global__ __launch_bounds__(256) void vq_ema_partial_kernel(const float* __rest
   __builtin_amdgcn_wave_barrier();
   const long wid = (long)blockIdx.x * 4 + wave, nw = (long)gridDim.x * 4;
   const int D4 = D >> 2;
+  // RU rows per wave and pass.  Every fetch is unconditional (row index clamped; a clamped row is never accumulated) and the
+  // next pass's indices are requested before this pass's rows are used: the stream is latency-bound otherwise (guarded
+  // fetches make the compiler drain the memory counter before each dependent step).
+  auto row_of = [&](long r) { return r < N ? r : N - 1; };
+  long long kn[RU];
+#pragma unroll
+  for (int u = 0; u < RU; ++u) kn[u] = idx[row_of(wid * RU + u)];
   for (long r0 = wid * RU; r0 < N; r0 += nw * RU) {
     int k[RU];
 #pragma unroll
-    for (int u = 0; u < RU; ++u) k[u] = (r0 + u < N) ? (int)idx[r0 + u] : -1;
+    for (int u = 0; u < RU; ++u) k[u] = (r0 + u < N) ? (int)kn[u] : -1;
+#pragma unroll
+    for (int u = 0; u < RU; ++u) kn[u] = idx[row_of(r0 + nw * RU + u)];
     for (int c = lane; c < D4; c += 64) {
       f32x4 v[RU];
 #pragma unroll
-      for (int u = 0; u < RU; ++u)
-        if (k[u] >= 0 && k[u] < K) v[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(r0 + u) * D + 4 * c);
+      for (int u = 0; u < RU; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + (size_t)row_of(r0 + u) * D + 4 * c);
 #pragma unroll
       for (int u = 0; u < RU; ++u)
         if (k[u] >= 0 && k[u] < K) {
@@ -312,8 +334,8 @@ extern "C" int vqn_vq_ema_stats(const float* x, const int64_t* idx, int64_t N, i
     const long blocks = ema_grid(N, D, K);
     const size_t lds = (size_t)4 * (K * D + K) * sizeof(float);
     if (lds > 64 * 1024)
-      VQN_HIP(hipFuncSetAttribute((const void*)vq_ema_partial_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(vq_ema_partial_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, s, x,
+      VQN_HIP(hipFuncSetAttribute((const void*)vq_ema_partial_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(vq_ema_partial_kernel<8>, dim3((unsigned)blocks), dim3(256), lds, s, x,
                        reinterpret_cast<const long long*>(idx), (long)N, D, K, ws);
     VQN_LAUNCH_CHECK();
     const int tot = K * D + K;
