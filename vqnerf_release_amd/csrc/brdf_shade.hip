@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void brdf_shade_kernel(const ShadeArgs a) {
   constexpr int LP = 4 * LQ;                       // lights per lane
   constexpr int L = 64 * LP;
   const int lane = threadIdx.x & 63;
-  const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long wave_id = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: per-point scalars by scalar loads
   const long n_waves = (long)gridDim.x * 4;
 
   // ---- this lane's lights: light index = 256 g + 4 lane + e ----
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void brdf_shade_bwd_kernel(const ShadeBwdArgs 
   constexpr int LP = 4 * LQ;
   constexpr int L = 64 * LP;
   const int lane = threadIdx.x & 63;
-  const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long wave_id = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: per-point scalars by scalar loads
   const long n_waves = (long)gridDim.x * 4;
   float lx[LP], ly[LP], lz[LP], area[LP], Lr[LP], Lg[LP], Lb[LP], gL[LP][3];
 #pragma unroll
