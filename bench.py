@@ -467,8 +467,8 @@ def main():
         traffic = pmc['dominant_kernel_traffic_bytes_per_launch'] * args.rays / pmc['rays_per_launch']
         traffic_note = ('2*FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 PMC, separate passes); counts fabric requests incl. '
                         'Infinity-Cache hits: the per-workgroup activation stash of the reverse sweep (8 x 32 KB per tile, '
-                        '134 MB in flight, Infinity-Cache resident) is written once and read once per tile; algorithmic bytes '
-                        'are 32 B in + 28 B out per sample')
+                        '134 MB in flight, Infinity-Cache resident) is written once and read once per tile with streaming (nt) '
+                        'accesses, 2 x 82 GB of the total; algorithmic bytes are 32 B in + 28 B out per sample')
     except Exception:
         pass
     result = {
@@ -479,7 +479,7 @@ def main():
         'config': {'workload': 'nerf/hotdog-shaped NeuS render: 800x800 pin-hole rays, n_samples=64, n_importance=64, '
                                'up_sample_steps=4, sdf 8x256 (skip 4, posenc 6), colour 4x256 (idr, posenc_view 4), '
                                'random-init weights', 'rays_per_step_per_gpu': args.rays, 'parallelism': f'rays x{world}'},
-        'roofline': {'bound': 'mfma', 'kernel': 'neus_points_kernel<FINE> (vqn_neus_fine_points)', 'achieved': achieved,
+        'roofline': {'bound': 'mfma', 'kernel': 'neus_points2_kernel<FINE> (vqn_neus_fine_points)', 'achieved': achieved,
                      'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
                      'traffic': traffic, 'traffic_note': traffic_note, 'avg_launch_ms': avg_ms, 'flop_per_launch': flop_fine,
                      'macs_per_point': {'sdf': m_sdf, 'colour': m_col}},

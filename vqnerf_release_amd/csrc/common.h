@@ -43,6 +43,13 @@ void vqn_set_error(const char* fmt, ...);
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// streaming (non-temporal) accesses for data that is written once and read once (the per-workgroup activation stash of the
+// fused NeuS kernels): keeps it from evicting the weight packs, which every workgroup re-reads, out of the 4 MB L2s
+#ifdef __HIPCC__
+__device__ __forceinline__ void st_stream(f32x4* p, const f32x4 v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ f32x4 ld_stream(const f32x4* p) { return __builtin_nontemporal_load(p); }
+#endif
+
 static inline int vqn_num_cus() {
   static int cus = 0;
   if (!cus) {

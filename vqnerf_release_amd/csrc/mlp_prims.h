@@ -147,6 +147,78 @@ __device__ __forceinline__ void gemm_tiles_chain(const f32x4* __restrict__ lds, 
   }
 }
 
+// Two-image form of gemm_tiles / gemm_tiles_chain: the workgroup (8 waves) holds TWO 32-point images `img_stride` float4
+// apart and a wave applies each weight fragment to both (8 MFMAs per fetched float4 pair).  One workgroup per CU whose
+// waves all do the same amount of matrix work between two barriers: no cross-workgroup interference on the matrix pipe,
+// half the barriers and half the L2 weight stream per point.  init(ot, img, acc) / epi(ot, img, acc) run once per image.
+// `pre` (optional, may be nullptr-like via use_pre = false): the chain prefetch of gemm_tiles_chain.
+template <int NW = 8, class Init, class Epi>
+__device__ __forceinline__ void gemm_tiles2(const f32x4* __restrict__ lds, const int img_stride, const KSegs ks,
+                                            const f32x4* __restrict__ w, const int n_out_tiles, const int wave,
+                                            const int lane, f32x4 (&pre)[4], const bool use_pre,
+                                            const f32x4* __restrict__ next_wp, Init init, Epi epi) {
+  const int ng = ks.nA + ks.nB;
+  for (int ot = wave; ot < n_out_tiles; ot += NW) {
+    f32x16 acc0, acc1;
+    const f32x4* __restrict__ wp = w + (size_t)ot * ng * 64 + lane;
+    auto brow = [&](int g) { return ((g < ks.nA) ? (ks.rowA + g) : (ks.rowB + (g - ks.nA))) * 64 + lane; };
+    f32x4 a0[4], p0[4], q0[4], a1[4], p1[4], q1[4];          // p: image 0, q: image 1
+    const bool first = use_pre && ot == wave;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int g = min(i, ng - 1);
+      if (first) a0[i] = pre[i]; else a0[i] = wp[g * 64];
+      const int r = brow(g);
+      p0[i] = lds[r]; q0[i] = lds[r + img_stride];
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) only (see gemm_tiles)
+    init(ot, 0, acc0);
+    init(ot, 1, acc1);
+    __builtin_amdgcn_s_setprio(1);
+    for (int g = 0; g < ng; g += 8) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gg = min(g + 4 + i, ng - 1), r = brow(gg);
+        a1[i] = wp[gg * 64]; p1[i] = lds[r]; q1[i] = lds[r + img_stride];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (g + i < ng) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][j], p0[i][j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][j], q0[i][j], acc1, 0, 0, 0);
+          }
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gg = min(g + 8 + i, ng - 1), r = brow(gg);
+        a0[i] = wp[gg * 64]; p0[i] = lds[r]; q0[i] = lds[r + img_stride];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (g + 4 + i < ng) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], p1[i][j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], q1[i][j], acc1, 0, 0, 0);
+          }
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (use_pre && ot + NW >= n_out_tiles && next_wp != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pre[i] = next_wp[i * 64];
+    }
+    epi(ot, 0, acc0);
+    epi(ot, 1, acc1);
+  }
+  if (use_pre && wave >= n_out_tiles && next_wp != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pre[i] = next_wp[i * 64];
+  }
+}
+
 __device__ __forceinline__ f32x4 acc_quad(const f32x16& acc, int rq) {
   // static rq only (callers unroll)
   return (f32x4){acc[4 * rq + 0], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]};

@@ -12,6 +12,7 @@
 // per CU.  See mlp_prims.h for the LDS "activation image" and the weight-pack layout.
 #include "mlp_prims.h"
 #include "neus_desc.h"
+#include <stdlib.h>
 
 using namespace eng;
 
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void neus_points_kernel(
 #pragma unroll
                      for (int j = 0; j < 4; ++j) v[j] = act_fwd<ACT_SOFTPLUS100>(v[j]);
                      lds[(dst + ot * 4 + rq) * 64 + lane] = v;
-                     if (do_save) sv[(ot * 4 + rq) * 64 + lane] = v;
+                     if (do_save) st_stream(sv + (ot * 4 + rq) * 64 + lane, v);
                    }
                  });
       VQN_STAMP(2)
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void neus_points_kernel(
                  [&](int ot, f32x16& acc) { init_bias(bp, ot, lane, acc); },
                  [&](int ot, const f32x16& acc) {
 #pragma unroll
-                   for (int rq = 0; rq < 4; ++rq) sv[(ot * 4 + rq) * 64 + lane] = acc_quad(acc, rq);
+                   for (int rq = 0; rq < 4; ++rq) st_stream(sv + (ot * 4 + rq) * 64 + lane, acc_quad(acc, rq));
                  });
     }
     __syncthreads();
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void neus_points_kernel(
       gemm_tiles(lds, ks, wsdf + L.wT_off, sd.layers[l - 1].n_out_tiles, wave, lane,
                  [&](int ot, f32x16& acc) {
 #pragma unroll
-                   for (int rq = 0; rq < 4; ++rq) hv[rq] = sv[(ot * 4 + rq) * 64 + lane];
+                   for (int rq = 0; rq < 4; ++rq) hv[rq] = ld_stream(sv + (ot * 4 + rq) * 64 + lane);
                    init_zero(acc);
                  },
                  [&](int ot, const f32x16& acc) {
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void neus_points_kernel(
       for (int r0 = wave; r0 < feat_rows; r0 += 32) {          // feature rows back from the stash: 8 fetches in flight per pass
         f32x4 v[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = sv[min(r0 + 4 * c, feat_rows - 1) * 64 + lane];
+        for (int c = 0; c < 8; ++c) v[c] = ld_stream(sv + min(r0 + 4 * c, feat_rows - 1) * 64 + lane);
 #pragma unroll
         for (int c = 0; c < 8; ++c)
           if (r0 + 4 * c < feat_rows) lds[(X0 + r0 + 4 * c) * 64 + lane] = v[c];
@@ -315,6 +316,291 @@ __global__ __launch_bounds__(256, 2) void neus_points_kernel(
   VQN_STAMP_FLUSH
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Two-image form (the default for networks of >= 5 tiles that fit): one 512-thread workgroup per CU holds TWO 32-point
+// images; wave w owns output tiles w, w + 8, ... and applies each weight fragment to both images (gemm_tiles2).  All eight
+// waves do the same matrix work between two barriers and no second workgroup competes for the matrix pipe, so the waves
+// of a layer finish together (the one-image form loses ~20 % to barrier skew between its two co-resident workgroups);
+// barriers and the L2 weight stream per point halve.  The VALU phases split by image: waves 0-3 image 0, waves 4-7 image 1.
+// Results are bit-identical to the one-image kernel (same per-point arithmetic in the same order).
+struct Smalls2 {
+  float pts[2][96], dirs[2][96], part[2][512], grad[2][96];
+};
+
+template <bool FINE>
+__global__ __launch_bounds__(512, 1) void neus_points2_kernel(
+    const SdfDesc sd, const ColDesc cd, const f32x4* __restrict__ wsdf, const f32x4* __restrict__ wcol,
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ zv,
+    const float* __restrict__ pts_direct, const float* __restrict__ dirs_direct, const long P, const int S,
+    f32x4* __restrict__ scratch, float* __restrict__ out_sdf, float* __restrict__ out_grad,
+    float* __restrict__ out_rgb) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+  const int MT = sd.max_tiles;
+  const int IMG = E_ROWS + 8 * MT, IS = IMG * 64;
+  const int X0 = E_ROWS, Y0 = E_ROWS + 4 * MT;
+  Smalls2* sm = reinterpret_cast<Smalls2*>(lds + (size_t)2 * IS);
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int img = wave >> 2, w4 = wave & 3;
+  f32x4* ldsi = lds + (size_t)img * IS;
+  const int n_lin = sd.n_lin;
+  const int emb_tiles = (sd.emb_feats + 31) >> 5;
+  const long n_tiles = (P + 31) >> 5, n_pairs = (n_tiles + 1) >> 1;
+  const size_t per_img = (size_t)(n_lin - 1) * 4 * MT * 64;
+  f32x4* save0 = FINE ? scratch + (size_t)blockIdx.x * 2 * per_img : nullptr;
+  const int feat_slot = (n_lin - 2) * 4 * MT;
+  f32x4 pre[4];
+  f32x4 nopre[4];
+
+  for (long pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+    // ---------------- points of both tiles ----------------
+    if (tid < 64) {
+      const int im = tid >> 5, t = tid & 31;
+      long pt = ((2 * pair + im) << 5) + t;
+      if (pt >= P) pt = P - 1;
+      float x, y, z, dx = 0.f, dy = 0.f, dz = 0.f;
+      if (pts_direct != nullptr) {
+        x = pts_direct[pt * 3 + 0]; y = pts_direct[pt * 3 + 1]; z = pts_direct[pt * 3 + 2];
+        if (FINE) { dx = dirs_direct[pt * 3 + 0]; dy = dirs_direct[pt * 3 + 1]; dz = dirs_direct[pt * 3 + 2]; }
+      } else {
+        const long ray = pt / S;
+        const float tt = zv[pt];
+        dx = rays_d[ray * 3 + 0]; dy = rays_d[ray * 3 + 1]; dz = rays_d[ray * 3 + 2];
+        x = rays_o[ray * 3 + 0] + __fmul_rn(dx, tt);
+        y = rays_o[ray * 3 + 1] + __fmul_rn(dy, tt);
+        z = rays_o[ray * 3 + 2] + __fmul_rn(dz, tt);
+      }
+      sm->pts[im][t * 3 + 0] = x; sm->pts[im][t * 3 + 1] = y; sm->pts[im][t * 3 + 2] = z;
+      sm->dirs[im][t * 3 + 0] = dx; sm->dirs[im][t * 3 + 1] = dy; sm->dirs[im][t * 3 + 2] = dz;
+    }
+    __syncthreads();
+    const float xs = sm->pts[img][p * 3 + 0] * sd.scale, ys = sm->pts[img][p * 3 + 1] * sd.scale, zs = sm->pts[img][p * 3 + 2] * sd.scale;
+    for (int r = w4; r < sd.emb_rows; r += 4) {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int f = row_feat(r, h, j);
+        v[j] = f < sd.emb_feats ? posenc_feat(f, xs, ys, zs) : 0.f;
+      }
+      ldsi[(E0 + r) * 64 + lane] = v;
+    }
+    __syncthreads();
+
+    // ---------------- SDF hidden layers ----------------
+    int cur = X0, oth = Y0;
+    if (wave < sd.layers[0].n_out_tiles) {
+      const f32x4* wp0 = wsdf + sd.layers[0].w_off + (size_t)wave * sd.emb_rows * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pre[i] = wp0[min(i, sd.emb_rows - 1) * 64];
+    }
+    for (int l = 0; l < n_lin - 1; ++l) {
+      const LayerDesc L = sd.layers[l];
+      const f32x4* next_wp = nullptr;
+      if (l + 1 < n_lin - 1 && wave < sd.layers[l + 1].n_out_tiles)
+        next_wp = wsdf + sd.layers[l + 1].w_off + (size_t)wave * (4 * L.n_out_tiles + ((l + 1 == sd.skip) ? sd.emb_rows : 0)) * 64 + lane;
+      const KSegs ks = (l == 0) ? KSegs{E0, sd.emb_rows, 0, 0}
+                                : KSegs{cur, 4 * sd.layers[l - 1].n_out_tiles, E0, (l == sd.skip) ? sd.emb_rows : 0};
+      const int dst = (l == 0) ? X0 : oth;
+      const bool do_save = FINE && (l < n_lin - 2);
+      const f32x4* bp = wsdf + L.b_off;
+      gemm_tiles2<8>(lds, IS, ks, wsdf + L.w_off, L.n_out_tiles, wave, lane, pre, true, next_wp,
+                     [&](int ot, int, f32x16& acc) { init_bias(bp, ot, lane, acc); },
+                     [&](int ot, int im, const f32x16& acc) {
+                       f32x4* li = lds + (size_t)im * IS;
+                       f32x4* sv = save0 + (size_t)im * per_img + (size_t)l * 4 * MT * 64;
+#pragma unroll
+                       for (int rq = 0; rq < 4; ++rq) {
+                         f32x4 v = acc_quad(acc, rq);
+#pragma unroll
+                         for (int j = 0; j < 4; ++j) v[j] = act_fwd<ACT_SOFTPLUS100>(v[j]);
+                         li[(dst + ot * 4 + rq) * 64 + lane] = v;
+                         if (do_save) st_stream(sv + (ot * 4 + rq) * 64 + lane, v);
+                       }
+                     });
+      __syncthreads();
+      if (l == 0) { cur = X0; oth = Y0; } else { const int t = cur; cur = oth; oth = t; }
+    }
+    const int hid_rows = 4 * sd.layers[n_lin - 2].n_out_tiles;
+
+    // ---------------- last layer: sdf row (VALU dot, per image) [+ feature rows -> stash] ----------------
+    rowdot<1>(ldsi, cur, hid_rows, wsdf + sd.last_w_off, sm->part[img], w4, lane);
+    if (FINE && sd.layers[n_lin - 1].n_out_tiles > 0) {
+      const LayerDesc L = sd.layers[n_lin - 1];
+      const f32x4* bp = wsdf + L.b_off;
+      gemm_tiles2<8>(lds, IS, KSegs{cur, hid_rows, 0, 0}, wsdf + L.w_off, L.n_out_tiles, wave, lane, nopre, false, nullptr,
+                     [&](int ot, int, f32x16& acc) { init_bias(bp, ot, lane, acc); },
+                     [&](int ot, int im, const f32x16& acc) {
+                       f32x4* sv = save0 + (size_t)im * per_img + (size_t)feat_slot * 64;
+#pragma unroll
+                       for (int rq = 0; rq < 4; ++rq) st_stream(sv + (ot * 4 + rq) * 64 + lane, acc_quad(acc, rq));
+                     });
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int im = tid >> 5, t = tid & 31;
+      const long pt = ((2 * pair + im) << 5) + t;
+      if (pt < P) {
+        const float* pr = sm->part[im];
+        const float s = ((pr[t] + pr[32 + t]) + (pr[64 + t] + pr[96 + t])) + (sd.last_b_off > 0 ? wsdf[sd.last_b_off][0] : sd.last_bias);
+        out_sdf[pt] = s / sd.scale;
+      }
+    }
+    if (!FINE) { __syncthreads(); continue; }
+
+    // ---------------- reverse sweep: d sdf / d x ----------------
+    for (int r0 = w4; r0 < hid_rows; r0 += 32) {
+      f32x4 v[8], wv[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int r = min(r0 + 4 * c, hid_rows - 1);
+        v[c] = ldsi[(cur + r) * 64 + lane];
+        wv[c] = wsdf[sd.last_w_off + r * 2 + h];
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (r0 + 4 * c < hid_rows) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[c][j] = wv[c][j] * act_bwd_from_out<ACT_SOFTPLUS100>(v[c][j]);
+          ldsi[(cur + r0 + 4 * c) * 64 + lane] = v[c];
+        }
+    }
+    __syncthreads();
+    for (int l = n_lin - 2; l >= 1; --l) {
+      const LayerDesc L = sd.layers[l];
+      const KSegs ks{cur, 4 * L.n_out_tiles, 0, 0};
+      const int dst = oth;
+      f32x4 hv[2][4];
+      gemm_tiles2<8>(lds, IS, ks, wsdf + L.wT_off, sd.layers[l - 1].n_out_tiles, wave, lane, nopre, false, nullptr,
+                     [&](int ot, int im, f32x16& acc) {
+                       const f32x4* sv = save0 + (size_t)im * per_img + (size_t)(l - 1) * 4 * MT * 64;
+#pragma unroll
+                       for (int rq = 0; rq < 4; ++rq) hv[im][rq] = ld_stream(sv + (ot * 4 + rq) * 64 + lane);
+                       init_zero(acc);
+                     },
+                     [&](int ot, int im, const f32x16& acc) {
+                       f32x4* li = lds + (size_t)im * IS;
+#pragma unroll
+                       for (int rq = 0; rq < 4; ++rq) {
+                         f32x4 v = acc_quad(acc, rq);
+#pragma unroll
+                         for (int j = 0; j < 4; ++j) v[j] *= act_bwd_from_out<ACT_SOFTPLUS100>(hv[im][rq][j]);
+                         li[(dst + ot * 4 + rq) * 64 + lane] = v;
+                       }
+                     });
+      if (l == sd.skip)
+        gemm_tiles2<8>(lds, IS, ks, wsdf + L.wTE_off, emb_tiles, wave, lane, nopre, false, nullptr,
+                       [&](int, int, f32x16& acc) { init_zero(acc); },
+                       [&](int ot, int im, const f32x16& acc) {
+                         f32x4* li = lds + (size_t)im * IS;
+#pragma unroll
+                         for (int rq = 0; rq < 4; ++rq) li[(E0 + ot * 4 + rq) * 64 + lane] = acc_quad(acc, rq);
+                       });
+      __syncthreads();
+      const int t = cur; cur = oth; oth = t;
+    }
+    {
+      const LayerDesc L = sd.layers[0];
+      const bool accumulate = sd.skip >= 1;
+      gemm_tiles2<8>(lds, IS, KSegs{cur, 4 * L.n_out_tiles, 0, 0}, wsdf + L.wTE_off, emb_tiles, wave, lane, nopre, false, nullptr,
+                     [&](int ot, int im, f32x16& acc) {
+                       if (accumulate) init_rows(lds + (size_t)im * IS + (E0 + ot * 4) * 64, lane, acc); else init_zero(acc);
+                     },
+                     [&](int ot, int im, const f32x16& acc) {
+                       f32x4* li = lds + (size_t)im * IS;
+#pragma unroll
+                       for (int rq = 0; rq < 4; ++rq) li[(E0 + ot * 4 + rq) * 64 + lane] = acc_quad(acc, rq);
+                     });
+    }
+    __syncthreads();
+    if (tid < 192) {
+      const int im = tid / 96, r = tid - 96 * im, pp = r & 31, c = r >> 5;
+      const float x0 = sm->pts[im][pp * 3 + 0] * sd.scale, x1 = sm->pts[im][pp * 3 + 1] * sd.scale, x2 = sm->pts[im][pp * 3 + 2] * sd.scale;
+      const float* ldsf = reinterpret_cast<const float*>(lds + (size_t)im * IS);
+      auto G = [&](int f) {
+        const int t = f >> 5, fi = f & 31, hh = fi & 1, rr = fi >> 1;
+        return ldsf[(((E0 + t * 4 + (rr >> 2)) * 64) + pp + 32 * hh) * 4 + (rr & 3)];
+      };
+      float g = G(c);
+      int cc;
+      for (int k = 0; k < sd.multires; ++k) {
+        const int fs = 3 + 6 * k + c, fc = fs + 3;
+        g = fmaf(G(fs), posenc_jac(fs, x0, x1, x2, &cc), g);
+        g = fmaf(G(fc), posenc_jac(fc, x0, x1, x2, &cc), g);
+      }
+      sm->grad[im][pp * 3 + c] = g;
+      const long pt = ((2 * pair + im) << 5) + pp;
+      if (pt < P) out_grad[pt * 3 + c] = g;
+    }
+    __syncthreads();
+    if (cd.n_lin == 0) continue;
+
+    // ---------------- colour network ----------------
+    {
+      const float px = sm->pts[img][p * 3 + 0], py = sm->pts[img][p * 3 + 1], pz = sm->pts[img][p * 3 + 2];
+      const float dx = sm->dirs[img][p * 3 + 0], dy = sm->dirs[img][p * 3 + 1], dz = sm->dirs[img][p * 3 + 2];
+      for (int r = w4; r < cd.extra_rows; r += 4) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int f = row_feat(r, h, j);
+          float val = 0.f;
+          if (f < 3) val = f == 0 ? px : (f == 1 ? py : pz);
+          else if (f < 3 + cd.n_view_feats) val = posenc_feat(f - 3, dx, dy, dz);
+          else if (f < cd.extra_feats) val = sm->grad[img][p * 3 + (f - 3 - cd.n_view_feats)];
+          v[j] = val;
+        }
+        ldsi[(E0 + r) * 64 + lane] = v;
+      }
+      const f32x4* sv = save0 + (size_t)img * per_img + (size_t)feat_slot * 64;
+      const int feat_rows = 4 * sd.layers[n_lin - 1].n_out_tiles;
+      for (int r0 = w4; r0 < feat_rows; r0 += 32) {
+        f32x4 v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = ld_stream(sv + min(r0 + 4 * c, feat_rows - 1) * 64 + lane);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (r0 + 4 * c < feat_rows) ldsi[(X0 + r0 + 4 * c) * 64 + lane] = v[c];
+      }
+      __syncthreads();
+      cur = X0; oth = Y0;
+      int in_rows = feat_rows;
+      for (int l = 0; l < cd.n_lin - 1; ++l) {
+        const LayerDesc L = cd.layers[l];
+        const KSegs ks{cur, in_rows, E0, l == 0 ? cd.extra_rows : 0};
+        const f32x4* bp = wcol + L.b_off;
+        const int dst = oth;
+        gemm_tiles2<8>(lds, IS, ks, wcol + L.w_off, L.n_out_tiles, wave, lane, nopre, false, nullptr,
+                       [&](int ot, int, f32x16& acc) { init_bias(bp, ot, lane, acc); },
+                       [&](int ot, int im, const f32x16& acc) {
+                         f32x4* li = lds + (size_t)im * IS;
+#pragma unroll
+                         for (int rq = 0; rq < 4; ++rq) {
+                           f32x4 v = acc_quad(acc, rq);
+#pragma unroll
+                           for (int j = 0; j < 4; ++j) v[j] = act_fwd<ACT_RELU>(v[j]);
+                           li[(dst + ot * 4 + rq) * 64 + lane] = v;
+                         }
+                       });
+        __syncthreads();
+        const int t = cur; cur = oth; oth = t;
+        in_rows = 4 * L.n_out_tiles;
+      }
+      rowdot<3>(ldsi, cur, in_rows, wcol + cd.last_w_off, sm->part[img], w4, lane);
+      __syncthreads();
+      if (tid < 192) {
+        const int im = tid / 96, r = tid - 96 * im, pp = r & 31, o = r >> 5;
+        const float* pr = sm->part[im];
+        float v = ((pr[(0 * 32 + pp) * 3 + o] + pr[(1 * 32 + pp) * 3 + o]) + (pr[(2 * 32 + pp) * 3 + o] + pr[(3 * 32 + pp) * 3 + o])) +
+                  (cd.last_b_off > 0 ? wcol[cd.last_b_off][o] : cd.last_bias[o]);
+        if (cd.squeeze_out) v = 1.f / (1.f + expf(-v));
+        const long pt = ((2 * pair + im) << 5) + pp;
+        if (pt < P) out_rgb[pt * 3 + o] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 int check_sdf_desc(const SdfDesc& d) {
   if (d.n_lin < 2 || d.n_lin > VQN_MAX_SDF_LAYERS) return 1;
   if (d.max_tiles < 1 || d.max_tiles > 16) return 2;
@@ -327,6 +613,14 @@ int check_sdf_desc(const SdfDesc& d) {
 }
 
 size_t lds_bytes(int MT) { return (size_t)(E_ROWS + 8 * MT) * 1024 + sizeof(Smalls); }
+size_t lds_bytes2(int MT) { return (size_t)2 * (E_ROWS + 8 * MT) * 1024 + sizeof(Smalls2); }
+
+// two 32-point images per workgroup for networks wide enough to give eight waves a tile each (and small enough to fit),
+// unless VQN_NEUS_TILE32 is set
+bool use_two_images(int MT) {
+  static const bool forced32 = getenv("VQN_NEUS_TILE32") != nullptr;
+  return !forced32 && MT >= 5 && lds_bytes2(MT) <= 160 * 1024;
+}
 
 }  // namespace
 
@@ -342,11 +636,22 @@ extern "C" int vqn_neus_sdf_points(const int32_t* sdf_desc, const float* wbuf_sd
   VQN_CHECK_SHAPE(check_sdf_desc(sd) == 0, "invalid SDF network descriptor");
   ColDesc cd;
   memset(&cd, 0, sizeof(cd));
+  const long n_tiles = (P + 31) / 32;
+  if (use_two_images(sd.max_tiles)) {
+    const size_t lds2 = lds_bytes2(sd.max_tiles);
+    VQN_HIP(hipFuncSetAttribute((const void*)neus_points2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    long grid = (long)vqn_num_cus();
+    if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;
+    hipLaunchKernelGGL(neus_points2_kernel<false>, dim3((unsigned)grid), dim3(512), lds2, (hipStream_t)stream, sd, cd,
+                       reinterpret_cast<const f32x4*>(wbuf_sdf), (const f32x4*)nullptr, rays_o, rays_d, z, pts,
+                       (const float*)nullptr, (long)P, S, (f32x4*)nullptr, out_sdf, (float*)nullptr, (float*)nullptr);
+    VQN_LAUNCH_CHECK();
+    return VQN_OK;
+  }
   const size_t lds = lds_bytes(sd.max_tiles);
   VQN_CHECK_SHAPE(lds <= 160 * 1024, "network too wide for LDS");
   if (lds > 64 * 1024)
     VQN_HIP(hipFuncSetAttribute((const void*)neus_points_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const long n_tiles = (P + 31) / 32;
   long grid = (long)vqn_num_cus() * 2;
   if (grid > n_tiles) grid = n_tiles;
   hipLaunchKernelGGL(neus_points_kernel<false>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, sd, cd,
@@ -388,12 +693,25 @@ extern "C" int vqn_neus_fine_points(const int32_t* sdf_desc, const float* wbuf_s
     for (int l = 0; l < cd.n_lin - 1; ++l)
       VQN_CHECK_SHAPE(cd.layers[l].n_out_tiles >= 1 && cd.layers[l].n_out_tiles <= sd.max_tiles, "colour layer wider than max_tiles");
   }
+  const long n_tiles = (P + 31) / 32;
+  const int64_t per_wg = (int64_t)(sd.n_lin - 1) * 4 * sd.max_tiles * 1024;
+  if (use_two_images(sd.max_tiles)) {
+    const size_t lds2 = lds_bytes2(sd.max_tiles);
+    VQN_HIP(hipFuncSetAttribute((const void*)neus_points2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    long grid = (long)vqn_num_cus();
+    if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;
+    if ((int64_t)grid * 2 * per_wg > scratch_bytes) grid = (long)(scratch_bytes / (2 * per_wg));
+    VQN_CHECK_ARG(grid >= 1, "scratch too small (see vqn_neus_fine_scratch_bytes)");
+    hipLaunchKernelGGL(neus_points2_kernel<true>, dim3((unsigned)grid), dim3(512), lds2, (hipStream_t)stream, sd, cd,
+                       reinterpret_cast<const f32x4*>(wbuf_sdf), reinterpret_cast<const f32x4*>(wbuf_col), rays_o, rays_d,
+                       z, pts, dirs, (long)P, S, reinterpret_cast<f32x4*>(scratch), out_sdf, out_grad, out_rgb);
+    VQN_LAUNCH_CHECK();
+    return VQN_OK;
+  }
   const size_t lds = lds_bytes(sd.max_tiles);
   VQN_CHECK_SHAPE(lds <= 160 * 1024, "network too wide for LDS");
   if (lds > 64 * 1024)
     VQN_HIP(hipFuncSetAttribute((const void*)neus_points_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const long n_tiles = (P + 31) / 32;
-  const int64_t per_wg = (int64_t)(sd.n_lin - 1) * 4 * sd.max_tiles * 1024;
   long grid = (long)vqn_num_cus() * 2;
   if (grid > n_tiles) grid = n_tiles;
   if ((int64_t)grid * per_wg > scratch_bytes) grid = (long)(scratch_bytes / per_wg);

@@ -183,8 +183,8 @@ __global__ __launch_bounds__(256, 2) void neus_points_f16s_kernel(
           if (do_save) {                            // what the reverse sweep needs of this layer: act'(x) = 1 - exp(-100 h)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              sv[(ot * 4 + q) * 64 + lane] = (f32x4){act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q]), act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q + 1]),
-                                                    act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q + 2]), act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q + 3])};
+              st_stream(sv + (ot * 4 + q) * 64 + lane, (f32x4){act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q]), act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q + 1]),
+                                                               act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q + 2]), act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q + 3])});
           }
         });
       FS(2)
@@ -205,8 +205,8 @@ __global__ __launch_bounds__(256, 2) void neus_points_f16s_kernel(
         [&](int ot, const f32x16& acc1, const f32x16& acc2) {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            sv[(ot * 4 + q) * 64 + lane] = (f32x4){fmaf(acc2[4 * q], LO_INV, acc1[4 * q]), fmaf(acc2[4 * q + 1], LO_INV, acc1[4 * q + 1]),
-                                                  fmaf(acc2[4 * q + 2], LO_INV, acc1[4 * q + 2]), fmaf(acc2[4 * q + 3], LO_INV, acc1[4 * q + 3])};
+            st_stream(sv + (ot * 4 + q) * 64 + lane, (f32x4){fmaf(acc2[4 * q], LO_INV, acc1[4 * q]), fmaf(acc2[4 * q + 1], LO_INV, acc1[4 * q + 1]),
+                                                             fmaf(acc2[4 * q + 2], LO_INV, acc1[4 * q + 2]), fmaf(acc2[4 * q + 3], LO_INV, acc1[4 * q + 3])});
         });
     }
     __syncthreads();
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void neus_points_f16s_kernel(
         [&](int ot, f32x16& acc) {
           FS(7)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) hv[q] = sv[(ot * 4 + q) * 64 + lane];
+          for (int q = 0; q < 4; ++q) hv[q] = ld_stream(sv + (ot * 4 + q) * 64 + lane);
           init_zero(acc);
         },
         [&](int ot, const f32x16& acc1, const f32x16& acc2) {
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void neus_points_f16s_kernel(
       for (int t = wave; t < feat_tiles; t += 4) {            // feature tiles back from the stash (register order) -> split rows
         f32x4 q4[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) q4[q] = sv[(t * 4 + q) * 64 + lane];
+        for (int q = 0; q < 4; ++q) q4[q] = ld_stream(sv + (t * 4 + q) * 64 + lane);
         float v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = q4[i >> 2][i & 3];
@@ -543,8 +543,8 @@ __global__ __launch_bounds__(512, 1) void neus_points_f16s2_kernel(
             f32x4* sv = save0 + (size_t)im * per_img + (size_t)l * 4 * MT * 64;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              sv[(ot * 4 + q) * 64 + lane] = (f32x4){act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q]), act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q + 1]),
-                                                    act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q + 2]), act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q + 3])};
+              st_stream(sv + (ot * 4 + q) * 64 + lane, (f32x4){act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q]), act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q + 1]),
+                                                               act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q + 2]), act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q + 3])});
           }
         });
       __syncthreads();
@@ -563,8 +563,8 @@ __global__ __launch_bounds__(512, 1) void neus_points_f16s2_kernel(
           f32x4* sv = save0 + (size_t)im * per_img + (size_t)feat_slot * 64;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            sv[(ot * 4 + q) * 64 + lane] = (f32x4){fmaf(acc2[4 * q], LO_INV, acc1[4 * q]), fmaf(acc2[4 * q + 1], LO_INV, acc1[4 * q + 1]),
-                                                  fmaf(acc2[4 * q + 2], LO_INV, acc1[4 * q + 2]), fmaf(acc2[4 * q + 3], LO_INV, acc1[4 * q + 3])};
+            st_stream(sv + (ot * 4 + q) * 64 + lane, (f32x4){fmaf(acc2[4 * q], LO_INV, acc1[4 * q]), fmaf(acc2[4 * q + 1], LO_INV, acc1[4 * q + 1]),
+                                                             fmaf(acc2[4 * q + 2], LO_INV, acc1[4 * q + 2]), fmaf(acc2[4 * q + 3], LO_INV, acc1[4 * q + 3])});
         });
     }
     __syncthreads();
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(512, 1) void neus_points_f16s2_kernel(
         [&](int ot, int im, f32x16& acc) {
           const f32x4* sv = save0 + (size_t)im * per_img + (size_t)(l - 1) * 4 * MT * 64;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) hv[im][q] = sv[(ot * 4 + q) * 64 + lane];
+          for (int q = 0; q < 4; ++q) hv[im][q] = ld_stream(sv + (ot * 4 + q) * 64 + lane);
           init_zero(acc);
         },
         [&](int ot, int im, const f32x16& acc1, const f32x16& acc2) {
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(512, 1) void neus_points_f16s2_kernel(
       for (int t = w4; t < feat_tiles; t += 4) {
         f32x4 q4[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) q4[q] = sv[(t * 4 + q) * 64 + lane];
+        for (int q = 0; q < 4; ++q) q4[q] = ld_stream(sv + (t * 4 + q) * 64 + lane);
         float v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = q4[i >> 2][i & 3];
