@@ -53,3 +53,18 @@ if hasattr(lib, 'vqn_debug_read_stamps16'):
         print('f16s fine' if fine else 'f16s sdf ', f'P={B*S}  wave-0 cycles per workgroup: total {v[14] / max(v[15], 1):.3e} over {v[15]} workgroups')
         for i in range(13):
             print(f'    {names16[i]:72s} {100.0 * v[i] / max(v[14], 1):5.1f} %')
+
+# ---- two-image f32 kernels (16 phases) ----
+if hasattr(lib, 'vqn_debug_read_stamps2'):
+    for S, fine in ((64, False), (128, True)):
+        z = (near + (far - near) * torch.linspace(0, 1, S, device='cuda')[None, :]).contiguous()
+        f = (lambda: _C.neus_fine_points(d_s, wb_s, d_c, wb_c, rays_o=o, rays_d=d, z=z)) if fine else (lambda: _C.neus_sdf_points(d_s, wb_s, rays_o=o, rays_d=d, z=z))
+        f(); torch.cuda.synchronize()
+        buf = (ctypes.c_ulonglong * 16)()
+        lib.vqn_debug_read_stamps2(buf, 1)
+        f(); torch.cuda.synchronize()
+        lib.vqn_debug_read_stamps2(buf, 1)
+        v = [int(x) for x in buf]
+        print('f32 two-image fine' if fine else 'f32 two-image sdf ', f'P={B*S}  wave-0 cycles per workgroup: total {v[14] / max(v[15], 1):.3e} over {v[15]} workgroups')
+        for i in range(13):
+            print(f'    {names16[i]:72s} {100.0 * v[i] / max(v[14], 1):5.1f} %')

@@ -36,6 +36,25 @@ extern "C" int vqn_debug_read_stamps(unsigned long long* out, int reset) {
 #define VQN_STAMP_FLUSH
 #endif
 
+// 16-phase stamps of the two-image kernel (same DIAGNOSTIC build): [0] set-up [1] forward K loops [2] forward epilogues [3] forward
+// barrier waits [4] sdf row + feature layer + sdf out [5] G_pre [6] reverse K loops (+ wTE) [7] reverse epilogues [8] reverse barrier
+// waits [9] embedding chain rule [10] colour set-up [11] colour layers [12] colour out / turn-around [14] total [15] workgroups.
+#ifdef VQN_STAMPS
+__device__ unsigned long long g_stamps2[16];
+#define FS_DECL unsigned long long fs_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long fs_prev = __builtin_amdgcn_s_memtime(); const unsigned long long fs_begin = fs_prev;
+#define FS(i) { const unsigned long long fs_now = __builtin_amdgcn_s_memtime(); fs_[i] += fs_now - fs_prev; fs_prev = fs_now; }
+#define FS_FLUSH if (threadIdx.x == 0) { fs_[14] = __builtin_amdgcn_s_memtime() - fs_begin; for (int i_ = 0; i_ < 15; ++i_) atomicAdd(&g_stamps2[i_], fs_[i_]); atomicAdd(&g_stamps2[15], 1ull); }
+extern "C" int vqn_debug_read_stamps2(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps2), sizeof(unsigned long long) * 16) != hipSuccess) return -3;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps2), z, sizeof(z)) != hipSuccess) return -3; }
+  return 0;
+}
+#else
+#define FS_DECL
+#define FS(i)
+#define FS_FLUSH
+#endif
+
 namespace {
 
 constexpr int E0 = 0;        // LDS rows [0,8): embedding / colour-net extras / d sdf / d embedding
@@ -352,7 +371,9 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
   f32x4 pre[4];
   f32x4 nopre[4];
 
+  FS_DECL
   for (long pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+    FS(12)
     // ---------------- points of both tiles ----------------
     if (tid < 64) {
       const int im = tid >> 5, t = tid & 31;
@@ -386,6 +407,7 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
     }
     __syncthreads();
 
+    FS(0)
     // ---------------- SDF hidden layers ----------------
     int cur = X0, oth = Y0;
     if (wave < sd.layers[0].n_out_tiles) {
@@ -404,8 +426,9 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
       const bool do_save = FINE && (l < n_lin - 2);
       const f32x4* bp = wsdf + L.b_off;
       gemm_tiles2<8>(lds, IS, ks, wsdf + L.w_off, L.n_out_tiles, wave, lane, pre, true, next_wp,
-                     [&](int ot, int, f32x16& acc) { init_bias(bp, ot, lane, acc); },
+                     [&](int ot, int im, f32x16& acc) { if (im == 0) { FS(2) } init_bias(bp, ot, lane, acc); },
                      [&](int ot, int im, const f32x16& acc) {
+                       if (im == 0) { FS(1) }
                        f32x4* li = lds + (size_t)im * IS;
                        f32x4* sv = save0 + (size_t)im * per_img + (size_t)l * 4 * MT * 64;
 #pragma unroll
@@ -417,7 +440,9 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
                          if (do_save) st_stream(sv + (ot * 4 + rq) * 64 + lane, v);
                        }
                      });
+      FS(2)
       __syncthreads();
+      FS(3)
       if (l == 0) { cur = X0; oth = Y0; } else { const int t = cur; cur = oth; oth = t; }
     }
     const int hid_rows = 4 * sd.layers[n_lin - 2].n_out_tiles;
@@ -445,7 +470,8 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
         out_sdf[pt] = s / sd.scale;
       }
     }
-    if (!FINE) { __syncthreads(); continue; }
+    if (!FINE) { __syncthreads(); FS(4) continue; }
+    FS(4)
 
     // ---------------- reverse sweep: d sdf / d x ----------------
     for (int r0 = w4; r0 < hid_rows; r0 += 32) {
@@ -465,6 +491,7 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
         }
     }
     __syncthreads();
+    FS(5)
     for (int l = n_lin - 2; l >= 1; --l) {
       const LayerDesc L = sd.layers[l];
       const KSegs ks{cur, 4 * L.n_out_tiles, 0, 0};
@@ -472,12 +499,14 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
       f32x4 hv[2][4];
       gemm_tiles2<8>(lds, IS, ks, wsdf + L.wT_off, sd.layers[l - 1].n_out_tiles, wave, lane, nopre, false, nullptr,
                      [&](int ot, int im, f32x16& acc) {
+                       if (im == 0) { FS(7) }
                        const f32x4* sv = save0 + (size_t)im * per_img + (size_t)(l - 1) * 4 * MT * 64;
 #pragma unroll
                        for (int rq = 0; rq < 4; ++rq) hv[im][rq] = ld_stream(sv + (ot * 4 + rq) * 64 + lane);
                        init_zero(acc);
                      },
                      [&](int ot, int im, const f32x16& acc) {
+                       if (im == 0) { FS(6) }
                        f32x4* li = lds + (size_t)im * IS;
 #pragma unroll
                        for (int rq = 0; rq < 4; ++rq) {
@@ -495,7 +524,9 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
 #pragma unroll
                          for (int rq = 0; rq < 4; ++rq) li[(E0 + ot * 4 + rq) * 64 + lane] = acc_quad(acc, rq);
                        });
+      FS(7)
       __syncthreads();
+      FS(8)
       const int t = cur; cur = oth; oth = t;
     }
     {
@@ -512,6 +543,7 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
                      });
     }
     __syncthreads();
+    FS(6)
     if (tid < 192) {
       const int im = tid / 96, r = tid - 96 * im, pp = r & 31, c = r >> 5;
       const float x0 = sm->pts[im][pp * 3 + 0] * sd.scale, x1 = sm->pts[im][pp * 3 + 1] * sd.scale, x2 = sm->pts[im][pp * 3 + 2] * sd.scale;
@@ -532,6 +564,7 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
       if (pt < P) out_grad[pt * 3 + c] = g;
     }
     __syncthreads();
+    FS(9)
     if (cd.n_lin == 0) continue;
 
     // ---------------- colour network ----------------
@@ -562,6 +595,7 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
           if (r0 + 4 * c < feat_rows) ldsi[(X0 + r0 + 4 * c) * 64 + lane] = v[c];
       }
       __syncthreads();
+      FS(10)
       cur = X0; oth = Y0;
       int in_rows = feat_rows;
       for (int l = 0; l < cd.n_lin - 1; ++l) {
@@ -585,6 +619,7 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
         const int t = cur; cur = oth; oth = t;
         in_rows = 4 * L.n_out_tiles;
       }
+      FS(11)
       rowdot<3>(ldsi, cur, in_rows, wcol + cd.last_w_off, sm->part[img], w4, lane);
       __syncthreads();
       if (tid < 192) {
@@ -599,6 +634,8 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
     }
     __syncthreads();
   }
+  FS(12)
+  FS_FLUSH
 }
 
 int check_sdf_desc(const SdfDesc& d) {
