@@ -139,3 +139,38 @@ def test_wide_network_takes_the_one_image_kernel():
     for a, b, tol in zip(out['f16s'], out['f32'], (5e-6, None, 5e-5, 5e-6)):
         tol = tol if tol is not None else 1e-4 * float(b.abs().max())
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=tol)
+
+
+def test_f16s_error_against_fp64_truth_is_fp32_level():
+    """Ground truth = the oracle evaluated in float64 (weights are the same fp32 numbers).  The split-precision kernels must be
+    as close to it as the exact-f32 kernels are, up to a small factor: sdf and colour within 3x the f32 kernels' own error
+    (+ 1e-7 floor), gradients within 3x (+ 1e-6).  Measured on MI355X: ratios 1.0-1.6."""
+    from oracle import geo as og
+    from vqnerf_release_amd import _C
+    cfg = og.FULL_CFG
+    p_sdf, p_col, wb_s, d_s, wb_c, d_c = _packed(cfg, 'f32')
+    _, _, wb_s16, d_s16, wb_c16, d_c16 = _packed(cfg, 'f16s')
+    rng = np.random.default_rng(11)
+    n = 2048
+    pts = rng.uniform(-1.0, 1.0, (n, 3)).astype(np.float32)
+    dirs = rng.normal(size=(n, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    P64, D64 = torch.tensor(pts, dtype=torch.float64), torch.tensor(dirs, dtype=torch.float64)
+    p64 = {k: v.double() for k, v in p_sdf.items()}
+    c64 = {k: v.double() for k, v in p_col.items()}
+    with torch.no_grad():
+        out64 = og.sdf_forward(p64, cfg, P64)
+    sdf64, feat64 = out64[:, 0], out64[:, 1:]
+    grad64 = og.sdf_gradient(p64, cfg, P64)
+    with torch.no_grad():
+        rgb64 = og.color_forward(c64, cfg, P64, grad64, D64, feat64)
+    Pg, Dg = torch.tensor(pts).cuda(), torch.tensor(dirs).cuda()
+    a = _C.neus_fine_points(d_s, wb_s, d_c, wb_c, pts=Pg, dirs=Dg)
+    b = _C.neus_fine_points(d_s16, wb_s16, d_c16, wb_c16, pts=Pg, dirs=Dg, mode='f16s')
+    report = {}
+    for name, x32, x16, ref, floor in (('sdf', a[0], b[0], sdf64, 1e-7), ('grad', a[1], b[1], grad64, 1e-6), ('rgb', a[2], b[2], rgb64, 1e-7)):
+        e32 = float((x32.double().cpu() - ref).abs().max())
+        e16 = float((x16.double().cpu() - ref).abs().max())
+        report[name] = (e32, e16)
+        assert e16 <= 3.0 * e32 + floor, (name, e32, e16)
+    print('max |error| vs fp64 (f32 kernel, f16s kernel):', report)
