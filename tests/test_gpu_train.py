@@ -39,6 +39,26 @@ def test_geo_runner_trains(tmp_path):
     assert all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(r.bucket.params, r.bucket.views))
 
 
+def test_geo_runner_trains_from_a_blender_image_set(tmp_path):
+    """conf `dataset.data_dir` -> models/nerfset.Dataset (images resident on the device) -> Runner.train_step."""
+    from tests.test_datasets import _write_blender_set
+    from vqnerf_release_amd.geo.nerf_runner import Runner
+    from vqnerf_release_amd.geo.models.nerfset import Dataset
+    data = tmp_path / 'scene'
+    data.mkdir()
+    _write_blender_set(str(data), n=3, H=24, W=32)
+    text = open(os.path.join(HERE, 'golden', 'neus_like.conf')).read().replace('./exp/', str(tmp_path) + '/exp/')
+    text = text.replace('warm_up_end = 5000', 'warm_up_end = 0').replace('batch_size = 64', 'batch_size = 128')
+    import re
+    text = re.sub(r'data_dir = [^\n]*', 'data_dir = %s/\n    longint = false' % data, text, count=1)
+    torch.manual_seed(0)
+    r = Runner(conf_text=text, case='lego')
+    assert isinstance(r.dataset, Dataset) and r.dataset.n_images == 3 and r.dataset.images.is_cuda
+    r.update_learning_rate()
+    losses = [float(r.train_step(r.dataset.gen_random_rays_at(it % 3, r.batch_size))['loss']) for it in range(4)]
+    assert all(np.isfinite(losses)) and r.iter_step == 4
+
+
 def test_decomp_trainer_trains():
     from oracle import decomp as od
     from vqnerf_release_amd.decomp.nerfactor import train_nfr
