@@ -130,6 +130,34 @@ def test_decomp_trainer_graph_replays_the_eager_step():
         train_nfr.Trainer(model, torch.optim.Adam(model.trainable_variables, lr=1e-3), graph=True)
 
 
+def test_decomp_trains_from_geometry_buffers_on_disk(tmp_path):
+    """The whole hand-off of the pipeline: per-view buffers in the layout gen_geo writes -> datasets.shape_unit (device-resident
+    views) -> outer_sample pairs -> Trainer.train_iter (eager, then replayed from the captured HIP graph)."""
+    from oracle import decomp as od
+    from tests.test_datasets import _write_decomp_view, _decomp_cfg
+    from vqnerf_release_amd.decomp.nerfactor import train_nfr
+    from vqnerf_release_amd.decomp.nerfactor.datasets import get_dataset_class
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    rng = np.random.default_rng(3)
+    for vid in ('train_000', 'train_001'):
+        _write_decomp_view(str(tmp_path / 'data'), str(tmp_path / 'geo'), vid, 24, 32, 512, rng, collapse=False)
+    cfg = _decomp_cfg(tmp_path, imh=24, n_rays_per_step=64)
+    ds = get_dataset_class('shape_unit')(cfg, 'train', device='cuda')
+    p, _ = od.make_model_params(seed=0, K=15)
+    model = load_oracle_params(get_model_class('vq_nfr')(cfg), p, 'cuda')
+    model.get_codebook(); _ = model.light
+    opt, sched, clip = train_nfr.make_optimizer(cfg, model.trainable_variables, capturable=True)
+    tr = train_nfr.Trainer(model, opt, clip=clip, sched=sched, graph=True)
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    losses = []
+    for epoch in range(3):
+        for view in ds.build_pipeline(seed=epoch):
+            batch = train_nfr.outer_sample(view, cfg, 'nerf', generator=gen)
+            assert batch[7].shape == (128, 3) and batch[7].is_cuda
+            losses.append(float(tr.train_iter(batch, global_bs=64)[0]))
+    assert len(losses) == 6 and all(np.isfinite(losses)) and tr._captured is not None
+
+
 def test_outer_sample_pairs_are_neighbours():
     from vqnerf_release_amd.decomp.nerfactor import train_nfr
     H, W = 40, 50

@@ -87,7 +87,7 @@ class Trainer:
             self._global_bs = global_bs
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._static_out = self._step(tuple(self._static_in), global_bs, None, None, sched=False)
+                self._static_out = self._step(tuple(self._static_in), global_bs, None, None, sched=False, fresh_leaves=True)
             self._captured = g
         if global_bs != self._global_bs:
             raise ValueError('global_bs is baked into the captured step')
@@ -101,10 +101,25 @@ class Trainer:
             self.sched.step()
         return self._static_out
 
-    def _step(self, batch, global_bs, thres, roll, sched=True):
+    def _step(self, batch, global_bs, thres, roll, sched=True, fresh_leaves=False):
         model = self.model
         if self.bucket is None:
             self.bucket = parallel.FlatBucket(model.trainable_variables, n_extra=1)
+        if fresh_leaves:
+            # (capture only) run the step on fresh leaf aliases of the parameters.  A parameter's AccumulateGrad node is bound to the
+            # stream the parameter was first used on and lives as long as ANY tensor derived from it (a caller holding `model.light`,
+            # say): under capture the engine would synchronise the capture stream with that old (default) stream, which pulls it
+            # into the capture and crashes hipStreamEndCapture.  Fresh leaves share the storage, get their nodes on the capture
+            # stream, and their gradients are copied into the bucket the optimiser reads.
+            from torch.nn.utils.stateless import _reparametrize_module
+            names = {id(p): n for n, p in model.named_parameters()}
+            leaves = [p.detach().requires_grad_(True) for p in self.bucket.params]
+            with _reparametrize_module(model, {names[id(p)]: q for p, q in zip(self.bucket.params, leaves)}):
+                return self._step_body(batch, global_bs, thres, roll, sched, leaves)
+        return self._step_body(batch, global_bs, thres, roll, sched, None)
+
+    def _step_body(self, batch, global_bs, thres, roll, sched, leaves):
+        model = self.model
         self.optimizer.zero_grad(set_to_none=True)
         self.bucket.attach()
         kw = {'thres': thres}
@@ -114,7 +129,16 @@ class Trainer:
         loss_kwargs.pop('pretrain', None), loss_kwargs.pop('env', None)
         per_example, loss_dict = model.compute_loss(pred, gt, **loss_kwargs)
         weighted = compute_average_loss(per_example, global_bs)
-        weighted.backward()
+        if leaves is None:
+            weighted.backward()
+        else:
+            grads = torch.autograd.grad(weighted, leaves, allow_unused=True)
+            with torch.no_grad():
+                for v, g in zip(self.bucket.views, grads):
+                    if g is None:
+                        v.zero_()
+                    else:
+                        v.copy_(g)
         with torch.no_grad():
             self.bucket.extra[0] = weighted
         extra = self.bucket.all_reduce()
