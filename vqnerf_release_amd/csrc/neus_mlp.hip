@@ -341,10 +341,60 @@ __global__ __launch_bounds__(256, 2) void neus_points_kernel(
 // waves do the same matrix work between two barriers and no second workgroup competes for the matrix pipe, so the waves
 // of a layer finish together (the one-image form loses ~20 % to barrier skew between its two co-resident workgroups);
 // barriers and the L2 weight stream per point halve.  The VALU phases split by image: waves 0-3 image 0, waves 4-7 image 1.
-// Results are bit-identical to the one-image kernel (same per-point arithmetic in the same order).
+// Same per-point arithmetic as the one-image kernel except the two embedding-gradient GEMMs of the reverse sweep, which are
+// split over K (wte_split_k: a different, still fixed, summation order for d sdf / d x).
 struct Smalls2 {
   float pts[2][96], dirs[2][96], part[2][512], grad[2][96];
 };
+
+// d sdf / d embedding of one layer for both images: E rows (+)= W_E^T . G over the K rows [k_row0, k_row0 + ng).  The result
+// has only emb_tiles (<= 2) output tiles, so as a plain gemm_tiles2 call it keeps 2 of the 8 waves busy for a whole K = 256 pass;
+// here the 8 waves split it as (tile, K slice) units, park their partial tiles in the free activation buffer `tmp_row0`
+// (4 rows per unit and image) and sum them in a fixed slice order.  Ends with the E rows written and a barrier passed.
+__device__ __forceinline__ void wte_split_k(f32x4* __restrict__ lds, const int IS, const int k_row0, const int ng,
+                                            const f32x4* __restrict__ w, const int emb_tiles, const int tmp_row0, const int e_row0,
+                                            const bool accumulate, const int wave, const int lane) {
+  const int KS = 8 / emb_tiles, gk = (ng + KS - 1) / KS;          // K slices, groups per slice
+  const int t = wave % emb_tiles, kq = wave / emb_tiles;
+  if (kq < KS) {
+    f32x16 acc0, acc1;
+    init_zero(acc0); init_zero(acc1);
+    const int g0 = kq * gk, g1 = min(ng, g0 + gk);
+    const f32x4* __restrict__ wp = w + (size_t)t * ng * 64 + lane;
+    for (int g = g0; g < g1; g += 8) {
+      f32x4 a[8], p[8], q[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int gg = min(g + i, ng - 1), r = (k_row0 + gg) * 64 + lane;
+        a[i] = wp[gg * 64]; p[i] = lds[r]; q[i] = lds[r + IS];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (g + i < g1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], p[i][j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], q[i][j], acc1, 0, 0, 0);
+          }
+        }
+    }
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      lds[(tmp_row0 + wave * 4 + rq) * 64 + lane] = acc_quad(acc0, rq);
+      lds[IS + (tmp_row0 + wave * 4 + rq) * 64 + lane] = acc_quad(acc1, rq);
+    }
+  }
+  __syncthreads();
+  for (int r = wave; r < 8 * emb_tiles; r += 8) {                   // (image, tile, row quad) units
+    const int im = r / (4 * emb_tiles), er = r - im * 4 * emb_tiles, tt = er >> 2, rq = er & 3;
+    f32x4* li = lds + (size_t)im * IS;
+    f32x4 sum = li[(tmp_row0 + tt * 4 + rq) * 64 + lane];
+    for (int k = 1; k < KS; ++k) sum += li[(tmp_row0 + (k * emb_tiles + tt) * 4 + rq) * 64 + lane];
+    if (accumulate) sum += li[(e_row0 + er) * 64 + lane];
+    li[(e_row0 + er) * 64 + lane] = sum;
+  }
+  __syncthreads();
+}
 
 template <bool FINE>
 __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
@@ -496,6 +546,8 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
       const LayerDesc L = sd.layers[l];
       const KSegs ks{cur, 4 * L.n_out_tiles, 0, 0};
       const int dst = oth;
+      if (l == sd.skip)                                 // embedding part of the skip layer first: `oth` is still free for the partials
+        wte_split_k(lds, IS, cur, 4 * L.n_out_tiles, wsdf + L.wTE_off, emb_tiles, oth, E0, false, wave, lane);
       f32x4 hv[2][4];
       gemm_tiles2<8>(lds, IS, ks, wsdf + L.wT_off, sd.layers[l - 1].n_out_tiles, wave, lane, nopre, false, nullptr,
                      [&](int ot, int im, f32x16& acc) {
@@ -516,33 +568,12 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
                          li[(dst + ot * 4 + rq) * 64 + lane] = v;
                        }
                      });
-      if (l == sd.skip)
-        gemm_tiles2<8>(lds, IS, ks, wsdf + L.wTE_off, emb_tiles, wave, lane, nopre, false, nullptr,
-                       [&](int, int, f32x16& acc) { init_zero(acc); },
-                       [&](int ot, int im, const f32x16& acc) {
-                         f32x4* li = lds + (size_t)im * IS;
-#pragma unroll
-                         for (int rq = 0; rq < 4; ++rq) li[(E0 + ot * 4 + rq) * 64 + lane] = acc_quad(acc, rq);
-                       });
       FS(7)
       __syncthreads();
       FS(8)
       const int t = cur; cur = oth; oth = t;
     }
-    {
-      const LayerDesc L = sd.layers[0];
-      const bool accumulate = sd.skip >= 1;
-      gemm_tiles2<8>(lds, IS, KSegs{cur, 4 * L.n_out_tiles, 0, 0}, wsdf + L.wTE_off, emb_tiles, wave, lane, nopre, false, nullptr,
-                     [&](int ot, int im, f32x16& acc) {
-                       if (accumulate) init_rows(lds + (size_t)im * IS + (E0 + ot * 4) * 64, lane, acc); else init_zero(acc);
-                     },
-                     [&](int ot, int im, const f32x16& acc) {
-                       f32x4* li = lds + (size_t)im * IS;
-#pragma unroll
-                       for (int rq = 0; rq < 4; ++rq) li[(E0 + ot * 4 + rq) * 64 + lane] = acc_quad(acc, rq);
-                     });
-    }
-    __syncthreads();
+    wte_split_k(lds, IS, cur, 4 * sd.layers[0].n_out_tiles, wsdf + sd.layers[0].wTE_off, emb_tiles, oth, E0, sd.skip >= 1, wave, lane);
     FS(6)
     if (tid < 192) {
       const int im = tid / 96, r = tid - 96 * im, pp = r & 31, c = r >> 5;
