@@ -198,3 +198,71 @@ def test_dtu_projection_decomposition():
         np.testing.assert_allclose(intr[:3, :3], K, rtol=1e-9, atol=1e-9)
         np.testing.assert_allclose(pose[:3, :3], c2w[:3, :3], atol=1e-6)
         np.testing.assert_allclose(pose[:3, 3], c, atol=1e-5)
+
+
+def _cv_pose(angle, dist=2.5):
+    """OpenCV-style c2w (x right, y down, z forward) looking at the origin."""
+    o = np.array([dist * math.sin(angle), 0.3, dist * math.cos(angle)])
+    z = -o / np.linalg.norm(o)
+    x = np.cross(z, [0.0, -1.0, 0.0]); x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    m = np.eye(4)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = x, y, z, o
+    return m
+
+
+def _write_dtu_set(root, n=3, H=10, W=14, seed=5):
+    """train.json with world_mat / scale_mat lists + train_*/rgba.png; returns (images, unit-frame c2w poses, K)."""
+    rng = np.random.default_rng(seed)
+    K = np.array([[30.0 * W / 14, 0.0, W / 2.0, 0], [0, 28.0 * H / 10, H / 2.0, 0], [0, 0, 1.0, 0], [0, 0, 0, 1.0]])
+    scale = np.diag([2.0, 2.0, 2.0, 1.0]); scale[:3, 3] = [0.1, -0.2, 0.3]      # unit sphere -> world
+    world, imgs, poses = [], [], []
+    for i in range(n):
+        d = os.path.join(str(root), 'train_%03d' % i)
+        os.makedirs(d)
+        im = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+        PIL.fromarray(im, 'RGBA').save(os.path.join(d, 'rgba.png'))
+        imgs.append(im)
+        c2w = _cv_pose(0.9 * i)                                    # pose in the normalised (unit-sphere) frame
+        poses.append(c2w)
+        world.append((K @ np.linalg.inv(c2w) @ np.linalg.inv(scale)).tolist())    # so that world @ scale = K [R|t]
+    with open(os.path.join(str(root), 'train.json'), 'w') as f:
+        json.dump({'world_mat': world, 'scale_mat': [scale.tolist()] * n}, f)
+    return np.stack(imgs), poses, K
+
+
+def test_dtuset_matches_the_files(tmp_path):
+    """models/dtuset.py contract (dtuset.py:12-154): world_mat @ scale_mat is factored into K and the pose, rays come from
+    K^-1 and the pose, near / far from the unit sphere."""
+    from vqnerf_release_amd.geo import conf as hocon
+    from vqnerf_release_amd.geo.models.dtuset import Dataset
+    n, H, W = 3, 10, 14
+    imgs, poses, K = _write_dtu_set(tmp_path, n, H, W)
+    conf = hocon.parse_string('dataset { data_dir = %s }' % tmp_path)['dataset']
+    ds = Dataset(conf, device='cpu', seed=1)
+    assert (ds.n_images, ds.H, ds.W, ds.max_radius) == (n, H, W, 1.0)
+    np.testing.assert_allclose(ds.images.numpy(), imgs[..., [2, 1, 0]] / 255.0, atol=1e-7)
+    np.testing.assert_allclose(ds.pose_all.numpy(), np.stack(poses), atol=1e-5)
+    np.testing.assert_allclose(ds.intrinsics_all[0].numpy(), K, atol=1e-4)
+    np.testing.assert_allclose(ds.object_bbox_max, [1.01] * 3, atol=1e-6)
+    # cameras sit at |c| = sqrt(2.5^2 + 0.3^2) looking at the origin: depth of the sphere's near / far points
+    dist = math.sqrt(2.5 ** 2 + 0.3 ** 2)
+    assert abs(ds.near - (dist - 1.0)) < 1e-5 and abs(ds.far - (dist + 1.0)) < 1e-5
+    o, v = ds.gen_rays_at(1)
+    assert o.shape == v.shape == (H, W, 3)
+    np.testing.assert_allclose(v.norm(dim=-1).numpy(), 1.0, atol=1e-6)
+    np.testing.assert_allclose(v[5, 7].numpy(), poses[1][:3, 2], atol=1e-5)       # the principal-point pixel looks down +z
+    rays = ds.gen_random_rays_at(2, 150)
+    p = (rays[:, 3:6] @ ds.pose_all[2, :3, :3]).double()                          # R^T d, camera frame
+    px = torch.round(p[:, 0] / p[:, 2] * 30.0 + 7.0).long()
+    py = torch.round(p[:, 1] / p[:, 2] * 28.0 + 5.0).long()
+    assert torch.equal(rays[:, 6:9], ds.images[2][py, px]) and torch.equal(rays[:, 9], ds.masks[2][py, px][:, 0])
+    near, far = ds.near_far_from_sphere(rays[:, :3], rays[:, 3:6])
+    mid = -(rays[:, :3] * rays[:, 3:6]).sum(-1, keepdim=True)
+    np.testing.assert_allclose(near.numpy(), (mid - 1).numpy(), atol=1e-6)
+    np.testing.assert_allclose((far - near).numpy(), 2.0, atol=1e-6)
+    # new_h scales the intrinsics with the image (dtuset.py:37-45, :60)
+    ds2 = Dataset(hocon.parse_string('dataset { data_dir = %s\n new_h = 20 }' % tmp_path)['dataset'], device='cpu')
+    assert (ds2.H, ds2.W) == (20, 28)
+    np.testing.assert_allclose(ds2.intrinsics_all[0, :2, :3].numpy(), 2 * K[:2, :3], atol=1e-3)
+    assert ds.image_at(0, 2).shape == (H // 2, W // 2, 3)

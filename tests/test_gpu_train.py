@@ -59,6 +59,27 @@ def test_geo_runner_trains_from_a_blender_image_set(tmp_path):
     assert all(np.isfinite(losses)) and r.iter_step == 4
 
 
+def test_geo_runner_trains_from_a_projection_matrix_set(tmp_path):
+    """conf `dataset.data_dir` with train.json (world_mat / scale_mat) -> models/dtuset.Dataset -> Runner.train_step with
+    per-ray near / far from the unit sphere (dtu_runner.py:36, dtuset.py:142-149)."""
+    from tests.test_datasets import _write_dtu_set
+    from vqnerf_release_amd.geo.nerf_runner import Runner
+    from vqnerf_release_amd.geo.models.dtuset import Dataset
+    data = tmp_path / 'scan'
+    data.mkdir()
+    _write_dtu_set(data, n=3, H=24, W=32)
+    text = open(os.path.join(HERE, 'golden', 'neus_like.conf')).read().replace('./exp/', str(tmp_path) + '/exp/')
+    text = text.replace('warm_up_end = 5000', 'warm_up_end = 0').replace('batch_size = 64', 'batch_size = 128')
+    import re
+    text = re.sub(r'data_dir = [^\n]*', 'data_dir = %s/' % data, text, count=1)
+    torch.manual_seed(0)
+    r = Runner(conf_text=text, case='scan24')
+    assert isinstance(r.dataset, Dataset) and r.dataset.n_images == 3 and r.dataset.images.is_cuda and r.dataset.max_radius == 1.0
+    r.update_learning_rate()
+    losses = [float(r.train_step(r.dataset.gen_random_rays_at(it % 3, r.batch_size))['loss']) for it in range(4)]
+    assert all(np.isfinite(losses)) and r.iter_step == 4
+
+
 def test_decomp_trainer_trains():
     from oracle import decomp as od
     from vqnerf_release_amd.decomp.nerfactor import train_nfr

@@ -5,7 +5,7 @@ classes, plus rank-sharded data parallelism (the reference trains on one GPU).
 Out of scope here: TensorBoard, mesh export.  The dataset is any object with the reference's
 dataset contract -- `n_images`, `max_radius`, `gen_random_rays_at(img_idx, batch_size) -> [B,10]` (o, d, rgb, mask) and
 `near_far_from_sphere(rays_o, rays_d)`: `models.nerfset.Dataset` when the conf's `dataset.data_dir` holds a Blender-format
-image set (as nerf_runner.py:36 does), `SyntheticDataset` (tests, bench) otherwise.
+image set (as nerf_runner.py:36 does), `models.dtuset.Dataset` for a world_mat / scale_mat set (dtu_runner.py:36), `SyntheticDataset` (tests, bench) otherwise.
 """
 import math
 import os
@@ -81,6 +81,9 @@ class Runner:
             if data_dir and os.path.isfile(os.path.join(data_dir, 'transforms_train.json')):
                 from vqnerf_release_amd.geo.models.nerfset import Dataset
                 dataset = Dataset(dconf, is_train=(mode == 'train'), device=self.device)
+            elif data_dir and os.path.isfile(os.path.join(data_dir, 'train.json')):     # world_mat / scale_mat sets (dtu_runner.py:36)
+                from vqnerf_release_amd.geo.models.dtuset import Dataset
+                dataset = Dataset(dconf, is_train=(mode == 'train'), device=self.device)
             else:
                 dataset = SyntheticDataset(dconf, device=self.device)
         self.dataset = dataset
@@ -89,6 +92,7 @@ class Runner:
         self.end_iter, self.save_freq, self.report_freq = t.get_int('end_iter'), t.get_int('save_freq'), t.get_int('report_freq')
         self.val_freq, self.val_mesh_freq = t.get_int('val_freq'), t.get_int('val_mesh_freq')
         self.batch_size = t.get_int('batch_size')
+        self.lr_end_iter = t.get_int('lr_end_iter', -1)                 # dtu_runner.py:41, :192-194
         self.validate_resolution_level = t.get_int('validate_resolution_level')
         self.learning_rate, self.learning_rate_alpha = t.get_float('learning_rate'), t.get_float('learning_rate_alpha')
         self.use_white_bkgd = t.get_bool('use_white_bkgd')
@@ -124,7 +128,8 @@ class Runner:
         if self.iter_step < self.warm_up_end:
             factor = self.iter_step / self.warm_up_end
         else:
-            progress = (self.iter_step - self.warm_up_end) / (self.end_iter - self.warm_up_end)
+            end = self.end_iter if self.lr_end_iter < 0 else self.lr_end_iter
+            progress = (self.iter_step - self.warm_up_end) / (end - self.warm_up_end)
             factor = (np.cos(np.pi * progress) + 1.0) * 0.5 * (1 - self.learning_rate_alpha) + self.learning_rate_alpha
         for g in self.optimizer.param_groups:
             g['lr'] = float(self.learning_rate * factor)
