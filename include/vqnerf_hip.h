@@ -40,8 +40,10 @@ int vqn_vq_assign(const float* x, int64_t N, int D, const float* codebook, int K
  * counts [K], dw [D,K] are overwritten. */
 int vqn_vq_ema_stats(const float* x, const int64_t* idx, int64_t N, int D, int K, float* counts, float* dw,
                      float* ws, int64_t ws_bytes, void* stream);
-/* Bytes of device scratch `ws` that make vqn_vq_ema_stats use its deterministic two-pass form (per-wave LDS images,
- * fixed-order reduction; K*D <= 4096); 0 = not applicable.  With ws == NULL the single-pass LDS-atomic form runs. */
+/* Bytes of device scratch `ws` that make vqn_vq_ema_stats use a deterministic form with fixed-order reductions: the
+ * matrix-pipe form x^T . onehot(idx) for D % 64 == 0, D <= 256, K <= 64, else per-wave LDS images for K*D <= 4096;
+ * 0 = not applicable.  With ws == NULL (or too small) the single-pass LDS-atomic form runs.  Rows whose idx is outside
+ * [0, K) contribute nothing in every form. */
 int64_t vqn_vq_ema_stats_ws_bytes(int64_t N, int D, int K);
 
 /* ---- reflectance MLP stacks + shading (decomp/nerfvq_nfr3/nerfactor) ------------------------- */

@@ -65,7 +65,8 @@ def test_assign_ties_and_dropout_mask():
         np.testing.assert_array_equal(quant.cpu().numpy(), rquant)
 
 
-@pytest.mark.parametrize('N,D,K', [(5000, 256, 15), (2048, 256, 64), (33, 64, 5), (0, 256, 15)])
+@pytest.mark.parametrize('N,D,K', [(5000, 256, 15), (2048, 256, 64), (33, 64, 5), (0, 256, 15), (4099, 128, 20), (1, 256, 15),
+                                   (777, 32, 5), (3000, 320, 9)])
 def test_ema_stats(N, D, K):
     from oracle import vq_strict as vs
     from vqnerf_release_amd import _C
@@ -133,15 +134,16 @@ def test_full_size_properties():
     assert torch.equal(idx_p, idx[perm])                              # row-order independence
 
 
-def test_ema_stats_two_pass_is_deterministic_and_matches_atomic_form():
-    """K*D <= 4096 takes the two-pass form (per-wave LDS images, fixed-order reduction): bit-identical across runs;
-    larger codebooks take the LDS-atomic form; both agree with the fp64-accumulated oracle."""
+def test_ema_stats_is_deterministic_and_ignores_out_of_range_codes():
+    """D % 64 == 0, K <= 64 takes the matrix-pipe form (x^T . onehot on v_mfma_f32_16x16x4_f32, fixed-order reductions),
+    other K*D <= 4096 shapes the per-wave LDS images: both bit-identical across runs; all agree with the fp64-accumulated
+    oracle; rows whose index is outside [0, K) contribute nothing."""
     import torch
     from oracle import vq_strict
     from vqnerf_release_amd import _C
     rng = np.random.default_rng(3)
-    for K in (15, 64):
-        x = rng.uniform(0, 1, (50001, 256)).astype(np.float32)
+    for K, D in ((15, 256), (64, 256), (32, 192), (7, 96)):
+        x = rng.uniform(0, 1, (50001, D)).astype(np.float32)
         idx = rng.integers(0, K, 50001)
         xt, it = torch.tensor(x).cuda(), torch.tensor(idx).cuda()
         c1, d1 = _C.vq_ema_stats(xt, it, K)
@@ -149,5 +151,12 @@ def test_ema_stats_two_pass_is_deterministic_and_matches_atomic_form():
         rc, rd = vq_strict.ema_stats(x, idx, K)
         np.testing.assert_array_equal(c1.cpu().numpy(), rc)
         np.testing.assert_allclose(d1.cpu().numpy(), rd, rtol=2e-5, atol=1e-3)
-        if K * 256 <= 4096:
-            assert torch.equal(d1, d2) and torch.equal(c1, c2)
+        assert torch.equal(d1, d2) and torch.equal(c1, c2)
+        bad = idx.copy()
+        bad[::7] = K + (np.arange(len(bad[::7])) % 3)               # K, K+1, K+2: inside the padded code tile, outside [0, K)
+        bad[3::11] = -1
+        keep = (bad >= 0) & (bad < K)
+        c3, d3 = _C.vq_ema_stats(xt, torch.tensor(bad).cuda(), K)
+        rc3, rd3 = vq_strict.ema_stats(x[keep], bad[keep], K)
+        np.testing.assert_array_equal(c3.cpu().numpy(), rc3)
+        np.testing.assert_allclose(d3.cpu().numpy(), rd3, rtol=2e-5, atol=1e-3)

@@ -349,12 +349,12 @@ struct Smalls2 {
 
 // d sdf / d embedding of one layer for both images: E rows (+)= W_E^T . G over the K rows [k_row0, k_row0 + ng).  The result
 // has only emb_tiles (<= 2) output tiles, so as a plain gemm_tiles2 call it keeps 2 of the 8 waves busy for a whole K = 256 pass;
-// here the 8 waves split it as (tile, K slice) units, park their partial tiles in the free activation buffer `tmp_row0`
-// (4 rows per unit and image) and sum them in a fixed slice order.  Ends with the E rows written and a barrier passed.
+// here the waves split it as (tile, K slice) units, park their partial tiles in the free activation buffer `tmp_row0`
+// (4 rows per unit and image, `tmp_rows` available: 8 units at d_hidden = 256) and sum them in a fixed slice order.  Ends with the E rows written and a barrier passed.
 __device__ __forceinline__ void wte_split_k(f32x4* __restrict__ lds, const int IS, const int k_row0, const int ng,
-                                            const f32x4* __restrict__ w, const int emb_tiles, const int tmp_row0, const int e_row0,
-                                            const bool accumulate, const int wave, const int lane) {
-  const int KS = 8 / emb_tiles, gk = (ng + KS - 1) / KS;          // K slices, groups per slice
+                                            const f32x4* __restrict__ w, const int emb_tiles, const int tmp_row0, const int tmp_rows,
+                                            const int e_row0, const bool accumulate, const int wave, const int lane) {
+  const int KS = min(8, tmp_rows >> 2) / emb_tiles, gk = (ng + KS - 1) / KS;          // K slices (4 parking rows each), groups per slice
   const int t = wave % emb_tiles, kq = wave / emb_tiles;
   if (kq < KS) {
     f32x16 acc0, acc1;
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
       const KSegs ks{cur, 4 * L.n_out_tiles, 0, 0};
       const int dst = oth;
       if (l == sd.skip)                                 // embedding part of the skip layer first: `oth` is still free for the partials
-        wte_split_k(lds, IS, cur, 4 * L.n_out_tiles, wsdf + L.wTE_off, emb_tiles, oth, E0, false, wave, lane);
+        wte_split_k(lds, IS, cur, 4 * L.n_out_tiles, wsdf + L.wTE_off, emb_tiles, oth, 4 * MT, E0, false, wave, lane);
       f32x4 hv[2][4];
       gemm_tiles2<8>(lds, IS, ks, wsdf + L.wT_off, sd.layers[l - 1].n_out_tiles, wave, lane, nopre, false, nullptr,
                      [&](int ot, int im, f32x16& acc) {
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
       FS(8)
       const int t = cur; cur = oth; oth = t;
     }
-    wte_split_k(lds, IS, cur, 4 * sd.layers[0].n_out_tiles, wsdf + sd.layers[0].wTE_off, emb_tiles, oth, E0, sd.skip >= 1, wave, lane);
+    wte_split_k(lds, IS, cur, 4 * sd.layers[0].n_out_tiles, wsdf + sd.layers[0].wTE_off, emb_tiles, oth, 4 * MT, E0, sd.skip >= 1, wave, lane);
     FS(6)
     if (tid < 192) {
       const int im = tid / 96, r = tid - 96 * im, pp = r & 31, c = r >> 5;

@@ -257,6 +257,135 @@ __global__ void vq_ema_reduce_kernel(const float* __restrict__ part, long n_part
   else counts[i - KD] = s;
 }
 
+// ---- EMA statistics on the matrix pipe (D % 64 == 0, K <= 64): dw = x^T . onehot(idx) -------------------------------
+// This is literally the reference's statement (vq_layers.py:307-309, matmul(x, encodings, transpose_a=True)): a one-hot
+// operand is exact in f32 (x * 1, x * 0), so v_mfma_f32_16x16x4_f32 computes the segmented sums bit-for-bit as chains of
+// f32 adds, with no LDS read-modify-write per row and no atomics.  One wave step = 4 rows: lane (i, kq) fetches row kq's
+// features 64 j + 4 i + (0..3) (one dwordx4 per j: fully coalesced 1 KB rows) as the A operand of tiles (j, e) and builds
+// the B operand 1[idx[row kq] == 16 kt + i] on the fly; RU steps are in flight per wave.  Rows map to waves and steps in a
+// fixed pattern, the 4 waves of a workgroup are summed in wave order through LDS, and the per-workgroup images are summed
+// in index order by vq_ema_reduce2_kernel: bit-reproducible from launch to launch.
+template <int KT, int RU>
+__global__ __launch_bounds__(256) void vq_ema_mfma_kernel(const f32x4* __restrict__ x4, const long long* __restrict__ idx,
+                                                          long N, int DJ /* D / 64 */, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];        // [16 KT][D + 1] then [16 KT] counts
+  constexpr int MAXDJ = 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, kq = lane >> 4;
+  const int D = DJ * 64, D4 = DJ * 16;
+  f32x4 acc[MAXDJ][4][KT];
+  float cnt[KT];
+#pragma unroll
+  for (int j = 0; j < MAXDJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) acc[j][e][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) cnt[kt] = 0.f;
+
+  const long n_steps = (N + 3) >> 2, wid = (long)blockIdx.x * 4 + wave, nw = (long)gridDim.x * 4;
+  for (long s0 = wid; s0 < n_steps; s0 += nw * RU) {
+    f32x4 v[RU][MAXDJ];
+    long long kk[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {                       // unconditional, clamped fetches (a clamped row is zeroed below)
+      const long r = 4 * (s0 + u * nw) + kq, rc = r < N ? r : N - 1;
+      kk[u] = idx[rc];
+#pragma unroll
+      for (int j = 0; j < MAXDJ; ++j) v[u][j] = x4[rc * D4 + (j < DJ ? j : DJ - 1) * 16 + i];
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const bool valid = 4 * (s0 + u * nw) + kq < N;
+      float b[KT];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        b[kt] = (valid && kk[u] == (long long)(16 * kt + i)) ? 1.f : 0.f;
+        cnt[kt] += b[kt];
+      }
+#pragma unroll
+      for (int j = 0; j < MAXDJ; ++j) {
+        if (j < DJ) {
+          const f32x4 a = valid ? v[u][j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) acc[j][e][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[kt], acc[j][e][kt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // counts: lane (i, kq) holds the matches of code 16 kt + i among its rows -> sum the four kq groups in a fixed order
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    const float c1 = cnt[kt] + __shfl_xor(cnt[kt], 16);
+    cnt[kt] = c1 + __shfl_xor(c1, 32);
+  }
+  // accumulator tile (j, e), lane (n = i, q = kq), reg g  ->  code 16 kt + n, feature 64 j + 4 (4 q + g) + e
+  const int ld = D + 1;
+  float* cn = smem + (size_t)16 * KT * ld;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        float* row = smem + (size_t)(16 * kt + i) * ld;
+#pragma unroll
+        for (int j = 0; j < MAXDJ; ++j)
+          if (j < DJ) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int f = 64 * j + 4 * (4 * kq + g) + e;
+                row[f] = (w == 0 ? 0.f : row[f]) + acc[j][e][kt][g];
+              }
+          }
+        if (kq == 0) cn[16 * kt + i] = (w == 0 ? 0.f : cn[16 * kt + i]) + cnt[kt];
+      }
+    }
+    __syncthreads();
+  }
+  const int KP = 16 * KT;
+  float* out = part + (size_t)blockIdx.x * ((size_t)KP * D + KP);
+  for (int t = threadIdx.x; t < KP * D; t += 256) out[t] = smem[(size_t)(t / D) * ld + (t % D)];
+  for (int t = threadIdx.x; t < KP; t += 256) out[(size_t)KP * D + t] = cn[t];
+}
+
+// counts[k], dw[d][k] = sums over the per-workgroup images in index order.  16 thread groups split the images (independent
+// loads), thread group 0 adds the 16 group sums in group order.
+__global__ __launch_bounds__(256) void vq_ema_reduce2_kernel(const float* __restrict__ part, int n_part, int D, int K, int KP,
+                                                             float* __restrict__ counts, float* __restrict__ dw) {
+  __shared__ float sums[16][17];
+  const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int tot = K * D + K, t = blockIdx.x * 16 + o;            // output t: (k, d) for t < K D, else count of code t - K D
+  const size_t stride = (size_t)KP * D + KP;
+  const size_t src = t < K * D ? (size_t)t : (size_t)KP * D + (t - K * D);
+  const int per = (n_part + 15) >> 4, p0 = g * per, p1 = min(n_part, p0 + per);
+  float a = 0.f;
+  if (t < tot)
+    for (int p = p0; p < p1; ++p) a += part[(size_t)p * stride + src];
+  sums[g][o] = a;
+  __syncthreads();
+  if (g == 0 && t < tot) {
+    float r = sums[0][o];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) r += sums[k][o];
+    if (t < K * D) { const int k = t / D, d = t - k * D; dw[(size_t)d * K + k] = r; }
+    else counts[t - K * D] = r;
+  }
+}
+
+static bool ema_mfma_ok(int D, int K) { return D > 0 && (D & 63) == 0 && D <= 256 && K > 0 && K <= 64; }
+static int ema_mfma_kt(int K) { return K <= 16 ? 1 : K <= 32 ? 2 : 4; }
+static long ema_mfma_grid(long N, int K) {
+  const long per_cu = ema_mfma_kt(K) == 4 ? 1 : 2;          // KT = 4 keeps 256 accumulator registers: one wave per SIMD
+  long blocks = ((N + 3) / 4 + 3) / 4;                      // >= one 4-row step per wave
+  const long cap = (long)vqn_num_cus() * per_cu;
+  if (blocks > cap) blocks = cap;
+  return blocks < 1 ? 1 : blocks;
+}
+
 static long ema_grid(long N, int D, int K) {
   const size_t lds = (size_t)4 * (K * D + K) * sizeof(float);
   const long per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
@@ -318,6 +447,10 @@ extern "C" int vqn_vq_assign(const float* x, int64_t N, int D, const float* code
 }
 
 extern "C" int64_t vqn_vq_ema_stats_ws_bytes(int64_t N, int D, int K) {
+  if (N > 0 && ema_mfma_ok(D, K)) {
+    const int KP = 16 * ema_mfma_kt(K);
+    return ema_mfma_grid(N, K) * ((int64_t)KP * D + KP) * (int64_t)sizeof(float);
+  }
   if (N <= 0 || D <= 0 || K <= 0 || (long)K * D > 4096 || (D & 3)) return 0;       // 0: the single-pass (LDS-atomic) form is used
   return ema_grid(N, D, K) * 4 * (int64_t)(K * D + K) * (int64_t)sizeof(float);
 }
@@ -328,6 +461,30 @@ extern "C" int vqn_vq_ema_stats(const float* x, const int64_t* idx, int64_t N, i
   VQN_CHECK_ARG(counts && dw, "counts and dw must be non-null");
   hipStream_t s = (hipStream_t)stream;
   const int64_t need = vqn_vq_ema_stats_ws_bytes(N, D, K);
+  if (N > 0 && need > 0 && ws != nullptr && ws_bytes >= need && ema_mfma_ok(D, K)) {
+    VQN_CHECK_ARG(x && idx, "x and idx must be non-null");
+    VQN_CHECK_SHAPE(((uintptr_t)x % 16) == 0, "x must be 16-byte aligned");
+    const int KT = ema_mfma_kt(K), KP = 16 * KT, DJ = D / 64;
+    const long blocks = ema_mfma_grid(N, K);
+    const size_t lds = ((size_t)KP * (D + 1) + KP) * sizeof(float);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const long long* il = reinterpret_cast<const long long*>(idx);
+#define VQN_EMA_LAUNCH(KT_, RU_)                                                                                              \
+    do {                                                                                                                      \
+      if (lds > 64 * 1024)                                                                                                    \
+        VQN_HIP(hipFuncSetAttribute((const void*)vq_ema_mfma_kernel<KT_, RU_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      hipLaunchKernelGGL((vq_ema_mfma_kernel<KT_, RU_>), dim3((unsigned)blocks), dim3(256), lds, s, x4, il, (long)N, DJ, ws);  \
+    } while (0)
+    if (KT == 1) VQN_EMA_LAUNCH(1, 8);
+    else if (KT == 2) VQN_EMA_LAUNCH(2, 4);
+    else VQN_EMA_LAUNCH(4, 4);
+#undef VQN_EMA_LAUNCH
+    VQN_LAUNCH_CHECK();
+    const int tot = K * D + K;
+    hipLaunchKernelGGL(vq_ema_reduce2_kernel, dim3((tot + 15) / 16), dim3(256), 0, s, ws, (int)blocks, D, K, KP, counts, dw);
+    VQN_LAUNCH_CHECK();
+    return VQN_OK;
+  }
   if (N > 0 && need > 0 && ws != nullptr && ws_bytes >= need) {
     VQN_CHECK_ARG(x && idx, "x and idx must be non-null");
     VQN_CHECK_SHAPE(((uintptr_t)x % 16) == 0, "x must be 16-byte aligned");
