@@ -13,7 +13,7 @@ def t_gpu(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e-3
 
-N, D = 1 << 20, 256
+N, D = (int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20), 256
 g = torch.Generator(device='cuda'); g.manual_seed(0)
 x = torch.rand((N, D), device='cuda', generator=g)
 for K in (15, 32, 64):
