@@ -37,7 +37,7 @@ int vqn_vq_assign(const float* x, int64_t N, int D, const float* codebook, int K
 
 /* Replaces vq_layers.py:304-309 (the two reductions that feed the EMAs):
  *   counts[k] = #{n : idx[n] == k}   (as float),   dw[d,k] = sum_n x[n,d] [idx[n] == k].
- * counts [K], dw [D,K] are overwritten. */
+ * counts [K], dw [D,K] are overwritten.  dw == NULL: counts only (x is not read). */
 int vqn_vq_ema_stats(const float* x, const int64_t* idx, int64_t N, int D, int K, float* counts, float* dw,
                      float* ws, int64_t ws_bytes, void* stream);
 /* Bytes of device scratch `ws` that make vqn_vq_ema_stats use a deterministic form with fixed-order reductions: the
@@ -45,6 +45,15 @@ int vqn_vq_ema_stats(const float* x, const int64_t* idx, int64_t N, int D, int K
  * 0 = not applicable.  With ws == NULL (or too small) the single-pass LDS-atomic form runs.  Rows whose idx is outside
  * [0, K) contribute nothing in every form. */
 int64_t vqn_vq_ema_stats_ws_bytes(int64_t N, int D, int K);
+
+/* Replaces vq_layers.py:302 + :327 (and their autograd-free arithmetic) in one pass over the rows:
+ *   ste[i]  = x[i] + (quant[i] - x[i])          (the straight-through output as the reference writes it; NULL = skip)
+ *   *loss   = scale * sum_i (quant[i] - x[i])^2 (scale = 1 / numel gives mean((sg(q) - x)^2), the e_latent term)
+ * summed in a fixed order (bit-reproducible for a given numel).  numel = N * D, a multiple of 4; ws: VQN_STE_WS_FLOATS
+ * floats of device scratch.  numel == 0 writes NaN (the reference's mean over nothing). */
+#define VQN_STE_WS_FLOATS 1024
+int vqn_vq_ste_loss(const float* x, const float* quant, int64_t numel, float scale, float* ste, float* loss, float* ws,
+                    void* stream);
 
 /* ---- reflectance MLP stacks + shading (decomp/nerfvq_nfr3/nerfactor) ------------------------- */
 

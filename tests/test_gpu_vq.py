@@ -160,3 +160,29 @@ def test_ema_stats_is_deterministic_and_ignores_out_of_range_codes():
         rc3, rd3 = vq_strict.ema_stats(x[keep], bad[keep], K)
         np.testing.assert_array_equal(c3.cpu().numpy(), rc3)
         np.testing.assert_allclose(d3.cpu().numpy(), rd3, rtol=2e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize('N,D', [(4097, 256), (33, 64), (1, 4), (300000, 256)])
+def test_ste_and_commitment_pass(N, D):
+    """vqn_vq_ste_loss: x + (q - x) bit-exact against the same torch expression, mean((q - x)^2) against fp64, bit-identical
+    across runs; through the module: identity + 2 beta (x - q) / numel gradients (vq_layers.py:302, :327)."""
+    from vqnerf_release_amd import _C
+    g = torch.Generator(device='cuda'); g.manual_seed(N)
+    x = torch.rand((N, D), device='cuda', generator=g)
+    q = torch.rand((N, D), device='cuda', generator=g)
+    ste, loss = _C.vq_ste_loss(x, q)
+    assert torch.equal(ste, x + (q - x))
+    want = ((q.double() - x.double()) ** 2).mean()
+    assert abs(float(loss) - float(want)) <= 2e-6 * float(want)
+    _, loss2 = _C.vq_ste_loss(x, q, want_ste=False)
+    assert torch.equal(loss, loss2)
+
+
+def test_counts_only_path():
+    from vqnerf_release_amd import _C
+    rng = np.random.default_rng(0)
+    for N, K in ((100003, 15), (5, 64), (0, 8)):
+        idx = rng.integers(-1, K + 2, N)                              # includes out-of-range codes: ignored
+        got = _C.vq_counts(torch.tensor(idx, dtype=torch.int64).cuda(), K).cpu().numpy()
+        want = np.array([(idx == k).sum() for k in range(K)], np.float32)
+        np.testing.assert_array_equal(got, want)

@@ -142,6 +142,32 @@ def vq_ema_stats(x, idx, K):
     return counts, dw
 
 
+
+def vq_counts(idx, K):
+    """idx [N] int64 -> counts [K] float32 (= one_hot(idx, K).sum(0) without the [N,K] pass)."""
+    assert idx.dtype == torch.int64 and idx.is_contiguous()
+    counts = torch.empty((K,), dtype=torch.float32, device=idx.device)
+    with _clock('vqn_vq_ema_stats'):
+        rc = lib().vqn_vq_ema_stats(None, _ptr(idx), ctypes.c_int64(idx.numel()), ctypes.c_int(4), ctypes.c_int(K), _ptr(counts),
+                                    None, None, ctypes.c_int64(0), _stream())
+    _check(rc, 'vqn_vq_ema_stats')
+    return counts
+
+
+def vq_ste_loss(x, quant, want_ste=True):
+    """x, quant [N,D] -> (x + (quant - x) [N,D] or None, mean((quant - x)^2) scalar tensor), one fused pass."""
+    _f32c(x, 'x'); _f32c(quant, 'quant')
+    assert x.shape == quant.shape
+    n = x.numel()
+    ste = torch.empty_like(x) if want_ste else None
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    ws = torch.empty((1024,), dtype=torch.float32, device=x.device)
+    with _clock('vqn_vq_ste_loss'):
+        rc = lib().vqn_vq_ste_loss(_ptr(x), _ptr(quant), ctypes.c_int64(n), ctypes.c_float(1.0 / n if n else 0.0), _ptr(ste),
+                                   _ptr(loss), _ptr(ws), _stream())
+    _check(rc, 'vqn_vq_ste_loss')
+    return ste, loss
+
 # --------------------------------------------------------------------------------------
 # fused NeuS networks (csrc/neus_mlp.hip)
 _scratch = {}

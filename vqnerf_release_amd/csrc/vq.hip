@@ -388,6 +388,64 @@ __global__ __launch_bounds__(256) void vq_ema_reduce2_kernel(const float* __rest
   }
 }
 
+// ---- straight-through output + commitment term (vq_layers.py:302, :327) in one pass ---------------------------------
+//   ste = x + (q - x)   (the reference's expression, kept as written: it is q up to one rounding)
+//   loss = scale * sum((q - x)^2): per-thread chains over a fixed element pattern, fixed-order tree per workgroup,
+//   workgroup sums added in index order by the last kernel  -> bit-reproducible for a given shape.
+__global__ __launch_bounds__(256) void vq_ste_loss_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ q, long n4,
+                                                          f32x4* __restrict__ ste, float* __restrict__ part) {
+  __shared__ float red[256];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const long stride = (long)gridDim.x * 256;
+  for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+    f32x4 xv[4], qv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long i = min(i0 + u * stride, n4 - 1);
+      xv[u] = x[i]; qv[u] = q[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long i = i0 + u * stride;
+      if (i < n4) {
+        const f32x4 d = qv[u] - xv[u];
+        if (ste != nullptr) ste[i] = xv[u] + d;
+        s0 = fmaf(d[0], d[0], s0); s1 = fmaf(d[1], d[1], s1); s2 = fmaf(d[2], d[2], s2); s3 = fmaf(d[3], d[3], s3);
+      }
+    }
+  }
+  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(64) void vq_ste_loss_final_kernel(const float* __restrict__ part, int n, float scale, float* __restrict__ loss) {
+  float s = 0.f;                                         // lane l: part[l], part[l + 64], ... then a fixed xor tree
+  for (int i = threadIdx.x; i < n; i += 64) s += part[i];
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m);
+  if (threadIdx.x == 0) *loss = s * scale;
+}
+
+// counts only (dw == NULL): per-workgroup LDS histogram, then one float add of an integer per code and workgroup (sums of
+// integers are exact in f32 below 2^24, so the order of the atomics does not matter)
+__global__ __launch_bounds__(256) void vq_counts_kernel(const long long* __restrict__ idx, long N, int K, float* __restrict__ counts) {
+  extern __shared__ int hist[];
+  for (int k = threadIdx.x; k < K; k += 256) hist[k] = 0;
+  __syncthreads();
+  for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < N; r += (long)gridDim.x * 256) {
+    const long long k = idx[r];
+    if (k >= 0 && k < K) atomicAdd(&hist[(int)k], 1);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += 256)
+    if (hist[k]) atomicAdd(&counts[k], (float)hist[k]);
+}
+
 static bool ema_mfma_ok(int D, int K) { return D > 0 && (D & 63) == 0 && D <= 256 && K > 0 && K <= 64; }
 static int ema_mfma_kt(int K) { return K <= 16 ? 1 : K <= 32 ? 2 : 4; }
 static long ema_mfma_grid(long N, int K) {
@@ -470,8 +528,19 @@ extern "C" int64_t vqn_vq_ema_stats_ws_bytes(int64_t N, int D, int K) {
 extern "C" int vqn_vq_ema_stats(const float* x, const int64_t* idx, int64_t N, int D, int K, float* counts, float* dw,
                                 float* ws, int64_t ws_bytes, void* stream) {
   VQN_CHECK_ARG(N >= 0 && D > 0 && K > 0, "N >= 0, D > 0, K > 0 required");
-  VQN_CHECK_ARG(counts && dw, "counts and dw must be non-null");
+  VQN_CHECK_ARG(counts, "counts must be non-null");
   hipStream_t s = (hipStream_t)stream;
+  if (dw == nullptr) {                                  /* counts only */
+    VQN_HIP(hipMemsetAsync(counts, 0, sizeof(float) * K, s));
+    if (N == 0) return VQN_OK;
+    VQN_CHECK_ARG(idx, "idx must be non-null");
+    long blocks = (N + 4095) / 4096;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(vq_counts_kernel, dim3((unsigned)blocks), dim3(256), sizeof(int) * K, s,
+                       reinterpret_cast<const long long*>(idx), (long)N, K, counts);
+    VQN_LAUNCH_CHECK();
+    return VQN_OK;
+  }
   const int64_t need = vqn_vq_ema_stats_ws_bytes(N, D, K);
   if (N > 0 && need > 0 && ws != nullptr && ws_bytes >= need && ema_mfma_ok(D, K)) {
     VQN_CHECK_ARG(x && idx, "x and idx must be non-null");
@@ -527,6 +596,29 @@ extern "C" int vqn_vq_ema_stats(const float* x, const int64_t* idx, int64_t N, i
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(vq_ema_stats_kernel, dim3((unsigned)blocks), dim3(256), lds, s, x,
                      reinterpret_cast<const long long*>(idx), (long)N, D, K, counts, dw);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
+
+extern "C" int vqn_vq_ste_loss(const float* x, const float* quant, int64_t numel, float scale, float* ste, float* loss,
+                               float* ws, void* stream) {
+  VQN_CHECK_ARG(numel >= 0 && loss && ws, "numel >= 0, loss and ws (VQN_STE_WS_FLOATS floats) must be non-null");
+  hipStream_t s = (hipStream_t)stream;
+  if (numel == 0) {                                     /* mean over nothing: the reference yields NaN (0 / 0) */
+    const float nan = NAN;
+    VQN_HIP(hipMemcpyAsync(loss, &nan, sizeof(float), hipMemcpyHostToDevice, s));
+    return VQN_OK;
+  }
+  VQN_CHECK_ARG(x && quant, "x and quant must be non-null");
+  VQN_CHECK_SHAPE((numel & 3) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)quant % 16) == 0 && (ste == nullptr || ((uintptr_t)ste % 16) == 0),
+                  "numel multiple of 4 and 16-byte aligned tensors");
+  const long n4 = numel / 4;
+  long blocks = (n4 + 1023) / 1024;
+  if (blocks > 1024) blocks = 1024;                     /* = VQN_STE_WS_FLOATS */
+  hipLaunchKernelGGL(vq_ste_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const f32x4*>(x),
+                     reinterpret_cast<const f32x4*>(quant), n4, reinterpret_cast<f32x4*>(ste), ws);
+  VQN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(vq_ste_loss_final_kernel, dim3(1), dim3(64), 0, s, ws, (int)blocks, scale, loss);
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }

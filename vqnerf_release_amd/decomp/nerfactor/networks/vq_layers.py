@@ -47,6 +47,27 @@ class ExponentialMovingAverage(torch.nn.Module):
         return self.average
 
 
+class _SteAndCommitment(torch.autograd.Function):
+    """(inputs + sg(q - inputs), mean((sg(q) - inputs)^2)) in one fused pass (vq_layers.py:302, :327); gradients: identity
+    through the first output, 2 (inputs - q) / numel through the second."""
+
+    @staticmethod
+    def forward(ctx, inputs, quant):
+        x = inputs.detach().contiguous()
+        ste, loss = _C.vq_ste_loss(x.reshape(quant.shape), quant)
+        ctx.save_for_backward(x, quant)
+        return ste.reshape(inputs.shape), loss
+
+    @staticmethod
+    def backward(ctx, g_ste, g_loss):
+        x, q = ctx.saved_tensors
+        g = g_ste
+        if g_loss is not None:
+            gl = (x - q.reshape(x.shape)) * (g_loss * (2.0 / x.numel()))
+            g = gl if g is None else g + gl
+        return g, None
+
+
 class VectorQuantizerEMA(torch.nn.Module):
     def __init__(self, embedding_dim, num_embeddings, commitment_cost, seed, decay=0.999, epsilon=1e-5,
                  dtype=torch.float32, name='vector_quantizer_ema'):
@@ -86,11 +107,12 @@ class VectorQuantizerEMA(torch.nn.Module):
         idx, quant, dist = _C.vq_assign(x, cb, sel_mask=sel, want_quant=True, want_dist=return_distances)
         encodings = torch.nn.functional.one_hot(idx, K).to(flat.dtype)
         encoding_indices = idx.reshape(inputs.shape[:-1])
-        quantized = quant.reshape(inputs.shape)
-        e_latent_loss = torch.nn.functional.mse_loss(quantized, inputs)          # = mean((quantized - inputs)^2), one pass
+        quantized, e_latent_loss = _SteAndCommitment.apply(inputs, quant)        # straight-through estimator + mean((sg(q) - x)^2)
         ret = {}
+        counts = None
         if is_training:
             counts, dw = _C.vq_ema_stats(x, idx, K)
+            local_counts = counts
             if self.stats_all_reduce is not None:
                 counts, dw = self.stats_all_reduce(counts, dw)
             cs = self.ema_cluster_size(counts)
@@ -100,9 +122,11 @@ class VectorQuantizerEMA(torch.nn.Module):
             w = ema_dw / cs.reshape(1, -1)
             used = (counts > 0).to(w.dtype)
             ret['update'] = w * used[None, :] + cb * (1.0 - used[None, :])
+            counts = local_counts
+        else:
+            counts = _C.vq_counts(idx, K)
         loss = self.commitment_cost * e_latent_loss
-        quantized = inputs + (quantized - inputs).detach()          # straight-through estimator
-        avg_probs = encodings.mean(0)
+        avg_probs = counts / max(idx.numel(), 1)                  # = mean(encodings, 0) of this replica's rows
         perplexity = torch.exp(-torch.sum(avg_probs * torch.log(avg_probs + 1e-10)))
         ret.update({'quantize': quantized, 'loss': loss, 'perplexity': perplexity, 'encodings': encodings,
                     'encoding_indices': encoding_indices, 'distances': dist})
