@@ -361,6 +361,14 @@ class BrdfModel(ShapeModel):
             lvis = None
         return id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz, normal, lvis
 
+    def vis_batch(self, data_dict, outdir, mode='train', dump_raw_to=None, light_vis_h=256, alpha_thres=0.8, simp=False,
+                  full_vis_path=None, writer=None):
+        """Per-view output files of vq_nfr.py:988-1134, queued on an asynchronous writer (util/vis.py); returns the writer
+        (`.flush()` joins)."""
+        from vqnerf_release_amd.decomp.nerfactor.util import vis
+        return vis.vis_batch(self, data_dict, outdir, mode=mode, light_vis_h=light_vis_h, alpha_thres=alpha_thres, simp=simp,
+                             full_vis_path=full_vis_path, writer=writer)
+
 
 class Model(BrdfModel):
     def _init_net(self):
