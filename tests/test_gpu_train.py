@@ -57,6 +57,27 @@ def test_geo_runner_trains_from_a_blender_image_set(tmp_path):
     r.update_learning_rate()
     losses = [float(r.train_step(r.dataset.gen_random_rays_at(it % 3, r.batch_size))['loss']) for it in range(4)]
     assert all(np.isfinite(losses)) and r.iter_step == 4
+    # validation images (nerf_runner.py:236-343): prediction over the input view, alpha, inside-sphere weight, normals
+    from PIL import Image
+    r.renderer.perturb = 0.0                                     # (the conf's per-ray jitter would make two renders differ)
+    imgs = r.validate_image(idx=1, resolution_level=2)
+    base = os.path.join(str(tmp_path), 'exp')
+    found = {}
+    for root, _, files in os.walk(base):
+        for f in files:
+            if f.endswith('_0_1.png'):
+                found[os.path.basename(root)] = np.asarray(Image.open(os.path.join(root, f)))
+    assert set(found) == {'validations_fine', 'alpha', 'inside_sphere', 'normals'}
+    assert found['validations_fine'].shape == (24, 16, 3) and found['alpha'].shape == (12, 16) and found['normals'].shape == (12, 16, 3)
+    np.testing.assert_array_equal(found['validations_fine'][..., ::-1], imgs['validations_fine'])       # file = RGB of the (B,G,R) array
+    np.testing.assert_array_equal(found['validations_fine'][12:], r.dataset.image_at(1, 2)[..., ::-1])  # lower half: the input image
+    out = r.renderer.render(*[t.reshape(-1, 3).contiguous() for t in r.dataset.gen_rays_at(1, resolution_level=2)],
+                            *r.dataset.near_far_from_sphere(torch.zeros(192, 3).cuda(), torch.zeros(192, 3).cuda()), r.dataset.max_radius,
+                            cos_anneal_ratio=r.get_cos_anneal_ratio(), background_rgb=torch.ones(1, 3).cuda())
+    want = (out['color_fine'].reshape(12, 16, 3) * 256).clip(0, 255).to(torch.uint8).cpu().numpy()
+    np.testing.assert_array_equal(imgs['validations_fine'][:12], want)
+    bgn = found['normals'][found['alpha'] == 0]
+    assert bgn.size == 0 or (np.abs(bgn.astype(int) - int(128 / np.sqrt(3) + 128)) <= 1).all()        # background normal (1,1,1)/sqrt 3
 
 
 def test_geo_runner_trains_from_a_projection_matrix_set(tmp_path):

@@ -186,8 +186,59 @@ class Runner:
                 (log or print)(msg)
             if self.iter_step % self.save_freq == 0 and parallel.rank() == 0:
                 self.save_checkpoint()
+            if self.val_freq > 0 and self.iter_step % self.val_freq == 0 and parallel.rank() == 0 and hasattr(self.dataset, 'gen_rays_at'):
+                self.validate_image()                         # nerf_runner.py:152-153
             if self.iter_step % len(perm) == 0:
                 perm = self.get_image_perm()
+
+    # ---- validation images (nerf_runner.py:236-343) ----
+    @torch.no_grad()
+    def validate_image(self, idx=-1, resolution_level=-1, is_train=True, max_rays=1 << 18):
+        """Render view `idx` at 1/resolution_level and write what the reference writes: `validations_fine/` (prediction
+        stacked over the input image), `alpha/` (weight_sum > 0.5), `inside_sphere/`, `normals/` (unit normals over a
+        (1,1,1)/sqrt(3) background, * 128 + 128), named `{iter:08d}_0_{idx}.png` under base_exp_dir (`test/` below it when
+        not is_train).  Rays are rendered `max_rays` at a time by the fused kernels and the images are composed on the
+        device: one copy per image.  Arrays are handed to the PNG encoder in cv2's channel convention (B, G, R), as the
+        reference does with cv.imwrite.  Returns {name: uint8 array as written}."""
+        from PIL import Image
+        if idx < 0:
+            idx = int(np.random.randint(self.dataset.n_images))
+        if resolution_level < 0:
+            resolution_level = self.validate_resolution_level
+        rays_o, rays_d = self.dataset.gen_rays_at(idx, resolution_level=resolution_level)[:2]
+        H, W, _ = rays_o.shape
+        rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+        bg = torch.ones([1, 3], device=rays_o.device) if self.use_white_bkgd else None
+        n_s = self.renderer.n_samples + self.renderer.n_importance
+        rgb, mask, inside, normals = [], [], [], []
+        for o, d in zip(rays_o.split(max_rays), rays_d.split(max_rays)):
+            o, d = o.contiguous(), d.contiguous()
+            near, far = self.dataset.near_far_from_sphere(o, d)
+            out = self.renderer.render(o, d, near, far, self.dataset.max_radius, cos_anneal_ratio=self.get_cos_anneal_ratio(),
+                                       background_rgb=bg)
+            rgb.append(out['color_fine'])
+            mask.append((out['weight_sum'] > 0.5).float())
+            w = out['weights'][:, :n_s, None] * out['inside_sphere'][..., None]
+            normals.append((out['gradients'] * w).sum(dim=1))
+            inside.append(w.sum(dim=1))
+        rgb, mask, inside, normals = torch.cat(rgb), torch.cat(mask), torch.cat(inside), torch.cat(normals)
+
+        def unit(v):                                             # _np_norm (nerf_runner.py:397-403)
+            r = v.norm(dim=-1, keepdim=True)
+            return torch.where(r == 0, torch.full_like(v, math.sqrt(1.0 / 3.0)), v / r)
+
+        nrm = unit(normals) * mask + unit(torch.ones_like(normals)) * (1.0 - mask)
+        u8 = lambda t: t.clip(0, 255).to(torch.uint8).cpu().numpy()
+        imgs = {'validations_fine': u8(rgb.reshape(H, W, 3) * 256), 'alpha': u8(mask.reshape(H, W) * 256),
+                'inside_sphere': u8(inside.reshape(H, W) * 256), 'normals': u8(nrm.reshape(H, W, 3) * 128 + 128)}
+        if is_train:
+            imgs['validations_fine'] = np.concatenate([imgs['validations_fine'], self.dataset.image_at(idx, resolution_level)])
+        base = self.base_exp_dir if is_train else os.path.join(self.base_exp_dir, 'test')
+        for name, arr in imgs.items():
+            os.makedirs(os.path.join(base, name), exist_ok=True)
+            a = arr[..., ::-1] if arr.ndim == 3 else arr         # (B, G, R) array -> RGB file, what cv.imwrite does
+            Image.fromarray(np.ascontiguousarray(a)).save(os.path.join(base, name, '{:0>8d}_{}_{}.png'.format(self.iter_step, 0, idx)))
+        return imgs
 
     # ---- checkpoints: same keys / file names as nerf_runner.py:210-232 ----
     def save_checkpoint(self):
