@@ -1,0 +1,76 @@
+"""Epoch driver of the VQ stage (train_nfr.fit; reference main(), train_nfr.py:93-378): threshold schedule, main codebook
+size selection, per-epoch metrics (CPU); the whole loop on a two-view set with checkpoints, resume and validation
+output (GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.decomp_util import make_config
+
+
+def test_thres_schedule_and_main_vq_selection():
+    from vqnerf_release_amd.decomp.nerfactor import train_nfr
+    cfg = make_config(num_embed=8, num_drop=3, thres_str='0.1;0.2;0.4')
+    tt, vl, xs = train_nfr.thres_schedule(cfg)
+    np.testing.assert_allclose(tt, [0, 0, 0, 0, 0, 0.1, 0.2, 0.4])
+    assert xs == [5, 6, 7, 8] and len(vl) == 4
+    np.testing.assert_array_equal(vl[0], [0, 0, 0, 0, 0, 1, 1, 1])           # first: the fewest codes (5) ...
+    np.testing.assert_array_equal(vl[-1], [0] * 8)                             # ... last: all 8
+    tt2, _, _ = train_nfr.thres_schedule(make_config(num_embed=8, num_drop=3, thres_str='-'))
+    assert len(tt2) == 5 and not tt2.any()
+    sel = train_nfr.select_main_vq
+    assert sel([0.5, 0.3, 0.29, 0.28], 0.05) == 1       # drops, and no later size is more than 0.05 better
+    assert sel([0.5, 0.3, 0.2, 0.19], 0.05) == 2        # size 1 is beaten by > 0.05 later on; 2 is not
+    assert sel([0.3, 0.5, 0.6, 0.7], 0.05) == 3         # never improves on its predecessor: the full codebook
+    assert sel([0.5, 0.3, 0.2, 0.1], 0.05) == 3
+    assert sel([0.4, 0.3], 0.05) == 1
+
+
+def test_save_metas(tmp_path):
+    from vqnerf_release_amd.decomp.nerfactor import train_nfr
+    for e, vals in ((1, (30.0, 32.0)), (2, (35.0,))):
+        for b, psnr in enumerate(vals):
+            d = tmp_path / 'vis_vali' / ('epoch%09d' % e) / 'main_15' / ('batch%09d' % b)
+            d.mkdir(parents=True)
+            json.dump({'id': 'v', 'psnr': psnr}, open(d / 'metadata.json', 'w'))
+    m = train_nfr.save_metas(str(tmp_path))
+    assert m['psnr'] == [31.0, 35.0] and m['ssim'] == [None, None]
+    assert json.load(open(tmp_path / 'vis_vali' / 'metas.json'))['psnr'] == [31.0, 35.0]
+
+
+@pytest.mark.gpu
+def test_fit_trains_checkpoints_resumes_and_validates(tmp_path):
+    from tests.test_datasets import _write_decomp_view, _decomp_cfg
+    from vqnerf_release_amd.decomp.nerfactor import train_nfr
+    from vqnerf_release_amd.decomp.nerfactor.datasets import get_dataset_class
+    rng = np.random.default_rng(3)
+    for vid in ('train_000', 'train_001', 'val_000'):
+        _write_decomp_view(str(tmp_path / 'data'), str(tmp_path / 'geo'), vid, 24, 32, 512, rng, collapse=False)
+    cfg = _decomp_cfg(tmp_path, imh=24, n_rays_per_step=64, num_embed=6, num_drop=2, thres_str='0.2;0.4', epochs=4, ckpt_period=2,
+                      vali_period=4, vali_batches=1, total_sample_vq=64, best_thres=0.01, keep_recent_epochs=1, random_seed=5,
+                      cluster_center_path='')
+    Dataset = get_dataset_class('shape_unit')
+    tr, va = Dataset(cfg, 'train', device='cuda'), Dataset(cfg, 'vali', device='cuda')
+    out = str(tmp_path / 'run')
+    model, hist = train_nfr.fit(cfg, out, tr, va, epochs=2, log=lambda *_: None)
+    assert len(hist['loss']) == 2 and all(np.isfinite(hist['loss'])) and hist['vali'] == []
+    assert os.listdir(os.path.join(out, 'checkpoints')) == ['ckpt-2.pt'] and os.path.exists(os.path.join(out, 'cluster_init.npy'))
+    cb2 = model.get_codebook().detach().clone()
+    # resume: two more epochs from the checkpoint, then the validation pass with its output tree
+    model2, hist2 = train_nfr.fit(cfg, out, tr, va, log=lambda *_: None)
+    assert len(hist2['loss']) == 2 and os.listdir(os.path.join(out, 'checkpoints')) == ['ckpt-4.pt']
+    assert not torch.equal(model2.get_codebook(), cb2)
+    (v,) = hist2['vali']
+    assert v['step'] == 4 and len(v['drop_losses']) == 3 and 0 <= v['main_vq'] <= 2 and len(v['vis_dirs']) == 3
+    edir = os.path.join(out, 'vis_vali', 'epoch%09d' % 4)
+    subs = sorted(d for d in os.listdir(edir) if os.path.isdir(os.path.join(edir, d)))
+    assert len(subs) == 3 and sum(s.startswith('main_') for s in subs) == 1 and {s.replace('main_', '') for s in subs} == {'4', '5', '6'}
+    for s in subs:
+        files = os.listdir(os.path.join(edir, s, 'batch%09d' % 0))
+        assert 'pred_vq_rgb.png' in files and 'pred_rgb.png' in files and 'embed_map.png' in files
+    assert {'loss.json', 'vq_test_loss.json'} <= set(os.listdir(edir))
+    assert os.path.exists(os.path.join(out, 'vis_vali', 'vis_params', 'epoch%09d' % 4, 'vq_embed.npy'))
+    assert os.path.exists(os.path.join(edir, subs[0], 'pred_light.png')) and os.path.exists(os.path.join(out, 'vis_vali', 'metas.json'))

@@ -3,7 +3,9 @@
 classes, with rank-sharded data parallelism added (the reference's VQ stage is single-device; its only DP site is
 trainvali.py:436-486 for stages 1/3, which `train_iter` covers as well since the step contract is the same).
 
-The view loader is datasets/shape_unit.py; out of scope here: checkpoint managers, TensorBoard.
+The view loader is datasets/shape_unit.py.  `fit` (bottom of the file) is the epoch loop of the reference's main()
+(:93-378): threshold schedule, VQ test set, k-means init, checkpoints, validation output.  Out of scope: absl flags,
+tf.train.CheckpointManager, TensorBoard.
 """
 import torch
 
@@ -229,3 +231,194 @@ def z_cluster(model, init_batch_vis, init_z_path, num_embed, device='cuda', n_sa
     if init_z_path:
         np.save(init_z_path, z_centers)
     return z_centers
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Epoch driver of the VQ stage: the body of the reference's main() (train_nfr.py:93-378) as a function.  Kept: the code-
+# dropout threshold schedule, the VQ test set, the k-means codebook init at step 0, one optimisation step per training
+# view and epoch, `ckpt_period` / `vali_period`, the choice of the main codebook size from the drop-loss curve, the
+# validation output tree `vis_vali/epoch{e:09d}/{n | main_n}/batch{b:09d}` and `metas.json`.  Not kept (control plane):
+# absl flags, tf.train.CheckpointManager (-> torch.save files `ckpt-{step}.pt`), TensorBoard summaries, the matplotlib plot.
+
+def thres_schedule(config):
+    """(train_thres [K], val_thres_list (num_drop + 1 arrays, the last one dropping the most codes), x_list)
+    (train_nfr.py:183-197).  `thres_str` is ';'-separated (a ',' would split --config_override)."""
+    import numpy as np
+    num_embed, num_drop = config.getint('DEFAULT', 'num_embed'), config.getint('DEFAULT', 'num_drop')
+    thres_str = config.get('DEFAULT', 'thres_str')
+    train_thres = [0.0] * (num_embed - num_drop)
+    if thres_str != '-':
+        train_thres = train_thres + [float(x) for x in thres_str.split(';')]
+    val_thres_list = [np.array([0.0] * (num_embed - i) + [1.0] * i) for i in range(num_drop + 1)]
+    val_thres_list.reverse()
+    return np.array(train_thres), val_thres_list, list(range(num_embed - num_drop, num_embed + 1))
+
+
+def select_main_vq(drop_losses, main_thres):
+    """Index into val_thres_list of the codebook size to present as the main result (train_nfr.py:312-327): the first
+    interior i whose loss is lower than its predecessor's and within `main_thres` of every later one; else the last."""
+    n = len(drop_losses)
+    for i in range(1, n - 1):
+        if drop_losses[i - 1] > drop_losses[i] and all(drop_losses[i] - drop_losses[j] <= main_thres for j in range(i + 1, n)):
+            return i
+    return n - 1
+
+
+@torch.no_grad()
+def prepare_vq_data(config, per_sample_n, views, data_type, generator=None):
+    """`per_sample_n` random foreground rows of one pair sample per training view, concatenated (train_nfr.py:489-541)."""
+    cols = None
+    for view in views:
+        batch = outer_sample(view, config, data_type, generator=generator)
+        rows = torch.nonzero(batch[5][:, 0] > 0)[:, 0]
+        sel = rows[torch.randint(0, rows.numel(), (per_sample_n,), device=rows.device, generator=generator)]
+        picked = [t[sel] if torch.is_tensor(t) else t for t in batch]
+        if cols is None:
+            cols = [[p] for p in picked]
+        else:
+            for c, p in zip(cols, picked):
+                c.append(p)
+    return tuple(torch.cat(c, 0) if torch.is_tensor(c[0]) else c[0] for c in cols)
+
+
+def save_metas(outdir):
+    """vis_vali/metas.json: per-epoch means of the per-view metadata metrics (train_nfr.py:387-409)."""
+    import json, os
+    import numpy as np
+    root = os.path.join(outdir, 'vis_vali')
+    keys = ('psnr', 'ssim', 'lpips', 'psnr_luma', 'ssim_luma', 'mse')
+    metrics = {k: [] for k in keys}
+    for e_dir in sorted(os.listdir(root)) if os.path.isdir(root) else []:
+        if not e_dir.startswith('epoch'):
+            continue
+        ep = {k: [] for k in keys}
+        for sub, _, files in os.walk(os.path.join(root, e_dir)):
+            if os.path.basename(sub).startswith('batch') and 'metadata.json' in files:
+                with open(os.path.join(sub, 'metadata.json')) as f:
+                    for k, v in json.load(f).items():
+                        if k in ep:
+                            ep[k].append(v)
+        for k in keys:
+            metrics[k].append(float(np.mean(ep[k])) if ep[k] else None)
+    with open(os.path.join(root, 'metas.json'), 'w') as f:
+        json.dump(metrics, f)
+    return metrics
+
+
+def _latest_checkpoint(ckptdir):
+    import os, re
+    best = None
+    for n in os.listdir(ckptdir) if os.path.isdir(ckptdir) else []:
+        m = re.fullmatch(r'ckpt-(\d+)\.pt', n)
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), os.path.join(ckptdir, n))
+    return best
+
+
+def fit(config, outdir, dataset_train, dataset_vali=None, model=None, device='cuda', epochs=None, graph=False, seed=None,
+        log=print):
+    """Train the VQ stage for `epochs` (config `epochs`) passes over the training views; returns (model, history).
+
+    history: {'loss': [mean step loss per epoch], 'vali': [{'step', 'drop_losses', 'main_vq', 'vis_dirs'} ...]}."""
+    import json, os
+    import numpy as np
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    g = lambda k, cast, fb: cast(config.get('DEFAULT', k, fallback=str(fb)))
+    data_type = config.get('DEFAULT', 'data_type')
+    seed = g('random_seed', int, 0) if seed is None else seed
+    torch.manual_seed(seed)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    os.makedirs(outdir, exist_ok=True)
+    global_bs = dataset_train.bs
+    views_train = list(dataset_train.build_pipeline(no_shuffle=True))
+    vq_test_batch = prepare_vq_data(config, max(1, g('total_sample_vq', int, 4096) // max(1, dataset_train.get_n_views())),
+                                    views_train, data_type, generator=gen)
+    vali_views = []
+    if dataset_vali is not None and dataset_vali.get_n_views() > 0:
+        vali_views = list(dataset_vali.build_pipeline())[:g('vali_batches', int, 4)]
+    if model is None:
+        model = get_model_class(config.get('DEFAULT', 'model'))(config)
+        model.build_nets(device=device, seed=seed).to(device)
+    train_thres, val_thres_list, _ = thres_schedule(config)
+    num_embed, num_drop = config.getint('DEFAULT', 'num_embed'), config.getint('DEFAULT', 'num_drop')
+    epochs = config.getint('DEFAULT', 'epochs') if epochs is None else epochs
+    ckpt_period, vali_period = g('ckpt_period', int, 100), g('vali_period', int, 100)
+    keep = g('keep_recent_epochs', int, -1)
+    vis_view = g('vis_view', int, 0)
+    ckptdir = os.path.join(outdir, 'checkpoints')
+
+    # codebook: k-means over the encoder's latents of the training views at step 0 (train_nfr.py:206-228), else the checkpoint
+    latest = _latest_checkpoint(ckptdir)
+    step = 0
+    if latest is None:
+        zs = [model.init_z(outer_sample(v, config, data_type, generator=gen))['z_pred'] for v in views_train]
+        init_z_path = config.get('DEFAULT', 'cluster_center_path', fallback='') or os.path.join(outdir, 'cluster_init.npy')
+        model.set_codebook(z_cluster(model, zs, init_z_path, num_embed, device=device, seed=seed))
+    elif model._codebook is None:
+        model.set_codebook(np.zeros((num_embed, model.z_dim), np.float32))      # placeholder: the checkpoint below holds the values
+    _ = model.light                                              # lazy variables exist before the optimiser is built
+    model.register_trainable()
+    use_graph = bool(graph) and np.all(train_thres == 0.0)        # the captured step has no code dropout
+    opt, sched, clip = make_optimizer(config, model.trainable_variables, capturable=use_graph)
+    if latest is not None:
+        state = torch.load(latest[1], map_location=device, weights_only=False)
+        model.load_state_dict(state['net'])
+        opt.load_state_dict(state['optimizer'])
+        step = int(state['step'])
+        log(f'Resumed from step {step}: {latest[1]}')
+    trainer = Trainer(model, opt, clip=clip, sched=sched, graph=use_graph)
+    thres_arg = None if np.all(train_thres == 0.0) else torch.tensor(train_thres, dtype=torch.float32, device=device)
+
+    history = {'loss': [], 'vali': []}
+    for _ in range(step, epochs):
+        losses, loss_dicts = [], []
+        for view in views_train:
+            batch = outer_sample(view, config, data_type, generator=gen)
+            loss, _, loss_dict = trainer.train_iter(batch, global_bs, thres=thres_arg)
+            losses.append(loss.detach().clone())
+            loss_dicts.append({k: v.detach().float().mean() for k, v in loss_dict.items()})
+        step += 1
+        history['loss'].append(float(torch.stack(losses).mean()))           # one host sync per epoch
+        if step % ckpt_period == 0:
+            os.makedirs(ckptdir, exist_ok=True)
+            torch.save({'step': step, 'net': model.state_dict(), 'optimizer': opt.state_dict()}, os.path.join(ckptdir, f'ckpt-{step}.pt'))
+            if keep > 0:
+                olds = sorted(int(n[5:-3]) for n in os.listdir(ckptdir) if n.startswith('ckpt-') and n.endswith('.pt'))
+                for s in olds[:-keep]:
+                    os.remove(os.path.join(ckptdir, f'ckpt-{s}.pt'))
+            log(f'Checkpointed step {step}: loss_train {history["loss"][-1]:.6f}')
+        if vali_views and vali_period > 0 and step % vali_period == 0:
+            edir = os.path.join(outdir, 'vis_vali', 'epoch{e:09d}'.format(e=step))
+            os.makedirs(edir, exist_ok=True)
+            sums = {}
+            for d in loss_dicts:
+                for k, v in d.items():
+                    sums[k] = sums.get(k, 0.0) + float(v)
+            with open(os.path.join(edir, 'loss.json'), 'w') as f:
+                json.dump(sums, f)
+            scores = {'vqrgb': [], 'chromaticity': []}
+            for vt in val_thres_list:                            # drop-loss curve on the fixed VQ test set (:285-300)
+                ld = vali_vq(model, vq_test_batch, torch.tensor(vt, dtype=torch.float32, device=device))
+                scores['vqrgb'].append(float(ld['vqrgb'].mean()))
+                scores['chromaticity'].append(float(ld['chromaticity'].mean()) if 'chromaticity' in ld else scores['vqrgb'][-1])
+            with open(os.path.join(edir, 'vq_test_loss.json'), 'w') as f:
+                json.dump(scores, f)
+            main_vq = select_main_vq(scores['chromaticity'], g('best_thres', float, 0.0))
+            vis_dirs, writer = [], None
+            for i, vt in enumerate(val_thres_list):
+                vt_t = torch.tensor(vt, dtype=torch.float32, device=device)
+                for b, view in enumerate(vali_views):
+                    _, to_vis, _ = vali_iter(model, view, dataset_vali.bs, vt_t, full_vis=(b == vis_view))
+                    n_codes = str(num_embed - num_drop + i)
+                    vdir = os.path.join(edir, ('main_' + n_codes) if i == main_vq else n_codes, 'batch{b:09d}'.format(b=b))
+                    full = os.path.join(outdir, 'vis_vali', 'vis_params', 'epoch{e:09d}'.format(e=step)) \
+                        if (b == vis_view and i == len(val_thres_list) - 1) else None
+                    writer = model.vis_batch(to_vis, vdir, mode='vali', simp=True, full_vis_path=full)
+                    vis_dirs.append(vdir)
+            if writer is not None:
+                writer.flush()
+            history['vali'].append({'step': step, 'drop_losses': scores['chromaticity'], 'main_vq': main_vq, 'vis_dirs': vis_dirs})
+    if history['vali']:
+        save_metas(outdir)
+    return model, history
