@@ -123,9 +123,9 @@ class Model(BrdfModel):
         """dict(rgb=[per set], normal, rgb_diff, rgb_spec[, rgb_probes]) -- fused kernel without a graph, torch with."""
         if self._fused(xyz, *[t for m in materials for t in m]):
             pr = None
-            if probes and len(self.novel_probes) > 0:
-                pr = torch.stack([torch.as_tensor(lp, dtype=torch.float32, device=xyz.device).reshape(-1, 3)
-                                  for lp in self.novel_probes.values()], 0)
+            maps = list(self.novel_probes.values()) if probes is True else list(probes or [])
+            if maps:
+                pr = torch.stack([torch.as_tensor(lp, dtype=torch.float32, device=xyz.device).reshape(-1, 3) for lp in maps], 0)
             return self._shade(xyz, normal, rayo, lvis, materials, split=split, light=light, probes=pr)
         if self.train_backend == 'hip' and xyz.is_cuda and not split and not probes:
             return self._shade_train(xyz, normal, rayo, lvis, materials, light=light)
@@ -135,7 +135,7 @@ class Model(BrdfModel):
         out = {'rgb': [], 'normal': n_pred, 'rgb_diff': None, 'rgb_spec': None}
         for i, (a, s, r) in enumerate(materials):
             brdf, brdf_s, brdf_d = self._eval_brdf_at(surf2l, surf2c, n_pred, a, s, r)
-            rgb, _, rp = self._render(brdf, surf2l, n_pred, lvis, relight_probes=(probes and i == 0), light=light)
+            rgb, _, rp = self._render(brdf, surf2l, n_pred, lvis, relight_probes=(probes if i == 0 else False), light=light)
             out['rgb'].append(rgb)
             if probes and i == 0:
                 out['rgb_probes'] = rp
@@ -220,8 +220,10 @@ class Model(BrdfModel):
         scaled = (opt_scale is not None) and (not vis_scale)
         s_albedo, s_spec = (albedo * opt_scale, spec * opt_scale) if scaled else (albedo, spec)
         light = None if dst_env is None else self.novel_probes[dst_env]
-        sh = self._shade_or_render(xyz_m, normal_m, rayo, lvis_m, [(s_albedo, s_spec, rough)], light=light,
-                                   probes=relight_probes)
+        # every relighting condition of this call -- OLAT maps first, then the probes -- goes through ONE shading pass
+        n_olat = len(self.novel_olat) if relight_olat else 0
+        maps = (list(self.novel_olat.values()) if relight_olat else []) + (list(self.novel_probes.values()) if relight_probes else [])
+        sh = self._shade_or_render(xyz_m, normal_m, rayo, lvis_m, [(s_albedo, s_spec, rough)], light=light, probes=maps or False)
         rgb_pred = sh['rgb'][0]
         srgb = (lambda t: imgutil.linear2srgb(t)) if self.data_type == 'nerf' else (lambda t: t)
         if (opt_scale is not None) and vis_scale:
@@ -233,8 +235,10 @@ class Model(BrdfModel):
             pred['embed'] = scatter_rows(mask, embed_ind[:, None], n)
         if dst_env is not None:
             pred['rgb'] = scatter_rows(mask, srgb(rgb_pred), n)
-        if relight_probes:
-            pred['rgb_probes'] = scatter_rows(mask, srgb(sh['rgb_probes']), n)
+        if relight_olat and n_olat > 0:
+            pred['rgb_olat'] = scatter_rows(mask, srgb(sh['rgb_probes'][:, :n_olat]), n)
+        if relight_probes and len(maps) > n_olat:
+            pred['rgb_probes'] = scatter_rows(mask, srgb(sh['rgb_probes'][:, n_olat:]), n)
         gt = {'rgb': scatter_rows(mask, rgb_m, n), 'alpha': alpha}
         to_vis = {'id': id_, 'hw': hw}
         for k, v in pred.items():

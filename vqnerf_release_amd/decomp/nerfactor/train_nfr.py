@@ -422,3 +422,22 @@ def fit(config, outdir, dataset_train, dataset_vali=None, model=None, device='cu
     if history['vali']:
         save_metas(outdir)
     return model, history
+
+
+@torch.no_grad()
+def render_views(model, dataset, outroot, relight_olat=False, relight_probes=False, opt_scale=None, writer=None, log=None,
+                 **fast_render_kwargs):
+    """The inference loops of the reference's test.py (:180-266: `raw_test` / `pd_test` / `pd_relit` passes): every view of
+    `dataset` through `model.fast_render(mode='test', ...)`, its files queued into `outroot/batch{i:09d}` by the
+    asynchronous `vis_batch`.  Rendering of view i + 1 overlaps the encoding of view i; the returned writer's `.flush()`
+    waits for the files.  Returns (writer, number of views)."""
+    import os
+    n = 0
+    for i, batch in enumerate(dataset.build_pipeline()):
+        _, _, _, to_vis = model.fast_render(batch, mode='test', relight_olat=relight_olat, relight_probes=relight_probes,
+                                            opt_scale=opt_scale, **fast_render_kwargs)
+        writer = model.vis_batch(to_vis, os.path.join(outroot, 'batch{i:09d}'.format(i=i)), mode='test', writer=writer)
+        n += 1
+        if log is not None:
+            log(f'view {i} queued')
+    return writer, n
