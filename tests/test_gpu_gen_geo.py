@@ -46,3 +46,34 @@ def test_compute_geo_and_vis(tmp_path):
     ex.save_view(str(tmp_path / 'train_000'), H, W, geo, lvis)
     assert np.load(tmp_path / 'train_000' / 'lvis.npy').shape == (H, W, 512)
     assert np.load(tmp_path / 'train_000' / 'xyz.npy').dtype == np.float32
+
+
+def test_extract_views_shards_and_resumes(tmp_path):
+    """The per-view loop of gen_geo.py:126-180 over a Blender-format set: view range split `num_p / p_i` (the reference's
+    multi-GPU extraction), finished views skipped, files = the decomp loaders' contract."""
+    import os
+    from tests.test_datasets import _write_blender_set
+    from tests.test_gpu_neus_render import _build
+    from vqnerf_release_amd.geo import conf as hocon
+    from vqnerf_release_amd.geo.gen_geo import GeoExtractor
+    from vqnerf_release_amd.geo.models.nerfset import Dataset
+    _write_blender_set(str(tmp_path / 'scene'), n=3, H=10, W=12)
+    ds = Dataset(hocon.parse_string('dataset { data_dir = %s\n longint = false }' % (tmp_path / 'scene'))['dataset'], device='cuda')
+    cfg, sdf, col, var, ren = _build('small')
+    ren.n_importance, ren.up_sample_steps, ren.perturb = 16, 4, 0.0
+    ex = GeoExtractor(ren, max_radius=ds.max_radius, light_h=16, max_rays=8192)
+    out = str(tmp_path / 'surf')
+    assert ex.extract_views(ds, out, is_train=True, num_p=2, p_i=1) == [2]          # ceil(3 / 2) = 2 views per shard
+    assert ex.extract_views(ds, out, is_train=True, num_p=2, p_i=0) == [0, 1]
+    assert sorted(os.listdir(out)) == ['train_000', 'train_001', 'train_002']
+    assert set(os.listdir(os.path.join(out, 'train_001'))) == set(GeoExtractor.VIEW_FILES)
+    lv = np.load(os.path.join(out, 'train_001', 'lvis.npy'))
+    xyz, nrm = np.load(os.path.join(out, 'train_001', 'xyz.npy')), np.load(os.path.join(out, 'train_001', 'normal.npy'))
+    assert lv.shape == (10, 12, 512) and xyz.shape == nrm.shape == (10, 12, 3) and lv.dtype == np.float32
+    gt_bg = ds.masks[1, :, :, 0].cpu().numpy() == 0
+    assert (lv[gt_bg] == 0).all()                                                    # visibility lives on the ground-truth mask
+    assert ex.extract_views(ds, out, is_train=True) == []                            # everything finished: nothing to do
+    os.remove(os.path.join(out, 'train_002', 'lvis.npy'))
+    assert ex.extract_views(ds, out, is_train=True) == [2]
+    assert ex.extract_views(ds, str(tmp_path / 'val'), is_train=False, no_vis=True, alpha_thres=0.8) == [0, 1, 2]
+    assert 'lvis.npy' not in os.listdir(tmp_path / 'val' / 'val_000') and ex.extract_views(ds, str(tmp_path / 'val'), is_train=False, no_vis=True) == []

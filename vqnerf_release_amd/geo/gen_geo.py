@@ -115,3 +115,50 @@ class GeoExtractor:
         Image.fromarray(u8(npf(geo['normal'], 3) * 128 + 128)).save(os.path.join(view_dir, 'normal.png'))
         if lvis is not None:
             Image.fromarray(u8(npf(lvis, lvis.shape[-1]).mean(-1) * 256)).save(os.path.join(view_dir, 'lvis.png'))
+        Image.fromarray(u8(npf(geo['surf'], 3))).save(os.path.join(view_dir, 'xyz.png'))    # the reference's clipped preview
+
+    VIEW_FILES = ('lvis.npy', 'lvis.png', 'alpha.png', 'normal.npy', 'normal.png', 'rgb.png', 'xyz.npy', 'xyz.png')
+
+    @classmethod
+    def check_finished(cls, view_dir, no_vis=False):
+        """All files of a view present (gen_geo.py:371-381): lets an interrupted / sharded run pick up where it stopped."""
+        return all(os.path.exists(os.path.join(view_dir, f)) for f in cls.VIEW_FILES if not (no_vis and f.startswith('lvis')))
+
+    @torch.no_grad()
+    def extract_views(self, dataset, scene_out_dir, is_train=True, resolution_level=1, num_p=None, p_i=None, no_vis=False,
+                      alpha_thres=0.5, log=None):
+        """The per-view loop of gen_geo.py:126-180: geometry buffers (+ light visibility unless `no_vis`) of every view of
+        `dataset` into `scene_out_dir/{train,val}_{idx:03d}/`.  Views are independent, so multi-GPU extraction is a split of
+        the view range with no collective -- `--num_p / --p_i` in the reference (README.md:45-53), by default rank /
+        world_size of the process group here.  Training views use the ground-truth mask for visibility (the decomp stage
+        trains on it) and alpha_thres 0.5; validation views use the predicted mask at `alpha_thres`.  Returns the indices done."""
+        import math
+        from vqnerf_release_amd import parallel
+        if num_p is None:
+            num_p, p_i = parallel.world_size(), parallel.rank()
+        n = dataset.n_images
+        p_step = math.ceil(n / num_p)
+        prefix = 'train_' if is_train else 'val_'
+        done = []
+        for idx in range(p_i * p_step, min(n, (p_i + 1) * p_step)):
+            view_dir = os.path.join(scene_out_dir, prefix + '{i:03d}'.format(i=idx))
+            if self.check_finished(view_dir, no_vis=no_vis):
+                continue
+            rays = dataset.gen_rays_at(idx, resolution_level=resolution_level)
+            rays_o, rays_d = rays[0], rays[1]
+            H, W, _ = rays_o.shape
+            o, d = rays_o.reshape(-1, 3).contiguous(), rays_d.reshape(-1, 3).contiguous()
+            near, far = dataset.near_far_from_sphere(o, d)
+            geo = self.compute_geo(o, d, near, far, alpha_thres=0.5 if is_train else alpha_thres)
+            lvis = None
+            if not no_vis:
+                mask = geo['mask']
+                gt = getattr(dataset, 'masks', None)
+                if is_train and gt is not None and tuple(gt.shape[1:3]) == (H, W):
+                    mask = (gt[idx, :, :, :1].reshape(-1, 1) > 0).float().to(o.device)
+                lvis = self.compute_vis(geo['surf'], geo['normal'], mask)
+            self.save_view(view_dir, H, W, geo, lvis)
+            done.append(idx)
+            if log is not None:
+                log(f'{prefix}{idx:03d}: done')
+        return done
