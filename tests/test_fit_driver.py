@@ -86,3 +86,48 @@ def test_fit_trains_checkpoints_resumes_and_validates(tmp_path):
     w.flush()
     files = set(os.listdir(tmp_path / 'pd_relit' / ('batch%09d' % 0)))
     assert n == 1 and {'pred_rgb_probes_city.png', 'pred_rgb_probes_forest.png', 'pred_rgb_olat_0004-0008.png', 'metadata.json'} <= files
+
+
+def test_outer_sample_max_colour_difference_neighbour():
+    """trainvali.py:327-336: every pixel is paired with the 8-neighbour whose colour differs most (first one on ties)."""
+    from vqnerf_release_amd.decomp.nerfactor import train_nfr
+    H, W = 9, 11
+    rng = np.random.default_rng(0)
+    rgb = rng.uniform(0, 1, (H, W, 3)).astype(np.float32)
+    rgb[4, 5] = rgb[4, 4]                                            # a tie candidate
+    N = H * W
+    hw = torch.tensor([[H, W]] * N)
+    flat_idx = torch.arange(N, dtype=torch.float32)[:, None]
+    batch = (['v'], hw, flat_idx.clone(), torch.zeros(N, 3), torch.tensor(rgb.reshape(N, 3)), torch.ones(N, 1), torch.ones(N, 1),
+             torch.zeros(N, 3), torch.zeros(N, 3), torch.zeros(N, 4))
+    cfg = make_config(n_rays_per_step=200)
+    out = train_nfr.outer_sample(batch, cfg, 'nerf', generator=torch.Generator().manual_seed(0), neighbour='max_diff')
+    idx = out[2][:, 0].long().numpy()                                # rayo slot carries the flat pixel index
+    jit = [(-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1)]
+    for p, q in zip(idx[0::2], idx[1::2]):
+        y, x = divmod(int(p), W)
+        d = [np.abs(rgb[y + dy, x + dx] - rgb[y, x]).max() for dy, dx in jit]
+        k = int(np.argmax(d))
+        assert 1 <= y < H - 1 and 1 <= x < W - 1 and int(q) == (y + jit[k][0]) * W + x + jit[k][1]
+
+
+@pytest.mark.gpu
+def test_fit_stage_trains_stage1_with_a_pretrain_epoch(tmp_path):
+    from tests.test_datasets import _write_decomp_view, _decomp_cfg
+    from vqnerf_release_amd.decomp.nerfactor import train_nfr
+    from vqnerf_release_amd.decomp.nerfactor.datasets import get_dataset_class
+    rng = np.random.default_rng(3)
+    for vid in ('train_000', 'train_001', 'val_000'):
+        _write_decomp_view(str(tmp_path / 'data'), str(tmp_path / 'geo'), vid, 24, 32, 512, rng, collapse=False)
+    cfg = _decomp_cfg(tmp_path, imh=24, n_rays_per_step=64, model='nfr_unit', epochs=3, pretrain_epochs=1, ckpt_period=3, vali_period=3,
+                      vali_batches=1, random_seed=2)
+    Dataset = get_dataset_class('shape_unit')
+    tr, va = Dataset(cfg, 'train', device='cuda'), Dataset(cfg, 'vali', device='cuda')
+    model, hist = train_nfr.fit_stage(cfg, str(tmp_path / 'run1'), tr, va, log=lambda *_: None)
+    assert type(model).__module__.endswith('nfr_unit') and len(hist['loss']) == 3 and all(np.isfinite(hist['loss']))
+    assert os.listdir(tmp_path / 'run1' / 'checkpoints') == ['ckpt-3.pt'] and len(hist['vali_dirs']) == 1
+    files = set(os.listdir(hist['vali_dirs'][0]))
+    assert {'pred_rgb.png', 'gt_rgb.png', 'pred_albedo.png', 'pred_albedo.npy', 'metadata.json'} <= files
+    meta = json.load(open(os.path.join(hist['vali_dirs'][0], 'metadata.json')))
+    assert meta['id'] == 'val_000' and np.isfinite(meta['psnr'])
+    assert json.load(open(tmp_path / 'run1' / 'vis_vali' / 'metas.json'))['psnr'] == [meta['psnr']]

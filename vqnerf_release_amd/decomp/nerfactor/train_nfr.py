@@ -72,12 +72,14 @@ class Trainer:
             model.get_codebook()
             model.vq_layer.stats_all_reduce = parallel.VQStatsReducer()
 
-    def train_iter(self, batch, global_bs, thres=None, roll=None):
-        """One step (train_nfr.py:562-576).  `global_bs` is the reference's normaliser (n_rays_per_step, :571-572) times
+    def train_iter(self, batch, global_bs, thres=None, roll=None, **call_kwargs):
+        """One step (train_nfr.py:562-576; trainvali.py:450-486 for the stage-1 / stage-3 models, whose extra call
+        arguments -- `pretrain`, `bias_weight` -- go through `call_kwargs`).  `global_bs` is the reference's normaliser (n_rays_per_step, :571-572) times
         the number of ranks when each rank draws its own rays.  Returns (weighted_loss summed over ranks, to_vis, loss_dict)."""
+        self._call_kwargs = call_kwargs
         if self.graph:
-            if thres is not None or roll is not None:
-                raise ValueError('code dropout (`thres` / `roll`) is drawn on the host: not available under graph=True')
+            if thres is not None or roll is not None or call_kwargs:
+                raise ValueError('code dropout (`thres` / `roll`) and per-call arguments are host-side: not available under graph=True')
             self._calls += 1
             if self._calls > self.GRAPH_WARMUP:
                 return self._replay(batch, global_bs)
@@ -127,7 +129,8 @@ class Trainer:
         kw = {'thres': thres}
         if roll is not None:
             kw['roll'] = roll
-        pred, gt, loss_kwargs, to_vis = model(batch, mode='train', **kw) if hasattr(model, 'vq_layer') else model(batch, mode='train')
+        pred, gt, loss_kwargs, to_vis = model(batch, mode='train', **kw) if hasattr(model, 'vq_layer') \
+            else model(batch, mode='train', **getattr(self, '_call_kwargs', {}))
         loss_kwargs.pop('pretrain', None), loss_kwargs.pop('env', None)
         per_example, loss_dict = model.compute_loss(pred, gt, **loss_kwargs)
         weighted = compute_average_loss(per_example, global_bs)
@@ -184,8 +187,9 @@ def vali_vq(model, batch, thres=None, full_vis=False):
 
 
 @torch.no_grad()
-def outer_sample(batch, config, data_type, alpha_thres=0.9, generator=None):
-    """Pair sampler (train_nfr.py:380-467): `n_rays_per_step` interior foreground pixels, each with one random
+def outer_sample(batch, config, data_type, alpha_thres=0.9, generator=None, neighbour='random'):
+    """Pair sampler (train_nfr.py:380-467; `neighbour='max_diff'`: the variant of trainvali.py:327-336 used by stages 1 / 3,
+    which pairs every pixel with the 8-neighbour whose colour differs most, first one on ties): `n_rays_per_step` interior foreground pixels, each with one random
     8-neighbour, interleaved [p1, p1_n, p2, p2_n, ...] -- entirely on the device (the reference syncs `hw[0,:]`
     to the host and gathers with TF ops).  `batch` holds one full view, rays on dim 0 in row-major (h, w) order."""
     bs = config.getint('DEFAULT', 'n_rays_per_step')
@@ -196,7 +200,13 @@ def outer_sample(batch, config, data_type, alpha_thres=0.9, generator=None):
     jit = torch.tensor([[-1, -1], [-1, 0], [-1, 1], [0, -1], [0, 1], [1, -1], [1, 0], [1, 1]], device=dev)
     ii, jj = torch.meshgrid(torch.arange(1, H - 1, device=dev), torch.arange(1, W - 1, device=dev), indexing='ij')
     coords = torch.stack([ii, jj], -1).reshape(-1, 2)
-    pick = torch.randint(0, 8, (coords.shape[0],), device=dev, generator=generator)
+    if neighbour == 'max_diff':
+        rgb2 = tensors[4].reshape(H, W, -1)
+        nb = coords[None, :, :] + jit[:, None, :]                                          # [8, n, 2]
+        diff = (rgb2[nb[..., 0], nb[..., 1]] - rgb2[coords[:, 0], coords[:, 1]][None]).abs().amax(-1)
+        pick = torch.argmax((diff == diff.amax(0, keepdim=True)).to(torch.uint8), dim=0)  # first maximum, as tf.argmax
+    else:
+        pick = torch.randint(0, 8, (coords.shape[0],), device=dev, generator=generator)
     coords_n = coords + jit[pick]
     a2 = alpha.reshape(H, W)
     if alpha_thres is not None:
@@ -441,3 +451,77 @@ def render_views(model, dataset, outroot, relight_olat=False, relight_probes=Fal
         if log is not None:
             log(f'view {i} queued')
     return writer, n
+
+
+def fit_stage(config, outdir, dataset_train, dataset_vali=None, model=None, device='cuda', epochs=None, seed=None, log=print):
+    """Epoch loop of the stage-1 (`nfr_unit`) and stage-3 (`ref_nfr`) models: the shape_unit branch of trainvali.py:201-318.
+    One max-colour-difference pair sample and one step per training view and epoch; `pretrain=True` with `bias_weight` for
+    the first `pretrain_epochs` epochs; checkpoints every `ckpt_period`; every `vali_period` the summed loss terms
+    (`loss.json`) and the validation views through `vis_batch` into `vis_vali/epoch{e:09d}/batch{b:09d}`, then `metas.json`.
+    Returns (model, {'loss': [...], 'vali_dirs': [...]})."""
+    import json, os
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    g = lambda k, cast, fb: cast(config.get('DEFAULT', k, fallback=str(fb)))
+    data_type = config.get('DEFAULT', 'data_type')
+    seed = g('random_seed', int, 0) if seed is None else seed
+    torch.manual_seed(seed)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    os.makedirs(outdir, exist_ok=True)
+    if model is None:
+        model = get_model_class(config.get('DEFAULT', 'model'))(config)
+        model.build_nets(device=device, seed=seed).to(device)
+    _ = model.light
+    model.register_trainable()
+    opt, sched, clip = make_optimizer(config, model.trainable_variables)
+    ckptdir = os.path.join(outdir, 'checkpoints')
+    latest, step = _latest_checkpoint(ckptdir), 0
+    if latest is not None:
+        state = torch.load(latest[1], map_location=device, weights_only=False)
+        model.load_state_dict(state['net'])
+        opt.load_state_dict(state['optimizer'])
+        step = int(state['step'])
+        log(f'Resumed from step {step}: {latest[1]}')
+    trainer = Trainer(model, opt, clip=clip, sched=sched)
+    epochs = config.getint('DEFAULT', 'epochs') if epochs is None else epochs
+    pretrain_epochs = g('pretrain_epochs', int, 0)
+    ckpt_period, vali_period = g('ckpt_period', int, 100), g('vali_period', int, 100)
+    views_train = list(dataset_train.build_pipeline(no_shuffle=True))
+    vali_views = list(dataset_vali.build_pipeline())[:g('vali_batches', int, 4)] if dataset_vali is not None and dataset_vali.get_n_views() else []
+    import inspect
+    accepted = set(inspect.signature(model.call).parameters)
+    only = lambda d: {k: v for k, v in d.items() if k in accepted}      # nfr_unit takes `pretrain`, ref_nfr only `bias_weight`
+    hist = {'loss': [], 'vali_dirs': []}
+    for _ in range(step, epochs):
+        kw = only({'pretrain': step < pretrain_epochs, 'bias_weight': 1.0})
+        losses, sums = [], {}
+        for view in views_train:
+            batch = outer_sample(view, config, data_type, generator=gen, neighbour='max_diff')
+            loss, _, loss_dict = trainer.train_iter(batch, dataset_train.bs, **kw)
+            losses.append(loss.detach().clone())
+            for k, v in loss_dict.items():
+                sums[k] = sums.get(k, 0.0) + v.detach().float().mean()
+        pre = step < pretrain_epochs
+        step += 1
+        hist['loss'].append(float(torch.stack(losses).mean()))
+        if step % ckpt_period == 0:
+            os.makedirs(ckptdir, exist_ok=True)
+            torch.save({'step': step, 'net': model.state_dict(), 'optimizer': opt.state_dict()}, os.path.join(ckptdir, f'ckpt-{step}.pt'))
+            log(f'Checkpointed step {step}: loss_train {hist["loss"][-1]:.6f}')
+        if vali_views and vali_period > 0 and step % vali_period == 0:
+            edir = os.path.join(outdir, 'vis_vali', 'epoch{e:09d}'.format(e=step))
+            os.makedirs(edir, exist_ok=True)
+            with open(os.path.join(edir, 'loss.json'), 'w') as f:
+                json.dump({k: float(v) for k, v in sums.items()}, f)
+            writer = None
+            with torch.no_grad():
+                for b, view in enumerate(vali_views):
+                    _, _, _, to_vis = model(view, mode='vali', **only({'pretrain': pre, 'bias_weight': 1.0}))
+                    vdir = os.path.join(edir, 'batch{b:09d}'.format(b=b))
+                    writer = model.vis_batch(to_vis, vdir, mode='vali')
+                    hist['vali_dirs'].append(vdir)
+            if writer is not None:
+                writer.flush()
+    if hist['vali_dirs']:
+        save_metas(outdir)
+    return model, hist
