@@ -220,10 +220,12 @@ def test_outer_sample_pairs_are_neighbours():
     assert (p[:, 1] >= 10).all() and (out[5] > 0.9).all()          # both foreground
 
 
-@pytest.mark.parametrize('name,B', [('small', 96), ('full', 48), ('small', 7), ('full', 2)])
+@pytest.mark.parametrize('name,B', [('small', 96), ('full', 48), ('small', 7), ('full', 2), ('full', 700)])
 def test_hip_training_programs_match_torch_autograd(name, B):
     """The explicit forward / backward tile programs (+ compositing backward kernel + weight-gradient contraction)
-    against torch autograd over the torch statements of the same modules: loss, every parameter gradient."""
+    against torch autograd over the torch statements of the same modules: loss, every parameter gradient.  B = 700 rays of
+    the full networks = 89,600 fine samples = 2,800 point tiles: more than one pass of the persistent workgroups and of the
+    split-K weight-gradient partials."""
     from oracle import geo as og
     from tests.test_gpu_neus_render import _build
     cfg, sdf, col, var, ren = _build(name)
