@@ -4,7 +4,7 @@
 // RenderingNetwork), once per adjoint stream.
 //
 // One workgroup = 4 waves owns the whole [<=256 x <=256] output block for a strided subset of the 32-point tiles
-// (split-K over points); wave w accumulates output tiles (ot in {w, w+4}) x (it in 0..7) in 256 accumulator
+// (split-K over points); wave w accumulates output tiles (ot in {w, w+4}) x (it in 0..7) in up to 256 accumulator
 // registers.  Operands stream straight from HBM into MFMA fragments: lane (feature, kk) reads 4 consecutive points
 // (one dwordx4) per 4 MFMAs; the point -> K-slot assignment is a fixed permutation shared by A and B, which a sum
 // over points does not care about.  Partial blocks go to a workspace [n_split][rows][cols]; the caller reduces them
@@ -13,30 +13,33 @@
 
 namespace {
 
-template <int NOT /* ot per wave */>
+// NOT: output tiles per wave (1: a_nt <= 4, 2: a_nt <= 8); BT: B tiles held (4 or 8); D: operand buffers = steps in flight.
+template <int NOT, int BT, int D>
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__ A, int a_tiles, int a_t0, int a_nt,
                                                        const float* __restrict__ B, int b_tiles, int b_t0, int b_nt,
                                                        long n_ptiles, float* __restrict__ ws, float* __restrict__ rowsum_ws) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: scalar guards around the MFMA groups
   const int fi = lane & 31, kk = lane >> 5;
-  f32x16 acc[NOT][8];
+  f32x16 acc[NOT][BT];
 #pragma unroll
   for (int a = 0; a < NOT; ++a)
 #pragma unroll
-    for (int b = 0; b < 8; ++b)
+    for (int b = 0; b < BT; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
   f32x4 rs[NOT];                                 // running sum over points of this lane's A values (-> bias gradients)
 #pragma unroll
   for (int a = 0; a < NOT; ++a) rs[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // One register-resident wave per SIMD: nothing else hides the HBM latency of the operand fetches, so they are double
-  // buffered by hand -- step q = (point tile, quarter u) is fetched while step q - 1 multiplies.  The fetches are
-  // UNCONDITIONAL (tile indices clamped; an out-of-range tile is fetched and never multiplied): with guarded fetches the
-  // compiler falls back to s_waitcnt vmcnt(0) right after issuing them (mlp_prims.h, gemm_tiles).
+  // One register-resident wave per SIMD: nothing else hides the HBM latency of the operand fetches, so they run D - 1 steps
+  // ahead of the multiplies through a ring of D register buffers; step q = (point tile, quarter u).  A full 256 x 256 block
+  // multiplies for ~1.7 us per step and two buffers cover the latency; a 128 x 128 block (the reflectance stacks) multiplies
+  // for 0.4 us per step and needs six, or it runs at the latency, not the bandwidth (13 TFLOP/s measured with two).  The
+  // fetches are UNCONDITIONAL (tile indices clamped; an out-of-range tile is fetched and never multiplied): with guarded
+  // fetches the compiler falls back to s_waitcnt vmcnt(0) right after issuing them (mlp_prims.h, gemm_tiles).
   const long my_tiles = (n_ptiles - blockIdx.x + gridDim.x - 1) / gridDim.x, n_q = 4 * my_tiles;
-  auto fetch = [&](long q, f32x4 (&af)[NOT], f32x4 (&bf)[8]) {
+  auto fetch = [&](long q, f32x4 (&af)[NOT], f32x4 (&bf)[BT]) {
     long t = blockIdx.x + (q >> 2) * (long)gridDim.x;
     if (t >= n_ptiles) t = n_ptiles - 1;
     const int u = (int)(q & 3);
@@ -45,27 +48,29 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
 #pragma unroll
     for (int a = 0; a < NOT; ++a) af[a] = *reinterpret_cast<const f32x4*>(At + (long)min(wave + 4 * a, a_nt - 1) * 1024);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) bf[b] = *reinterpret_cast<const f32x4*>(Bt + (long)min(b, b_nt - 1) * 1024);
+    for (int b = 0; b < BT; ++b) bf[b] = *reinterpret_cast<const f32x4*>(Bt + (long)min(b, b_nt - 1) * 1024);
   };
-  auto multiply = [&](const f32x4 (&af)[NOT], const f32x4 (&bf)[8]) {
+  auto multiply = [&](const f32x4 (&af)[NOT], const f32x4 (&bf)[BT]) {
 #pragma unroll
     for (int a = 0; a < NOT; ++a) {
       rs[a] += af[a];
 #pragma unroll
-      for (int b = 0; b < 8; ++b)
+      for (int b = 0; b < BT; ++b)
         if (wave + 4 * a < a_nt && b < b_nt) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
         }
     }
   };
-  f32x4 af0[NOT], bf0[8], af1[NOT], bf1[8];
-  fetch(0, af0, bf0);
-  for (long q = 0; q < n_q; q += 2) {            // n_q is a multiple of 4
-    fetch(q + 1, af1, bf1);
-    multiply(af0, bf0);
-    fetch(q + 2, af0, bf0);
-    multiply(af1, bf1);
+  f32x4 af[D][NOT], bf[D][BT];
+#pragma unroll
+  for (int s = 0; s < D - 1; ++s) fetch(s, af[s], bf[s]);
+  for (long q = 0; q < n_q; q += D) {
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+      fetch(q + s + D - 1, af[(s + D - 1) % D], bf[(s + D - 1) % D]);      // the buffer multiplied one step ago
+      if (q + s < n_q) multiply(af[s], bf[s]);
+    }
   }
   // partial block of this workgroup: ws[blockIdx][a_nt*32][b_nt*32]; accumulator reg e of lane (n, hh): row (e&3) + 8 (e>>2) + 4 hh, col n
   const int cols = b_nt * 32;
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
     const int ot = wave + 4 * a;
     if (ot >= a_nt) continue;
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < BT; ++b) {
       if (b >= b_nt) continue;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -142,12 +147,13 @@ extern "C" int vqn_wgrad_partials(const float* A, int a_tiles, int a_t0, int a_n
   long grid = n_split;
   if (grid > n_point_tiles) grid = n_point_tiles;
   hipStream_t s = (hipStream_t)stream;
-  if (a_nt <= 4)
-    hipLaunchKernelGGL(wgrad_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, A, a_tiles, a_t0, a_nt, B, b_tiles, b_t0, b_nt,
-                       (long)n_point_tiles, ws, rowsum_ws);
-  else
-    hipLaunchKernelGGL(wgrad_kernel<2>, dim3((unsigned)grid), dim3(256), 0, s, A, a_tiles, a_t0, a_nt, B, b_tiles, b_t0, b_nt,
-                       (long)n_point_tiles, ws, rowsum_ws);
+#define VQN_WGRAD(NOT_, BT_, D_)                                                                                       \
+  hipLaunchKernelGGL((wgrad_kernel<NOT_, BT_, D_>), dim3((unsigned)grid), dim3(256), 0, s, A, a_tiles, a_t0, a_nt, B, \
+                     b_tiles, b_t0, b_nt, (long)n_point_tiles, ws, rowsum_ws)
+  if (a_nt <= 4 && b_nt <= 4) VQN_WGRAD(1, 4, 6);
+  else if (a_nt <= 4) VQN_WGRAD(1, 8, 4);
+  else VQN_WGRAD(2, 8, 2);
+#undef VQN_WGRAD
   VQN_LAUNCH_CHECK();
   return (int)grid;      // number of partial blocks written (>= 1)
 }

@@ -34,7 +34,8 @@ def from_tfmt(t, N, F):
 
 class _Engine:
     """shared: program packing / launching / weight-gradient contraction"""
-    n_split = 64
+    n_split = 256        # upper bound on the split-over-points workgroups of a weight-gradient call (one per CU); a call uses
+                         # min(n_split, point tiles), so the reference batch (2048 points = 64 tiles) still runs 64 of them
 
     def _finish(self, progs):
         for name, build in progs:
@@ -200,7 +201,7 @@ class EncoderEngine(_Engine):
         T['GZ'].copy_(to_tfmt(delta, self.specs['GZ'][1]))
         T['D%d' % top] = T['GZ']
         self.run('prog_bwd', descs, wbuf, T, self.specs, N)
-        ws = torch.empty(self.n_split * 256 * 256, dtype=torch.float32, device=g_z.device)
+        ws = torch.empty(min(self.n_split, (N + 31) // 32) * 256 * 256, dtype=torch.float32, device=g_z.device)
         dW, db = [], []
         for k, L in enumerate(self.layers):
             D = T['D%d' % k]
@@ -325,7 +326,7 @@ class HeadsEngine(_Engine):
             gg = torch.zeros_like(out) if g is None else g
             T['D%d_2' % h].copy_(to_tfmt(gg * out * (1 - out), 1))
         self.run('prog_bwd', descs, wbuf, T, self.specs, N)
-        ws = torch.empty(self.n_split * 256 * 256, dtype=torch.float32, device=T['Z'].device)
+        ws = torch.empty(min(self.n_split, (N + 31) // 32) * 256 * 256, dtype=torch.float32, device=T['Z'].device)
         dW, db = [], []
         for h, net in enumerate(self.nets):
             w0, w1, c = net.widths
