@@ -201,6 +201,12 @@ int vqn_neus_composite_bwd(const float* rays_o, const float* rays_d, const float
 int vqn_tile_program(const void* desc_dev, const int32_t* desc_host, const float* wbuf, float* const* tensors,
                      const int32_t* tensor_ld, int n_tensors, int64_t N, void* stream);
 
+/* Row-major [N, F] (row stride ldx floats) <-> the feature-major tile format of the training programs
+ * (TFMT [ceil(N/32)][tiles_f][32 features][32 points], csrc/vm_desc.h), zero padded on pack.  In the reference these
+ * hand-offs are implicit (autograd passes dense [N, F] tensors between the Keras layers, the VQ layer and the renderer). */
+int vqn_tfmt_pack(const float* x, int64_t N, int F, int64_t ldx, float* t, int tiles_f, void* stream);
+int vqn_tfmt_unpack(const float* t, int tiles_f, int64_t N, int F, float* x, int64_t ldx, void* stream);
+
 /* Weight-gradient contraction over points (autograd's grad_weight GEMMs): partial blocks
  * ws[s][a_nt*32][b_nt*32] = sum over the point tiles of split s of A[o][p] * B[i][p], A/B in TFMT with
  * a_tiles/b_tiles feature tiles of which [t0, t0+nt) are used.  Returns the number of partial blocks written

@@ -279,3 +279,21 @@ def test_empty_and_degenerate_inputs():
     rc = lib.vqn_brdf_shade_fwd(p(one), p(one), p(one), z, p(one), p(one), p(one), ctypes.c_int64(4), 100, 1, p(one), p(one), p(one),
                                 z, z, z, z, z, p(one), z, z, z, 0, z, 0, z, z)
     assert rc == -2 and b'256, 512 or 1024' in lib.vqn_last_error()
+
+
+@pytest.mark.parametrize('N,F,tiles', [(100, 70, None), (1, 3, 1), (4097, 256, 8), (64, 33, 4)])
+def test_tfmt_pack_and_unpack(N, F, tiles):
+    """vqn_tfmt_pack / vqn_tfmt_unpack against the index formula of csrc/vm_desc.h: element (p, f) of the rows sits at
+    [p // 32][f // 32][f % 32][p % 32]; padding rows / features are zero; strided inputs are accepted."""
+    from vqnerf_release_amd.decomp.train_programs import to_tfmt, from_tfmt
+    g = torch.Generator(device='cuda').manual_seed(N + F)
+    wide = torch.rand((N, F + 5), device='cuda', generator=g)
+    x = wide[:, :F]                                                  # row stride F + 5
+    t = to_tfmt(x, tiles)
+    nt, ft = (N + 31) // 32, tiles or (F + 31) // 32
+    ref = torch.zeros(nt * 32, ft * 32, device='cuda')
+    ref[:N, :F] = x
+    assert torch.equal(t, ref.view(nt, 32, ft, 32).permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(from_tfmt(t, N, F), x)
+    out = torch.full((nt, ft, 32, 32), 7.0, device='cuda')
+    assert to_tfmt(x.contiguous(), tiles, out=out) is out and torch.equal(out, t)

@@ -265,7 +265,64 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void tile_vm_kernel(const
   }
 }
 
+// ---- row-major [N, F] <-> TFMT: one 32 x 32 transpose per (point tile, feature tile) through LDS ------------------
+// (the reflectance trainer hands z, the head outputs and their adjoints between the tile programs, which want TFMT, and
+// the VQ / shading kernels and torch, which want rows)
+template <bool PACK>
+__global__ __launch_bounds__(256) void tfmt_convert_kernel(const float* __restrict__ src, float* __restrict__ dst, long N, int F,
+                                                           long ld, int tiles_f) {
+  __shared__ float sq[32][33];
+  const long tile = blockIdx.x;
+  const int ft = blockIdx.y, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long tbase = ((tile * tiles_f + ft) * 32) * 32;
+  if (PACK) {
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {                       // r: point in tile, tx: feature in tile
+      const long pt = tile * 32 + r;
+      const int f = ft * 32 + tx;
+      sq[r][tx] = (pt < N && f < F) ? src[pt * ld + f] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) dst[tbase + r * 32 + tx] = sq[tx][r];        // r: feature, tx: point
+  } else {
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) sq[r][tx] = src[tbase + r * 32 + tx];        // r: feature, tx: point
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+      const long pt = tile * 32 + r;
+      const int f = ft * 32 + tx;
+      if (pt < N && f < F) dst[pt * ld + f] = sq[tx][r];
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int vqn_tfmt_pack(const float* x, int64_t N, int F, int64_t ldx, float* t, int tiles_f, void* stream) {
+  VQN_CHECK_ARG(N >= 0 && F >= 1 && ldx >= F && tiles_f * 32 >= F, "N >= 0, 1 <= F <= ldx, tiles_f * 32 >= F");
+  if (N == 0) return VQN_OK;
+  VQN_CHECK_ARG(x && t, "null pointer");
+  const long n_tiles = (N + 31) / 32;
+  VQN_CHECK_SHAPE(tiles_f <= 65535, "at most 65535 feature tiles");
+  hipLaunchKernelGGL((tfmt_convert_kernel<true>), dim3((unsigned)n_tiles, (unsigned)tiles_f), dim3(256), 0, (hipStream_t)stream, x, t,
+                     (long)N, F, (long)ldx, tiles_f);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
+
+extern "C" int vqn_tfmt_unpack(const float* t, int tiles_f, int64_t N, int F, float* x, int64_t ldx, void* stream) {
+  VQN_CHECK_ARG(N >= 0 && F >= 1 && ldx >= F && tiles_f * 32 >= F, "N >= 0, 1 <= F <= ldx, tiles_f * 32 >= F");
+  if (N == 0) return VQN_OK;
+  VQN_CHECK_ARG(x && t, "null pointer");
+  const long n_tiles = (N + 31) / 32;
+  const int ft_used = (F + 31) / 32;
+  hipLaunchKernelGGL((tfmt_convert_kernel<false>), dim3((unsigned)n_tiles, (unsigned)ft_used), dim3(256), 0, (hipStream_t)stream, t, x,
+                     (long)N, F, (long)ldx, tiles_f);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
 
 extern "C" int vqn_tile_program(const void* desc_dev, const int32_t* desc_host, const float* wbuf,
                                 float* const* tensors, const int32_t* tensor_ld, int n_tensors, int64_t N,
