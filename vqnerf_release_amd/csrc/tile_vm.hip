@@ -79,12 +79,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void tile_vm_kernel(const
         const float* a2 = ia2 >= 0 ? tab.t[ia2].ptr : nullptr;
         float* st = ist >= 0 ? tab.t[ist].ptr : nullptr;
         float* st2 = ist2 >= 0 ? tab.t[ist2].ptr : nullptr;
+#ifdef VQN_DIAG_VM_NO_ST                          // timing-only builds (make diag FLAG=...): results are wrong
+        st = nullptr; st2 = nullptr;
+#endif
         const int tf1 = ia1 >= 0 ? tab.t[ia1].ld : 0, tf2 = ia2 >= 0 ? tab.t[ia2].ld : 0;
         const int tfs = ist >= 0 ? tab.t[ist].ld : 0, tfs2 = ist2 >= 0 ? tab.t[ist2].ld : 0;
         const f32x4* bp = wbuf + b_off;
         float r1[16], r2[16];                       // epilogue operands, fetched before the K loop so that their latency hides under it
         gemm_tiles<NW>(lds, ks, wbuf + w_off, n_out_tiles, wave, lane,
                        [&](int ot, f32x16& acc) {
+#ifdef VQN_DIAG_VM_NO_AUX
+                         for (int e = 0; e < 16; ++e) { r1[e] = 0.5f; r2[e] = 0.25f; }
+#else
                          if (epi != VM_EPI_ACT) {
 #pragma unroll
                            for (int e = 0; e < 16; ++e) r1[e] = a1[tf_off(tile, tf1, ot, 8 * (e >> 2) + 2 * (e & 3) + h, p)];
@@ -93,6 +99,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void tile_vm_kernel(const
                              for (int e = 0; e < 16; ++e) r2[e] = a2[tf_off(tile, tf2, ot, 8 * (e >> 2) + 2 * (e & 3) + h, p)];
                            }
                          }
+#endif
                          if (accum) init_rows(lds + (dst + ot * 4) * 64, lane, acc);
                          else if (b_off >= 0) init_bias(bp, ot, lane, acc);
                          else init_zero(acc);
