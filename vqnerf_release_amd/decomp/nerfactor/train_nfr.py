@@ -337,13 +337,18 @@ def fit(config, outdir, dataset_train, dataset_vali=None, model=None, device='cu
     data_type = config.get('DEFAULT', 'data_type')
     seed = g('random_seed', int, 0) if seed is None else seed
     torch.manual_seed(seed)
+    # data parallel: every rank sees all views and draws its OWN pairs (generator seeded per rank); what must agree across
+    # ranks -- the VQ test set, the k-means codebook -- comes from a generator with the common seed; files are rank 0's
+    rank0 = parallel.rank() == 0
+    gen_common = torch.Generator(device=device)
+    gen_common.manual_seed(seed)
     gen = torch.Generator(device=device)
-    gen.manual_seed(seed)
+    gen.manual_seed(seed + 7919 * parallel.rank())
     os.makedirs(outdir, exist_ok=True)
-    global_bs = dataset_train.bs
+    global_bs = dataset_train.bs * parallel.world_size()
     views_train = list(dataset_train.build_pipeline(no_shuffle=True))
     vq_test_batch = prepare_vq_data(config, max(1, g('total_sample_vq', int, 4096) // max(1, dataset_train.get_n_views())),
-                                    views_train, data_type, generator=gen)
+                                    views_train, data_type, generator=gen_common)
     vali_views = []
     if dataset_vali is not None and dataset_vali.get_n_views() > 0:
         vali_views = list(dataset_vali.build_pipeline())[:g('vali_batches', int, 4)]
@@ -362,7 +367,7 @@ def fit(config, outdir, dataset_train, dataset_vali=None, model=None, device='cu
     latest = _latest_checkpoint(ckptdir)
     step = 0
     if latest is None:
-        zs = [model.init_z(outer_sample(v, config, data_type, generator=gen))['z_pred'] for v in views_train]
+        zs = [model.init_z(outer_sample(v, config, data_type, generator=gen_common))['z_pred'] for v in views_train]
         init_z_path = config.get('DEFAULT', 'cluster_center_path', fallback='') or os.path.join(outdir, 'cluster_init.npy')
         model.set_codebook(z_cluster(model, zs, init_z_path, num_embed, device=device, seed=seed))
     elif model._codebook is None:
@@ -390,7 +395,7 @@ def fit(config, outdir, dataset_train, dataset_vali=None, model=None, device='cu
             loss_dicts.append({k: v.detach().float().mean() for k, v in loss_dict.items()})
         step += 1
         history['loss'].append(float(torch.stack(losses).mean()))           # one host sync per epoch
-        if step % ckpt_period == 0:
+        if step % ckpt_period == 0 and rank0:
             os.makedirs(ckptdir, exist_ok=True)
             torch.save({'step': step, 'net': model.state_dict(), 'optimizer': opt.state_dict()}, os.path.join(ckptdir, f'ckpt-{step}.pt'))
             if keep > 0:
@@ -398,7 +403,7 @@ def fit(config, outdir, dataset_train, dataset_vali=None, model=None, device='cu
                 for s in olds[:-keep]:
                     os.remove(os.path.join(ckptdir, f'ckpt-{s}.pt'))
             log(f'Checkpointed step {step}: loss_train {history["loss"][-1]:.6f}')
-        if vali_views and vali_period > 0 and step % vali_period == 0:
+        if vali_views and vali_period > 0 and step % vali_period == 0 and rank0:
             edir = os.path.join(outdir, 'vis_vali', 'epoch{e:09d}'.format(e=step))
             os.makedirs(edir, exist_ok=True)
             sums = {}
@@ -465,8 +470,9 @@ def fit_stage(config, outdir, dataset_train, dataset_vali=None, model=None, devi
     data_type = config.get('DEFAULT', 'data_type')
     seed = g('random_seed', int, 0) if seed is None else seed
     torch.manual_seed(seed)
+    rank0 = parallel.rank() == 0                                 # data parallel: own pairs per rank, files from rank 0
     gen = torch.Generator(device=device)
-    gen.manual_seed(seed)
+    gen.manual_seed(seed + 7919 * parallel.rank())
     os.makedirs(outdir, exist_ok=True)
     if model is None:
         model = get_model_class(config.get('DEFAULT', 'model'))(config)
@@ -497,18 +503,18 @@ def fit_stage(config, outdir, dataset_train, dataset_vali=None, model=None, devi
         losses, sums = [], {}
         for view in views_train:
             batch = outer_sample(view, config, data_type, generator=gen, neighbour='max_diff')
-            loss, _, loss_dict = trainer.train_iter(batch, dataset_train.bs, **kw)
+            loss, _, loss_dict = trainer.train_iter(batch, dataset_train.bs * parallel.world_size(), **kw)
             losses.append(loss.detach().clone())
             for k, v in loss_dict.items():
                 sums[k] = sums.get(k, 0.0) + v.detach().float().mean()
         pre = step < pretrain_epochs
         step += 1
         hist['loss'].append(float(torch.stack(losses).mean()))
-        if step % ckpt_period == 0:
+        if step % ckpt_period == 0 and rank0:
             os.makedirs(ckptdir, exist_ok=True)
             torch.save({'step': step, 'net': model.state_dict(), 'optimizer': opt.state_dict()}, os.path.join(ckptdir, f'ckpt-{step}.pt'))
             log(f'Checkpointed step {step}: loss_train {hist["loss"][-1]:.6f}')
-        if vali_views and vali_period > 0 and step % vali_period == 0:
+        if vali_views and vali_period > 0 and step % vali_period == 0 and rank0:
             edir = os.path.join(outdir, 'vis_vali', 'epoch{e:09d}'.format(e=step))
             os.makedirs(edir, exist_ok=True)
             with open(os.path.join(edir, 'loss.json'), 'w') as f:
