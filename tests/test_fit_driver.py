@@ -74,6 +74,11 @@ def test_fit_trains_checkpoints_resumes_and_validates(tmp_path):
     assert {'loss.json', 'vq_test_loss.json'} <= set(os.listdir(edir))
     assert os.path.exists(os.path.join(out, 'vis_vali', 'vis_params', 'epoch%09d' % 4, 'vq_embed.npy'))
     assert os.path.exists(os.path.join(edir, subs[0], 'pred_light.png')) and os.path.exists(os.path.join(out, 'vis_vali', 'metas.json'))
+    # the same loop with the step replayed from a captured HIP graph (code-dropout thresholds as a graph input)
+    cfg_g = _decomp_cfg(tmp_path, imh=24, n_rays_per_step=64, num_embed=6, num_drop=2, thres_str='0.2;0.4', epochs=4, ckpt_period=4,
+                        vali_period=0, total_sample_vq=64, random_seed=5, cluster_center_path='')
+    model_g, hist_g = train_nfr.fit(cfg_g, str(tmp_path / 'run_graph'), tr, None, graph=True, log=lambda *_: None)
+    assert len(hist_g['loss']) == 4 and all(np.isfinite(hist_g['loss'])) and os.path.exists(tmp_path / 'run_graph' / 'checkpoints' / 'ckpt-4.pt')
     # inference pass of test.py: every validation view relit under the probes of `test_envmap_dir` and the OLAT maps
     from vqnerf_release_amd.decomp.nerfactor.util import io as ioutil
     os.makedirs(tmp_path / 'probes')

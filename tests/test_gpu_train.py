@@ -135,6 +135,45 @@ def test_decomp_trainer_trains():
     assert set(ld2) >= {'rgb', 'vqrgb', 'chromaticity'}
 
 
+def test_decomp_trainer_graph_with_code_dropout():
+    """Trainer(graph=True) with the code-dropout thresholds as a graph input: a code whose threshold is 1 is never assigned
+    (its draw in [0, 1) never reaches it), one with threshold 0 always may be; new thresholds take effect at the next replay;
+    the draw itself comes from the device generator inside the graph, so consecutive replays differ."""
+    from oracle import decomp as od
+    from vqnerf_release_amd.decomp.nerfactor import train_nfr
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    p, specs = od.make_model_params(seed=0, K=15)
+    cfg = make_config(n_rays_per_step=128)
+    model = load_oracle_params(get_model_class('vq_nfr')(cfg), p, 'cuda')
+    model.get_codebook(); _ = model.light
+    opt, _, clip = train_nfr.make_optimizer(cfg, model.trainable_variables, capturable=True)
+    tr = train_nfr.Trainer(model, opt, clip=clip, graph=True)
+    batch = make_batch(od.make_points(256, seed=3), 'cuda')
+    with pytest.raises(ValueError):
+        tr.train_iter(batch, global_bs=128, thres=np.zeros(15, np.float32))      # host thresholds cannot be a graph input
+    tr._calls = 0
+    seen = []
+    hook = model.vq_layer.register_forward_hook(lambda m, i, o: seen.append(o['encoding_indices']))
+    half = torch.tensor([0.0] * 8 + [1.0] * 7, device='cuda')           # codes 8..14 always dropped
+    losses = [float(tr.train_iter(batch, global_bs=128, thres=half)[0]) for _ in range(train_nfr.Trainer.GRAPH_WARMUP + 1)]
+    assert tr._captured is not None and all(np.isfinite(losses))
+    static_idx = seen[-1]                                                # the captured step's index tensor: refreshed by every replay
+    hook.remove()
+    assert int(static_idx.max()) <= 7
+    mid = torch.tensor([0.5] * 15, device='cuda')                       # every code dropped with probability 1/2, drawn per replay
+    used = []
+    for _ in range(6):
+        l = float(tr.train_iter(batch, global_bs=128, thres=mid)[0])
+        assert np.isfinite(l)
+        used.append(tuple(sorted(set(static_idx.reshape(-1).tolist()))))
+    assert len(set(used)) > 1                                            # different draws -> different code subsets
+    only3 = torch.ones(15, device='cuda'); only3[3] = 0.0
+    tr.train_iter(batch, global_bs=128, thres=only3)
+    assert set(static_idx.reshape(-1).tolist()) == {3}
+    with pytest.raises(ValueError):
+        tr.train_iter(batch, global_bs=128)                             # recorded with dropout: cannot replay without
+
+
 def test_decomp_trainer_graph_replays_the_eager_step():
     """Trainer(graph=True): the captured step (forward, loss, backward, EMA codebook move, Adam) replayed on new batches is
     the eager step bit for bit (same kernels, same order; both sides use the capturable Adam so the update arithmetic is

@@ -89,8 +89,14 @@ class VectorQuantizerEMA(torch.nn.Module):
         self.stats_all_reduce = None
 
     def draw_roll(self, individual=True, device=None):
+        """The code-dropout draw tf.random.uniform((1, K)) (vq_layers.py:287).  Normally from the layer's seeded host generator;
+        inside a HIP-graph capture from the device generator (a host draw + copy cannot be captured; torch advances the
+        philox offset of captured draws at every replay)."""
         n = self.num_embeddings if individual else 1
-        return torch.rand((1, n), generator=self._gen).to(device or 'cpu')
+        dev = torch.device(device or 'cpu')
+        if dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            return torch.rand((1, n), device=dev)
+        return torch.rand((1, n), generator=self._gen).to(dev)
 
     def forward(self, inputs, codebook, is_training, thres=None, individual=True, roll=None,
                 return_distances=True):

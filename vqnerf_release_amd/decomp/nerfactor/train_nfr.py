@@ -44,8 +44,8 @@ class Trainer:
     `graph=True` (single rank): the step at the reference's batch size (n_rays_per_step = 1024 pairs) is ~150 short
     launches, i.e. launch-bound; the whole of it -- forward, loss, backward, EMA codebook move, Adam -- is captured once
     into a HIP graph and replayed on static buffers.  Conditions, all checked: batches of a fixed shape whose rows are all
-    foreground (`outer_sample` only yields such rows; sets `model.assume_foreground`), no `thres` / `roll`, a `capturable`
-    optimiser (make_optimizer(..., capturable=True)).  The first `GRAPH_WARMUP` calls run eagerly (they are real steps);
+    foreground (`outer_sample` only yields such rows; sets `model.assume_foreground`), no explicit `roll` (`thres` as a device
+    tensor is a graph input; its draw then comes from the device generator), a `capturable` optimiser (make_optimizer(..., capturable=True)).  The first `GRAPH_WARMUP` calls run eagerly (they are real steps);
     the tensors returned by later calls are the graph's static outputs, overwritten by the next call."""
 
     GRAPH_WARMUP = 2
@@ -78,23 +78,31 @@ class Trainer:
         the number of ranks when each rank draws its own rays.  Returns (weighted_loss summed over ranks, to_vis, loss_dict)."""
         self._call_kwargs = call_kwargs
         if self.graph:
-            if thres is not None or roll is not None or call_kwargs:
-                raise ValueError('code dropout (`thres` / `roll`) and per-call arguments are host-side: not available under graph=True')
+            if roll is not None or call_kwargs:
+                raise ValueError('an explicit `roll` and per-call arguments are host-side: not available under graph=True')
+            if thres is not None and not (torch.is_tensor(thres) and thres.is_cuda):
+                raise ValueError('under graph=True the code-dropout thresholds must be a device tensor (they are a graph input)')
             self._calls += 1
             if self._calls > self.GRAPH_WARMUP:
-                return self._replay(batch, global_bs)
+                return self._replay(batch, global_bs, thres)
         return self._step(batch, global_bs, thres, roll)
 
-    def _replay(self, batch, global_bs):
+    def _replay(self, batch, global_bs, thres=None):
         if self._captured is None:
             self._static_in = [t.clone() if torch.is_tensor(t) else t for t in batch]
+            self._static_thres = None if thres is None else thres.detach().clone()
             self._global_bs = global_bs
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._static_out = self._step(tuple(self._static_in), global_bs, None, None, sched=False, fresh_leaves=True)
+                # (code dropout: the thresholds are a static input, the draw comes from the device generator inside the graph)
+                self._static_out = self._step(tuple(self._static_in), global_bs, self._static_thres, None, sched=False, fresh_leaves=True)
             self._captured = g
         if global_bs != self._global_bs:
             raise ValueError('global_bs is baked into the captured step')
+        if (thres is None) != (self._static_thres is None):
+            raise ValueError('the captured step was recorded %s code dropout' % ('without' if self._static_thres is None else 'with'))
+        if thres is not None:
+            self._static_thres.copy_(thres)
         for dst, src in zip(self._static_in, batch):
             if torch.is_tensor(dst):
                 if dst.shape != src.shape:
@@ -374,7 +382,7 @@ def fit(config, outdir, dataset_train, dataset_vali=None, model=None, device='cu
         model.set_codebook(np.zeros((num_embed, model.z_dim), np.float32))      # placeholder: the checkpoint below holds the values
     _ = model.light                                              # lazy variables exist before the optimiser is built
     model.register_trainable()
-    use_graph = bool(graph) and np.all(train_thres == 0.0)        # the captured step has no code dropout
+    use_graph = bool(graph) and parallel.world_size() == 1        # the captured step holds no collective
     opt, sched, clip = make_optimizer(config, model.trainable_variables, capturable=use_graph)
     if latest is not None:
         state = torch.load(latest[1], map_location=device, weights_only=False)
