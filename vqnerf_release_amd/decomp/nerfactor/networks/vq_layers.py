@@ -140,3 +140,46 @@ class VectorQuantizerEMA(torch.nn.Module):
 
     def quantize(self, codebook, encoding_indices):
         return codebook.t()[encoding_indices]
+
+
+class VectorQuantizer(torch.nn.Module):
+    """The gradient-trained VQ layer of vq_layers.py:17-171 (van den Oord et al.; no model of the reference uses it, the EMA
+    layer above is the shipped one): nearest code by the same `vqn_vq_assign` kernel; the codebook receives gradients through
+    the gathered `quantized` (torch), the encoder through the straight-through estimator.  Per-row losses [N] as in the
+    reference: `qloss = mean((q - sg(x))^2, -1)`, `eloss = beta * mean((sg(q) - x)^2, -1)`, `loss = qloss + eloss`."""
+
+    def __init__(self, embedding_dim, num_embeddings, commitment_cost, seed, dtype=torch.float32, name='vector_quantizer'):
+        super().__init__()
+        self.embedding_dim, self.num_embeddings, self.commitment_cost, self.name = embedding_dim, num_embeddings, commitment_cost, name
+        self._gen = torch.Generator(device='cpu')
+        self._gen.manual_seed(int(seed))
+
+    def forward(self, inputs, codebook, is_training, thres=None, roll=None):
+        D, K = self.embedding_dim, self.num_embeddings
+        flat = inputs.reshape(-1, D)
+        x = flat.detach().contiguous()
+        sel = None
+        if thres is not None:
+            if roll is None:
+                roll = torch.rand((1, K), generator=self._gen)
+            thres_t = torch.as_tensor(thres, dtype=torch.float32, device=x.device)
+            sel = (roll.to(x.device) >= thres_t).to(torch.float32).expand(1, K).reshape(K).contiguous()
+        idx, _, dist = _C.vq_assign(x, codebook.detach().contiguous(), sel_mask=sel, want_quant=False, want_dist=True)
+        encodings = torch.nn.functional.one_hot(idx, K).to(flat.dtype)
+        encoding_indices = idx.reshape(inputs.shape[:-1])
+        quantized = self.quantize(codebook, encoding_indices)
+        e_latent = ((quantized.detach() - inputs) ** 2).mean(-1)
+        q_latent = ((quantized - inputs.detach()) ** 2).mean(-1)
+        if self.commitment_cost > 0:
+            e_w = self.commitment_cost * e_latent
+            loss = q_latent + e_w
+        else:
+            loss, e_w = q_latent, torch.zeros_like(q_latent)
+        quantized = inputs + (quantized - inputs).detach()
+        avg_probs = _C.vq_counts(idx, K) / max(idx.numel(), 1)
+        perplexity = torch.exp(-torch.sum(avg_probs * torch.log(avg_probs + 1e-10)))
+        return {'quantize': quantized, 'loss': loss, 'qloss': q_latent, 'eloss': e_w, 'perplexity': perplexity, 'encodings': encodings,
+                'encoding_indices': encoding_indices, 'distances': dist}
+
+    def quantize(self, codebook, encoding_indices):
+        return codebook.t()[encoding_indices]
