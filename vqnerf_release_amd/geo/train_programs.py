@@ -125,9 +125,49 @@ class Program:
 
         rec(0, 0, [])
         assert best['pos'] is not None
+        if best['top'] > 80:
+            # a packing over 80 rows costs the second resident workgroup: look once more for one that fits, now with every
+            # 4-row-aligned offset as a candidate (placing a region only at the end of an earlier one cannot leave room "in front"
+            # of a region that is requested later but lives shorter)
+            fit = self._solve_rows_under(80)
+            if fit is not None:
+                best['top'], best['pos'] = max(c + r.alloc_rows for (r, _), c in zip(reqs, fit)), fit
         for (reg, _), c in zip(reqs, best['pos']):
             reg.row0 = c
         return best['top']
+
+    def _solve_rows_under(self, cap, node_limit=300000):
+        reqs = self.requests
+        n = len(reqs)
+        nodes = [0]
+        pos = []
+
+        def rec(i):
+            if i == n:
+                return True
+            nodes[0] += 1
+            if nodes[0] > node_limit:
+                return False
+            reg, live = reqs[i]
+            need = reg.alloc_rows
+            for c in range(0, cap - need + 1, 4):
+                if any(c < r.row0 + r.alloc_rows and r.row0 < c + need for r in live):
+                    continue
+                reg.row0 = c
+                pos.append(c)
+                if rec(i + 1):
+                    return True
+                pos.pop()
+                reg.row0 = None
+                if nodes[0] > node_limit:
+                    return False
+            return False
+
+        ok = rec(0)
+        out = list(pos) if ok else None
+        for reg, _ in reqs:
+            reg.row0 = None
+        return out
 
     def finalize(self, n_waves=None):
         self.total_rows = self._solve_rows()
