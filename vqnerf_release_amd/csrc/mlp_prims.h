@@ -219,6 +219,96 @@ __device__ __forceinline__ void gemm_tiles2(const f32x4* __restrict__ lds, const
   }
 }
 
+// gemm_tiles2 with image 1 one half-step (4 K groups = 16 MFMAs) behind image 0 at the end of the K loop: image 0's
+// epilogue, given per row quad as epi_rq(ot, img, rq, acc), is issued between the four MFMA groups image 1 still owes, so
+// its VALU / LDS / store work runs in the shadow of matrix instructions instead of after them (all 8 waves of the two-image
+// workgroup reach their epilogues together, so nothing else covers them).  Only for ng % 8 == 0 (the 256-wide layers);
+// other shapes take gemm_tiles2 with the quads in order.  Same arithmetic, same accumulation order per image.
+template <int NW = 8, class Init, class EpiRq>
+__device__ __forceinline__ void gemm_tiles2_lag(const f32x4* __restrict__ lds, const int img_stride, const KSegs ks,
+                                                const f32x4* __restrict__ w, const int n_out_tiles, const int wave,
+                                                const int lane, f32x4 (&pre)[4], const bool use_pre,
+                                                const f32x4* __restrict__ next_wp, Init init, EpiRq epi_rq) {
+  const int ng = ks.nA + ks.nB;
+  if ((ng & 7) != 0) {
+    gemm_tiles2<NW>(lds, img_stride, ks, w, n_out_tiles, wave, lane, pre, use_pre, next_wp, init,
+                    [&](int ot, int im, const f32x16& acc) {
+#pragma unroll
+                      for (int rq = 0; rq < 4; ++rq) epi_rq(ot, im, rq, acc);
+                    });
+    return;
+  }
+  for (int ot = wave; ot < n_out_tiles; ot += NW) {
+    f32x16 acc0, acc1;
+    const f32x4* __restrict__ wp = w + (size_t)ot * ng * 64 + lane;
+    auto brow = [&](int g) { return ((g < ks.nA) ? (ks.rowA + g) : (ks.rowB + (g - ks.nA))) * 64 + lane; };
+    f32x4 a0[4], p0[4], q0[4], a1[4], p1[4], q1[4];          // p: image 0, q: image 1
+    const bool first = use_pre && ot == wave;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (first) a0[i] = pre[i]; else a0[i] = wp[i * 64];
+      const int r = brow(i);
+      p0[i] = lds[r]; q0[i] = lds[r + img_stride];
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) only (see gemm_tiles)
+    init(ot, 0, acc0);
+    init(ot, 1, acc1);
+    __builtin_amdgcn_s_setprio(1);
+    for (int g = 0; g < ng; g += 8) {
+      const bool last = g + 8 >= ng;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = brow(g + 4 + i);
+        a1[i] = wp[(g + 4 + i) * 64]; p1[i] = lds[r]; q1[i] = lds[r + img_stride];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][j], p0[i][j], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][j], q0[i][j], acc1, 0, 0, 0);
+        }
+      if (!last) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = brow(g + 8 + i);
+          a0[i] = wp[(g + 8 + i) * 64]; p0[i] = lds[r]; q0[i] = lds[r + img_stride];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], p1[i][j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], q1[i][j], acc1, 0, 0, 0);
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], p1[i][j], acc0, 0, 0, 0);
+      }
+    }
+    if (use_pre && ot + NW >= n_out_tiles && next_wp != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pre[i] = next_wp[i * 64];
+    }
+    // image 1's last half, one K group (4 MFMAs) at a time, each followed by a quarter of image 0's epilogue
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], q1[i][j], acc1, 0, 0, 0);
+      epi_rq(ot, 0, i, acc0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) epi_rq(ot, 1, rq, acc1);
+  }
+  if (use_pre && wave >= n_out_tiles && next_wp != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pre[i] = next_wp[i * 64];
+  }
+}
+
 __device__ __forceinline__ f32x4 acc_quad(const f32x16& acc, int rq) {
   // static rq only (callers unroll)
   return (f32x4){acc[4 * rq + 0], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]};

@@ -475,21 +475,27 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
       const int dst = (l == 0) ? X0 : oth;
       const bool do_save = FINE && (l < n_lin - 2);
       const f32x4* bp = wsdf + L.b_off;
-      gemm_tiles2<8>(lds, IS, ks, wsdf + L.w_off, L.n_out_tiles, wave, lane, pre, true, next_wp,
-                     [&](int ot, int im, f32x16& acc) { if (im == 0) { FS(2) } init_bias(bp, ot, lane, acc); },
-                     [&](int ot, int im, const f32x16& acc) {
-                       if (im == 0) { FS(1) }
-                       f32x4* li = lds + (size_t)im * IS;
-                       f32x4* sv = save0 + (size_t)im * per_img + (size_t)l * 4 * MT * 64;
+      auto bias_init = [&](int ot, int im, f32x16& acc) { if (im == 0) { FS(2) } init_bias(bp, ot, lane, acc); };
+      auto epi_rq = [&](int ot, int im, int rq, const f32x16& acc) {
+        f32x4* li = lds + (size_t)im * IS;
+        f32x4* sv = save0 + (size_t)im * per_img + (size_t)l * 4 * MT * 64;
+        f32x4 v = {acc[4 * rq], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]};
 #pragma unroll
-                       for (int rq = 0; rq < 4; ++rq) {
-                         f32x4 v = acc_quad(acc, rq);
+        for (int j = 0; j < 4; ++j) v[j] = act_fwd<ACT_SOFTPLUS100>(v[j]);
+        li[(dst + ot * 4 + rq) * 64 + lane] = v;
+        if (do_save) st_stream(sv + (ot * 4 + rq) * 64 + lane, v);
+      };
+      // SDF-only kernel: image 1 runs half a step behind so that image 0's epilogue issues between its last MFMAs (+2 %); the
+      // fine kernel (stash stores in the epilogue, at the register limit) measured 0.5 % slower that way and keeps the plain form
+      if (FINE)
+        gemm_tiles2<8>(lds, IS, ks, wsdf + L.w_off, L.n_out_tiles, wave, lane, pre, true, next_wp, bias_init,
+                       [&](int ot, int im, const f32x16& acc) {
+                         if (im == 0) { FS(1) }
 #pragma unroll
-                         for (int j = 0; j < 4; ++j) v[j] = act_fwd<ACT_SOFTPLUS100>(v[j]);
-                         li[(dst + ot * 4 + rq) * 64 + lane] = v;
-                         if (do_save) st_stream(sv + (ot * 4 + rq) * 64 + lane, v);
-                       }
-                     });
+                         for (int rq = 0; rq < 4; ++rq) epi_rq(ot, im, rq, acc);
+                       });
+      else
+        gemm_tiles2_lag<8>(lds, IS, ks, wsdf + L.w_off, L.n_out_tiles, wave, lane, pre, true, next_wp, bias_init, epi_rq);
       FS(2)
       __syncthreads();
       FS(3)
