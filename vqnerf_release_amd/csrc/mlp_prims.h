@@ -148,95 +148,27 @@ __device__ __forceinline__ void gemm_tiles_chain(const f32x4* __restrict__ lds, 
 }
 
 // Two-image form of gemm_tiles / gemm_tiles_chain: the workgroup (8 waves) holds TWO 32-point images `img_stride` float4
-// apart and a wave applies each weight fragment to both (8 MFMAs per fetched float4 pair).  One workgroup per CU whose
-// waves all do the same amount of matrix work between two barriers: no cross-workgroup interference on the matrix pipe,
-// half the barriers and half the L2 weight stream per point.  init(ot, img, acc) / epi(ot, img, acc) run once per image.
-// `pre` (optional, may be nullptr-like via use_pre = false): the chain prefetch of gemm_tiles_chain.
-template <int NW = 8, class Init, class Epi>
+// apart and a wave applies each weight fragment to both (8 MFMAs per fetched float4).  One workgroup per CU whose waves all
+// do the same amount of matrix work between two barriers: no cross-workgroup interference on the matrix pipe, half the
+// barriers and half the L2 weight stream per point.  init(ot, img, acc) runs once per image, epi_rq(ot, img, rq, acc) once per
+// image and row quad.  `pre` (use_pre): the chain prefetch of gemm_tiles_chain.
+// Operand pipeline: the weight fragments (L2 latency) keep two 4-group register buffers; the activation rows of both images
+// (LDS latency, ~1/4 of one group's matrix time) are fetched ONE group ahead into two float4 pairs.  Fetching them four
+// groups ahead like the weights cost 48 more registers per wave, which put the fine kernel at the 256-VGPR limit of two
+// waves per SIMD with spills: 231.5 -> 224.5 ms per launch without them.
+template <int NW = 8, class Init, class EpiRq>
 __device__ __forceinline__ void gemm_tiles2(const f32x4* __restrict__ lds, const int img_stride, const KSegs ks,
                                             const f32x4* __restrict__ w, const int n_out_tiles, const int wave,
                                             const int lane, f32x4 (&pre)[4], const bool use_pre,
-                                            const f32x4* __restrict__ next_wp, Init init, Epi epi) {
+                                            const f32x4* __restrict__ next_wp, Init init, EpiRq epi_rq) {
   const int ng = ks.nA + ks.nB;
-  for (int ot = wave; ot < n_out_tiles; ot += NW) {
-    f32x16 acc0, acc1;
-    const f32x4* __restrict__ wp = w + (size_t)ot * ng * 64 + lane;
-    auto brow = [&](int g) { return ((g < ks.nA) ? (ks.rowA + g) : (ks.rowB + (g - ks.nA))) * 64 + lane; };
-    f32x4 a0[4], p0[4], q0[4], a1[4], p1[4], q1[4];          // p: image 0, q: image 1
-    const bool first = use_pre && ot == wave;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int g = min(i, ng - 1);
-      if (first) a0[i] = pre[i]; else a0[i] = wp[g * 64];
-      const int r = brow(g);
-      p0[i] = lds[r]; q0[i] = lds[r + img_stride];
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) only (see gemm_tiles)
-    init(ot, 0, acc0);
-    init(ot, 1, acc1);
-    __builtin_amdgcn_s_setprio(1);
-    for (int g = 0; g < ng; g += 8) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gg = min(g + 4 + i, ng - 1), r = brow(gg);
-        a1[i] = wp[gg * 64]; p1[i] = lds[r]; q1[i] = lds[r + img_stride];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (g + i < ng) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][j], p0[i][j], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][j], q0[i][j], acc1, 0, 0, 0);
-          }
-        }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gg = min(g + 8 + i, ng - 1), r = brow(gg);
-        a0[i] = wp[gg * 64]; p0[i] = lds[r]; q0[i] = lds[r + img_stride];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (g + 4 + i < ng) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], p1[i][j], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], q1[i][j], acc1, 0, 0, 0);
-          }
-        }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    if (use_pre && ot + NW >= n_out_tiles && next_wp != nullptr) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pre[i] = next_wp[i * 64];
-    }
-    epi(ot, 0, acc0);
-    epi(ot, 1, acc1);
-  }
-  if (use_pre && wave >= n_out_tiles && next_wp != nullptr) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) pre[i] = next_wp[i * 64];
-  }
-}
-
-// gemm_tiles2 with a shallow LDS operand pipeline: the weight fragments (L2 latency) keep their two 4-group buffers, but the
-// activation rows of both images (LDS latency, ~1/4 of one group's matrix time) are fetched ONE group ahead into two float4
-// pairs instead of four groups ahead into 16 -- 48 registers fewer per wave, which is what the fine kernel (at the 256-VGPR
-// limit of two waves per SIMD) needs.  LAG: image 1's last K group is multiplied after image 0's epilogue quads have been
-// issued between its MFMAs (see gemm_tiles2_lag).  epi_rq(ot, img, rq, acc).  Same arithmetic and order per image.
-template <int NW, bool LAG, class Init, class EpiRq>
-__device__ __forceinline__ void gemm_tiles2n(const f32x4* __restrict__ lds, const int img_stride, const KSegs ks,
-                                             const f32x4* __restrict__ w, const int n_out_tiles, const int wave,
-                                             const int lane, f32x4 (&pre)[4], const bool use_pre,
-                                             const f32x4* __restrict__ next_wp, Init init, EpiRq epi_rq) {
-  const int ng = ks.nA + ks.nB;
-  const bool lag = LAG && (ng & 3) == 0 && ng >= 8;
   for (int ot = wave; ot < n_out_tiles; ot += NW) {
     f32x16 acc0, acc1;
     const f32x4* __restrict__ wp = w + (size_t)ot * ng * 64 + lane;
     auto brow = [&](int g) { g = min(g, ng - 1); return ((g < ks.nA) ? (ks.rowA + g) : (ks.rowB + (g - ks.nA))) * 64 + lane; };
-    f32x4 a0[4], a1[4], pc, qc, pn, qn, at[4], qt[4];
+    f32x4 a0[4], a1[4], pc, qc, pn, qn;                       // p: image 0, q: image 1
     const bool first = use_pre && ot == wave;
+    // (unconditional, clamped operand fetches + one drain per tile: see gemm_tiles)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (first) a0[i] = pre[i]; else a0[i] = wp[min(i, ng - 1) * 64];
@@ -251,12 +183,10 @@ __device__ __forceinline__ void gemm_tiles2n(const f32x4* __restrict__ lds, cons
       for (int i = 0; i < 4; ++i) {
         { const int r = brow(g0 + i + 1); pn = lds[r]; qn = lds[r + img_stride]; }
         if (g0 + i < ng) {
-          const bool defer = lag && g0 + i >= ng - 4;         // image 1's last four groups wait for the tail below
-          if (defer) { at[i] = a[i]; qt[i] = qc; }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], pc[j], acc0, 0, 0, 0);
-            if (!defer) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], qc[j], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], qc[j], acc1, 0, 0, 0);
           }
         }
         pc = pn; qc = qn;
@@ -274,108 +204,9 @@ __device__ __forceinline__ void gemm_tiles2n(const f32x4* __restrict__ lds, cons
 #pragma unroll
       for (int i = 0; i < 4; ++i) pre[i] = next_wp[i * 64];
     }
-    if (lag) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(at[i][j], qt[i][j], acc1, 0, 0, 0);
-        epi_rq(ot, 0, i, acc0);
-      }
-    } else {
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) epi_rq(ot, 0, rq, acc0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) epi_rq(ot, 1, rq, acc1);
-  }
-  if (use_pre && wave >= n_out_tiles && next_wp != nullptr) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) pre[i] = next_wp[i * 64];
-  }
-}
-
-// gemm_tiles2 with image 1 one half-step (4 K groups = 16 MFMAs) behind image 0 at the end of the K loop: image 0's
-// epilogue, given per row quad as epi_rq(ot, img, rq, acc), is issued between the four MFMA groups image 1 still owes, so
-// its VALU / LDS / store work runs in the shadow of matrix instructions instead of after them (all 8 waves of the two-image
-// workgroup reach their epilogues together, so nothing else covers them).  Only for ng % 8 == 0 (the 256-wide layers);
-// other shapes take gemm_tiles2 with the quads in order.  Same arithmetic, same accumulation order per image.
-template <int NW = 8, class Init, class EpiRq>
-__device__ __forceinline__ void gemm_tiles2_lag(const f32x4* __restrict__ lds, const int img_stride, const KSegs ks,
-                                                const f32x4* __restrict__ w, const int n_out_tiles, const int wave,
-                                                const int lane, f32x4 (&pre)[4], const bool use_pre,
-                                                const f32x4* __restrict__ next_wp, Init init, EpiRq epi_rq) {
-  const int ng = ks.nA + ks.nB;
-  if ((ng & 7) != 0) {
-    gemm_tiles2<NW>(lds, img_stride, ks, w, n_out_tiles, wave, lane, pre, use_pre, next_wp, init,
-                    [&](int ot, int im, const f32x16& acc) {
-#pragma unroll
-                      for (int rq = 0; rq < 4; ++rq) epi_rq(ot, im, rq, acc);
-                    });
-    return;
-  }
-  for (int ot = wave; ot < n_out_tiles; ot += NW) {
-    f32x16 acc0, acc1;
-    const f32x4* __restrict__ wp = w + (size_t)ot * ng * 64 + lane;
-    auto brow = [&](int g) { return ((g < ks.nA) ? (ks.rowA + g) : (ks.rowB + (g - ks.nA))) * 64 + lane; };
-    f32x4 a0[4], p0[4], q0[4], a1[4], p1[4], q1[4];          // p: image 0, q: image 1
-    const bool first = use_pre && ot == wave;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (first) a0[i] = pre[i]; else a0[i] = wp[i * 64];
-      const int r = brow(i);
-      p0[i] = lds[r]; q0[i] = lds[r + img_stride];
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) only (see gemm_tiles)
-    init(ot, 0, acc0);
-    init(ot, 1, acc1);
-    __builtin_amdgcn_s_setprio(1);
-    for (int g = 0; g < ng; g += 8) {
-      const bool last = g + 8 >= ng;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = brow(g + 4 + i);
-        a1[i] = wp[(g + 4 + i) * 64]; p1[i] = lds[r]; q1[i] = lds[r + img_stride];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][j], p0[i][j], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i][j], q0[i][j], acc1, 0, 0, 0);
-        }
-      if (!last) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = brow(g + 8 + i);
-          a0[i] = wp[(g + 8 + i) * 64]; p0[i] = lds[r]; q0[i] = lds[r + img_stride];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], p1[i][j], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], q1[i][j], acc1, 0, 0, 0);
-          }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], p1[i][j], acc0, 0, 0, 0);
-      }
-    }
-    if (use_pre && ot + NW >= n_out_tiles && next_wp != nullptr) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pre[i] = next_wp[i * 64];
-    }
-    // image 1's last half, one K group (4 MFMAs) at a time, each followed by a quarter of image 0's epilogue
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], q1[i][j], acc1, 0, 0, 0);
-      epi_rq(ot, 0, i, acc0);
-    }
-    __builtin_amdgcn_s_setprio(0);
+    for (int rq = 0; rq < 4; ++rq) epi_rq(ot, 0, rq, acc0);
+    __builtin_amdgcn_s_setprio(0);             // (image 0's epilogue still at raised priority: measured 0.5 % better)
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) epi_rq(ot, 1, rq, acc1);
   }

@@ -485,12 +485,7 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
         li[(dst + ot * 4 + rq) * 64 + lane] = v;
         if (do_save) st_stream(sv + (ot * 4 + rq) * 64 + lane, v);
       };
-      // SDF-only kernel: image 1 runs half a step behind so that image 0's epilogue issues between its last MFMAs (+2 %); the
-      // fine kernel (stash stores in the epilogue, at the register limit) measured 0.5 % slower that way and keeps the plain form
-      if (FINE)
-        gemm_tiles2n<8, false>(lds, IS, ks, wsdf + L.w_off, L.n_out_tiles, wave, lane, pre, true, next_wp, bias_init, epi_rq);
-      else
-        gemm_tiles2_lag<8>(lds, IS, ks, wsdf + L.w_off, L.n_out_tiles, wave, lane, pre, true, next_wp, bias_init, epi_rq);
+      gemm_tiles2<8>(lds, IS, ks, wsdf + L.w_off, L.n_out_tiles, wave, lane, pre, true, next_wp, bias_init, epi_rq);
       FS(2)
       __syncthreads();
       FS(3)
@@ -503,7 +498,7 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
     if (FINE && sd.layers[n_lin - 1].n_out_tiles > 0) {
       const LayerDesc L = sd.layers[n_lin - 1];
       const f32x4* bp = wsdf + L.b_off;
-      gemm_tiles2n<8, false>(lds, IS, KSegs{cur, hid_rows, 0, 0}, wsdf + L.w_off, L.n_out_tiles, wave, lane, nopre, false, nullptr,
+      gemm_tiles2<8>(lds, IS, KSegs{cur, hid_rows, 0, 0}, wsdf + L.w_off, L.n_out_tiles, wave, lane, nopre, false, nullptr,
                      [&](int ot, int, f32x16& acc) { init_bias(bp, ot, lane, acc); },
                      [&](int ot, int im, int rq, const f32x16& acc) {
                        f32x4* sv = save0 + (size_t)im * per_img + (size_t)feat_slot * 64;
@@ -549,7 +544,7 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
       if (l == sd.skip)                                 // embedding part of the skip layer first: `oth` is still free for the partials
         wte_split_k(lds, IS, cur, 4 * L.n_out_tiles, wsdf + L.wTE_off, emb_tiles, oth, 4 * MT, E0, false, wave, lane);
       f32x4 hv[2][4];
-      gemm_tiles2n<8, false>(lds, IS, ks, wsdf + L.wT_off, sd.layers[l - 1].n_out_tiles, wave, lane, nopre, false, nullptr,
+      gemm_tiles2<8>(lds, IS, ks, wsdf + L.wT_off, sd.layers[l - 1].n_out_tiles, wave, lane, nopre, false, nullptr,
                      [&](int ot, int im, f32x16& acc) {
                        if (im == 0) { FS(7) }
                        const f32x4* sv = save0 + (size_t)im * per_img + (size_t)(l - 1) * 4 * MT * 64;
@@ -630,7 +625,7 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
         const KSegs ks{cur, in_rows, E0, l == 0 ? cd.extra_rows : 0};
         const f32x4* bp = wcol + L.b_off;
         const int dst = oth;
-        gemm_tiles2n<8, false>(lds, IS, ks, wcol + L.w_off, L.n_out_tiles, wave, lane, nopre, false, nullptr,
+        gemm_tiles2<8>(lds, IS, ks, wcol + L.w_off, L.n_out_tiles, wave, lane, nopre, false, nullptr,
                        [&](int ot, int, f32x16& acc) { init_bias(bp, ot, lane, acc); },
                        [&](int ot, int im, int rq, const f32x16& acc) {
                          f32x4* li = lds + (size_t)im * IS;
