@@ -12,14 +12,14 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCP_TCC_READ_REQ_sum TCC_
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -o c -- python3 scripts/probe_neus_f16s.py f32 f16s > $OUT/p$i.log 2>&1 || { tail -5 $OUT/p$i.log; exit 1; }
 done
 python3 - <<PY
-import csv, glob, json, collections
+import csv, glob, json, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"]
-        if "neus_points" not in k:
+        m = re.search(r"neus_points\\w*<\\w+>", r["Kernel_Name"])
+        if not m:
             continue
-        name = k.split("(")[0].split("::")[-1].strip()
+        name = m.group(0)
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {"source": "rocprofv3 --kernel-trace --pmc <set> (4 separate passes) -- python3 scripts/probe_neus_f16s.py f32 f16s, PROBE_B=20480 rays "
                  "(SDF-only kernels at 64 samples/ray, fine kernels at 128), MI355X", "kernels": {}}
@@ -27,7 +27,8 @@ for name, cs in sorted(agg.items()):
     m = {c: sum(v) / len(v) for c, v in cs.items()}
     d = dict(m)
     if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m:
-        d["mfma_busy_frac_of_1024_simd_cycles"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * m["GRBM_GUI_ACTIVE"])
+        # GRBM_GUI_ACTIVE comes summed over the 8 XCDs (= 8 x kernel duration x shader clock)
+        d["mfma_busy_frac"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * m["GRBM_GUI_ACTIVE"] / 8.0)
     if "TCC_REQ_sum" in m and "TCC_MISS_sum" in m:
         d["l2_hit_rate"] = 1.0 - m["TCC_MISS_sum"] / max(m["TCC_REQ_sum"], 1.0)
     d["launches_seen"] = max(len(v) for v in cs.values())
