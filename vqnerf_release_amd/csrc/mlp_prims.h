@@ -196,6 +196,46 @@ __device__ __forceinline__ void gemm_tiles2(const f32x4* __restrict__ lds, const
         pc = pn; qc = qn;
       }
     };
+    if ((ng & 7) == 0) {
+      // K a whole number of double blocks (the 256-wide layers): the last block is peeled and image 1's half of it is issued one
+      // K group (4 MFMAs) at a time between image 0's epilogue quads, so that quarter of the workgroup's epilogue work runs in
+      // the shadow of matrix instructions (all 8 waves reach their epilogues together; nothing else covers them).  +0.9 %.
+      // Same accumulation order per image.
+      for (int g = 0; g < ng - 8; g += 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a1[i] = wp[(g + 4 + i) * 64];
+        block(a0, g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a0[i] = wp[(g + 8 + i) * 64];
+        block(a1, g + 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a1[i] = wp[(ng - 4 + i) * 64];
+      block(a0, ng - 8);
+      if (use_pre && ot + NW >= n_out_tiles && next_wp != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pre[i] = next_wp[i * 64];
+      }
+      f32x4 qt[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        { const int r = brow(ng - 4 + i + 1); pn = lds[r]; qn = lds[r + img_stride]; }
+        qt[i] = qc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], pc[j], acc0, 0, 0, 0);
+        pc = pn; qc = qn;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], qt[i][j], acc1, 0, 0, 0);
+        epi_rq(ot, 0, i, acc0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) epi_rq(ot, 1, rq, acc1);
+      continue;
+    }
     for (int g = 0; g < ng; g += 8) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) a1[i] = wp[min(g + 4 + i, ng - 1) * 64];
