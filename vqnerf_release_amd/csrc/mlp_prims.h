@@ -96,6 +96,91 @@ __device__ __forceinline__ void gemm_tiles(const f32x4* __restrict__ lds, const 
   }
 }
 
+// gemm_tiles with the epilogue of a wave's tile A issued inside the K loop of its tile B (software pipelining over the wave's
+// output tiles; a wave owns two at 256 outputs and 4 waves).  init(ot, slot, acc) / epi_rq(ot, slot, rq, acc): `slot` (0 / 1,
+// compile-time at every call) tells the caller which of two sets of per-tile epilogue operands to use -- tile B's are fetched
+// while tile A's are still needed.  Same arithmetic and order as gemm_tiles.
+template <int NW = 4, class Init, class EpiRq>
+__device__ __forceinline__ void gemm_tiles_sw(const f32x4* __restrict__ lds, const KSegs ks, const f32x4* __restrict__ w,
+                                              const int n_out_tiles, const int wave, const int lane, Init init, EpiRq epi_rq) {
+  const int ng = ks.nA + ks.nB;
+  auto brow = [&](int g) { g = min(g, ng - 1); return ((g < ks.nA) ? (ks.rowA + g) : (ks.rowB + (g - ks.nA))) * 64 + lane; };
+  for (int base = wave; base < n_out_tiles; base += 2 * NW) {
+    f32x16 accA, accB;
+    f32x4 a0[4], a1[4], bc, bn;
+    auto group = [&](const f32x4& a, f32x16& acc) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bc[j], acc, 0, 0, 0);
+    };
+    auto block = [&](const f32x4 (&a)[4], int g0, f32x16& acc) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bn = lds[brow(g0 + i + 1)];
+        if (g0 + i < ng) group(a[i], acc);
+        bc = bn;
+      }
+    };
+    // ---- tile A
+    {
+      const f32x4* __restrict__ wp = w + (size_t)base * ng * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a0[i] = wp[min(i, ng - 1) * 64];
+      bc = lds[brow(0)];
+      __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) only (see gemm_tiles)
+      init(base, 0, accA);
+      __builtin_amdgcn_s_setprio(1);
+      for (int g = 0; g < ng; g += 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a1[i] = wp[min(g + 4 + i, ng - 1) * 64];
+        block(a0, g, accA);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a0[i] = wp[min(g + 8 + i, ng - 1) * 64];
+        block(a1, g + 4, accA);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    const int otB = base + NW;
+    if (otB >= n_out_tiles) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) epi_rq(base, 0, rq, accA);
+      break;
+    }
+    // ---- tile B: its first four K groups carry tile A's epilogue quads
+    {
+      const f32x4* __restrict__ wp = w + (size_t)otB * ng * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a0[i] = wp[min(i, ng - 1) * 64];
+      bc = lds[brow(0)];
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      init(otB, 1, accB);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a1[i] = wp[min(4 + i, ng - 1) * 64];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bn = lds[brow(i + 1)];
+        if (i < ng) group(a0[i], accB);
+        bc = bn;
+        epi_rq(base, 0, i, accA);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a0[i] = wp[min(8 + i, ng - 1) * 64];
+      block(a1, 4, accB);
+      for (int g = 8; g < ng; g += 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a1[i] = wp[min(g + 4 + i, ng - 1) * 64];
+        block(a0, g, accB);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a0[i] = wp[min(g + 8 + i, ng - 1) * 64];
+        block(a1, g + 4, accB);
+      }
+      __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) epi_rq(otB, 1, rq, accB);
+    }
+  }
+}
+
 // gemm_tiles for a chain of layers: `pre` holds the first four weight fragments of this wave's FIRST tile (loaded by the
 // previous layer before its epilogue and barrier, so their L2 latency is not paid after the barrier); before the epilogue
 // of its LAST tile the function refills `pre` from `next_wp` (the same fragments of the next layer; nullptr = none).

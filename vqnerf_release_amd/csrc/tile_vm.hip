@@ -9,6 +9,7 @@
 // built by vqnerf_release_amd/geo/train_programs.py.  Weight gradients (contractions over points) are taken from the
 // saved TFMT tensors by csrc/wgrad.hip.  Formats: csrc/vm_desc.h.
 #include "mlp_prims.h"
+#include <type_traits>
 #include "vm_desc.h"
 
 using namespace eng;
@@ -85,50 +86,55 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void tile_vm_kernel(const
         const int tf1 = ia1 >= 0 ? tab.t[ia1].ld : 0, tf2 = ia2 >= 0 ? tab.t[ia2].ld : 0;
         const int tfs = ist >= 0 ? tab.t[ist].ld : 0, tfs2 = ist2 >= 0 ? tab.t[ist2].ld : 0;
         const f32x4* bp = wbuf + b_off;
-        float r1[16], r2[16];                       // epilogue operands, fetched before the K loop so that their latency hides under it
-        gemm_tiles<NW>(lds, ks, wbuf + w_off, n_out_tiles, wave, lane,
-                       [&](int ot, f32x16& acc) {
+        // epilogue operands of a tile, fetched before its K loop so that their latency hides under it; two sets: a wave's second
+        // tile is set up while the epilogue of its first one is still being issued (gemm_tiles_sw)
+        float r1[2][16], r2[2][16];
+        auto g_init = [&](int ot, auto slot, f32x16& acc) {
+          constexpr int S = decltype(slot)::value;
 #ifdef VQN_DIAG_VM_NO_AUX
-                         for (int e = 0; e < 16; ++e) { r1[e] = 0.5f; r2[e] = 0.25f; }
+          for (int e = 0; e < 16; ++e) { r1[S][e] = 0.5f; r2[S][e] = 0.25f; }
 #else
-                         if (epi != VM_EPI_ACT) {
+          if (epi != VM_EPI_ACT) {
 #pragma unroll
-                           for (int e = 0; e < 16; ++e) r1[e] = a1[tf_off(tile, tf1, ot, 8 * (e >> 2) + 2 * (e & 3) + h, p)];
-                           if (epi != VM_EPI_MUL_DACT) {
+            for (int e = 0; e < 16; ++e) r1[S][e] = a1[tf_off(tile, tf1, ot, 8 * (e >> 2) + 2 * (e & 3) + h, p)];
+            if (epi != VM_EPI_MUL_DACT) {
 #pragma unroll
-                             for (int e = 0; e < 16; ++e) r2[e] = a2[tf_off(tile, tf2, ot, 8 * (e >> 2) + 2 * (e & 3) + h, p)];
-                           }
-                         }
+              for (int e = 0; e < 16; ++e) r2[S][e] = a2[tf_off(tile, tf2, ot, 8 * (e >> 2) + 2 * (e & 3) + h, p)];
+            }
+          }
 #endif
-                         if (accum) init_rows(lds + (dst + ot * 4) * 64, lane, acc);
-                         else if (b_off >= 0) init_bias(bp, ot, lane, acc);
-                         else init_zero(acc);
-                       },
-                       [&](int ot, const f32x16& acc) {
+          if (accum) init_rows(lds + (dst + ot * 4) * 64, lane, acc);
+          else if (b_off >= 0) init_bias(bp, ot, lane, acc);
+          else init_zero(acc);
+        };
+        auto g_epi = [&](int ot, auto slot, int rq, const f32x16& acc) {
+          constexpr int S = decltype(slot)::value;
+          f32x4 y;
 #pragma unroll
-                         for (int rq = 0; rq < 4; ++rq) {
-                           f32x4 y;
-#pragma unroll
-                           for (int j = 0; j < 4; ++j) {
-                             const float a = acc[4 * rq + j];
-                             const int fi = 8 * rq + 2 * j + h;
-                             float v;
-                             if (epi == VM_EPI_ACT) v = vm_act(act, a);
-                             else {
-                               const float o1 = r1[4 * rq + j];
-                               const float d1 = vm_dact(act, o1);
-                               if (epi == VM_EPI_MUL_DACT) v = a * d1;
-                               else if (epi == VM_EPI_TANGENT) {
-                                 v = a * d1;
-                                 if (st2) st2[tf_off(tile, tfs2, ot, fi, p)] = pvalid ? r2[4 * rq + j] * a * vm_d2ratio(act, o1) : 0.f;
-                               } else v = a * d1 + r2[4 * rq + j];
-                             }
-                             y[j] = v;
-                             if (st) st[tf_off(tile, tfs, ot, fi, p)] = pvalid ? v : 0.f;
-                           }
-                           if (dst >= 0) lds[(dst + ot * 4 + rq) * 64 + lane] = y;
-                         }
-                       });
+          for (int j = 0; j < 4; ++j) {
+            const float a = acc[4 * rq + j];
+            const int fi = 8 * rq + 2 * j + h;
+            float v;
+            if (epi == VM_EPI_ACT) v = vm_act(act, a);
+            else {
+              const float o1 = r1[S][4 * rq + j];
+              const float d1 = vm_dact(act, o1);
+              if (epi == VM_EPI_MUL_DACT) v = a * d1;
+              else if (epi == VM_EPI_TANGENT) {
+                v = a * d1;
+                if (st2) st2[tf_off(tile, tfs2, ot, fi, p)] = pvalid ? r2[S][4 * rq + j] * a * vm_d2ratio(act, o1) : 0.f;
+              } else v = a * d1 + r2[S][4 * rq + j];
+            }
+            y[j] = v;
+            if (st) st[tf_off(tile, tfs, ot, fi, p)] = pvalid ? v : 0.f;
+          }
+          if (dst >= 0) lds[(dst + ot * 4 + rq) * 64 + lane] = y;
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        gemm_tiles_sw<NW>(lds, ks, wbuf + w_off, n_out_tiles, wave, lane,
+                          [&](int ot, int slot, f32x16& acc) { if (slot == 0) g_init(ot, S0{}, acc); else g_init(ot, S1{}, acc); },
+                          [&](int ot, int slot, int rq, const f32x16& acc) { if (slot == 0) g_epi(ot, S0{}, rq, acc); else g_epi(ot, S1{}, rq, acc); });
         __syncthreads();
       } else if (kind == VM_LD_POSENC || kind == VM_LD_POSENC_JVP) {
         const bool jvp = kind == VM_LD_POSENC_JVP;
