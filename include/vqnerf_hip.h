@@ -201,6 +201,14 @@ int vqn_neus_composite_bwd(const float* rays_o, const float* rays_d, const float
 int vqn_tile_program(const void* desc_dev, const int32_t* desc_host, const float* wbuf, float* const* tensors,
                      const int32_t* tensor_ld, int n_tensors, int64_t N, void* stream);
 
+/* Weight normalisation of all layers of a network in one launch and its backward in another (the geo trainer's per-step
+ * chain rule through nn.utils.weight_norm, fields.py:65-66 / :139-140: w = g * v / ||v||_row).  Host arrays of n_layers
+ * (<= 24) device pointers: v [rows_l, cols_l], g [rows_l], w / dw / dv [rows_l, cols_l], dg [rows_l]; contiguous fp32. */
+int vqn_weight_norm_fwd(int n_layers, const float* const* v, const float* const* g, float* const* w, const int32_t* rows,
+                        const int32_t* cols, void* stream);
+int vqn_weight_norm_bwd(int n_layers, const float* const* v, const float* const* g, const float* const* dw, float* const* dv,
+                        float* const* dg, const int32_t* rows, const int32_t* cols, void* stream);
+
 /* Row-major [N, F] (row stride ldx floats) <-> the feature-major tile format of the training programs
  * (TFMT [ceil(N/32)][tiles_f][32 features][32 points], csrc/vm_desc.h), zero padded on pack.  In the reference these
  * hand-offs are implicit (autograd passes dense [N, F] tensors between the Keras layers, the VQ layer and the renderer). */

@@ -336,3 +336,30 @@ def test_tfmt_pack_and_unpack(N, F, tiles):
     assert torch.equal(from_tfmt(t, N, F), x)
     out = torch.full((nt, ft, 32, 32), 7.0, device='cuda')
     assert to_tfmt(x.contiguous(), tiles, out=out) is out and torch.equal(out, t)
+
+
+def test_fused_weight_norm_matches_torch_autograd():
+    """vqn_weight_norm_fwd / _bwd for a list of layers against nn.utils.weight_norm's expression under torch autograd."""
+    from vqnerf_release_amd.geo.models.fields import _Lin, effective_weights
+    torch.manual_seed(0)
+    lins = [_Lin(39, 256, True), _Lin(256, 217, True), _Lin(7, 3, True), _Lin(256, 257, False), _Lin(295, 256, True)]
+    lins = [m.cuda() for m in lins]
+    with torch.no_grad():
+        for m in lins:
+            if m.weight_norm:
+                m.weight_g.mul_(1.3)
+    ws = effective_weights(lins)
+    ref = [m.effective_weight() for m in lins]
+    for w, r in zip(ws, ref):
+        np.testing.assert_allclose(w.detach().cpu().numpy(), r.detach().cpu().numpy(), rtol=5e-7, atol=0)   # row norms summed in another order: <= 2 ulp
+    seeds = [torch.randn_like(w) for w in ws]
+    sum((w * s).sum() for w, s in zip(ws, seeds)).backward()
+    got = [(m.weight_g.grad.clone(), m.weight_v.grad.clone()) if m.weight_norm else (m.weight.grad.clone(),) for m in lins]
+    for m in lins:
+        m.zero_grad(set_to_none=True)
+    sum((w * s).sum() for w, s in zip(ref, seeds)).backward()
+    for m, g in zip(lins, got):
+        want = (m.weight_g.grad, m.weight_v.grad) if m.weight_norm else (m.weight.grad,)
+        for a, b in zip(g, want):
+            scale = float(b.abs().max())
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-6 * scale)

@@ -51,6 +51,61 @@ class _Lin(nn.Module):
         return F.linear(x, self.effective_weight(), self.bias)
 
 
+class _WeightNormAll(torch.autograd.Function):
+    """effective weights of a list of weight-normed layers in ONE kernel launch, gradients in another (csrc/weight_norm.hip);
+    the reference's per-layer norm / div / mul and their autograd are ~150 launches per step for the 13 NeuS layers."""
+
+    @staticmethod
+    def forward(ctx, n, *gv):
+        import ctypes
+        import numpy as np
+        from vqnerf_release_amd import _C
+        gs, vs = gv[:n], gv[n:]
+        ws = [torch.empty_like(v) for v in vs]
+        rows = np.array([v.shape[0] for v in vs], np.int32)
+        cols = np.array([v.shape[1] for v in vs], np.int32)
+        P = ctypes.c_void_p * n
+        rc = _C.lib().vqn_weight_norm_fwd(ctypes.c_int(n), P(*[v.data_ptr() for v in vs]), P(*[g.data_ptr() for g in gs]),
+                                          P(*[w.data_ptr() for w in ws]), rows.ctypes.data_as(ctypes.c_void_p),
+                                          cols.ctypes.data_as(ctypes.c_void_p), _C._stream())
+        _C._check(rc, 'vqn_weight_norm_fwd')
+        ctx.n = n
+        ctx.save_for_backward(*gv)
+        return tuple(ws)
+
+    @staticmethod
+    def backward(ctx, *dws):
+        import ctypes
+        import numpy as np
+        from vqnerf_release_amd import _C
+        n = ctx.n
+        gs, vs = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        dws = [torch.zeros_like(v) if d is None else d.contiguous() for d, v in zip(dws, vs)]
+        dvs = [torch.empty_like(v) for v in vs]
+        dgs = [torch.empty_like(g) for g in gs]
+        rows = np.array([v.shape[0] for v in vs], np.int32)
+        cols = np.array([v.shape[1] for v in vs], np.int32)
+        P = ctypes.c_void_p * n
+        rc = _C.lib().vqn_weight_norm_bwd(ctypes.c_int(n), P(*[v.data_ptr() for v in vs]), P(*[g.data_ptr() for g in gs]),
+                                          P(*[d.data_ptr() for d in dws]), P(*[d.data_ptr() for d in dvs]),
+                                          P(*[d.data_ptr() for d in dgs]), rows.ctypes.data_as(ctypes.c_void_p),
+                                          cols.ctypes.data_as(ctypes.c_void_p), _C._stream())
+        _C._check(rc, 'vqn_weight_norm_bwd')
+        return (None,) + tuple(dgs) + tuple(dvs)
+
+
+def effective_weights(lins):
+    """[lin.effective_weight() for lin in lins]; weight-normed layers on a GPU go through the fused kernels (up to 24 per call)."""
+    idx = [i for i, m in enumerate(lins) if m.weight_norm and m.weight_v.is_cuda and m.weight_v.dtype == torch.float32]
+    out = [None if i in idx else m.effective_weight() for i, m in enumerate(lins)]
+    for c0 in range(0, len(idx), 24):
+        chunk = idx[c0:c0 + 24]
+        ws = _WeightNormAll.apply(len(chunk), *[lins[i].weight_g for i in chunk], *[lins[i].weight_v for i in chunk])
+        for i, w in zip(chunk, ws):
+            out[i] = w
+    return out
+
+
 def _needs_graph(module, *tensors):
     if not torch.is_grad_enabled():
         return False

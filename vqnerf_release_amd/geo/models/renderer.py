@@ -244,8 +244,9 @@ class NeuSRenderer:
         engine = self._train_engine(sdf_network, color_network)
         s_lins = [getattr(sdf_network, 'lin%d' % l) for l in range(sdf_network.num_layers - 1)]
         c_lins = [getattr(color_network, 'lin%d' % l) for l in range(color_network.num_layers - 1)]
-        params = [m.effective_weight() for m in s_lins] + [m.bias for m in s_lins] + \
-                 [m.effective_weight() for m in c_lins] + [m.bias for m in c_lins]
+        from vqnerf_release_amd.geo.models.fields import effective_weights
+        ws = effective_weights(list(s_lins) + list(c_lins))          # all weight-norm chains of the step: one launch each way
+        params = ws[:len(s_lins)] + [m.bias for m in s_lins] + ws[len(s_lins):] + [m.bias for m in c_lins]
         sdf, grad, rgb = NeusCoreFunction.apply(engine, pts, dirs, *params)
         inv_s = torch.exp(deviation_network.variance * 10.0).reshape(1)
         bg = None if background_rgb is None else background_rgb.detach().float().to(z_vals.device)
