@@ -477,6 +477,7 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
       const f32x4* bp = wsdf + L.b_off;
       auto bias_init = [&](int ot, int im, f32x16& acc) { if (im == 0) { FS(2) } init_bias(bp, ot, lane, acc); };
       auto epi_rq = [&](int ot, int im, int rq, const f32x16& acc) {
+        if (im == 0 && rq == 0) { FS(1) }
         f32x4* li = lds + (size_t)im * IS;
         f32x4* sv = save0 + (size_t)im * per_img + (size_t)l * 4 * MT * 64;
         f32x4 v = {acc[4 * rq], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]};
@@ -553,6 +554,7 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
                        init_zero(acc);
                      },
                      [&](int ot, int im, int rq, const f32x16& acc) {
+                       if (im == 0 && rq == 0) { FS(6) }
                        f32x4* li = lds + (size_t)im * IS;
                        f32x4 v = {acc[4 * rq], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]};
 #pragma unroll
