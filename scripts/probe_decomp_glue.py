@@ -7,9 +7,10 @@ from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
 from vqnerf_release_amd.decomp.nerfactor.util.io import config_from_dict
 dev = torch.device('cuda:0')
 rng = np.random.default_rng(1)
-model = get_model_class('vq_nfr')(config_from_dict(bench.DECOMP_INI))
+K = int(os.environ.get('VQN_K', '15'))                         # codebook size (BASELINE configs[2]: 64)
+model = get_model_class('vq_nfr')(config_from_dict(dict(bench.DECOMP_INI, num_embed=K)))
 model.build_nets(device=dev, seed=0).to(dev)
-cb = rng.uniform(0, 1, (15, 256)).astype(np.float32)
+cb = rng.uniform(0, 1, (K, 256)).astype(np.float32)
 model.set_codebook(cb / np.linalg.norm(cb, axis=1, keepdims=True))
 model.set_light(rng.uniform(0, 1, (16, 32, 3)).astype(np.float32))
 n = 640000
