@@ -91,6 +91,13 @@ def test_fit_trains_checkpoints_resumes_and_validates(tmp_path):
     w.flush()
     files = set(os.listdir(tmp_path / 'pd_relit' / ('batch%09d' % 0)))
     assert n == 1 and {'pred_rgb_probes_city.png', 'pred_rgb_probes_forest.png', 'pred_rgb_olat_0004-0008.png', 'metadata.json'} <= files
+    # view sharding of a multi-process inference run: process 1 of 2 gets views 1, 3, ... and keeps their global numbering
+    w, n = train_nfr.render_views(model2, tr, str(tmp_path / 'sharded'), num_p=2, p_i=1)
+    w.flush()
+    assert n == 1 and os.listdir(tmp_path / 'sharded') == ['batch%09d' % 1]
+    w, n = train_nfr.render_views(model2, tr, str(tmp_path / 'sharded'), num_p=2, p_i=0)
+    w.flush()
+    assert n == 1 and sorted(os.listdir(tmp_path / 'sharded')) == ['batch%09d' % 0, 'batch%09d' % 1]
 
 
 def test_outer_sample_max_colour_difference_neighbour():

@@ -449,20 +449,30 @@ def fit(config, outdir, dataset_train, dataset_vali=None, model=None, device='cu
 
 @torch.no_grad()
 def render_views(model, dataset, outroot, relight_olat=False, relight_probes=False, opt_scale=None, writer=None, log=None,
-                 **fast_render_kwargs):
+                 num_p=None, p_i=None, **fast_render_kwargs):
     """The inference loops of the reference's test.py (:180-266: `raw_test` / `pd_test` / `pd_relit` passes): every view of
-    `dataset` through `model.fast_render(mode='test', ...)`, its files queued into `outroot/batch{i:09d}` by the
-    asynchronous `vis_batch`.  Rendering of view i + 1 overlaps the encoding of view i; the returned writer's `.flush()`
-    waits for the files.  Returns (writer, number of views)."""
+    `dataset` through `model.fast_render(mode='test', ...)`, its files queued into `outroot/batch{i:09d}` (i = the view's
+    index in the sorted set) by the asynchronous `vis_batch`.  Rendering of view i + 1 overlaps the encoding of view i; the
+    returned writer's `.flush()` waits for the files.  Views are independent: with `num_p` processes (default: the ranks of
+    the process group) process `p_i` takes views p_i, p_i + num_p, ... -- multi-GPU batched inference with no collective.
+    Returns (writer, number of views this process rendered)."""
     import os
+    if num_p is None:
+        num_p, p_i = parallel.world_size(), parallel.rank()
+    order = {f: i for i, f in enumerate(sorted(dataset.files))}
+    mine = {f for f, i in order.items() if i % num_p == p_i}
     n = 0
-    for i, batch in enumerate(dataset.build_pipeline()):
+    for f in sorted(mine):
+        batch = dataset.view(f)
         _, _, _, to_vis = model.fast_render(batch, mode='test', relight_olat=relight_olat, relight_probes=relight_probes,
                                             opt_scale=opt_scale, **fast_render_kwargs)
-        writer = model.vis_batch(to_vis, os.path.join(outroot, 'batch{i:09d}'.format(i=i)), mode='test', writer=writer)
+        writer = model.vis_batch(to_vis, os.path.join(outroot, 'batch{i:09d}'.format(i=order[f])), mode='test', writer=writer)
         n += 1
         if log is not None:
-            log(f'view {i} queued')
+            log(f'view {order[f]} queued')
+    if writer is None:
+        from vqnerf_release_amd.decomp.nerfactor.util import vis
+        writer = vis.default_writer()
     return writer, n
 
 
