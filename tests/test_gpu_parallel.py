@@ -91,3 +91,75 @@ def test_geo_trainer_dp2_equals_single_process(tmp_path):
     # same gradient up to the order of the sums and the eikonal normaliser (a rank averages over ITS in-sphere samples and the
     # ranks are combined by their share of rays: a weighted mean of ratios, not the ratio of global sums)
     assert err <= 2e-4, err
+
+
+def _decomp_model():
+    from oracle import decomp as od
+    from tests.decomp_util import make_config, load_oracle_params
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    p, _ = od.make_model_params(seed=0, K=15)
+    model = load_oracle_params(get_model_class('vq_nfr')(make_config(n_rays_per_step=128)), p, 'cuda')
+    model.get_codebook(); _ = model.light
+    return model
+
+
+def _decomp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from oracle import decomp as od
+    from tests.decomp_util import make_batch
+    from vqnerf_release_amd import parallel
+    from vqnerf_release_amd.decomp.nerfactor import train_nfr
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        model = _decomp_model()
+        opt = torch.optim.Adam(model.trainable_variables, lr=5e-4, eps=1e-7, amsgrad=True)
+        tr = train_nfr.Trainer(model, opt)
+        full = make_batch(od.make_points(256, seed=9), 'cuda')
+        lo, hi = parallel.shard_range(256)
+        half = tuple(t[lo:hi].contiguous() if torch.is_tensor(t) else t for t in full)
+        wl, _, _ = tr.train_iter(half, global_bs=256)
+        parallel.assert_replicas_identical(list(model.trainable_variables), 'reflectance model after the step')
+        if rank == 0:
+            q.put(dict(loss=float(wl), codebook=model._codebook.detach().cpu().numpy().copy(),
+                       counts=model.vq_layer.ema_cluster_size.hidden.detach().cpu().numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_decomp_trainer_dp2_shares_codebook_statistics():
+    """The VQ stage under data parallelism: EMA statistics (code counts, x^T . onehot) are summed over the ranks before the
+    codebook moves, so both replicas hold the same codebook -- and it is the one a single process computes from all rows."""
+    import time
+    import torch.multiprocessing as mp
+    from oracle import decomp as od
+    from tests.decomp_util import make_batch
+    from vqnerf_release_amd.decomp.nerfactor import train_nfr
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_decomp_worker, args=(rk, 2, port, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        t0 = time.time()
+        while q.empty():
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), 'a rank died'
+            assert time.time() - t0 < 240, 'ranks did not finish'
+            time.sleep(0.2)
+        got = q.get()
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    model = _decomp_model()
+    opt = torch.optim.Adam(model.trainable_variables, lr=5e-4, eps=1e-7, amsgrad=True)
+    tr = train_nfr.Trainer(model, opt)
+    wl, _, _ = tr.train_iter(make_batch(od.make_points(256, seed=9), 'cuda'), global_bs=256)
+    np.testing.assert_array_equal(got['counts'], model.vq_layer.ema_cluster_size.hidden.cpu().numpy())        # integer counts: exact
+    np.testing.assert_allclose(got['codebook'], model._codebook.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+    assert abs(got['loss'] - float(wl)) <= 5e-3 * max(1.0, abs(float(wl)))     # batch-level terms (pair similarity, code spread) are per rank
