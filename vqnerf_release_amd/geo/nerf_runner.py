@@ -87,6 +87,9 @@ class Runner:
             else:
                 dataset = SyntheticDataset(dconf, device=self.device)
         self.dataset = dataset
+        # data parallel: every rank must draw its OWN pixels (an unseeded device generator starts from the same state everywhere)
+        if parallel.world_size() > 1 and hasattr(dataset, 'gen'):
+            dataset.gen.manual_seed(dataset.gen.initial_seed() + 7919 * parallel.rank())
         self.iter_step = 0
         t = self.conf['train']
         self.end_iter, self.save_freq, self.report_freq = t.get_int('end_iter'), t.get_int('save_freq'), t.get_int('report_freq')
