@@ -146,7 +146,7 @@ __device__ __forceinline__ void gemm_tiles_f16s_ring(const f32x4* __restrict__ l
 // fragment to both (6 MFMAs per step), so the L2 weight stream per point halves -- on this engine that stream, not the
 // matrix pipe, is what binds with one image per fragment (measured: 15 TB/s of L2 reads, the L2's limit).  init / epi
 // are called once per image: init(ot, img, acc), epi(ot, img, acc1, acc2).
-template <int NW = 8, int R = 2, class Init, class Epi>
+template <int NW = 8, int R = 2, int BD = 2 /* activation fragments fetched BD steps ahead (1 or 2) */, class Init, class Epi>
 __device__ __forceinline__ void gemm_tiles_f16s_ring2(const f32x4* __restrict__ lds, const int img_stride, const KSegs ks,
                                                       const f32x4* __restrict__ w, const int n_out_tiles, const int wave,
                                                       const int lane, f32x4 (&A)[R][8],
@@ -164,10 +164,10 @@ __device__ __forceinline__ void gemm_tiles_f16s_ring2(const f32x4* __restrict__ 
     f32x16 p1, p2, q1, q2;                     // image 0: p1 (hi*hi + init), p2 (cross terms);  image 1: q1, q2
 #pragma unroll
     for (int i = 0; i < 16; ++i) { p2[i] = 0.f; q2[i] = 0.f; }
-    // activation fragments two steps ahead (measured: one step ahead is 3 % slower although it frees 32 registers)
+    // activation fragments BD steps ahead (BD = 1 frees 32 registers; 3 % slower where registers are not the limit)
     f32x4 Bh0[4], Bl0[4], Bh1[4], Bl1[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < BD; ++j) {
       const int a = bstep(j);
       Bh0[j] = lds[a]; Bl0[j] = lds[a + 64]; Bh1[j] = lds[a + img_stride]; Bl1[j] = lds[a + img_stride + 64];
     }
@@ -181,11 +181,11 @@ __device__ __forceinline__ void gemm_tiles_f16s_ring2(const f32x4* __restrict__ 
         const int blk = bi + u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int a = bstep(blk * 4 + j + 2);
-          Bh0[(j + 2) & 3] = lds[a];
-          Bl0[(j + 2) & 3] = lds[a + 64];
-          Bh1[(j + 2) & 3] = lds[a + img_stride];
-          Bl1[(j + 2) & 3] = lds[a + img_stride + 64];
+          const int a = bstep(blk * 4 + j + BD);
+          Bh0[(j + BD) & 3] = lds[a];
+          Bl0[(j + BD) & 3] = lds[a + 64];
+          Bh1[(j + BD) & 3] = lds[a + img_stride];
+          Bl1[(j + BD) & 3] = lds[a + img_stride + 64];
           if (blk < nb) {
             p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(A[u][2 * j]), as_h8(Bh0[j]), p1, 0, 0, 0);
             q1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(A[u][2 * j]), as_h8(Bh1[j]), q1, 0, 0, 0);
