@@ -169,3 +169,21 @@ def test_full_image_properties():
         r1 = ren.render(o[:3001], d[:3001], near[:3001], far[:3001], 2.0, perturb_overwrite=0,
                         background_rgb=torch.ones(1, 3).cuda(), cos_anneal_ratio=1.0)
         assert torch.equal(r1['color_fine'], rr['color_fine'][:3001])
+
+
+def test_background_branch_runs_where_the_reference_raises():
+    """n_outside > 0 (NeRF++ background, renderer.py:93-129, :309-331): dead in every shipped conf, and the reference's own
+    render_core raises there (renderer.py:267 multiplies [B, n, 3] points by [B, n + n_outside] weights), so there are no
+    values to match; the API is kept: this checks shapes, finiteness and that the inside / outside weights partition."""
+    from oracle import geo as og
+    from vqnerf_release_amd.geo.models.fields import NeRF
+    cfg, sdf, col, var, ren = _build('small')
+    ren.n_importance, ren.up_sample_steps, ren.n_outside = 16, 4, 8
+    ren.nerf = NeRF(D=2, W=32, d_in=4, d_in_view=3, multires=4, multires_view=2, output_ch=4, skips=[], use_viewdirs=True).cuda()
+    o, d, near, far = [torch.tensor(a).cuda() for a in og.make_rays(24, 5)]
+    n = ren.n_samples + ren.n_importance
+    with torch.no_grad():
+        r = ren.render(o, d, near, far, 2.0, perturb_overwrite=0, background_rgb=torch.ones(1, 3).cuda(), cos_anneal_ratio=0.6)
+    assert r['weights'].shape == (24, n + 8) and r['gradients'].shape == (24, n, 3) and r['color_fine'].shape == (24, 3)
+    assert all(torch.isfinite(v).all() for v in r.values() if torch.is_tensor(v))
+    assert float(r['weights'].min()) >= 0 and float(r['weights'].sum(-1).max()) <= 1 + 1e-5
