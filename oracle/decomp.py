@@ -16,7 +16,9 @@ text, the arithmetic of
     .../util/img.py:142-186                                    -> linear2srgb / srgb2linear
     .../models/shape.py:103-119                                -> calc_ldir / calc_vdir
     .../models/vq_nfr.py:534-692                               -> model_call
+    .../models/vq_nfr.py:262-398                               -> fast_render
     .../models/vq_nfr.py:694-733                               -> render_integrate
+    .../models/vq_nfr.py:736-745                               -> gamma_param (data types 'dtu' / 'hw')
     .../models/vq_nfr.py:761-769                               -> get_codebook
     .../models/vq_nfr.py:771-833                               -> pred_enc / pred_diff / pred_spec / pred_rough / normal_correct
     .../models/vq_nfr.py:876-986                               -> compute_loss
@@ -313,6 +315,50 @@ def model_call(p, specs, batch, lxyz, lareas, ema_cs, ema_dw, mode='train', thre
     if mode != 'train':
         out['rgb_diff'] = render_integrate(brdf_d, surf2l, n_pred, lareas, light, lvis, gamma)
         out['rgb_spec'] = render_integrate(brdf_s, surf2l, n_pred, lareas, light, lvis, gamma)
+    return out
+
+
+def gamma_param(gamma_bias, gamma_index):
+    """vq_nfr.py:736-745 (twins nfr_unit.py:309-318, ref_nfr.py:461-470): the learnable display curve of the non-'nerf'
+    data types, `(rgb * gamma[0]) ** gamma[1]` with gamma = concat([bias, clip_by_value_preserve_gradient(index, 0, 5)])."""
+    idx = gamma_index + (gamma_index.clamp(0.0, 5.0) - gamma_index).detach()
+    return torch.cat([gamma_bias.reshape(1), idx.reshape(1)], 0)
+
+
+def displayed(rgb, data_type):
+    """What `call` / `fast_render` put into `pred`: sRGB for data_type 'nerf' (vq_nfr.py:638-639, :676-677, :350-358, :380-381),
+    the rendered value itself for 'dtu' / 'hw' (their gamma curve is already inside `_render`)."""
+    return linear2srgb(rgb) if data_type == 'nerf' else rgb
+
+
+def fast_render(p, specs, batch, lxyz, lareas, data_type='nerf', gamma=None, probes=(), dst_env=None, opt_scale=None,
+                vis_scale=False):
+    """vq_nfr.Model.fast_render (vq_nfr.py:262-398) on already-masked foreground points: main heads only, optional
+    albedo / spec scale (:332-335), one render under the model light or `dst_env` (:340-343, :694-699) and one per probe
+    (:724-733).  Returns the `pred`-level values (sRGB for 'nerf', see `displayed`)."""
+    xyz, normal, rayo = batch['xyz'], batch['normal'], batch['rayo']
+    lvis = batch.get('lvis') if data_type == 'nerf' else None
+    surf2l = calc_ldir(lxyz, xyz)
+    surf2c = calc_vdir(rayo, xyz)
+    n_pred = normal_correct(normal, surf2c)
+    z_enc = pred_enc(p, specs, xyz)
+    basecolor, ks, rough = heads(p, specs, z_enc, vq=False)
+    spec = ks * basecolor
+    albedo = (1 - ks) * basecolor
+    scaled = (opt_scale is not None) and (not vis_scale)
+    s_albedo, s_spec = (albedo * opt_scale, spec * opt_scale) if scaled else (albedo, spec)
+    brdf, _, _ = get_brdf(surf2l, surf2c, n_pred, s_albedo, rough, s_spec)
+    light = p['light'].clamp(min=0.0) if dst_env is None else dst_env
+    out = dict(albedo=albedo, spec=spec, rough=rough, basecolor=basecolor, normal=n_pred)
+    rgb = render_integrate(brdf, surf2l, n_pred, lareas, light, lvis, gamma)
+    if (opt_scale is not None) and vis_scale:                                  # :360-364
+        out['basecolor'] = linear2srgb(basecolor) * opt_scale
+        out['spec'] = linear2srgb(spec) * opt_scale
+    if dst_env is not None:
+        out['rgb'] = displayed(rgb, data_type)
+    if len(probes):
+        out['rgb_probes'] = displayed(torch.stack([render_integrate(brdf, surf2l, n_pred, lareas, lp, lvis, gamma)
+                                                   for lp in probes], 1), data_type)
     return out
 
 

@@ -1,0 +1,187 @@
+"""Model-level GPU parity of the reflectance path on the BASELINE configurations round 1 left untested:
+  * configs[3] / configs[4]: data_type 'dtu' and 'hw' -- no light-visibility rows, the learnable display curve
+    `(rgb * gamma[0]) ** gamma[1]` inside `_render` (vq_nfr.py:715-716, :736-745), no sRGB transfer on `pred` (:638, :676) nor
+    on the loss targets (:896-901); shipped codebook size 8 (scripts/train/vq_dtu.sh:25, vq_hw.sh:25);
+  * configs[2]: the 64-entry codebook through `vq_nfr.Model.call` (not only the bare VQ kernels);
+  * configs[4]: both of the above on the f32 kernels and on the opt-in split-precision (fp16 MFMA) kernels, incl. the
+    16-probe relighting pass `fast_render(relight_probes=True)` (test.py:254-266).
+Everything is compared with oracle/decomp.py (a from-source restatement: PARITY UNPINNED against the TF reference, see
+DESIGN.md) on the same seeded inputs.  Tolerances as in tests/test_gpu_decomp.py; VQ indices exact (f32 kernels) / exact on
+rows whose top-2 distance gap exceeds 1e-5 (split-precision kernels, whose z differs from the f32 one by ~1e-6)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.decomp_util import make_config, load_oracle_params, make_batch
+
+pytestmark = pytest.mark.gpu
+
+GAMMA = (1.3, 0.8)          # (bias, index): away from the (1, 1) initial value so that the curve is exercised
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _set_gamma(model, bias, index):
+    model.gamma                                           # created lazily, like the reference's tf.Variables
+    with torch.no_grad():
+        model._gamma_bias.fill_(bias)
+        model._gamma_index.fill_(index)
+
+
+def _build(data_type, K, seed=0):
+    from oracle import decomp as od
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    p, specs = od.make_model_params(seed=seed, K=K)
+    model = load_oracle_params(get_model_class('vq_nfr')(make_config(data_type=data_type, num_embed=K)), p, 'cuda')
+    gamma = None
+    if data_type != 'nerf':
+        _set_gamma(model, *GAMMA)
+        gamma = od.gamma_param(torch.tensor([GAMMA[0]]), torch.tensor([GAMMA[1]]))
+    pt = {k: ([(od.T(W), od.T(b)) for W, b in v] if isinstance(v, list) else od.T(v)) for k, v in p.items()}
+    lxyz, lareas = od.gen_light_xyz(16, 32)
+    return od, p, pt, specs, model, gamma, od.T(lxyz), od.T(lareas)
+
+
+CALL_CASES = [
+    # data_type, K, mode, matrix_mode
+    ('dtu', 8, 'train', 'f32'), ('dtu', 8, 'vali', 'f32'), ('dtu', 64, 'vali', 'f32'),
+    ('hw', 8, 'train', 'f32'), ('hw', 8, 'vali', 'f32'), ('hw', 8, 'vali', 'f16s'), ('hw', 8, 'train', 'f16s'),
+    ('nerf', 64, 'train', 'f32'), ('nerf', 64, 'vali', 'f32'), ('nerf', 64, 'vali', 'f16s'),
+]
+
+
+@pytest.mark.parametrize('data_type,K,mode,matrix_mode', CALL_CASES)
+def test_model_call_and_loss_vs_oracle(data_type, K, mode, matrix_mode):
+    od, p, pt, specs, model, gamma, lxyz, lareas = _build(data_type, K)
+    model.matrix_mode = matrix_mode
+    N = 600
+    pts = od.make_points(N, seed=3, lvis=(data_type == 'nerf'))
+    batch = make_batch(pts, 'cuda', bg_every=7)
+    assert len(batch) == (10 if data_type == 'nerf' else 9)          # the batch tuple of shape_unit.py:109-110
+    keep = np.ones(N, bool); keep[::7] = False
+    ob = {k: od.T(v[keep]) for k, v in pts.items()}
+    want = od.model_call(pt, specs, ob, lxyz, lareas, od.EMA(0.999, (K,)), od.EMA(0.999, (256, K)), mode=mode,
+                         data_type=data_type, gamma=gamma)
+    with torch.no_grad():
+        pred, gt, lk, to_vis = model.call(batch, mode=mode)
+    m = torch.tensor(keep).cuda()
+    f32 = matrix_mode == 'f32'
+    t_rgb, t_mat = (2e-5, 5e-6) if f32 else (1e-4, 1e-5)
+    # rows on which the nearest code is unambiguous in fp32 (all of them matter for the f32 kernels: indices must be exact)
+    d = np.sort(want['vq']['distances'].numpy(), 1)
+    clear = (d[:, 1] - d[:, 0]) > 1e-5
+    rows = np.ones_like(clear) if f32 else clear
+    assert rows.mean() > 0.98
+    np.testing.assert_array_equal(_np(pred['rgb'][~m]), 0.0)                 # background rays stay zero
+    np.testing.assert_allclose(_np(pred['rgb'][m]), od.displayed(want['rgb'], data_type).numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(_np(lk['rgb']), want['rgb'].numpy(), rtol=0, atol=t_rgb)
+    np.testing.assert_allclose(_np(lk['vqrgb'])[rows], want['vq_rgb'].numpy()[rows], rtol=0, atol=t_rgb)
+    np.testing.assert_allclose(_np(pred['albedo'][m]), want['albedo'].numpy(), rtol=0, atol=t_mat)
+    np.testing.assert_allclose(_np(pred['spec'][m]), want['spec'].numpy(), rtol=0, atol=t_mat)
+    np.testing.assert_allclose(_np(pred['rough'][m]), want['rough'].numpy(), rtol=0, atol=t_mat)
+    np.testing.assert_allclose(_np(lk['z'])[rows], want['z_vq'].numpy()[rows], rtol=0, atol=1e-6 if f32 else 3e-6)
+    np.testing.assert_allclose(float(lk['vqloss']), float(want['vq']['loss']), rtol=1e-4 if f32 else 1e-3)
+    if mode != 'train':
+        got_idx, want_idx = _np(pred['embed'][m])[:, 0], want['embed'].numpy()
+        np.testing.assert_array_equal(got_idx[rows], want_idx[rows])         # VQ indices exact
+        assert got_idx.min() >= 1 and got_idx.max() <= K
+        np.testing.assert_allclose(_np(pred['rgb_diff'][m]), want['rgb_diff'].numpy(), rtol=0, atol=t_rgb)
+        np.testing.assert_allclose(_np(pred['rgb_spec'][m]), want['rgb_spec'].numpy(), rtol=0, atol=1e-4)
+        np.testing.assert_allclose(_np(pred['vq_rgb'][m])[rows], od.displayed(want['vq_rgb'], data_type).numpy()[rows], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(_np(pred['vq_albedo'][m])[rows], want['vq_albedo'].numpy()[rows], rtol=0, atol=t_mat)
+        np.testing.assert_allclose(_np(pred['vq_spec'][m])[rows], want['vq_spec'].numpy()[rows], rtol=0, atol=t_mat)
+    elif f32:
+        # the EMA moved the codebook (vq_nfr.py:582-583)
+        np.testing.assert_allclose(_np(model._codebook), want['vq']['update'].numpy(), rtol=0, atol=2e-6)
+    if f32 or rows.all():
+        loss, ld = model.compute_loss(pred, gt, **dict(lk))
+        cb_for_loss = want['vq']['update'] if mode == 'train' else pt['codebook_raw']
+        wl, wd = od.compute_loss(want, ob['rgb'], cb_for_loss, mode=mode, data_type=data_type)
+        np.testing.assert_allclose(_np(loss), wl.numpy(), rtol=1e-4 if f32 else 1e-3, atol=2e-6 if f32 else 2e-5)
+        for k in ('rgb', 'vqrgb', 'chromaticity'):
+            np.testing.assert_allclose(_np(ld[k]), wd[k].numpy(), rtol=1e-4 if f32 else 1e-3, atol=2e-6 if f32 else 2e-5, err_msg=k)
+
+
+@pytest.mark.parametrize('data_type,K,matrix_mode', [('hw', 8, 'f32'), ('hw', 8, 'f16s'), ('dtu', 8, 'f32'), ('nerf', 64, 'f32')])
+def test_fast_render_relight_vs_oracle(data_type, K, matrix_mode):
+    """BASELINE configs[4]: `fast_render(relight_probes=True)` under 16 probes (vq_nfr.py:262-398, :724-733), one shading pass
+    for all of them, against the oracle's probe-by-probe statement -- every probe, every data type's display transfer."""
+    od, p, pt, specs, model, gamma, lxyz, lareas = _build(data_type, K)
+    model.matrix_mode = matrix_mode
+    rng = np.random.default_rng(2)
+    probes = [rng.uniform(0, 2, (16, 32, 3)).astype(np.float32) for _ in range(16)]
+    model.novel_probes = {f'probe{i:02d}': torch.tensor(a).cuda() for i, a in enumerate(probes)}
+    N = 300
+    pts = od.make_points(N, seed=12, lvis=(data_type == 'nerf'))
+    batch = make_batch(pts, 'cuda', bg_every=5)
+    keep = np.ones(N, bool); keep[::5] = False
+    m = torch.tensor(keep).cuda()
+    ob = {k: od.T(v[keep]) for k, v in pts.items()}
+    want = od.fast_render(pt, specs, ob, lxyz, lareas, data_type=data_type, gamma=gamma, probes=[od.T(a) for a in probes],
+                          dst_env=od.T(probes[3]))
+    with torch.no_grad():
+        pred, gt, lk, to_vis = model.fast_render(batch, mode='test', relight_probes=True)
+        one, _, _, _ = model.fast_render(batch, mode='test', dst_env='probe03')
+    assert pred['rgb_probes'].shape == (N, 16, 3)
+    assert float(pred['rgb_probes'][~m].abs().max()) == 0.0
+    tol = 2e-4 if matrix_mode == 'f32' else 4e-4
+    np.testing.assert_allclose(_np(pred['rgb_probes'][m]), want['rgb_probes'].numpy(), rtol=0, atol=tol)
+    np.testing.assert_allclose(_np(one['rgb'][m]), want['rgb'].numpy(), rtol=0, atol=tol)
+    np.testing.assert_allclose(_np(pred['albedo'][m]), want['albedo'].numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(_np(pred['rough'][m]), want['rough'].numpy(), rtol=0, atol=1e-5)
+    assert 'rgb' not in pred                                    # only with dst_env (vq_nfr.py:378-382)
+    # the albedo / spec scale of the 'nerf' relighting pass (test.py:238, vq_nfr.py:332-335)
+    if data_type == 'nerf':
+        scale = torch.tensor([[1.2, 0.9, 0.8]])
+        want_s = od.fast_render(pt, specs, ob, lxyz, lareas, data_type=data_type, gamma=gamma, probes=[od.T(probes[0])],
+                                opt_scale=scale)
+        model.novel_probes = {'probe00': model.novel_probes['probe00']}
+        with torch.no_grad():
+            pred_s, _, _, _ = model.fast_render(batch, mode='test', relight_probes=True, opt_scale=scale.cuda())
+        np.testing.assert_allclose(_np(pred_s['rgb_probes'][m]), want_s['rgb_probes'].numpy(), rtol=0, atol=tol)
+        np.testing.assert_allclose(_np(pred_s['albedo'][m]), want_s['albedo'].numpy(), rtol=0, atol=1e-5)   # unscaled (:366)
+
+
+@pytest.mark.parametrize('data_type,K', [('dtu', 8), ('hw', 64)])
+def test_training_step_grads_non_nerf_vs_oracle(data_type, K):
+    """Training path with the display curve: d loss / d (every Dense kernel and bias, light, gamma bias, gamma index) through
+    the HIP training engines (tile programs + fused shading fwd/bwd; the curve itself is a torch epilogue) vs the CPU oracle
+    under torch autograd."""
+    od, p, pt_, specs, model, _, lxyz, lareas = _build(data_type, K)
+    model.train_backend = 'hip'
+    N = 256
+    pts = od.make_points(N, seed=9, lvis=False)
+    batch = make_batch(pts, 'cuda')
+    pred, gt, lk, _ = model.call(batch, mode='train')
+    loss, _ = model.compute_loss(pred, gt, **dict(lk))
+    loss.sum().div(N).backward()
+    pt = {k: ([(od.T(W).requires_grad_(True), od.T(b).requires_grad_(True)) for W, b in v] if isinstance(v, list)
+              else od.T(v).requires_grad_(True)) for k, v in p.items()}
+    gb, gi = torch.tensor([GAMMA[0]], requires_grad=True), torch.tensor([GAMMA[1]], requires_grad=True)
+    ob = {k: od.T(v) for k, v in pts.items()}
+    want = od.model_call(pt, specs, ob, lxyz, lareas, od.EMA(0.999, (K,)), od.EMA(0.999, (256, K)), mode='train',
+                         data_type=data_type, gamma=od.gamma_param(gb, gi))
+    wl, _ = od.compute_loss(want, ob['rgb'], pt['codebook_raw'], mode='train', data_type=data_type)
+    wl.sum().div(N).backward()
+    for name, net in model.net.items():
+        for layer, (W, b) in zip(net.layers, pt[name]):
+            for got, ref in ((layer.kernel.grad, W.grad), (layer.bias.grad, b.grad)):
+                ref = ref.numpy()
+                scale = max(np.abs(ref).max(), 1e-8)
+                assert np.abs(_np(got) - ref).max() <= 2e-3 * scale + 1e-9, name
+    ref = pt['light'].grad.numpy()
+    assert np.abs(_np(model._light.grad) - ref).max() <= 2e-3 * np.abs(ref).max()
+    np.testing.assert_allclose(_np(model._gamma_bias.grad), gb.grad.numpy(), rtol=2e-3)
+    np.testing.assert_allclose(_np(model._gamma_index.grad), gi.grad.numpy(), rtol=2e-3)
+
+
+def test_non_nerf_batch_with_a_visibility_row_is_rejected():
+    """`_unpack` follows the reference's tuple arity per data type (vq_nfr.py:543-547): a 10-tuple for 'dtu' is an error there
+    (too many values to unpack) and must be one here, not a silently ignored lvis."""
+    od, p, pt, specs, model, gamma, lxyz, lareas = _build('dtu', 8)
+    pts = od.make_points(64, seed=1, lvis=True)
+    with pytest.raises(ValueError):
+        with torch.no_grad():
+            model.call(make_batch(pts, 'cuda'), mode='vali')

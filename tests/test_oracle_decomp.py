@@ -169,3 +169,47 @@ def test_model_call_and_loss_shapes_and_grads():
     assert all(torch.isfinite(W.grad).all() for W, _ in pt['fine_enc'])
     assert torch.isfinite(pt['codebook_raw'].grad).all() and pt['codebook_raw'].grad.abs().sum() > 0
     assert out['vq']['update'].shape == (256, 15)
+
+
+def test_gamma_curve_and_display_transfer_of_non_nerf_data():
+    """data types 'dtu' / 'hw' (vq_nfr.py:715-716, :736-745): `(rgb * bias) ** index` with the index clipped to [0, 5] (identity
+    gradient), no sRGB transfer on `pred` (:638, :676)."""
+    g = od.gamma_param(torch.tensor([1.3]), torch.tensor([7.0], requires_grad=True))
+    assert g.tolist() == [pytest.approx(1.3), 5.0]
+    gi = torch.tensor([7.0], requires_grad=True)
+    od.gamma_param(torch.tensor([1.3]), gi)[1].backward()
+    assert gi.grad.item() == 1.0                                        # clip_by_value_preserve_gradient
+    # a Lambertian point under a white sky: sum = albedo * S (S ~ 1) -> curve -> clip
+    lxyz, lareas = od.gen_light_xyz(16, 32)
+    xyz, n, o = torch.zeros(1, 3), torch.tensor([[0.0, 0.0, 1.0]]), torch.tensor([[0.0, 0.0, 4.0]])
+    l = od.calc_ldir(od.T(lxyz), xyz)
+    brdf = (torch.tensor([[0.6, 0.3, 0.1]]) / od.PI)[:, None, :].expand(1, 512, 3)
+    plain = od.render_integrate(brdf, l, n, od.T(lareas), torch.ones(16, 32, 3))
+    same = od.render_integrate(brdf, l, n, od.T(lareas), torch.ones(16, 32, 3), gamma=od.gamma_param(torch.ones(1), torch.ones(1)))
+    np.testing.assert_allclose(same.numpy(), plain.numpy(), rtol=1e-6)
+    curved = od.render_integrate(brdf, l, n, od.T(lareas), torch.ones(16, 32, 3), gamma=torch.tensor([1.3, 0.8]))
+    np.testing.assert_allclose(curved.numpy(), ((plain * 1.3) ** 0.8).numpy(), rtol=1e-6)
+    big = od.render_integrate(brdf, l, n, od.T(lareas), 50 * torch.ones(16, 32, 3), gamma=torch.tensor([1.3, 0.8]))
+    assert big.max().item() == 1.0                                      # tonemapping clip AFTER the curve
+    assert torch.equal(od.displayed(plain, 'dtu'), plain) and torch.equal(od.displayed(plain, 'nerf'), od.linear2srgb(plain))
+
+
+@pytest.mark.parametrize('data_type', ['nerf', 'hw'])
+def test_fast_render_probe_loop_is_dst_env_per_probe(data_type):
+    p, specs = od.make_model_params(seed=0, K=8)
+    pt = {k: ([(od.T(W), od.T(b)) for W, b in v] if isinstance(v, list) else od.T(v)) for k, v in p.items()}
+    lxyz, lareas = od.gen_light_xyz(16, 32)
+    pts = od.make_points(40, seed=5, lvis=(data_type == 'nerf'))
+    ob = {k: od.T(v) for k, v in pts.items()}
+    rng = np.random.default_rng(0)
+    probes = [od.T(rng.uniform(0, 2, (16, 32, 3)).astype(np.float32)) for _ in range(3)]
+    gamma = None if data_type == 'nerf' else torch.tensor([1.3, 0.8])
+    fr = od.fast_render(pt, specs, ob, od.T(lxyz), od.T(lareas), data_type=data_type, gamma=gamma, probes=probes, dst_env=probes[2])
+    assert fr['rgb_probes'].shape == (40, 3, 3)
+    np.testing.assert_allclose(fr['rgb_probes'][:, 2].numpy(), fr['rgb'].numpy(), rtol=0, atol=1e-6)
+    # the model light as a "probe" reproduces call()'s main-branch render
+    light = pt['light'].clamp(min=0)
+    fr2 = od.fast_render(pt, specs, ob, od.T(lxyz), od.T(lareas), data_type=data_type, gamma=gamma, probes=[light])
+    mc = od.model_call(pt, specs, ob, od.T(lxyz), od.T(lareas), None, None, mode='vali', data_type=data_type, gamma=gamma)
+    np.testing.assert_allclose(fr2['rgb_probes'][:, 0].numpy(), od.displayed(mc['rgb'], data_type).numpy(), rtol=0, atol=1e-6)
+    assert 'rgb' not in fr2
