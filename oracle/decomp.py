@@ -22,6 +22,7 @@ text, the arithmetic of
     .../models/vq_nfr.py:761-769                               -> get_codebook
     .../models/vq_nfr.py:771-833                               -> pred_enc / pred_diff / pred_spec / pred_rough / normal_correct
     .../models/vq_nfr.py:876-986                               -> compute_loss
+    .../models/ref_nfr.py:137-159, :176-300, :303-418, :584-610 -> ref_net_specs / ref_nfr_call / ref_nfr_fast_render / ref_nfr_loss
     decomp/nerfvq_nfr3/brdf/renderer.py:184-219                -> gen_light_xyz (twin at geo/NeuS-ours2/models/util.py:84-119,
         which IS importable: tests/golden/light_xyz_16x32.npz pins it)
 It is pinned by analytic known-answer tests only (tests/test_oracle_decomp.py).
@@ -414,3 +415,84 @@ def compute_loss(out, rgb_gt, codebook_raw, mode='train', data_type='nerf', chr_
         loss = loss + ld['lambert']
     ld['loss'] = loss
     return loss, ld
+
+
+# ----------------------------------------------------------------------------
+# stage 3, `ref_nfr`: residual baking through a per-point reference colour
+# ----------------------------------------------------------------------------
+def ref_net_specs(z_dim=256, **kw):
+    """ref_nfr.py:137-159: encoder + specular head are the frozen stage-2 ones; `rgb_enc` 3 -> z -> z -> z (no activation on
+    the first layer), diffuse / roughness heads read [z_xyz ; z_ref] (2 z wide, concatenated again into their last layer)."""
+    s = net_specs(z_dim=z_dim, **kw)
+    head2 = lambda out: dict(widths=[z_dim, z_dim // 2, out], act=['relu', 'relu', 'sigmoid'], skip_at=[1], d_in=2 * z_dim)
+    return {'fine_enc': s['fine_enc'], 'bottleneck': s['bottleneck'], 'spec_out': s['spec_main'],
+            'rgb_enc': dict(widths=[z_dim] * 3, act=[None, 'relu', 'sigmoid'], skip_at=None, d_in=3),
+            'diff_out': head2(3), 'rough_out': head2(1)}
+
+
+def make_ref_params(seed=5, **kw):
+    rng = np.random.default_rng(seed)
+    specs = ref_net_specs(**kw)
+    p = {name: make_mlp_params(s, rng) for name, s in specs.items()}
+    p['light'] = rng.uniform(0.0, 1.0, (16, 32, 3)).astype(np.float32)     # the stage-2 light as saved to np_light.npy: >= 0, constant here
+    return p, specs
+
+
+def _ref_materials(p, specs, xyz, ref):
+    z_xyz = pred_enc(p, specs, xyz)
+    ks = mlp_forward(p['spec_out'], specs['spec_out'], z_xyz)
+    z_bias = torch.cat([z_xyz, mlp_forward(p['rgb_enc'], specs['rgb_enc'], ref)], -1)
+    basecolor = mlp_forward(p['diff_out'], specs['diff_out'], z_bias)
+    rough = mlp_forward(p['rough_out'], specs['rough_out'], z_bias)
+    return z_xyz, ks, basecolor, rough
+
+
+def ref_nfr_call(p, specs, batch, lxyz, lareas, mode='train', data_type='nerf', gamma=None, probes=(), opt_scale=None):
+    """ref_nfr.Model.call (ref_nfr.py:176-300) on already-masked foreground points; batch has the extra `ref` [N,3].
+    The light is the constant tensor loaded at :86-87 (not a variable, not clipped)."""
+    xyz, normal, rayo, ref = batch['xyz'], batch['normal'], batch['rayo'], batch['ref']
+    lvis = batch.get('lvis') if data_type == 'nerf' else None
+    surf2l, surf2c = calc_ldir(lxyz, xyz), calc_vdir(rayo, xyz)
+    n_pred = normal_correct(normal, surf2c)
+    z_xyz, ks, basecolor, rough = _ref_materials(p, specs, xyz, ref)
+    spec, albedo = ks * basecolor, (1 - ks) * basecolor
+    if (opt_scale is not None) and (mode == 'test'):
+        albedo, spec = albedo * opt_scale, spec * opt_scale
+    brdf, brdf_s, brdf_d = get_brdf(surf2l, surf2c, n_pred, albedo, rough, spec)
+    rgb = render_integrate(brdf, surf2l, n_pred, lareas, p['light'], lvis, gamma)
+    out = dict(rgb=rgb, pred_rgb=displayed(rgb, data_type), albedo=albedo, spec=spec, rough=rough, ks=ks, basecolor=basecolor,
+               normal=n_pred, z_xyz=z_xyz)
+    if mode != 'train':
+        out['rgb_diff'] = render_integrate(brdf_d, surf2l, n_pred, lareas, p['light'], lvis, gamma)
+        out['rgb_spec'] = render_integrate(brdf_s, surf2l, n_pred, lareas, p['light'], lvis, gamma)
+    if len(probes):
+        out['rgb_probes'] = displayed(torch.stack([render_integrate(brdf, surf2l, n_pred, lareas, lp, lvis, gamma) for lp in probes], 1),
+                                      data_type)
+    return out
+
+
+def ref_nfr_fast_render(p, specs, batch, lxyz, lareas, data_type='nerf', gamma=None, probes=(), opt_scale=None):
+    """ref_nfr.Model.fast_render (ref_nfr.py:303-418): `rgb` from the UNscaled materials under the model light (:359-360, :372-374),
+    the probe renders from the scaled ones (:362-368, :376-378)."""
+    xyz, normal, rayo, ref = batch['xyz'], batch['normal'], batch['rayo'], batch['ref']
+    lvis = batch.get('lvis') if data_type == 'nerf' else None
+    surf2l, surf2c = calc_ldir(lxyz, xyz), calc_vdir(rayo, xyz)
+    n_pred = normal_correct(normal, surf2c)
+    _, ks, basecolor, rough = _ref_materials(p, specs, xyz, ref)
+    spec, albedo = ks * basecolor, (1 - ks) * basecolor
+    raw_brdf, _, _ = get_brdf(surf2l, surf2c, n_pred, albedo, rough, spec)
+    if opt_scale is not None:
+        albedo, spec = albedo * opt_scale, spec * opt_scale
+    brdf, _, _ = get_brdf(surf2l, surf2c, n_pred, albedo, rough, spec)
+    rgb = render_integrate(raw_brdf, surf2l, n_pred, lareas, p['light'], lvis, gamma)
+    out = dict(rgb=rgb, pred_rgb=displayed(rgb, data_type))
+    if len(probes):
+        out['rgb_probes'] = displayed(torch.stack([render_integrate(brdf, surf2l, n_pred, lareas, lp, lvis, gamma) for lp in probes], 1),
+                                      data_type)
+    return out
+
+
+def ref_nfr_loss(out, rgb_gt, data_type='nerf'):
+    """ref_nfr.Model.compute_loss (ref_nfr.py:584-610): per-example MSE against the linearised target."""
+    linear_gt = srgb2linear(rgb_gt) if data_type == 'nerf' else rgb_gt
+    return _mse(linear_gt, out['rgb'])

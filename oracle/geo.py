@@ -10,6 +10,9 @@ A functional restatement (weights are plain dicts of arrays, no nn.Module) of
     geo/NeuS-ours2/models/renderer.py:177-191  -> cat_z_vals
     geo/NeuS-ours2/models/renderer.py:193-297  -> render_core
     geo/NeuS-ours2/models/renderer.py:299-401  -> render
+    geo/NeuS-ours2/gen_geo.py:182-257          -> compute_vis        (restated from the text: gen_geo.py is not importable
+    geo/NeuS-ours2/gen_geo.py:259-344          -> compute_geo         here -- cv2 / pyhocon / trimesh absent -- so these two
+    geo/NeuS-ours2/gen_geo.py:346-369          -> intersect_circle, normal_correct_np, _np_norm    are unpinned callers of the pinned `render`)
 It is *faithful*: it keeps the reference's redundant second SDF forward inside
 ``sdf_gradient`` (fields.py:98) and its op order, because it doubles as the
 timed CPU baseline.  Pinned against the real reference by
@@ -127,6 +130,57 @@ def make_rays(n_rays, seed=2, cam=(0.0, 0.0, 4.0), spread=0.35):
     near = np.full((n_rays, 1), 2.0, np.float32)
     far = np.full((n_rays, 1), 6.0, np.float32)
     return o.astype(np.float32), d.astype(np.float32), near, far
+
+
+def make_hit_rays(n_hit=56, n_miss=8, seed=21):
+    """Inputs of tests/golden/geo_hits.npz: `n_hit` rays aimed at the disc the 0.5-sphere projects to (about half of them hit
+    it; with variance 0.5, i.e. inv_s = e^5, those reach weight_sum ~ 1) followed by `n_miss` rays that leave the radius-2
+    bounding sphere untouched (all `inside_sphere` flags 0: the all-masked branch of up_sample, renderer.py:137-164).
+    Also returns the per-ray near / far of the to_light case and the injected jitter (renderer.py:318, `torch.rand([B,1]) - 0.5`)."""
+    o, d, near, far = make_rays(n_hit, seed=seed, spread=0.12)
+    rng = np.random.default_rng(seed + 1)
+    th = np.deg2rad(rng.uniform(40.0, 70.0, n_miss))
+    ph = rng.uniform(0.0, 2 * np.pi, n_miss)
+    dm = np.stack([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), -np.cos(th)], -1).astype(np.float32)
+    o = np.concatenate([o, np.tile(o[:1], (n_miss, 1))], 0)
+    d = np.concatenate([d, dm], 0)
+    B = n_hit + n_miss
+    near = np.full((B, 1), 2.0, np.float32)
+    far = np.full((B, 1), 6.0, np.float32)
+    near_l = rng.uniform(1.5, 2.5, (B, 1)).astype(np.float32)
+    far_l = (near_l + rng.uniform(3.0, 4.0, (B, 1))).astype(np.float32)
+    t_rand = (rng.uniform(0.0, 1.0, (B, 1)) - 0.5).astype(np.float32)
+    return dict(o=o, d=d, near=near, far=far, near_l=near_l, far_l=far_l, t_rand=t_rand)
+
+
+def make_upsample_edge_inputs(n, seed=30):
+    """Inputs of tests/golden/geo_upsample_edge.npz: 8 rays x n sorted depths with hand-made SDF profiles that drive
+    `up_sample` + `sample_pdf` (renderer.py:131-175, :39-69) into their edge branches:
+      0 ray that misses the bounding sphere (every `inside_sphere` 0 -> cos clipped to 0 -> near-uniform weights)
+      1 sdf = +5 everywhere (both sigmoids saturate at 1: alpha = 1e-5 / (1 + 1e-5) in every section)
+      2 sdf = -5 everywhere (both sigmoids 0: alpha = 1 in section 0 -> one spike, all later cdf steps < 1e-5 -> `denom` = 1)
+      3 one steep zero crossing between samples 5 and 6 (single spike in the interior)
+      4 gentle linear decrease through zero (the regular case)
+      5 zero crossing in the very last section
+      6 in - out - in (two crossings)
+      7 smooth random profile."""
+    rng = np.random.default_rng(seed + n)
+    o = np.tile(np.array([[0.0, 0.0, 4.0]], np.float32), (8, 1))
+    d = np.tile(np.array([[0.0, 0.0, -1.0]], np.float32), (8, 1))
+    d[0] = np.array([np.sin(1.0), 0.0, -np.cos(1.0)], np.float32)
+    z = np.sort(np.concatenate([np.tile(np.linspace(2.0, 6.0, 64, dtype=np.float32)[None], (8, 1)),
+                                rng.uniform(2.0, 6.0, (8, n - 64)).astype(np.float32)], 1), 1)
+    t = (z - 2.0) / 4.0
+    sdf = np.zeros((8, n), np.float32)
+    sdf[0] = rng.normal(0.0, 0.3, n)
+    sdf[1] = 5.0
+    sdf[2] = -5.0
+    sdf[3] = np.where(np.arange(n) <= 5, 0.5, -0.5)
+    sdf[4] = 0.4 - 0.8 * t[4]
+    sdf[5] = np.where(np.arange(n) < n - 1, 0.3, -0.3)
+    sdf[6] = 0.25 * np.cos(4 * np.pi * t[6])
+    sdf[7] = np.convolve(rng.normal(0.0, 0.2, n + 8), np.ones(9) / 9.0, 'valid')
+    return o, d, z.astype(np.float32), sdf.astype(np.float32)
 
 
 def to_torch(params, dtype=torch.float32):
@@ -269,12 +323,14 @@ def up_sample(rays_o, rays_d, z_vals, sdf, r_limit, n_new, inv_s):
 
 
 def cat_z_vals(p_sdf, cfg, rays_o, rays_d, z_vals, new_z, sdf, last):
-    """renderer.py:177-191.  Returns (z_sorted, sdf_sorted, had_ties)."""
+    """renderer.py:177-191.  Returns (z_sorted, sdf_sorted, had_ties).  `had_ties` reports equal depths only where they
+    matter: the order `torch.sort` gives equal keys is unspecified and decides how `sdf` is permuted (:187-189); in the last
+    step nothing is permuted and the sorted depths are the same values either way."""
     B, n = z_vals.shape
     m = new_z.shape[1]
     z_cat = torch.cat([z_vals, new_z], -1)
     z_sorted, index = torch.sort(z_cat, dim=-1)
-    ties = bool((z_sorted[:, 1:] == z_sorted[:, :-1]).any())
+    ties = (not last) and bool((z_sorted[:, 1:] == z_sorted[:, :-1]).any())
     if not last:
         pts = rays_o[:, None, :] + rays_d[:, None, :] * new_z[..., None]
         new_sdf = sdf_only(p_sdf, cfg, pts.reshape(-1, 3)).reshape(B, m)
@@ -283,11 +339,12 @@ def cat_z_vals(p_sdf, cfg, rays_o, rays_d, z_vals, new_z, sdf, last):
 
 
 def render_core(p_sdf, p_col, variance, cfg, rays_o, rays_d, z_vals, sample_dist, radius,
-                background_rgb=None, cos_anneal_ratio=0.0, create_graph=False):
-    """renderer.py:193-297 (n_outside == 0 branch)."""
+                background_rgb=None, cos_anneal_ratio=0.0, create_graph=False, to_light=False):
+    """renderer.py:193-297 (n_outside == 0 branch).  to_light: `sample_dist` is the per-ray [B,1] tensor of :302 (:211)."""
     B, n = z_vals.shape
     dists = z_vals[..., 1:] - z_vals[..., :-1]
-    dists = torch.cat([dists, torch.full_like(dists[..., :1], float(sample_dist))], -1)
+    tail = sample_dist if to_light else torch.full_like(dists[..., :1], float(sample_dist))
+    dists = torch.cat([dists, tail], -1)
     mid_z = z_vals + dists * 0.5
     pts = (rays_o[:, None, :] + rays_d[:, None, :] * mid_z[..., None]).reshape(-1, 3)
     dirs = rays_d[:, None, :].expand(B, n, 3).reshape(-1, 3)
@@ -346,14 +403,14 @@ def coarse_to_fine_z(p_sdf, cfg, rays_o, rays_d, z_vals, radius):
 
 
 def render(p_sdf, p_col, variance, cfg, rays_o, rays_d, near, far, radius, jitter=None,
-           background_rgb=None, cos_anneal_ratio=0.0, create_graph=False):
-    """renderer.py:299-401 (n_outside == 0, to_light=False).
+           background_rgb=None, cos_anneal_ratio=0.0, create_graph=False, to_light=False):
+    """renderer.py:299-401 (n_outside == 0).  to_light: per-ray last-section length (far - near) / n_samples (:302).
 
     `jitter` is the explicit stand-in for ``torch.rand([B,1]) - 0.5`` at
     renderer.py:318 (None == perturb 0)."""
     r = cfg['renderer']
     B = rays_o.shape[0]
-    sample_dist = 2.0 * radius / r['n_samples']
+    sample_dist = (far - near) / r['n_samples'] if to_light else 2.0 * radius / r['n_samples']
     z = torch.linspace(0.0, 1.0, r['n_samples'], dtype=torch.float32).to(rays_o.dtype)
     z_vals = near + (far - near) * z[None, :]
     if jitter is not None:
@@ -364,7 +421,7 @@ def render(p_sdf, p_col, variance, cfg, rays_o, rays_d, near, far, radius, jitte
     n = r['n_samples'] + r['n_importance']
     rc = render_core(p_sdf, p_col, variance, cfg, rays_o, rays_d, z_vals, sample_dist, radius,
                      background_rgb=background_rgb, cos_anneal_ratio=cos_anneal_ratio,
-                     create_graph=create_graph)
+                     create_graph=create_graph, to_light=to_light)
     w = rc['weights']
     return dict(color_fine=rc['color'],
                 s_val=rc['s_val'].reshape(B, n).mean(-1, keepdim=True),
@@ -373,3 +430,105 @@ def render(p_sdf, p_col, variance, cfg, rays_o, rays_d, near, far, radius, jitte
                 weights=w, gradient_error=rc['gradient_error'],
                 inside_sphere=rc['inside_sphere'], surf=rc['surf'], depth=rc['depth'],
                 z_vals=z_vals, had_ties=ties)
+
+
+# ----------------------------------------------------------------------------
+# per-view geometry / light-visibility extraction (geo/NeuS-ours2/gen_geo.py) -- SURVEY 8(f1)
+# gen_geo.py itself cannot be imported here (cv2, pyhocon, trimesh are absent), so this is a restatement from its text;
+# it runs on the pinned `render` above.  The reference renders with the conf's `perturb = 1` (a fresh torch.rand jitter per
+# call, gen_geo.py:229-235 / :275-281 pass no perturb_overwrite): here the jitter is an explicit argument (None = none).
+# ----------------------------------------------------------------------------
+
+def intersect_circle(x, d, r, eps=1e-7):
+    """gen_geo.py:346-357: the larger root of |x + t d| = r, and the point there."""
+    b = 2.0 * torch.sum(x * d, dim=-1)
+    a = torch.sum(d * d, dim=-1)
+    c = torch.sum(x * x, dim=-1) - r ** 2
+    eps = torch.ones_like(a) * eps
+    denom = torch.where(2 * a > eps, 2 * a, eps)
+    t1 = (-b + torch.sqrt(torch.square(b) - 4.0 * a * c)) / denom
+    t2 = (-b - torch.sqrt(torch.square(b) - 4.0 * a * c)) / denom
+    t = torch.where(t1 > t2, t1, t2)
+    return t[:, None], x + t[:, None] * d
+
+
+def _np_norm(src, dim):
+    """gen_geo.py:367-369."""
+    return src / np.sqrt(np.sum(np.square(src), axis=dim, keepdims=True))
+
+
+def normal_correct_np(rays_o, surf, normal):
+    """gen_geo.py:358-365: flip normals that face away from the camera."""
+    surf2c = rays_o - surf
+    surf2c = surf2c / np.linalg.norm(surf2c, ord=2, axis=-1, keepdims=True)
+    cos = np.sum(surf2c * normal, axis=-1, keepdims=True)
+    return np.where(cos >= 0.0, normal, -normal)
+
+
+def compute_geo(p_sdf, p_col, variance, cfg, rays_o, rays_d, near, far, max_radius, alpha_thres=0.5, use_white_bkgd=True,
+                cos_anneal_ratio=1.0, batch_size=512, jitter=None):
+    """gen_geo.py:259-344 for the rays of one view, flattened [R,3] (the file / image writing at :329-342 is not restated).
+    Returns numpy arrays: rgb [R,3] (`color_fine`), surf [R,3], normal [R,3] (`rot_normal`: the weight- and inside-sphere-
+    weighted mean gradient, normalised, camera-facing, the unit diagonal on background pixels :321-326), mask [R,1]."""
+    out_rgb, out_normal, out_surf, out_mask = [], [], [], []
+    R = rays_o.shape[0]
+    for s in range(0, R, batch_size):
+        o, d = rays_o[s:s + batch_size], rays_d[s:s + batch_size]
+        bg = torch.ones(1, 3) if use_white_bkgd else None
+        ro = render(p_sdf, p_col, variance, cfg, o, d, near[s:s + batch_size], far[s:s + batch_size], max_radius,
+                    jitter=None if jitter is None else jitter[s:s + batch_size], background_rgb=bg, cos_anneal_ratio=cos_anneal_ratio)
+        out_rgb.append(ro['color_fine'].detach().numpy())
+        alpha_mask = ro['weight_sum'].detach().numpy()
+        out_mask.append(np.where(alpha_mask > alpha_thres, 1.0, 0.0))
+        surf = ro['surf'].detach().numpy()
+        out_surf.append(surf)
+        n_samples = cfg['renderer']['n_samples'] + cfg['renderer']['n_importance']
+        normals = ro['gradients'] * ro['weights'][:, :n_samples, None]
+        normals = normals * ro['inside_sphere'][..., None]
+        normals = _np_norm(normals.sum(dim=1).detach().numpy(), dim=-1)
+        out_normal.append(normal_correct_np(o.numpy(), surf, normals))
+    rgb, surf = np.concatenate(out_rgb, 0), np.concatenate(out_surf, 0)
+    img_mask = (np.concatenate(out_mask, 0) * 256).clip(0, 255)                       # :318-319 (the 8-bit mask image)
+    normal = np.concatenate(out_normal, 0)
+    rot_normal = normal * (img_mask / 255.0) + _np_norm(np.ones_like(normal), dim=-1) * (1.0 - img_mask / 255.0)
+    return dict(rgb=rgb, surf=surf, normal=rot_normal, mask=img_mask / 255.0)
+
+
+def compute_vis(p_sdf, p_col, variance, cfg, lxyz_flat, surf, normal, mask, max_radius, use_white_bkgd=True, cos_anneal_ratio=1.0,
+                batch_size=512, lpix_chunk=1):
+    """gen_geo.py:182-257 for one view, flattened: surf / normal [R,3], mask [R,1], lxyz_flat [1,L,3] -> lvis [R,L] float32
+    (1 - weight_sum of the secondary ray towards every FRONT-LIT light of every foreground pixel, zeros elsewhere).  Walks the
+    lights `lpix_chunk` at a time like the reference (one `render` per light by default)."""
+    n_lights = lxyz_flat.shape[1]
+    alpha = mask[..., 0] > 0.0
+    surf_fg, normal_fg = surf[alpha], normal[alpha]
+    batch_lvis = []
+    for surf_batch, normal_batch in zip(surf_fg.split(batch_size), normal_fg.split(batch_size)):
+        lvis_hit = np.zeros((surf_batch.shape[0], n_lights), dtype=np.float32)
+        for i in range(0, n_lights, lpix_chunk):
+            end_i = min(n_lights, i + lpix_chunk)
+            lxyz_chunk = lxyz_flat[:, i:end_i, :]
+            surf2l = lxyz_chunk - surf_batch[:, None, :]
+            surf2l = surf2l / torch.linalg.norm(surf2l, ord=2, dim=-1, keepdim=True)
+            surf2l_flat = surf2l.reshape((-1, 3))
+            surf_flat = surf_batch[:, None, :].repeat(1, surf2l.shape[1], 1).reshape((-1, 3))
+            lcos = torch.einsum('ijk,ik->ij', surf2l, normal_batch)
+            front_lit = lcos > 0
+            if torch.sum(front_lit) == 0:
+                continue
+            front_lit_flat = front_lit.reshape((-1,))
+            o, d = surf_flat[front_lit_flat], surf2l_flat[front_lit_flat]
+            far, _ = intersect_circle(o, d, max_radius)
+            n_far, n_near = far / 2.0, torch.ones_like(far) * 0.1
+            near = torch.where(n_near < n_far, n_near, n_far)
+            bg = torch.ones(1, 3) if use_white_bkgd else None
+            ro = render(p_sdf, p_col, variance, cfg, o, d, near, far, max_radius, background_rgb=bg, cos_anneal_ratio=cos_anneal_ratio)
+            occu = ro['weight_sum'].detach().numpy()
+            front_lit_full = np.zeros(lvis_hit.shape, dtype=bool)
+            front_lit_full[:, i:end_i] = front_lit.numpy()
+            lvis_hit[front_lit_full] = 1.0 - occu[:, 0]
+        batch_lvis.append(lvis_hit)
+    lvis_hit = np.concatenate(batch_lvis, axis=0) if batch_lvis else np.zeros((0, n_lights), np.float32)
+    lvis = np.zeros((surf.shape[0], n_lights), dtype=np.float32)
+    lvis[alpha.numpy()] = lvis_hit
+    return lvis

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from tests.decomp_util import make_config, load_oracle_params, make_batch
+from tests.gpu_util import launches
 
 pytestmark = pytest.mark.gpu
 
@@ -212,8 +213,9 @@ def test_model_call_vs_oracle(setup, mode):
 
 @pytest.mark.parametrize('backend', ['hip', 'torch'])
 def test_training_step_grads_vs_oracle(setup, backend):
-    """Training path of the model -- 'hip': fused shading forward/backward kernels under autograd (MLPs through torch
-    ops), 'torch': torch statements only; both with the HIP VQ kernels -- d loss / d parameters vs the CPU oracle."""
+    """Training path of the model -- 'hip': encoder / heads forward + backward tile programs (`vqn_tile_program`,
+    `vqn_wgrad_partials`) and the fused shading forward / backward kernels under autograd, 'torch': torch statements only;
+    both with the HIP VQ kernels -- d loss / d parameters vs the CPU oracle.  Asserts which kernels each backend launched."""
     od, p, specs = setup['od'], setup['p'], setup['specs']
     from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
     model = load_oracle_params(get_model_class('vq_nfr')(make_config()), p, 'cuda')
@@ -221,9 +223,13 @@ def test_training_step_grads_vs_oracle(setup, backend):
     N = 256
     pts = od.make_points(N, seed=9)
     batch = make_batch(pts, 'cuda')
-    pred, gt, lk, _ = model.call(batch, mode='train')
-    loss, _ = model.compute_loss(pred, gt, **dict(lk))
-    loss.sum().div(N).backward()
+    with launches() as rec:
+        pred, gt, lk, _ = model.call(batch, mode='train')
+        loss, _ = model.compute_loss(pred, gt, **dict(lk))
+        loss.sum().div(N).backward()
+    hip = backend == 'hip'
+    assert rec.ran('vqn_tile_program') == hip and rec.ran('vqn_brdf_shade_bwd') == hip and rec.ran('vqn_wgrad_partials') == hip
+    assert rec.ran('vqn_vq_assign')
     # oracle with torch autograd on the CPU
     pt = {k: ([(od.T(W).requires_grad_(True), od.T(b).requires_grad_(True)) for W, b in v] if isinstance(v, list)
               else od.T(v).requires_grad_(True)) for k, v in p.items()}

@@ -13,6 +13,7 @@ import pytest
 import torch
 
 from tests.decomp_util import make_config, load_oracle_params, make_batch
+from tests.gpu_util import launches
 
 pytestmark = pytest.mark.gpu
 
@@ -154,9 +155,11 @@ def test_training_step_grads_non_nerf_vs_oracle(data_type, K):
     N = 256
     pts = od.make_points(N, seed=9, lvis=False)
     batch = make_batch(pts, 'cuda')
-    pred, gt, lk, _ = model.call(batch, mode='train')
-    loss, _ = model.compute_loss(pred, gt, **dict(lk))
-    loss.sum().div(N).backward()
+    with launches() as rec:
+        pred, gt, lk, _ = model.call(batch, mode='train')
+        loss, _ = model.compute_loss(pred, gt, **dict(lk))
+        loss.sum().div(N).backward()
+    assert rec.ran('vqn_tile_program') and rec.ran('vqn_brdf_shade_bwd') and rec.ran('vqn_wgrad_partials')
     pt = {k: ([(od.T(W).requires_grad_(True), od.T(b).requires_grad_(True)) for W, b in v] if isinstance(v, list)
               else od.T(v).requires_grad_(True)) for k, v in p.items()}
     gb, gi = torch.tensor([GAMMA[0]], requires_grad=True), torch.tensor([GAMMA[1]], requires_grad=True)

@@ -1,0 +1,163 @@
+"""GPU parity of the NeuS ray marcher on the round-2 reference fixtures (oracle/gen_golden_geo.py: gen_hits, gen_upsample_edge):
+
+  tests/golden/geo_hits.npz           full-size nets, variance 0.5 (inv_s = e^5: a trained net's sharpness), 64 rays of which > 1/3
+                                      composite to weight_sum > 0.9, 8 never enter the bounding sphere; `render` plain, with the
+                                      jitter of renderer.py:318 injected (`t_rand`), and with `to_light=True`; stage-isolated
+                                      `render_core`; up-sampling stages; parameter gradients of the training loss
+  tests/golden/geo_upsample_edge.npz  `up_sample` (-> `sample_pdf`) of the reference on hand-made SDF profiles that reach the edge
+                                      branches of both (saturated sigmoids, single spikes, all-masked rays, denom < 1e-5)
+
+Every array in them is an OUTPUT OF THE REAL REFERENCE.  Tolerances are fp32 and stated per quantity below; end-to-end,
+per-sample keys are compared on the bulk (see `assert_render_matches`)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import launches
+from tests.test_oracle_geo import assert_render_matches
+
+pytestmark = pytest.mark.gpu
+HITS_VARIANCE = 0.5
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope='module')
+def hits(golden_dir):
+    from oracle import geo as og
+    from tests.test_gpu_neus_render import _build
+    g = dict(np.load(os.path.join(golden_dir, 'geo_hits.npz')))
+    cfg, sdf, col, var, ren = _build('full')
+    with torch.no_grad():
+        var.variance.fill_(HITS_VARIANCE)
+    rays = {k: torch.tensor(v).cuda() for k, v in og.make_hit_rays().items()}
+    return dict(g=g, cfg=cfg, sdf=sdf, col=col, var=var, ren=ren, rays=rays)
+
+
+@pytest.mark.parametrize('n', [64, 80, 96, 112])
+def test_upsample_edge_profiles_through_the_fused_kernel(golden_dir, n):
+    """`vqn_neus_upsample` (up_sample + sample_pdf fused, one wave per ray) on the reference's edge cases."""
+    from oracle import geo as og
+    from vqnerf_release_amd import _C
+    g = np.load(os.path.join(golden_dir, 'geo_upsample_edge.npz'))
+    i = (64, 80, 96, 112).index(n)
+    o, d, z, s = [torch.tensor(a).cuda() for a in og.make_upsample_edge_inputs(n)]
+    u = torch.linspace(0.5 / 16, 1.0 - 0.5 / 16, 16).cuda()
+    new_z = _C.neus_upsample(o, d, z, s, 2.0, float(64 * 2 ** i), u)
+    # 2e-5 abs on depths in [2, 6] (the inverse-CDF lerp; same bound as the stage-wise test on the round-1 fixtures)
+    np.testing.assert_allclose(_np(new_z), g[f'new_z_{n}'], rtol=0, atol=2e-5)
+
+
+def test_hits_upsample_and_merge_stagewise(hits):
+    g, ren, r = hits['g'], hits['ren'], hits['rays']
+    o, d = r['o'], r['d']
+    z0 = (r['near'] + (r['far'] - r['near']) * torch.linspace(0, 1, 64, device='cuda')[None]).contiguous()
+    with torch.no_grad():
+        for i in range(4):
+            zz = torch.tensor(g[f'up_z_{i - 1}']).cuda() if i else z0
+            ss = torch.tensor(g[f'up_sdf_{i - 1}']).cuda() if i else torch.tensor(g['coarse_sdf']).cuda()
+            new_z = ren.up_sample(o, d, zz, ss, 2.0, 16, 64 * 2 ** i)
+            np.testing.assert_allclose(_np(new_z), g[f'up_new_z_{i}'], rtol=0, atol=2e-5)
+            z2, s2 = ren.cat_z_vals(o, d, zz, torch.tensor(g[f'up_new_z_{i}']).cuda(), ss, last=(i == 3))
+            np.testing.assert_array_equal(_np(z2), g[f'up_z_{i}'])          # merge is exact
+            np.testing.assert_allclose(_np(s2), g[f'up_sdf_{i}'], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize('prefix', ['core', 'coretl'])
+def test_hits_render_core_stage_isolated(hits, prefix):
+    """render_core on the reference's own depths: all 12 keys on every sample, hits (weight_sum ~ 1) and misses alike."""
+    g, ren, r = hits['g'], hits['ren'], hits['rays']
+    z_in = torch.tensor(g['up_z_3']).cuda()
+    white = torch.ones(1, 3).cuda()
+    with torch.no_grad():
+        if prefix == 'core':
+            rc = ren.render_core(r['o'], r['d'], z_in, 2 * 2.0 / 64, 2.0, hits['sdf'], hits['var'], hits['col'],
+                                 background_rgb=white, cos_anneal_ratio=1.0)
+        else:
+            rc = ren.render_core(r['o'], r['d'], z_in, (r['far_l'] - r['near_l']) / 64, 2.0, hits['sdf'], hits['var'], hits['col'],
+                                 background_rgb=white, cos_anneal_ratio=0.5, to_light=True)
+    # inv_s = 148 turns an SDF error of 2e-6 into a cdf / weight error of ~1e-4 at the surface
+    tol = dict(color=3e-4, sdf=2e-5, dists=0, gradients=3e-4, s_val=1e-7, mid_z_vals=0, weights=5e-4, cdf=5e-4,
+               gradient_error=1e-5, inside_sphere=0, surf=5e-4, depth=5e-4)
+    for k, t in tol.items():
+        np.testing.assert_allclose(_np(rc[k]).reshape(g[f'{prefix}_{k}'].shape), g[f'{prefix}_{k}'], rtol=0, atol=t, err_msg=k)
+
+
+@pytest.mark.parametrize('matrix_mode', ['f32', 'f16s'])
+@pytest.mark.parametrize('variant', ['render', 'render_none0.5', 'perturb', 'tolight'])
+def test_hits_render_variants_vs_reference(hits, variant, matrix_mode):
+    g, ren, r = hits['g'], hits['ren'], hits['rays']
+    kw = dict(perturb_overwrite=0, background_rgb=torch.ones(1, 3).cuda(), cos_anneal_ratio=1.0)
+    near, far = r['near'], r['far']
+    if variant == 'render_none0.5':
+        kw.update(background_rgb=None, cos_anneal_ratio=0.5)
+    elif variant == 'perturb':
+        kw.update(perturb_overwrite=1, t_rand=r['t_rand'])
+    elif variant == 'tolight':
+        kw['to_light'] = True
+        near, far = r['near_l'], r['far_l']
+    ren.matrix_mode = matrix_mode
+    try:
+        with torch.no_grad(), launches() as rec:
+            rr = ren.render(r['o'], r['d'], near, far, 2.0, **kw)
+    finally:
+        ren.matrix_mode = 'f32'
+    suffix = '' if matrix_mode == 'f32' else '_f16s'
+    assert rec.ran('vqn_neus_fine_points' + suffix) and rec.ran('vqn_neus_upsample') and rec.ran('vqn_neus_composite_fwd')
+    assert_render_matches({k: _np(v) for k, v in rr.items()}, g, variant,
+                          ray_tol=dict(color_fine=2e-4, s_val=1e-7, weight_sum=3e-4, weight_max=5e-4, surf=3e-4, depth=3e-4,
+                                       gradient_error=2e-5),
+                          sample_tol=5e-4, frac=0.97)
+    psnr = -10 * np.log10(np.mean((_np(rr['color_fine']) - g[f'{variant}_color_fine']) ** 2) + 1e-20)
+    print(f'hits {variant} {matrix_mode}: PSNR(hip, reference) = {psnr:.1f} dB')
+    assert psnr > 80
+
+
+def test_hits_training_grads_vs_reference(hits):
+    """Gradients of L1(colour) + 0.1 * eikonal wrt every parameter, HIP tile-program engine vs the REAL reference's autograd,
+    on rays that hit the surface: <= 5e-3 of each tensor's largest entry (the oracle itself holds 5e-3 against the same fixture)."""
+    g, ren = hits['g'], hits['ren']
+    r = hits['rays']
+    for m in (hits['sdf'], hits['col'], hits['var']):
+        m.zero_grad()
+    with launches() as rec:
+        rr = ren.render(r['o'], r['d'], r['near'], r['far'], 2.0, perturb_overwrite=0, background_rgb=torch.ones(1, 3).cuda(),
+                        cos_anneal_ratio=1.0)
+        tgt = torch.tensor(np.random.default_rng(4).uniform(0, 1, (64, 3)).astype(np.float32)).cuda()
+        loss = (rr['color_fine'] - tgt).abs().sum() / 64 + 0.1 * rr['gradient_error']
+        loss.backward()
+    assert ren.last_train_backend == 'hip' and rec.ran('vqn_tile_program:prog_sbwd') and rec.ran('vqn_wgrad_partials')
+    np.testing.assert_allclose(loss.item(), float(g['bwd_loss']), rtol=2e-4)
+    worst = 0.0
+    for name, m in (('sdf', hits['sdf']), ('col', hits['col']), ('var', hits['var'])):
+        for k, p in m.named_parameters():
+            ref = g[f'bwd_{name}.{k}']
+            scale = max(np.abs(ref).max(), 1e-6)
+            err = np.abs(_np(p.grad) - ref).max() / scale
+            worst = max(worst, err)
+            assert err <= 5e-3, (name, k, err)
+    print(f'hits: worst relative gradient error vs the reference {worst:.2e}')
+    for m in (hits['sdf'], hits['col'], hits['var']):
+        m.zero_grad()
+
+
+def test_unsupported_network_shape_falls_back_loudly():
+    """A network the tile programs do not cover (two skip layers) still trains -- on the torch-autograd statement -- and says so."""
+    from oracle import geo as og
+    from vqnerf_release_amd.geo.models.fields import SDFNetwork, RenderingNetwork, SingleVarianceNetwork
+    from vqnerf_release_amd.geo.models.renderer import NeuSRenderer
+    sdf = SDFNetwork(d_in=3, d_out=65, d_hidden=64, n_layers=6, skip_in=(2, 4), multires=4, bias=0.5, scale=1.0).cuda()
+    col = RenderingNetwork(d_feature=64, mode='idr', d_in=9, d_out=3, d_hidden=64, n_layers=2, multires_view=2, squeeze_out=True).cuda()
+    var = SingleVarianceNetwork(0.3).cuda()
+    ren = NeuSRenderer(None, sdf, var, col, n_samples=32, n_importance=0, n_outside=0, up_sample_steps=4, perturb=0.0)
+    o, d, near, far = [torch.tensor(a).cuda() for a in og.make_rays(8, 3)]
+    with pytest.warns(RuntimeWarning, match='tile-program training engine'):
+        with launches() as rec:
+            rr = ren.render(o, d, near, far, 2.0, perturb_overwrite=0, cos_anneal_ratio=1.0)
+            rr['color_fine'].sum().backward()
+    assert ren.last_train_backend == 'torch' and not rec.ran('vqn_tile_program')
+    assert sdf.lin0.weight_v.grad is not None

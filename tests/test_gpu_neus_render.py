@@ -127,21 +127,26 @@ def test_network_methods_hip_vs_autograd_path(case):
 
 
 def test_training_path_grads_vs_reference(case):
-    """Autograd path of the boundary class: grads of L1(colour)+0.1*eikonal wrt every parameter."""
+    """Training path of the boundary class (tile-program engine + compositing backward kernel): grads of L1(colour) +
+    0.1 * eikonal wrt every parameter against the REAL reference's autograd, <= 5e-3 of each tensor's largest entry."""
+    from tests.gpu_util import launches
     g, ren, B = case['g'], case['ren'], case['B']
     for m in (case['sdf'], case['col'], case['var']):
         m.zero_grad()
-    rr = ren.render(case['o'], case['d'], case['near'], case['far'], 2.0, perturb_overwrite=0,
-                    background_rgb=torch.ones(1, 3).cuda(), cos_anneal_ratio=1.0)
-    tgt = torch.tensor(np.random.default_rng(4).uniform(0, 1, (B, 3)).astype(np.float32)).cuda()
-    loss = (rr['color_fine'] - tgt).abs().sum() / B + 0.1 * rr['gradient_error']
-    loss.backward()
+    with launches() as rec:
+        rr = ren.render(case['o'], case['d'], case['near'], case['far'], 2.0, perturb_overwrite=0,
+                        background_rgb=torch.ones(1, 3).cuda(), cos_anneal_ratio=1.0)
+        tgt = torch.tensor(np.random.default_rng(4).uniform(0, 1, (B, 3)).astype(np.float32)).cuda()
+        loss = (rr['color_fine'] - tgt).abs().sum() / B + 0.1 * rr['gradient_error']
+        loss.backward()
+    assert ren.last_train_backend == 'hip' and rec.ran('vqn_tile_program:prog_fwd') and rec.ran('vqn_wgrad_partials')
     np.testing.assert_allclose(loss.item(), float(g['bwd_loss']), rtol=2e-4)
     for name, m in (('sdf', case['sdf']), ('col', case['col']), ('var', case['var'])):
         for k, p in m.named_parameters():
             ref = g[f'bwd_{name}.{k}']
             scale = max(np.abs(ref).max(), 1e-6)
-            assert np.abs(_np(p.grad) - ref).max() <= 2e-2 * scale + 1e-6, (name, k)
+            err = np.abs(_np(p.grad) - ref).max() / scale
+            assert err <= 5e-3, (name, k, err)
     for m in (case['sdf'], case['col'], case['var']):
         m.zero_grad()
 

@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.gpu_util import launches
+
 pytestmark = pytest.mark.gpu
 
 SHAPES = [
@@ -59,8 +61,12 @@ def test_inference_and_training_paths_agree_with_torch(c):
         ren.train_backend = backend
         for m in (sdf, col, var):
             m.zero_grad(set_to_none=True)
-        r = ren.render(o, d, near, far, 2.0, perturb_overwrite=0, background_rgb=bg, cos_anneal_ratio=0.5)
-        (r['color_fine'].square().sum() + 0.1 * r['gradient_error'] + r['weight_sum'].sum() * 0.01).backward()
+        with launches() as rec:
+            r = ren.render(o, d, near, far, 2.0, perturb_overwrite=0, background_rgb=bg, cos_anneal_ratio=0.5)
+            (r['color_fine'].square().sum() + 0.1 * r['gradient_error'] + r['weight_sum'].sum() * 0.01).backward()
+        # the 'hip' pass really is the tile-program engine (no silent fall-back to autograd), the 'torch' pass really is not
+        assert ren.last_train_backend == backend
+        assert rec.ran('vqn_tile_program') == (backend == 'hip') and rec.ran('vqn_wgrad_partials') == (backend == 'hip')
         res[backend] = (r, {k: p.grad.clone() for m in (sdf, col, var) for k, p in m.named_parameters()})
     for k in ('color_fine', 'weight_sum', 'surf'):
         np.testing.assert_allclose(r_inf[k].cpu().numpy(), res['torch'][0][k].detach().cpu().numpy(), rtol=0, atol=1e-3, err_msg=k)
@@ -109,7 +115,9 @@ def test_reflectance_model_shapes(width, z, nf):
         m.train_backend = backend
         m.zero_grad(set_to_none=True)
         cb0 = m._codebook.detach().clone()
-        p, g, lk, _ = m.call(batch, mode='train')
+        with launches() as rec:
+            p, g, lk, _ = m.call(batch, mode='train')
+        assert rec.ran('vqn_tile_program') == (backend == 'hip') and rec.ran('vqn_brdf_shade_fwd') == (backend == 'hip')
         with torch.no_grad():
             m._codebook.copy_(cb0)                              # undo the EMA move so that both passes see the same codebook
         m.vq_layer.ema_cluster_size.hidden.zero_(); m.vq_layer.ema_dw.hidden.zero_()

@@ -1,6 +1,8 @@
-"""GPU: the two trainers step end to end on the device (forward through the up-sampling kernels, torch-autograd
-render_core / reflectance statements, one flat gradient bucket, Adam), and the fused inference path sees the
-updated weights (pack caches are invalidated by the optimiser's in-place updates)."""
+"""GPU: the two trainers step end to end on the device -- up-sampling kernels, forward / backward tile programs
+(`vqn_tile_program`), weight-gradient contraction (`vqn_wgrad_partials`), compositing and shading forward / backward kernels,
+one flat gradient bucket, Adam -- and the fused inference path sees the updated weights (pack caches are invalidated by the
+optimiser's in-place updates).  The HIP training engines are compared with torch autograd over the torch statements of the
+same modules (`train_backend = 'torch'`); every such comparison asserts which kernels each side launched."""
 import os
 
 import numpy as np
@@ -8,6 +10,7 @@ import pytest
 import torch
 
 from tests.decomp_util import make_config, load_oracle_params, make_batch
+from tests.gpu_util import launches
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -278,10 +281,16 @@ def test_hip_training_programs_match_torch_autograd(name, B):
         ren.train_backend = backend
         for m in (sdf, col, var):
             m.zero_grad(set_to_none=True)
-        rr = ren.render(o, d, near, far, 2.0, perturb_overwrite=0, background_rgb=torch.ones(1, 3).cuda(), cos_anneal_ratio=0.7)
-        loss = ((rr['color_fine'] - tgt) * mask).abs().sum() / mask.sum() + 0.1 * rr['gradient_error'] + \
-            0.1 * torch.nn.functional.binary_cross_entropy(rr['weight_sum'].clip(1e-3, 1 - 1e-3), mask)
-        loss.backward()
+        with launches() as rec:
+            rr = ren.render(o, d, near, far, 2.0, perturb_overwrite=0, background_rgb=torch.ones(1, 3).cuda(), cos_anneal_ratio=0.7)
+            loss = ((rr['color_fine'] - tgt) * mask).abs().sum() / mask.sum() + 0.1 * rr['gradient_error'] + \
+                0.1 * torch.nn.functional.binary_cross_entropy(rr['weight_sum'].clip(1e-3, 1 - 1e-3), mask)
+            loss.backward()
+        # 'hip' must be the tile-program engine, not a silent fall-back to the autograd statement it is compared with
+        assert ren.last_train_backend == backend
+        hip = backend == 'hip'
+        assert rec.ran('vqn_tile_program:prog_fwd') == hip and rec.ran('vqn_tile_program:prog_sbwd') == hip
+        assert rec.ran('vqn_wgrad_partials') == hip and rec.ran('vqn_neus_composite_bwd') == hip
         res[backend] = (loss.item(), {f'{nm}.{k}': p.grad.detach().clone() for nm, m in (('sdf', sdf), ('col', col), ('var', var))
                                       for k, p in m.named_parameters()},
                         {k: v.detach().clone() for k, v in rr.items() if torch.is_tensor(v)})

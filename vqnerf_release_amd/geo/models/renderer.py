@@ -6,13 +6,17 @@ Render / inference (no graph needed) is HIP end to end:
     vqn_neus_upsample    -> up_sample + sample_pdf(det=True) (:131-175, :39-69)
     vqn_neus_merge       -> cat_z_vals (:177-191)
     vqn_neus_section_mids, vqn_neus_fine_points, vqn_neus_composite_fwd -> render_core (:193-297)
-Training (autograd needs the graph, incl. the second-order eikonal term) keeps the no_grad
-up-sampling on those kernels and evaluates render_core with torch ops on the GPU -- the fused
-backward kernels are the next row of the scope table.
+Training (a graph is needed, incl. the second-order eikonal term) keeps the no_grad up-sampling on those kernels and runs
+render_core as explicit forward / backward tile programs (`vqn_tile_program`, `vqn_wgrad_partials`, geo/train_programs.py)
+plus `vqn_neus_composite_fwd/_bwd` under two `torch.autograd.Function`s.  Networks whose shape the tile programs do not cover
+take the torch-autograd statement of render_core instead -- loudly: a RuntimeWarning names the reason and
+`renderer.last_train_backend` records which path the last graph-building render_core took ('hip' | 'torch').
 
 The one random draw of the reference (`torch.rand([B,1]) - 0.5`, renderer.py:318) can be injected as
 `t_rand` so that fixtures and data-parallel ranks are reproducible.
 """
+import warnings
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -119,6 +123,7 @@ class NeuSRenderer:
         self.weights_only = False         # True: no-graph renders skip the colour net (weights / weight_sum / surf stay exact)
         self.matrix_mode = 'f32'          # 'f16s': no-graph renders on the split-precision kernels (f16 hi/lo MFMA; ~1e-6 relative, opt-in)
         self.train_backend = 'hip'        # 'hip': tile programs of geo/train_programs.py; 'torch': autograd over torch ops
+        self.last_train_backend = None    # path of the last graph-building render_core: 'hip' (tile programs) | 'torch'
 
     # ---- packs shared by all kernels --------------------------------------------------------
     def _packs(self):
@@ -188,14 +193,17 @@ class NeuSRenderer:
                     background_alpha=None, background_sampled_color=None, background_rgb=None,
                     cos_anneal_ratio=0.0, to_light=False):
         if background_alpha is not None:
+            self.last_train_backend = 'torch'
             return self._render_core_autograd(rays_o, rays_d, z_vals, sample_dist, radius, sdf_network, deviation_network,
                                               color_network, background_rgb, cos_anneal_ratio, to_light,
                                               background_alpha=background_alpha, background_sampled_color=background_sampled_color)
         if _needs_graph(sdf_network, rays_o) or any(p.requires_grad and torch.is_grad_enabled()
                                                     for m in (deviation_network, color_network) for p in m.parameters()):
             if self.train_backend == 'hip' and rays_o.is_cuda and self._train_engine(sdf_network, color_network) is not None:
+                self.last_train_backend = 'hip'
                 return self._render_core_train_hip(rays_o, rays_d, z_vals, sample_dist, radius, sdf_network,
                                                    deviation_network, color_network, background_rgb, cos_anneal_ratio, to_light)
+            self.last_train_backend = 'torch'
             return self._render_core_autograd(rays_o, rays_d, z_vals, sample_dist, radius, sdf_network,
                                               deviation_network, color_network, background_rgb, cos_anneal_ratio, to_light)
         B, n = z_vals.shape
@@ -229,8 +237,12 @@ class NeuSRenderer:
             try:
                 from vqnerf_release_amd.geo.train_programs import NeusTrainEngine
                 self._engines[key] = NeusTrainEngine(sdf_network, color_network)
-            except AssertionError:
-                self._engines[key] = None          # network shape outside what the tile programs cover -> torch autograd path
+            except AssertionError as e:
+                # network shape outside what the tile programs cover -> torch autograd path, and say so
+                warnings.warn('NeuSRenderer: the tile-program training engine does not cover this network shape '
+                              f'({e or "shape assertion in NeusTrainEngine"}); training runs on the torch-autograd statement of '
+                              'render_core instead (renderer.last_train_backend == "torch")', RuntimeWarning, stacklevel=3)
+                self._engines[key] = None
         return self._engines[key]
 
     def _render_core_train_hip(self, rays_o, rays_d, z_vals, sample_dist, radius, sdf_network, deviation_network,
