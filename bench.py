@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- rays/sec of the NeuS ray-march hot path on MI355X (driver contract: one JSON line on rank 0).
 
-Workload (BASELINE.json configs[1]): NeuSRenderer.render on synthetic rays of an 800x800 image, full
+Workload (BASELINE.json configs[1]): NeuSRenderer.render on the rays of a synthetic 800x800 view, full
 nets (SDF 8x256 -> 257, colour 4x256), 64 coarse + 64 importance samples per ray (4 up-sampling steps),
-fp32 end to end.  A "step" = one render() call over a batch of `--rays` rays already resident in HBM
-(default 80,000 = 100 rows of the image; at 8 GPUs one step = one full image, weak scaling).
-Ranks shard rays with no data-path collective (gen_geo.py --num_p/--p_i is the reference's own scheme).
+fp32 end to end.  A "step" = one render() call over `--rays` rays already resident in HBM (default 640,000 = one whole
+800x800 image per rank per step; rank r renders the view from its own camera, weak scaling).
+Ranks shard views / rays with no data-path collective (gen_geo.py --num_p/--p_i is the reference's own scheme).
+
+--mode train: the timed step is the data-parallel geo TRAINING step instead (2560 rays per rank, forward + backward + Adam,
+one flat-bucket RCCL all-reduce of the gradients per step); `value` is then training rays/s.  In the default render mode a
+multi-rank run also times that step and the reflectance (VQ) training step -- gradient bucket + codebook-statistics
+all-reduce -- after the timed render region and reports them under "extra.dp_train" (all-reduce time per step included).
 
 Extra objects in the JSON line:
   roofline     -- dominant kernel (vqn_neus_fine_points): algorithmic FLOPs per launch / its average
                   launch duration measured with HIP events on the launch stream, vs the dense f32 MFMA peak
   cpu_baseline -- the faithful torch-CPU oracle (oracle/geo.py, a port of the reference op sequence) timed
-                  on this host's cores over a bounded sample of the same workload (rank 0, N=1 only)
+                  on this host's cores over a bounded sample of the same workload (rank 0, N=1 only): B = 2560 rays spread
+                  over the whole image, 1 warm-up + 3 timed calls, median
 """
 import argparse
 import json
@@ -29,8 +35,10 @@ import torch
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA (= f32 vector peak)
 
+# `bias` is the radius of the geometric-init sphere (fields.py:45-63; nerf.conf ships 0.5): 0.85 makes its silhouette cover
+# ~29 % of the 800x800 view from (0, 0, 4), the "~30 % of rays hit" of SURVEY 8(d), so hit and miss compositing both count
 FULL = dict(
-    sdf=dict(d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=(4,), multires=6, bias=0.5, scale=1.0,
+    sdf=dict(d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=(4,), multires=6, bias=0.85, scale=1.0,
              geometric_init=True, weight_norm=True),
     color=dict(d_feature=256, mode='idr', d_in=9, d_out=3, d_hidden=256, n_layers=4, weight_norm=True,
                multires_view=4, squeeze_out=True),
@@ -38,14 +46,31 @@ FULL = dict(
 )
 
 
-def image_rays(rows, H=800, W=800, fov=0.6911, cam_z=4.0):
-    """Pin-hole camera at (0,0,cam_z) looking down -z; returns o, d [len(rows)*W, 3]."""
+def image_rays(rows, H=800, W=800, fov=0.6911, cam_z=4.0, yaw=0.0):
+    """Pin-hole camera at distance cam_z from the origin, looking at it ((0,0,4) looking down -z), turned by `yaw`
+    about the y axis (each rank of a multi-GPU run renders its own view); returns o, d [len(rows)*W, 3]."""
     f = 0.5 * W / math.tan(0.5 * fov)
     j, i = np.meshgrid(np.asarray(rows, np.float64), np.arange(W, dtype=np.float64), indexing='ij')
     d = np.stack([(i - 0.5 * W + 0.5) / f, -(j - 0.5 * H + 0.5) / f, -np.ones_like(i)], -1).reshape(-1, 3)
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     o = np.tile(np.array([[0.0, 0.0, cam_z]]), (d.shape[0], 1))
+    if yaw != 0.0:
+        c, s_ = math.cos(yaw), math.sin(yaw)
+        R = np.array([[c, 0.0, s_], [0.0, 1.0, 0.0], [-s_, 0.0, c]])
+        o, d = o @ R.T, d @ R.T
     return o.astype(np.float32), d.astype(np.float32)
+
+
+def cpu_model_string():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or 'unknown'
 
 
 def macs_per_point(sdf, col):
@@ -127,7 +152,7 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
 
     # ---- the headline render on the split-precision kernels (renderer.matrix_mode = 'f16s'), opt-in mode ----
     Bq = 80000
-    o_np, d_np = image_rays(np.arange(Bq // 800))
+    o_np, d_np = image_rays(np.arange(0, 800, 8))             # 100 rows spread over the view: hits and misses
     oq, dq = torch.tensor(o_np, device=dev), torch.tensor(d_np, device=dev)
     nq, fq = torch.full((Bq, 1), 2.0, device=dev), torch.full((Bq, 1), 6.0, device=dev)
     bgq = torch.ones(1, 3, device=dev)
@@ -156,6 +181,31 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
         'kernel_ms_per_step': {k: v[1] / 3 for k, v in sorted(clk16.items())},
         'note': 'opt-in precision mode (renderer.matrix_mode = "f16s": f16 hi/lo operands, 3 f16 MFMAs per product, f32 accumulate); '
                 '`value` is the f32 path'}
+
+    # ---- the literal "x64 samples" headline of the metric string: n_samples = 64, n_importance = 0 -- no
+    # coarse pass at all (renderer.py:335), 169.0 MFLOP/ray -- one whole 800x800 view per step ----
+    from vqnerf_release_amd.geo.models.renderer import NeuSRenderer
+    ren64 = NeuSRenderer(None, sdf, var, col, n_samples=64, n_importance=0, n_outside=0, up_sample_steps=4, perturb=1.0)
+    B64 = 640000
+    o64, d64 = [torch.tensor(a, device=dev) for a in image_rays(np.arange(800))]
+    n64, f64 = torch.full((B64, 1), 2.0, device=dev), torch.full((B64, 1), 6.0, device=dev)
+    rend64 = lambda: ren64.render(o64, d64, n64, f64, 2.0, perturb_overwrite=0, background_rgb=bgq, cos_anneal_ratio=1.0)
+    with torch.no_grad():
+        rend64()
+        _C.KernelClock.reset(True)
+        dt64 = _time_gpu(rend64, 3, warm=0)
+        clk64 = _C.KernelClock.summary()
+        _C.KernelClock.reset(False)
+    t_fine64 = clk64['vqn_neus_fine_points'][1] / clk64['vqn_neus_fine_points'][0] * 1e-3
+    flop64 = 2.0 * (2 * m_sdf + m_col) * B64 * 64
+    out['geo_render_s64'] = {
+        'rays_per_s': B64 / dt64, 'ms_per_step': dt64 * 1e3, 'rays': B64, 'mflop_per_ray': flop64 / B64 / 1e6,
+        'fine_kernel': {'ms': t_fine64 * 1e3, 'achieved': flop64 / t_fine64 / 1e12, 'unit': 'TFLOP/s', 'peak': F32_MFMA_PEAK_TFLOPS,
+                        'frac': flop64 / t_fine64 / 1e12 / F32_MFMA_PEAK_TFLOPS},
+        'kernel_ms_per_step': {k: v[1] / 3 for k, v in sorted(clk64.items())},
+        'note': 'n_samples = 64, n_importance = 0 (the "800x800x64 samples" of the metric string): no up-sampling pass, one fused '
+                'SDF + gradient + colour launch over 64 section mid-points per ray; `value` is the shipped 64 + 64 configuration'}
+    del o64, d64, n64, f64
 
     # ---- light-visibility extraction (gen_geo.py compute_vis): secondary rays surface -> light, occupancy only ----
     from vqnerf_release_amd.geo.gen_geo import GeoExtractor
@@ -313,6 +363,145 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     return out
 
 
+def full_conf_text(batch_size=2560):
+    """The `model` / `train` blocks of geo/confs/nerf.conf with the bench's network shapes (the Runner parses the same grammar)."""
+    s, c, r = FULL['sdf'], FULL['color'], FULL['renderer']
+    return f"""
+general {{ base_exp_dir = /tmp/vqn_bench_exp/CASE_NAME }}
+dataset {{ data_dir = /nonexistent/CASE_NAME, near = 2., far = 6., n_train = 8 }}
+train {{
+    learning_rate = 5e-4, learning_rate_alpha = 0.05, end_iter = 300000, batch_size = {batch_size}, validate_resolution_level = 1
+    warm_up_end = 5000, anneal_end = 0, use_white_bkgd = True, save_freq = 100000000, val_freq = 0, val_mesh_freq = 0
+    report_freq = 100000000, igr_weight = 0.1, mask_weight = 0.1
+}}
+model {{
+    nerf {{ D = 8, d_in = 4, d_in_view = 3, W = 256, multires = 10, multires_view = 4, output_ch = 4, skips = [4], use_viewdirs = True }}
+    sdf_network {{ d_out = {s['d_out']}, d_in = 3, d_hidden = {s['d_hidden']}, n_layers = {s['n_layers']}, skip_in = [{', '.join(map(str, s['skip_in']))}]
+                  multires = {s['multires']}, bias = {s['bias']}, scale = {s['scale']}, geometric_init = True, weight_norm = True }}
+    variance_network {{ init_val = 0.3 }}
+    rendering_network {{ d_feature = {c['d_feature']}, mode = idr, d_in = 9, d_out = 3, d_hidden = {c['d_hidden']}, n_layers = {c['n_layers']}
+                        weight_norm = True, multires_view = {c['multires_view']}, squeeze_out = True }}
+    neus_renderer {{ n_samples = {r['n_samples']}, n_importance = {r['n_importance']}, n_outside = 0, up_sample_steps = {r['up_sample_steps']}, perturb = 1.0 }}
+}}
+"""
+
+
+def _max_over_ranks(x, dev, world, backend):
+    if world == 1:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def _timed_steps(fn, steps, warmup, dev, world, backend):
+    """W untimed + K timed calls bracketed by barrier + synchronize; returns (max-over-ranks seconds, kernel clock of the K calls)."""
+    from vqnerf_release_amd import _C
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        fn()
+    barrier()
+    _C.KernelClock.reset(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    barrier()
+    dt = time.perf_counter() - t0
+    clock = _C.KernelClock.summary()
+    _C.KernelClock.reset(False)
+    return _max_over_ranks(dt, dev, world, backend), clock
+
+
+def _collective_report(clock, steps):
+    """Device time of the step's collectives (HIP events on the launch stream around each dist.all_reduce), per step."""
+    rep = {k.split(':', 1)[1]: {'calls_per_step': v[0] / steps, 'us_per_step': v[1] / steps * 1e3}
+           for k, v in sorted(clock.items()) if k.startswith('all_reduce:')}
+    rep['total_us_per_step'] = sum(v['us_per_step'] for v in rep.values())
+    return rep
+
+
+def geo_train_setup(dev, rank, batch_rays=2560):
+    """The geo trainer (geo/nerf_runner.py `Runner`: nerf.conf batch of 2560 rays per rank, L1 colour + 0.1 eikonal + 0.1 mask
+    BCE, Adam, cosine schedule; forward / backward on the HIP tile programs; under N ranks one flat-bucket all-reduce of the
+    gradients + one 2-float all-reduce of the loss normalisers per step).  Every rank draws its own pixels."""
+    from vqnerf_release_amd.geo.nerf_runner import Runner, SyntheticDataset
+    torch.manual_seed(0)                                        # identical initial weights on every rank
+    runner = Runner(conf_text=full_conf_text(batch_rays), case='bench', dataset=SyntheticDataset(device=dev, n_images=8, seed=rank),
+                    device=dev)
+    runner.update_learning_rate()
+    it = [0]
+
+    def step():
+        data = runner.dataset.gen_random_rays_at(it[0] % 8, batch_rays)
+        it[0] += 1
+        return runner.train_step(data)
+    return runner, step
+
+
+def decomp_train_setup(dev, rank, world, batch_points=2048):
+    """The VQ-stage trainer (train_nfr.Trainer: n_rays_per_step = 1024 pixel pairs = 2048 surface points per rank, Keras-Adam with
+    amsgrad; under N ranks the [counts || dw] codebook statistics are summed in the middle of the forward pass and the gradient
+    bucket after the backward pass, the loss normaliser is the global batch)."""
+    from vqnerf_release_amd.decomp.nerfactor import train_nfr
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    from vqnerf_release_amd.decomp.nerfactor.util.io import config_from_dict
+    rng = np.random.default_rng(1)
+    model = get_model_class('vq_nfr')(config_from_dict(DECOMP_INI))
+    model.build_nets(device=dev, seed=0).to(dev)
+    cb = rng.uniform(0, 1, (15, 256)).astype(np.float32)
+    model.set_codebook(cb / np.linalg.norm(cb, axis=1, keepdims=True))
+    model.set_light(rng.uniform(0, 1, (16, 32, 3)).astype(np.float32))
+    model.get_codebook(); _ = model.light
+    opt = torch.optim.Adam(model.trainable_variables, lr=5e-4, eps=1e-7, amsgrad=True)
+    tr = train_nfr.Trainer(model, opt)
+    batch = synthetic_points(batch_points, dev, np.random.default_rng(100 + rank))      # this rank's points
+    return model, tr, (lambda: tr.train_iter(batch, global_bs=(batch_points // 2) * world))
+
+
+def synthetic_points(n, dev, rng):
+    """SURVEY 8(d) surface points as the 10-tuple view batch of datasets/shape_unit.py:109-110 (data_type nerf)."""
+    xyz = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    xyz /= np.linalg.norm(xyz, axis=1, keepdims=True)
+    nrm = xyz + 0.1 * rng.normal(size=(n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    T = lambda a: torch.tensor(a, device=dev)
+    one = torch.ones(n, 1, device=dev)
+    lvis = T((rng.uniform(size=(n, 512)) < 0.7).astype(np.float32))
+    return (['v'] * 1, torch.zeros(n, 2, device=dev), T(np.tile(np.array([[0, 0, 4.0]], np.float32), (n, 1))),
+            torch.zeros(n, 3, device=dev), T(rng.uniform(0, 1, (n, 3)).astype(np.float32)), one, one.clone(),
+            T(xyz * rng.uniform(0.5, 1.0, (n, 1)).astype(np.float32)), T(nrm), lvis)
+
+
+def dp_train_leg(dev, rank, world, backend, steps=10, warmup=3):
+    """Both data-parallel training steps at the reference batch sizes, K timed steps each (max over ranks), with the device time
+    of every collective.  All ranks call this; the dict is meaningful on rank 0."""
+    import torch.distributed as dist
+    out = {'n_ranks_seen': dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1, 'backend': backend if world > 1 else None}
+    runner, gstep = geo_train_setup(dev, rank)
+    dt, clk = _timed_steps(gstep, steps, warmup, dev, world, backend)
+    out['geo'] = {'rays_per_s': 2560 * world * steps / dt, 'ms_per_step': dt / steps * 1e3, 'batch_rays_per_rank': 2560,
+                  'grad_bucket_bytes': int(runner.bucket.flat.numel() * 4), 'all_reduce': _collective_report(clk, steps),
+                  'last_train_backend': runner.renderer.last_train_backend}
+    del runner, gstep
+    model, tr, dstep = decomp_train_setup(dev, rank, world)
+    dt, clk = _timed_steps(dstep, steps, warmup, dev, world, backend)
+    out['decomp'] = {'points_per_s': 2048 * world * steps / dt, 'ms_per_step': dt / steps * 1e3, 'batch_points_per_rank': 2048,
+                     'grad_bucket_bytes': int(tr.bucket.flat.numel() * 4), 'vq_stats_bytes': int((256 + 1) * 15 * 4),
+                     'all_reduce': _collective_report(clk, steps)}
+    if world > 1:
+        from vqnerf_release_amd import parallel
+        parallel.assert_replicas_identical([model._codebook] + list(model.trainable_variables), 'decomp replicas')
+        out['decomp']['replicas_bit_identical_after_steps'] = True
+    return out
+
+
 def decomp_cpu_leg(dev, cores, N=16384):
     """CPU-baseline leg of the reflectance model (R_dec,render next to its CPU figure, PSNR(build, oracle) on rgb and
     albedo, VQ index match %): one vali-mode call of vq_nfr.Model on N synthetic surface points, the oracle (oracle/decomp.py,
@@ -369,8 +558,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--rays', type=int, default=80000, help='rays per step per GPU')
-    ap.add_argument('--cpu-rays', type=int, default=4096, help='rays of the bounded CPU-baseline sample')
+    ap.add_argument('--mode', choices=('render', 'train'), default='render',
+                    help='render: the headline (one whole 800x800 view per rank per step); train: the DP geo training step is the timed step')
+    ap.add_argument('--rays', type=int, default=640000, help='rays per step per GPU (render mode); 640000 = one 800x800 view')
+    ap.add_argument('--cpu-rays', type=int, default=2560, help='rays per call of the bounded CPU-baseline sample (SURVEY 8d: B = 2560)')
+    ap.add_argument('--cpu-reps', type=int, default=3, help='timed CPU calls after one warm-up call (median is reported)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary workloads (train steps, decomp, VQ)')
     args = ap.parse_args()
@@ -396,6 +588,9 @@ def main():
     from vqnerf_release_amd.geo.models.renderer import NeuSRenderer
     _C.lib()
 
+    if args.mode == 'train':
+        return main_train(args, dev, rank, world, backend)
+
     # ---- random-init weights of the shipped architecture (same seed on every rank) ----
     torch.manual_seed(0)
     sdf = SDFNetwork(**FULL['sdf'])
@@ -407,43 +602,30 @@ def main():
     ren = NeuSRenderer(None, sdf, var, col, **FULL['renderer'])
     S_f = FULL['renderer']['n_samples'] + FULL['renderer']['n_importance']
 
-    # ---- this rank's rays: consecutive rows of the 800x800 image, resident in HBM ----
+    # ---- this rank's rays: the rows of its own 800x800 view (camera turned by rank * 2 pi / world), resident in HBM ----
     n_rows = (args.rays + 799) // 800
-    rows = (np.arange(n_rows) + rank * n_rows) % 800
-    o_np, d_np = image_rays(rows)
+    rows = np.arange(n_rows) % 800
+    o_np, d_np = image_rays(rows, yaw=2.0 * math.pi * rank / world)
     o_np, d_np = o_np[:args.rays], d_np[:args.rays]
     o, d = torch.tensor(o_np, device=dev), torch.tensor(d_np, device=dev)
     near = torch.full((args.rays, 1), 2.0, device=dev)
     far = torch.full((args.rays, 1), 6.0, device=dev)
     bg = torch.ones(1, 3, device=dev)
+    out_box = [None]
 
     def step():
         with torch.no_grad():
-            return ren.render(o, d, near, far, 2.0, perturb_overwrite=0, background_rgb=bg, cos_anneal_ratio=1.0)
+            out_box[0] = ren.render(o, d, near, far, 2.0, perturb_overwrite=0, background_rgb=bg, cos_anneal_ratio=1.0)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        out = step()
-    barrier()
-    _C.KernelClock.reset(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    clock = _C.KernelClock.summary()
-    _C.KernelClock.reset(False)
-    if world > 1:
-        t = torch.tensor([dt], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, clock = _timed_steps(step, args.steps, args.warmup, dev, world, backend)
+    out = out_box[0]
     assert torch.isfinite(out['color_fine']).all()
 
+    # every rank takes part in the data-parallel training legs (collectives); only rank 0 reports
+    dp = None
+    if world > 1 and not args.no_extras:
+        out_box[0] = None
+        dp = dp_train_leg(dev, rank, world, backend)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -458,27 +640,33 @@ def main():
     flop_fine = 2.0 * (2 * m_sdf + m_col) * args.rays * S_f
     avg_ms = ms_fine / n_fine
     achieved = flop_fine / (avg_ms * 1e-3) / 1e12
-    # fabric-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_render.json:
-    # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command); scaled by rays if --rays differs
+    # fabric-side bytes per launch of the dominant kernel: NOT measured by this run (PMC counters need rocprofv3 around the
+    # process) -- the builder's committed passes of this same command (scripts/pmc_traffic.sh: separate `rocprofv3 --pmc
+    # FETCH_SIZE` / `--pmc WRITE_SIZE` runs), per ray, scaled to this launch; null if the file is absent
     traffic, traffic_note = None, None
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_render.json')) as f:
-            pmc = json.load(f)
-        traffic = pmc['dominant_kernel_traffic_bytes_per_launch'] * args.rays / pmc['rays_per_launch']
-        traffic_note = ('2*FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 PMC, separate passes); counts fabric requests incl. '
-                        'Infinity-Cache hits: the per-workgroup activation stash of the reverse sweep (8 x 32 KB per tile, '
-                        '134 MB in flight, Infinity-Cache resident) is written once and read once per tile with streaming (nt) '
-                        'accesses, 2 x 82 GB of the total; algorithmic bytes are 32 B in + 28 B out per sample')
-    except Exception:
-        pass
+    for name in ('r02_pmc_render.json', 'r01_pmc_render.json'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                pmc = json.load(f)
+            traffic = pmc['dominant_kernel_traffic_bytes_per_launch'] * args.rays / pmc['rays_per_launch']
+            traffic_note = (f'from profiles/{name} (builder-run rocprofv3 PMC passes of this command, not re-measured here): '
+                            '2*FETCH_SIZE + WRITE_SIZE per launch; counts fabric requests incl. Infinity-Cache hits: the '
+                            'per-workgroup activation stash of the reverse sweep (8 x 32 KB per tile, 134 MB in flight, '
+                            'Infinity-Cache resident) is written once and read once per tile with streaming (nt) accesses; '
+                            'algorithmic bytes are 32 B in + 28 B out per sample')
+            break
+        except Exception:
+            continue
     result = {
         'metric': 'rays/sec (render) 800x800, 64+64 samples/ray, NeuS SDF 8x256 + colour 4x256',
         'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'nerf/hotdog-shaped NeuS render: 800x800 pin-hole rays, n_samples=64, n_importance=64, '
-                               'up_sample_steps=4, sdf 8x256 (skip 4, posenc 6), colour 4x256 (idr, posenc_view 4), '
-                               'random-init weights', 'rays_per_step_per_gpu': args.rays, 'parallelism': f'rays x{world}'},
+        'config': {'workload': 'BASELINE configs[1], nerf/hotdog-shaped NeuS render: one whole 800x800 pin-hole view per rank per step '
+                               '(camera at distance 4, fov 0.6911), n_samples=64, n_importance=64, up_sample_steps=4, '
+                               'sdf 8x256 (skip 4, posenc 6), colour 4x256 (idr, posenc_view 4), random-init weights '
+                               '(geometric-init sphere of radius 0.85: ~30 % of the rays hit)',
+                   'rays_per_step_per_gpu': args.rays, 'parallelism': f'views x{world} (no data-path collective)'},
         'roofline': {'bound': 'mfma', 'kernel': 'neus_points2_kernel<FINE> (vqn_neus_fine_points)', 'achieved': achieved,
                      'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
                      'traffic': traffic, 'traffic_note': traffic_note, 'avg_launch_ms': avg_ms, 'flop_per_launch': flop_fine,
@@ -486,16 +674,33 @@ def main():
         'kernel_ms_per_step': {k: v[1] / args.steps for k, v in sorted(clock.items())},
     }
 
+    # the rays the CPU leg will re-render, taken NOW: the training legs below step these same networks' weights
+    sel = np.linspace(0, args.rays - 1, args.cpu_rays).astype(np.int64)      # spread over the whole view: hits and misses
+    if world == 1 and not args.no_cpu_baseline:
+        sel_t = torch.tensor(sel, device=dev)
+        got, got_ws = out['color_fine'][sel_t].cpu(), out['weight_sum'][sel_t].cpu()[:, 0]
+        ren.matrix_mode = 'f16s'                                  # the opt-in split-precision mode on the same rays
+        try:
+            step()
+            got16 = out_box[0]['color_fine'][sel_t].cpu()
+        finally:
+            ren.matrix_mode = 'f32'
+    del out
+    out_box[0] = None
+
+    extra = {}
     if world == 1 and not args.no_extras:
         # before the CPU legs: a spun-up host thread pool slows the launch-heavy training steps that follow it
         extra = secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col)
+        extra['dp_train'] = dp_train_leg(dev, 0, 1, backend, steps=6, warmup=2)      # the same legs a multi-rank run reports
+    if dp is not None:
+        extra['dp_train'] = dp
     if world == 1 and not args.no_cpu_baseline:
         from oracle import geo as og                      # CPU-baseline leg only (test infrastructure)
         cfg = dict(og.FULL_CFG)
         p_sdf = {k: v.float() for k, v in state['sdf'].items()}
         p_col = {k: v.float() for k, v in state['col'].items()}
         n_cpu = args.cpu_rays
-        sel = np.linspace(0, args.rays - 1, n_cpu).astype(np.int64)      # spread over the step's rays
         oc, dc = torch.tensor(o_np[sel]), torch.tensor(d_np[sel])
         nc, fc = torch.full((n_cpu, 1), 2.0), torch.full((n_cpu, 1), 6.0)
         cores = os.cpu_count() or 1
@@ -506,32 +711,91 @@ def main():
         # a 1-GPU box shares its host: the CPU share of one GPU is 16 cores (more threads only oversubscribe)
         cores = int(os.environ.get('VQN_CPU_THREADS', min(cores, 16)))
         torch.set_num_threads(cores)
-        og.render(p_sdf, p_col, torch.tensor(0.3), cfg, oc[:32], dc[:32], nc[:32], fc[:32], 2.0,
-                  background_rgb=torch.ones(1, 3), cos_anneal_ratio=1.0)          # warm-up
-        t0 = time.perf_counter()
-        ref = og.render(p_sdf, p_col, torch.tensor(0.3), cfg, oc, dc, nc, fc, 2.0, background_rgb=torch.ones(1, 3),
-                        cos_anneal_ratio=1.0)
-        cpu_dt = time.perf_counter() - t0
-        got = out['color_fine'][torch.tensor(sel, device=dev)].cpu()
+        cpu_call = lambda: og.render(p_sdf, p_col, torch.tensor(0.3), cfg, oc, dc, nc, fc, 2.0, background_rgb=torch.ones(1, 3),
+                                     cos_anneal_ratio=1.0)
+        cpu_call()                                                        # warm-up: one full call at the same batch
+        times = []
+        for _ in range(max(1, args.cpu_reps)):
+            t0 = time.perf_counter()
+            ref = cpu_call()
+            times.append(time.perf_counter() - t0)
+        cpu_dt = float(np.median(times))
+        ws_ref = ref['weight_sum'].detach()[:, 0]
         mse = float(((got - ref['color_fine'].detach()) ** 2).mean())
         result['cpu_baseline'] = {'value': n_cpu / cpu_dt, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
-                                  'sample': f'{n_cpu} rays of the same step (same weights), one oracle.geo.render call, '
-                                            f'{cpu_dt:.1f} s, torch {torch.__version__} CPU fp32'}
+                                  'cpu_model': cpu_model_string(),
+                                  'sample': f'{n_cpu} rays spread over the whole 800x800 view (same weights) per oracle.geo.render call; '
+                                            f'1 warm-up + {len(times)} timed calls, median {cpu_dt:.1f} s '
+                                            f'(all: {", ".join("%.1f" % t for t in times)} s); torch {torch.__version__} CPU fp32, '
+                                            f'{cores} threads'}
         result['psnr_vs_oracle_db'] = -10.0 * math.log10(mse + 1e-20)
+        result['psnr_sample'] = {'rays': n_cpu, 'frac_weight_sum_gt_0.5': float((ws_ref > 0.5).float().mean()),
+                                 'frac_weight_sum_gt_0.9': float((ws_ref > 0.9).float().mean()),
+                                 'colour_std_of_sample': float(ref['color_fine'].detach().std()),
+                                 'max_abs_colour_diff': float((got - ref['color_fine'].detach()).abs().max()),
+                                 'max_abs_weight_sum_diff': float((got_ws - ws_ref).abs().max())}
         result['speedup_vs_cpu'] = value / (n_cpu / cpu_dt)
         # the same check for the opt-in split-precision mode (reported under extra.geo_render_f16s)
-        ren.matrix_mode = 'f16s'
-        try:
-            with torch.no_grad():
-                got16 = step()['color_fine'][torch.tensor(sel, device=dev)].cpu()
-        finally:
-            ren.matrix_mode = 'f32'
         mse16 = float(((got16 - ref['color_fine'].detach()) ** 2).mean())
         result['psnr_f16s_vs_oracle_db'] = -10.0 * math.log10(mse16 + 1e-20)
         if not args.no_extras:
             result['cpu_baseline_decomp'] = decomp_cpu_leg(dev, cores)
-    if world == 1 and not args.no_extras:
+    if extra:
         result['extra'] = extra
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main_train(args, dev, rank, world, backend):
+    """--mode train: the timed step is the data-parallel geo training step (2560 rays per rank; forward + backward on the HIP
+    tile programs, one flat-bucket all-reduce of the 1.4 M gradients over RCCL, Adam).  `value` = training rays/s, whole job."""
+    from vqnerf_release_amd import _C
+    runner, gstep = geo_train_setup(dev, rank)
+    dt, clock = _timed_steps(gstep, args.steps, args.warmup, dev, world, backend)
+    sdf, col = runner.sdf_network, runner.color_network
+    m_sdf, m_col = macs_per_point(sdf, col)
+    B = 2560
+    bucket_bytes = int(runner.bucket.flat.numel() * 4)
+    dec = None
+    if not args.no_extras:
+        del gstep
+        model, tr, dstep = decomp_train_setup(dev, rank, world)
+        ddt, dclk = _timed_steps(dstep, args.steps, args.warmup, dev, world, backend)
+        dec = {'points_per_s': 2048 * world * args.steps / ddt, 'ms_per_step': ddt / args.steps * 1e3, 'batch_points_per_rank': 2048,
+               'grad_bucket_bytes': int(tr.bucket.flat.numel() * 4), 'vq_stats_bytes': int((256 + 1) * 15 * 4),
+               'all_reduce': _collective_report(dclk, args.steps)}
+    if rank != 0:
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
+    # algorithmic FLOPs of one rank's step (DESIGN.md section 4): coarse SDF passes + [fwd, reverse sweep, tangent, reverse, 2 weight
+    # contractions] of the SDF net + [fwd, reverse, weight contraction] of the colour net, per fine sample
+    flop = 2.0 * B * ((64 + 48) * m_sdf + 128 * (6 * m_sdf + 3 * m_col))
+    t_prog = sum(v[1] for k, v in clock.items() if k.startswith('vqn_tile_program')) / args.steps * 1e-3
+    flop_prog = 2.0 * B * 128 * (4 * m_sdf + 2 * m_col)
+    step_s = dt / args.steps
+    import torch.distributed as dist
+    result = {
+        'metric': 'rays/sec (train) 2560 rays/step/GPU of 800x800 views, 64+64 samples/ray, NeuS SDF 8x256 + colour 4x256',
+        'value': B * world / step_s, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': step_s * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[1] / configs[3] training step: nerf.conf batch of 2560 rays per rank (random pixels of '
+                               'synthetic 800x800 views), L1 colour + 0.1 eikonal + 0.1 mask BCE, Adam; data parallel over ranks with ONE '
+                               'flat-bucket all-reduce of the gradients per step', 'rays_per_step_per_gpu': B,
+                   'parallelism': f'dp{world}', 'n_ranks_seen': dist.get_world_size() if world > 1 else 1},
+        'roofline': {'bound': 'mfma', 'kernel': 'tile_vm_kernel (vqn_tile_program: forward / colour-backward / SDF-backward programs)',
+                     'achieved': flop_prog / t_prog / 1e12, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': flop_prog / t_prog / 1e12 / F32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                     'whole_step_tflops': flop / step_s / 1e12, 'whole_step_frac': flop / step_s / 1e12 / F32_MFMA_PEAK_TFLOPS},
+        'kernel_ms_per_step': {k: v[1] / args.steps for k, v in sorted(clock.items())},
+        'all_reduce': dict(_collective_report(clock, args.steps), grad_bucket_bytes=bucket_bytes),
+        'last_train_backend': runner.renderer.last_train_backend,
+    }
+    if dec is not None:
+        result['extra'] = {'decomp_train_dp': dec}
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

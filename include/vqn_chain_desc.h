@@ -1,6 +1,6 @@
 // Layer program handed to the generic fused Dense-stack kernel (csrc/mlp_chain.hip).  Every field is 4 bytes so
 // that the host (vqnerf_release_amd/decomp/packing.py) can build it as a flat int32 array; weight offsets are in
-// float4 units into the pack buffer.  Not a public header: the C ABI takes `const int32_t*`.
+// float4 units into the pack buffer.  Public: the C ABI takes it as `const int32_t*`.
 #pragma once
 #include <stdint.h>
 

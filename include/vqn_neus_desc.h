@@ -1,6 +1,6 @@
 // Network descriptors handed to the fused NeuS kernels.  Every field is 4 bytes so that the host
 // side (Python) can build them as flat int32 arrays; offsets are in float4 units into the weight
-// pack buffer.  Not a public header: the C ABI takes `const int32_t*` (include/vqnerf_hip.h).
+// pack buffer.  Public: the C ABI takes them as `const int32_t*` (include/vqnerf_hip.h); vqn_neus_pack_* builds them in C.
 #pragma once
 #include <stdint.h>
 

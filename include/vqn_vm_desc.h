@@ -1,7 +1,7 @@
 // Tile-program descriptor of csrc/tile_vm.hip: a list of ops over LDS "activation image" regions of one
 // 32-point tile.  Every field is 4 bytes (host side: flat int32 array built by vqnerf_release_amd/geo/train_programs.py).
 // Weight offsets are in float4 units into the pack buffer; tensor operands are indices into the pointer table
-// handed to the launch.  Not a public header.
+// handed to the launch.  Public (the C ABI takes it as `const int32_t*`).
 //
 // Global tensor formats
 //   VEC  : [N, ld] row-major floats (points x few components)

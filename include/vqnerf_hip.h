@@ -7,7 +7,7 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch tensor.data_ptr());
- *     the library allocates nothing persistent
+ *     the library allocates nothing persistent except the weight-pack handles of vqn_neus_pack_create / _destroy
  *   - `stream` is a hipStream_t (NULL = default stream); all work is enqueued asynchronously
  *   - return 0 on success; -1 bad argument, -2 unsupported shape, -3 HIP runtime error;
  *     vqn_last_error() returns the thread-local message of the last failure
@@ -59,7 +59,7 @@ int vqn_vq_ste_loss(const float* x, const float* quant, int64_t numel, float sca
 
 /* Generic fused Dense-stack evaluator: [posenc ->] Dense -> Dense ... with skip-concats and several
  * heads per launch, driven by a layer program (flat int32 array in HOST memory, layout
- * csrc/chain_desc.h, built by vqnerf_release_amd/decomp/packing.py together with `wbuf`, device).
+ * include/vqn_chain_desc.h, built by vqnerf_release_amd/decomp/packing.py together with `wbuf`, device).
  * Replaces networks/embedder.py:23-47 + networks/mlp.py:24-50 + networks/seq.py:24-38 as evaluated by
  * models/vq_nfr.py:771-784 (_pred_enc_at: xyz [N,3] -> z [N,z_dim]) and :786-828 (_pred_diff_at,
  * _pred_spec_at, _pred_rough_at: z -> [N,3], [N,1|3], [N,1]); models/shape.py:169-179 (chunk_apply)
@@ -108,7 +108,7 @@ int vqn_brdf_shade_bwd(const float* xyz, const float* normal, const float* rayo,
 
 /* ---- fused NeuS networks (geo/NeuS-ours2/models/{fields,renderer}.py) ---------------------- */
 
-/* Network descriptors are flat int32 arrays in HOST memory (layout: csrc/neus_desc.h, built by
+/* Network descriptors are flat int32 arrays in HOST memory (layout: include/vqn_neus_desc.h, built by
  * vqnerf_release_amd/geo/packing.py together with the packed weight buffers `wbuf_*`, which are
  * device memory).  Points are either explicit (`pts` [P,3], `dirs` [P,3]) or ray samples
  * (rays_o, rays_d [B,3], z [B,S], P = B*S, point = o + d*z) -- pass NULL for the unused form. */
@@ -143,6 +143,42 @@ int vqn_neus_fine_points_f16s(const int32_t* sdf_desc, const float* wbuf_sdf, co
                               const float* wbuf_col, const float* rays_o, const float* rays_d, const float* z,
                               const float* pts, const float* dirs, int64_t P, int S, void* scratch,
                               int64_t scratch_bytes, float* out_sdf, float* out_grad, float* out_rgb, void* stream);
+
+/* ---- weight packs of the fused NeuS kernels, built in C ------------------------------------------------ */
+
+/* A pack handle owns the device memory of the two weight buffers + their gather tables and the two host descriptors
+ * (include/vqn_neus_desc.h) for one (SDFNetwork, RenderingNetwork) shape; these are the only persistent allocations the library
+ * makes (explicit create / destroy).  What it replaces in the reference: nothing computes there -- the networks' parameters
+ * (fields.py:24-66, :121-140) are consumed by nn.Linear; here they are re-laid as MFMA A-fragments.
+ *   sdf_dims [sdf_n_lin + 1] = [3 + 6 multires, hidden..., d_out] (fields.py:24); sdf_skip: the layer whose input is
+ *   [h, embedding] / sqrt(2) (fields.py:81-82; -1 none; one skip, not the last layer); col_mode 0 idr, 1 no_view_dir, 2 no_normal
+ *   (fields.py:147-158); col_n_layers hidden layers of col_d_hidden (0: no colour network, SDF-only packs); the colour net's
+ *   d_feature is d_out - 1.  f16s != 0: packs for the split-precision entry points (*_f16s). */
+typedef struct vqn_neus_pack vqn_neus_pack;
+int vqn_neus_pack_create(const int32_t* sdf_dims, int sdf_n_lin, int sdf_skip, int multires, float scale, int col_mode,
+                         int col_d_hidden, int col_n_layers, int multires_view, int squeeze_out, int f16s, vqn_neus_pack** out);
+/* Gather the current EFFECTIVE weights (weight-norm applied: vqn_weight_norm_fwd) into the packs: one launch per network.
+ * sdf_w[l] [out_l, in_l] row-major, sdf_b[l] [out_l], device pointers in host arrays of sdf_n_lin (col_n_layers + 1) entries;
+ * out_l of the layer before the skip is dims[l + 1] - dims[0] (fields.py:38-41).  Call again after every optimiser step. */
+int vqn_neus_pack_update(vqn_neus_pack* pack, const float* const* sdf_w, const float* const* sdf_b, const float* const* col_w,
+                         const float* const* col_b, void* stream);
+const int32_t* vqn_neus_pack_sdf_desc(const vqn_neus_pack* pack);   /* host, 108 ints: `sdf_desc` of the entry points below */
+const int32_t* vqn_neus_pack_col_desc(const vqn_neus_pack* pack);   /* host, 80 ints (all zero without a colour network) */
+const float* vqn_neus_pack_sdf_wbuf(const vqn_neus_pack* pack);     /* device: `wbuf_sdf` */
+const float* vqn_neus_pack_col_wbuf(const vqn_neus_pack* pack);     /* device: `wbuf_col` (NULL without a colour network) */
+int64_t vqn_neus_pack_sdf_floats(const vqn_neus_pack* pack);
+int64_t vqn_neus_pack_col_floats(const vqn_neus_pack* pack);
+void vqn_neus_pack_destroy(vqn_neus_pack* pack);
+
+/* Host-only halves of the above (no device needed): the descriptor and the gather table of one network's pack.  A table entry
+ * is 4 int32 per f32 word of the pack: (src, i0, i1, kind) -- src -1: zero, 2 l: element i0 of W_l, 2 l + 1: of bias_l, bit 30:
+ * times 1/sqrt(2); kind 0 copy, 1 / 2: the f16 hi / lo halves (hi = f16(w), lo = f16((w - hi) 2^11)) of elements (i0, i1).
+ * Return the number of words (entries are written only if words_cap is large enough; desc_out / words_out may be NULL), or a
+ * negative error code.  with_reverse: include the transposed packs of the input-gradient sweep. */
+int64_t vqn_neus_sdf_pack_plan(const int32_t* dims, int n_lin, int skip, int multires, float scale, int max_tiles, int with_reverse,
+                               int f16s, int32_t* desc_out, int32_t* words_out, int64_t words_cap);
+int64_t vqn_neus_col_pack_plan(int d_feature, int mode, int d_hidden, int n_layers, int d_out, int multires_view, int squeeze_out,
+                               int feat_tiles, int f16s, int32_t* desc_out, int32_t* words_out, int64_t words_cap);
 
 /* ---- per-ray NeuS kernels (geo/NeuS-ours2/models/renderer.py) ------------------------------ */
 
@@ -191,7 +227,7 @@ int vqn_neus_composite_bwd(const float* rays_o, const float* rays_d, const float
 
 /* ---- training engine of the fused NeuS networks ------------------------------------------------- */
 
-/* Tile-program interpreter (csrc/tile_vm.hip, descriptor csrc/vm_desc.h): runs a host-built op list over
+/* Tile-program interpreter (csrc/tile_vm.hip, descriptor include/vqn_vm_desc.h): runs a host-built op list over
  * the LDS activation image of 32-point tiles.  The training passes the reference gets from autograd
  * (loss.backward() through fields.py:72-107,147-172 with create_graph=True for the eikonal term) are such
  * programs (vqnerf_release_amd/geo/train_programs.py): forward with saved activations, colour-net reverse
@@ -210,7 +246,7 @@ int vqn_weight_norm_bwd(int n_layers, const float* const* v, const float* const*
                         float* const* dg, const int32_t* rows, const int32_t* cols, void* stream);
 
 /* Row-major [N, F] (row stride ldx floats) <-> the feature-major tile format of the training programs
- * (TFMT [ceil(N/32)][tiles_f][32 features][32 points], csrc/vm_desc.h), zero padded on pack.  In the reference these
+ * (TFMT [ceil(N/32)][tiles_f][32 features][32 points], include/vqn_vm_desc.h), zero padded on pack.  In the reference these
  * hand-offs are implicit (autograd passes dense [N, F] tensors between the Keras layers, the VQ layer and the renderer). */
 int vqn_tfmt_pack(const float* x, int64_t N, int F, int64_t ldx, float* t, int tiles_f, void* stream);
 int vqn_tfmt_unpack(const float* t, int tiles_f, int64_t N, int F, float* x, int64_t ldx, void* stream);

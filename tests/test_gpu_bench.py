@@ -1,0 +1,63 @@
+"""GPU: bench.py's multi-rank paths rehearsed with 2 ranks on ONE card (gloo stands in for RCCL: `VQN_BENCH_BACKEND=gloo`;
+the driver launches the real thing with one rank per GPU).  Checks the contract of the JSON line and that the data-parallel
+training legs really run their collectives (the gradient bucket + the VQ statistics all-reduce) on both ranks."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(extra_args, nproc=2):
+    env = dict(os.environ, VQN_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', str(nproc)] + extra_args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]                    # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_two_rank_render_line_and_dp_training_legs():
+    res = _run(['--steps', '2', '--warmup', '1', '--rays', '16000'])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline'):
+        assert k in res, k
+    assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['unit'] == 'rays/s' and res['vs_baseline'] is None
+    assert abs(res['value'] - 2 * 16000 * 2 / (res['ms_per_step'] * 2 * 1e-3)) < 1e-6 * res['value']     # whole job / max-over-ranks time
+    assert 0.05 < res['roofline']['frac'] < 1.0 and res['roofline']['bound'] == 'mfma'
+    assert 'cpu_baseline' not in res                             # rank 0 at N = 1 only
+    dp = res['extra']['dp_train']
+    assert dp['n_ranks_seen'] == 2
+    g, d = dp['geo'], dp['decomp']
+    assert g['last_train_backend'] == 'hip'
+    assert g['all_reduce']['grad_bucket']['calls_per_step'] == 1 and g['all_reduce']['loss_normalisers']['calls_per_step'] == 1
+    assert d['all_reduce']['grad_bucket']['calls_per_step'] == 1 and d['all_reduce']['vq_stats']['calls_per_step'] == 1
+    assert g['all_reduce']['total_us_per_step'] > 0 and d['all_reduce']['total_us_per_step'] > 0
+    assert g['grad_bucket_bytes'] > 3_000_000 and d['grad_bucket_bytes'] > 3_000_000           # 0.80 M and 0.78 M fp32 gradients (+ extras)
+    assert d['replicas_bit_identical_after_steps'] is True
+    assert g['rays_per_s'] > 0 and d['points_per_s'] > 0
+
+
+def test_two_rank_train_mode_times_the_dp_step():
+    res = _run(['--mode', 'train', '--steps', '3', '--warmup', '1'])
+    assert res['n_gpus'] == 2 and res['config']['n_ranks_seen'] == 2 and res['config']['parallelism'] == 'dp2'
+    assert abs(res['value'] - 2 * 2560 / (res['ms_per_step'] * 1e-3)) < 1e-6 * res['value']
+    assert res['all_reduce']['grad_bucket']['calls_per_step'] == 1 and res['all_reduce']['total_us_per_step'] > 0
+    assert res['last_train_backend'] == 'hip' and res['roofline']['bound'] == 'mfma'
+    assert any(k.startswith('vqn_tile_program') for k in res['kernel_ms_per_step'])
+    assert res['extra']['decomp_train_dp']['all_reduce']['vq_stats']['calls_per_step'] == 1

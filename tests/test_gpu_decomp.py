@@ -308,28 +308,107 @@ def test_relight_16_probes_single_pass(setup):
     model.novel_probes = {}
 
 
-def test_ref_nfr_stage3_model(setup):
-    """Stage-3 model (ref_nfr): fused inference == its own torch statements; frozen stage-2 parts get no gradient."""
-    od, p = setup['od'], setup['p']
+def _ref_setup(data_type, seed=5):
+    from oracle import decomp as od
     from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
-    m = get_model_class('ref_nfr')(make_config(model='ref_nfr'))
-    m.build_nets(device='cuda', seed=3).to('cuda')
-    m.load_stage2(setup['model'])
-    N = 400
-    pts = od.make_points(N, seed=21)
-    b = make_batch(pts, 'cuda', bg_every=9)
-    ref = torch.rand(N, 3, device='cuda')
-    batch = b[:9] + (ref,) + b[9:]
+    p, specs = od.make_ref_params(seed=seed)
+    m = load_oracle_params(get_model_class('ref_nfr')(make_config(model='ref_nfr', data_type=data_type)), p, 'cuda')
+    gamma = None
+    if data_type != 'nerf':
+        m.gamma
+        with torch.no_grad():
+            m._gamma_bias.fill_(1.3); m._gamma_index.fill_(0.8)
+        gamma = od.gamma_param(torch.tensor([1.3]), torch.tensor([0.8]))
+    pt = {k: ([(od.T(W), od.T(b)) for W, b in v] if isinstance(v, list) else od.T(v)) for k, v in p.items()}
+    return od, p, pt, specs, m, gamma
+
+
+def _ref_batch(od, N, data_type, seed, bg_every):
+    pts = od.make_points(N, seed=seed, lvis=(data_type == 'nerf'))
+    pts['ref'] = np.random.default_rng(seed + 1).uniform(0, 1, (N, 3)).astype(np.float32)
+    b = make_batch({k: v for k, v in pts.items() if k != 'ref'}, 'cuda', bg_every=bg_every)
+    batch = b[:9] + (torch.tensor(pts['ref']).cuda(),) + b[9:]
+    keep = np.ones(N, bool)
+    if bg_every:
+        keep[::bg_every] = False
+    return pts, batch, keep, {k: od.T(v[keep]) for k, v in pts.items()}
+
+
+@pytest.mark.parametrize('data_type,matrix_mode', [('nerf', 'f32'), ('hw', 'f32'), ('hw', 'f16s')])
+def test_ref_nfr_call_and_fast_render_vs_oracle(setup, data_type, matrix_mode):
+    """Stage-3 model (ref_nfr.py:176-300, :303-418) on the fused kernels against the oracle's statement: `call` in vali mode
+    with 3 probes, `fast_render` with the albedo / spec scale (rgb from the unscaled materials, probes from the scaled ones),
+    per-example loss.  'hw' + 'f16s' is BASELINE configs[4]'s model / data type / precision mode (scripts/test/relight_hw.sh)."""
+    od, p, pt, specs, m, gamma = _ref_setup(data_type)
+    m.matrix_mode = matrix_mode
+    lxyz, lareas = setup['lxyz'], setup['lareas']
+    rng = np.random.default_rng(2)
+    probes = [rng.uniform(0, 2, (16, 32, 3)).astype(np.float32) for _ in range(3)]
+    m.novel_probes = {f'probe{i}': torch.tensor(a).cuda() for i, a in enumerate(probes)}
+    N = 300
+    pts, batch, keep, ob = _ref_batch(od, N, data_type, 21, 9)
+    assert len(batch) == (11 if data_type == 'nerf' else 10)              # ref_nfr.py:180-184
+    mk = torch.tensor(keep).cuda()
+    want = od.ref_nfr_call(pt, specs, ob, lxyz, lareas, mode='vali', data_type=data_type, gamma=gamma, probes=[od.T(a) for a in probes])
     with torch.no_grad():
-        pred, gt, lk, _ = m.call(batch, mode='vali')                           # fused kernels
-    m.train_backend = 'torch'
-    pred_t, _, lk_t, _ = m.call(batch, mode='vali')                            # torch statements (graph path)
-    for k in ('rgb', 'albedo', 'spec', 'rough', 'rgb_diff', 'rgb_spec', 'normal'):
-        np.testing.assert_allclose(_np(pred[k]), _np(pred_t[k]), rtol=0, atol=1e-4, err_msg=k)
-    m.train_backend = 'hip'
-    pred_h, gt_h, lk_h, _ = m.call(batch, mode='train')
-    loss, ld = m.compute_loss(pred_h, gt_h, **dict(lk_h))
-    loss.mean().backward()
-    assert m.net['rgb_enc'].layers[0].kernel.grad.abs().sum() > 0 and m.net['diff_out'].layers[2].kernel.grad.abs().sum() > 0
-    assert m.net['fine_enc'].layers[0].kernel.grad is None and m.net['spec_out'].layers[0].kernel.grad is None
-    assert m._light.grad.abs().sum() > 0
+        pred, gt, lk, _ = m.call(batch, mode='vali', relight_probes=True)
+    t = 1 if matrix_mode == 'f32' else 3
+    np.testing.assert_allclose(_np(lk['rgb']), want['rgb'].numpy(), rtol=0, atol=t * 2e-5)
+    np.testing.assert_allclose(_np(pred['rgb'][mk]), want['pred_rgb'].numpy(), rtol=0, atol=t * 1e-4)
+    np.testing.assert_array_equal(_np(pred['rgb'][~mk]), 0.0)
+    for k in ('albedo', 'spec', 'rough', 'ks', 'basecolor'):
+        np.testing.assert_allclose(_np(pred[k][mk]), want[k].numpy(), rtol=0, atol=t * 5e-6, err_msg=k)
+    np.testing.assert_allclose(_np(pred['rgb_diff'][mk]), want['rgb_diff'].numpy(), rtol=0, atol=t * 2e-5)
+    np.testing.assert_allclose(_np(pred['rgb_spec'][mk]), want['rgb_spec'].numpy(), rtol=0, atol=t * 1e-4)
+    np.testing.assert_allclose(_np(pred['rgb_probes'][mk]), want['rgb_probes'].numpy(), rtol=0, atol=t * 2e-4)
+    np.testing.assert_array_equal(_np(pred['normal'][mk]), want['normal'].numpy())
+    loss = m.compute_loss(pred, gt, **dict(lk))                           # vali: the bare tensor (ref_nfr.py:606)
+    np.testing.assert_allclose(_np(loss), od.ref_nfr_loss(want, ob['rgb'], data_type).numpy(), rtol=1e-3, atol=t * 2e-6)
+    assert lk['env'] is None
+    # fast_render
+    scale = torch.tensor([[1.2, 0.9, 0.8]])
+    want_f = od.ref_nfr_fast_render(pt, specs, ob, lxyz, lareas, data_type=data_type, gamma=gamma, probes=[od.T(a) for a in probes],
+                                    opt_scale=scale)
+    with torch.no_grad():
+        pf, gf, lkf, _ = m.fast_render(batch, mode='test', relight_probes=True, opt_scale=scale.cuda())
+        p0, _, _, _ = m.fast_render(batch, mode='test')
+    assert set(pf) == {'rgb', 'alpha', 'rgb_probes'} and set(p0) == {'rgb', 'alpha'}
+    np.testing.assert_allclose(_np(pf['rgb'][mk]), want_f['pred_rgb'].numpy(), rtol=0, atol=t * 1e-4)
+    np.testing.assert_allclose(_np(p0['rgb'][mk]), want_f['pred_rgb'].numpy(), rtol=0, atol=t * 1e-4)
+    np.testing.assert_allclose(_np(lkf['rgb']), want_f['rgb'].numpy(), rtol=0, atol=t * 2e-5)
+    np.testing.assert_allclose(_np(pf['rgb_probes'][mk]), want_f['rgb_probes'].numpy(), rtol=0, atol=t * 2e-4)
+
+
+@pytest.mark.parametrize('data_type', ['nerf', 'dtu'])
+def test_ref_nfr_training_grads_vs_oracle(setup, data_type):
+    """Stage-3 training step: d loss / d (rgb_enc, diff_out, rough_out[, gamma]) through the HIP path vs the CPU oracle under
+    torch autograd; the stage-2 parts (encoder, specular head) and the light are frozen (ref_nfr.py:141-146, :87)."""
+    od, p, pt_, specs, m, _ = _ref_setup(data_type)
+    for name in ('fine_enc', 'bottleneck', 'spec_out'):                    # what load_stage2 does to the stage-2 parts
+        for prm in m.net[name].parameters():
+            prm.requires_grad_(False)
+    N = 200
+    pts, batch, keep, ob = _ref_batch(od, N, data_type, 33, 0)
+    with launches() as rec:
+        pred, gt, lk, _ = m.call(batch, mode='train')
+        loss, ld = m.compute_loss(pred, gt, **dict(lk))
+        loss.mean().backward()
+    assert rec.ran('vqn_brdf_shade_bwd')
+    pt = {k: ([(od.T(W).requires_grad_(True), od.T(b).requires_grad_(True)) for W, b in v] if isinstance(v, list) else od.T(v))
+          for k, v in p.items()}
+    gb, gi = torch.tensor([1.3], requires_grad=True), torch.tensor([0.8], requires_grad=True)
+    gamma = None if data_type == 'nerf' else od.gamma_param(gb, gi)
+    want = od.ref_nfr_call(pt, specs, ob, setup['lxyz'], setup['lareas'], mode='train', data_type=data_type, gamma=gamma)
+    od.ref_nfr_loss(want, ob['rgb'], data_type).mean().backward()
+    np.testing.assert_allclose(_np(loss), od.ref_nfr_loss(want, ob['rgb'], data_type).detach().numpy(), rtol=1e-3, atol=2e-6)
+    for name in ('rgb_enc', 'diff_out', 'rough_out'):
+        for layer, (W, b) in zip(m.net[name].layers, pt[name]):
+            for got, ref in ((layer.kernel.grad, W.grad), (layer.bias.grad, b.grad)):
+                ref = ref.numpy()
+                assert np.abs(_np(got) - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-8) + 1e-9, name
+    for name in ('fine_enc', 'bottleneck', 'spec_out'):
+        assert all(l.kernel.grad is None for l in m.net[name].layers), name
+    assert m._light.grad is None
+    if data_type != 'nerf':
+        np.testing.assert_allclose(_np(m._gamma_bias.grad), gb.grad.numpy(), rtol=2e-3)
+        np.testing.assert_allclose(_np(m._gamma_index.grad), gi.grad.numpy(), rtol=2e-3)

@@ -48,6 +48,49 @@ def test_compute_geo_and_vis(tmp_path):
     assert np.load(tmp_path / 'train_000' / 'xyz.npy').dtype == np.float32
 
 
+def test_compute_geo_and_vis_vs_oracle():
+    """`GeoExtractor.compute_geo` / `compute_vis` (all (point, light) pairs of a chunk in one batch, colour net skipped) against
+    the oracle's statement of gen_geo.py:182-344 (one `render` per light, lpix_chunk = 1, through the reference-pinned oracle
+    renderer).  Both sides run without jitter (the reference draws a fresh one per call).  Tolerances: fp32 end-to-end render
+    (1e-3 on weight sums / colours, see test_gpu_neus_render), 2e-3 on unit normals."""
+    from oracle import geo as og, decomp as od
+    from tests.test_gpu_neus_render import _build
+    from vqnerf_release_amd.geo.gen_geo import GeoExtractor
+    cfg, sdf, col, var, ren = _build('small')
+    cfg = dict(cfg, renderer=dict(cfg['renderer'], n_importance=16))
+    ren.n_importance, ren.up_sample_steps = 16, 4
+    with torch.no_grad():
+        var.variance.fill_(0.5)
+    p_sdf, p_col = og.to_torch(og.make_sdf_params(cfg, 0)), og.to_torch(og.make_color_params(cfg, 1))
+    R = 24
+    o, d, near, far = [torch.tensor(a) for a in og.make_rays(R, seed=5, spread=0.12)]
+    want = og.compute_geo(p_sdf, p_col, 0.5, cfg, o, d, near, far, 2.0, alpha_thres=0.5, batch_size=10)
+    ex = GeoExtractor(ren, max_radius=2.0, light_h=16, max_rays=4096)
+    got = ex.compute_geo(o.cuda(), d.cuda(), near.cuda(), far.cuda(), alpha_thres=0.5, perturb_overwrite=0)
+    np.testing.assert_array_equal(got['mask'].cpu().numpy(), want['mask'])
+    fg = want['mask'][:, 0] > 0
+    assert 4 < fg.sum() < R                                            # hits and misses
+    np.testing.assert_allclose(got['rgb'].cpu().numpy(), want['rgb'], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(got['surf'].cpu().numpy(), want['surf'], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(got['normal'].cpu().numpy()[fg], want['normal'][fg], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(got['normal'].cpu().numpy()[~fg], 1 / np.sqrt(3), rtol=0, atol=1e-6)      # gen_geo.py:325-326
+    # visibility from the SAME geometry buffers on both sides (isolates compute_vis)
+    lxyz, _ = od.gen_light_xyz(16, 32)
+    T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
+    want_l = og.compute_vis(p_sdf, p_col, 0.5, cfg, T(lxyz.reshape(1, -1, 3)), T(want['surf']), T(want['normal']), T(want['mask']), 2.0,
+                            batch_size=7)
+    got_l = ex.compute_vis(T(want['surf']).cuda(), T(want['normal']).cuda(), T(want['mask']).cuda(), perturb_overwrite=0).cpu().numpy()
+    assert got_l.shape == want_l.shape == (R, 512)
+    s2l = lxyz.reshape(1, -1, 3) - want['surf'][:, None, :]
+    lcos = ((s2l / np.linalg.norm(s2l, axis=-1, keepdims=True)) * want['normal'][:, None, :]).sum(-1)
+    sure = np.abs(lcos) > 1e-5                                          # front / back lit beyond rounding
+    np.testing.assert_allclose(got_l[sure], want_l[sure], rtol=0, atol=1e-3)
+    back = sure & (lcos <= 0)
+    assert (got_l[back] == 0).all() and (want_l[back] == 0).all()      # back-lit lights are never traced (gen_geo.py:214-222)
+    assert (want_l[~fg] == 0).all() and (got_l[~fg] == 0).all()
+    assert 0.2 < (want_l[fg] != 0).mean() < 0.8 and (want_l[fg][want_l[fg] != 0] < 0.9).sum() > 20       # lit / unlit / partly occluded
+
+
 def test_extract_views_shards_and_resumes(tmp_path):
     """The per-view loop of gen_geo.py:126-180 over a Blender-format set: view range split `num_p / p_i` (the reference's
     multi-GPU extraction), finished views skipped, files = the decomp loaders' contract."""

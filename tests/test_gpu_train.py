@@ -331,7 +331,7 @@ def test_empty_and_degenerate_inputs():
 
 @pytest.mark.parametrize('N,F,tiles', [(100, 70, None), (1, 3, 1), (4097, 256, 8), (64, 33, 4)])
 def test_tfmt_pack_and_unpack(N, F, tiles):
-    """vqn_tfmt_pack / vqn_tfmt_unpack against the index formula of csrc/vm_desc.h: element (p, f) of the rows sits at
+    """vqn_tfmt_pack / vqn_tfmt_unpack against the index formula of include/vqn_vm_desc.h: element (p, f) of the rows sits at
     [p // 32][f // 32][f % 32][p % 32]; padding rows / features are zero; strided inputs are accepted."""
     from vqnerf_release_amd.decomp.train_programs import to_tfmt, from_tfmt
     g = torch.Generator(device='cuda').manual_seed(N + F)

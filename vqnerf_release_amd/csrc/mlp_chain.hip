@@ -8,7 +8,7 @@
 // The layer program (which LDS rows feed a layer, where its output goes, which outputs leave for HBM) is built
 // on the host (vqnerf_release_amd/decomp/packing.py) -- the kernel is a small interpreter over it.
 #include "mlp_prims.h"
-#include "chain_desc.h"
+#include "vqn_chain_desc.h"
 
 using namespace eng;
 

@@ -4,7 +4,7 @@
 // with the f32 kernel to ~1e-6 relative, not bitwise.  Row counts of every K segment are even (16 features per step);
 // the host builds programs and packs for it with ChainBuilder(mode='f16s').
 #include "mlp_prims_f16s.h"
-#include "chain_desc.h"
+#include "vqn_chain_desc.h"
 
 using namespace eng;
 

@@ -11,7 +11,7 @@
 // Execution model: 256-thread workgroups (4 waves), persistent over tiles of 32 points, 2 workgroups
 // per CU.  See mlp_prims.h for the LDS "activation image" and the weight-pack layout.
 #include "mlp_prims.h"
-#include "neus_desc.h"
+#include "vqn_neus_desc.h"
 #include <stdlib.h>
 
 using namespace eng;

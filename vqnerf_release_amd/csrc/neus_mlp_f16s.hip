@@ -5,7 +5,7 @@
 // results agree with the f32 kernels to ~1e-6 relative, not bitwise.  Descriptors are SdfDesc / ColDesc; packs come from
 // SdfPackPlan(mode='f16s') / ColPackPlan(matrix_mode='f16s').
 #include "mlp_prims_f16s.h"
-#include "neus_desc.h"
+#include "vqn_neus_desc.h"
 #include <stdlib.h>
 
 using namespace eng;

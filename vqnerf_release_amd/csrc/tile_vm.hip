@@ -7,10 +7,10 @@
 //   backward  : colour-network reverse sweep; tangent (JVP) pass of the SDF net along d loss/d normal; reverse
 //               sweep carrying the first-order adjoints and the second-order source terms
 // built by vqnerf_release_amd/geo/train_programs.py.  Weight gradients (contractions over points) are taken from the
-// saved TFMT tensors by csrc/wgrad.hip.  Formats: csrc/vm_desc.h.
+// saved TFMT tensors by csrc/wgrad.hip.  Formats: include/vqn_vm_desc.h.
 #include "mlp_prims.h"
 #include <type_traits>
-#include "vm_desc.h"
+#include "vqn_vm_desc.h"
 
 using namespace eng;
 

@@ -1,5 +1,5 @@
 // Weight-gradient contraction over points for gfx950:  G[o][i] = sum_p A[o][p] * B[i][p]  with A, B in the
-// feature-major TFMT layout written by csrc/tile_vm.hip (csrc/vm_desc.h).  In the reference these are the
+// feature-major TFMT layout written by csrc/tile_vm.hip (include/vqn_vm_desc.h).  In the reference these are the
 // `grad_weight` GEMMs autograd runs inside loss.backward() for every nn.Linear of fields.py (SDFNetwork,
 // RenderingNetwork), once per adjoint stream.
 //

@@ -1,5 +1,5 @@
 """Stage-3 residual-baking model: mirror of decomp/nerfvq_nfr3/nerfactor/models/ref_nfr.py (nets :137-159, call :176-300,
-_pred_ref_at :487-496, compute_loss :584-610; fast_render / vis / HTML are out of scope).
+fast_render :303-418, _pred_ref_at :487-496, compute_loss :584-610; vis / HTML are out of scope).
 
 The encoder (`fine_enc`, `bottleneck`) and the specular head come frozen from the stage-2 vq_nfr model; a new `rgb_enc`
 (3 -> 256 -> 256 -> 256) embeds the per-point reference colour and the diffuse / roughness heads read [z_xyz ; z_ref]
@@ -46,7 +46,20 @@ class Model(BrdfModel):
             for p in self.net[dst].parameters():
                 p.requires_grad_(False)
         if vq_model._light is not None:
-            self.set_light(vq_model._light.detach().clone())
+            self.set_light(vq_model.light.detach().clone())       # what stage 2 saved to np_light.npy: the clipped light
+
+    def set_light(self, arr):
+        """The stage-3 light is a CONSTANT: the reference loads the light stage 2 wrote (`np_light.npy`) into a plain tensor
+        (ref_nfr.py:70-87), not a variable -- it gets no gradient and `loss_kwargs['env']` is None (:263, `self._light`)."""
+        super().set_light(arr)
+        self._light.requires_grad_(False)
+
+    @property
+    def light(self):
+        if self._light is None:
+            BrdfModel.light.fget(self)                            # `light_path` / `light_init_val` of the config
+            self._light.requires_grad_(False)
+        return self._light                                        # used as loaded: no clip (ref_nfr.py:87, :424)
 
     def _pred_ref_at(self, ref):
         if self._fused(ref):
@@ -93,7 +106,7 @@ class Model(BrdfModel):
                 sh['rgb_diff'] = self._render(brdf_d, surf2l, n_pred, lvis_m)[0]
                 sh['rgb_spec'] = self._render(brdf_s, surf2l, n_pred, lvis_m)[0]
         rgb_pred, normal_pred = sh['rgb'][0], sh['normal']
-        loss_kwargs = {'mode': mode, 'env': self._light, 'gtc': rgb_m, 'rgb': rgb_pred}
+        loss_kwargs = {'mode': mode, 'env': None, 'gtc': rgb_m, 'rgb': rgb_pred}
         srgb = (lambda t: imgutil.linear2srgb(t)) if self.data_type == 'nerf' else (lambda t: t)
         pred = {'rgb': scatter_rows(mask, srgb(rgb_pred), n), 'normal': scatter_rows(mask, normal_pred, n),
                 'albedo': scatter_rows(mask, albedo, n), 'alpha': pred_alpha, 'spec': scatter_rows(mask, spec, n),
@@ -101,6 +114,65 @@ class Model(BrdfModel):
         if mode != 'train':
             pred['rgb_spec'], pred['rgb_diff'] = scatter_rows(mask, sh['rgb_spec'], n), scatter_rows(mask, sh['rgb_diff'], n)
         if relight_probes and sh.get('rgb_probes') is not None:
+            pred['rgb_probes'] = scatter_rows(mask, srgb(sh['rgb_probes']), n)
+        gt = {'rgb': scatter_rows(mask, rgb_m, n), 'normal': scatter_rows(mask, normal_m, n), 'alpha': alpha}
+        to_vis = {'id': id_, 'hw': hw}
+        for k, v in pred.items():
+            to_vis['pred_' + k] = v
+        for k, v in gt.items():
+            to_vis['gt_' + k] = v
+        return pred, gt, loss_kwargs, to_vis
+
+    def fast_render(self, batch, mode='train', relight_olat=False, relight_probes=False, opt_scale=None, edit_mask=None,
+                    edit_material=None):
+        """ref_nfr.py:303-418 (the `pd_test` / `pd_vq` passes of test.py:216-300): `rgb` from the UNscaled materials under the
+        model light, the probe renders from the materials scaled by `opt_scale` -- one shading pass: when both are asked for,
+        the scaled set rides as material set 0 (the one the kernel relights) and the unscaled one as set 1."""
+        self._validate_mode(mode)
+        id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz, normal, ref = batch[:10]
+        lvis = batch[10] if self.data_type == 'nerf' else None
+        mask = fg_rows(alpha)
+        n = alpha.shape[0]
+        rayo, rgb_m, xyz_m, normal_m, ref_m = rayo[mask], rgb[mask], xyz[mask], normal[mask], ref[mask]
+        lvis_m = lvis[mask] if lvis is not None else None
+        if edit_mask is not None:
+            edit_mask = (edit_mask[mask][..., 0:1] > 0).to(torch.float32)
+        z_xyz = self._pred_bias_at(xyz_m)
+        ks = self._head('spec_out', z_xyz)
+        z_bias = torch.cat([z_xyz, self._pred_ref_at(ref_m)], -1)
+        basecolor = self._albedo_affine(self._head('diff_out', z_bias))
+        rough = self._head('rough_out', z_bias)
+        spec, albedo = ks * basecolor, (1 - ks) * basecolor
+        if edit_mask is not None:
+            upd = lambda src, v: src * (1 - edit_mask) + edit_mask * torch.as_tensor([v], dtype=torch.float32, device=src.device)
+            if not edit_material['diff'][0] < 0:
+                albedo = upd(albedo, edit_material['diff'])
+            if not edit_material['spec'][0] < 0:
+                spec = upd(spec, edit_material['spec'])
+            if not edit_material['rough'][0] < 0:
+                rough = upd(rough, edit_material['rough'])
+        maps = list(self.novel_probes.values()) if relight_probes else []
+        sets = [(albedo, spec, rough)]
+        if opt_scale is not None and maps:
+            sets = [(albedo * opt_scale, spec * opt_scale, rough), (albedo, spec, rough)]
+        if self._fused(xyz_m, albedo, spec, rough):
+            pr = torch.stack([torch.as_tensor(lp, dtype=torch.float32, device=xyz_m.device).reshape(-1, 3) for lp in maps], 0) if maps else None
+            sh = self._shade(xyz_m, normal_m, rayo, lvis_m, sets, probes=pr)
+        else:
+            surf2l, surf2c = self._calc_ldir(xyz_m), self._calc_vdir(rayo, xyz_m)
+            n_pred = self._normal_correct(normal_m, surf2c)
+            sh = {'rgb': [], 'rgb_probes': None}
+            for i, (a, s_, r) in enumerate(sets):
+                brdf, _, _ = self._eval_brdf_at(surf2l, surf2c, n_pred, a, s_, r)
+                r0, _, rp = self._render(brdf, surf2l, n_pred, lvis_m, relight_probes=(maps if (maps and i == 0) else False))
+                sh['rgb'].append(r0)
+                if i == 0:
+                    sh['rgb_probes'] = rp
+        rgb_pred = sh['rgb'][-1]
+        loss_kwargs = {'mode': mode, 'env': None, 'gtc': rgb_m, 'rgb': rgb_pred}
+        srgb = (lambda t: imgutil.linear2srgb(t)) if self.data_type == 'nerf' else (lambda t: t)
+        pred = {'rgb': scatter_rows(mask, srgb(rgb_pred), n), 'alpha': pred_alpha}
+        if maps and sh.get('rgb_probes') is not None:
             pred['rgb_probes'] = scatter_rows(mask, srgb(sh['rgb_probes']), n)
         gt = {'rgb': scatter_rows(mask, rgb_m, n), 'normal': scatter_rows(mask, normal_m, n), 'alpha': alpha}
         to_vis = {'id': id_, 'hw': hw}

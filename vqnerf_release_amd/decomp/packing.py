@@ -1,5 +1,5 @@
 """Host-side layer programs + weight packs for the generic fused Dense-stack kernel (csrc/mlp_chain.hip,
-descriptor layout csrc/chain_desc.h).  Activation-image / A-fragment layouts are those of geo/packing.py.
+descriptor layout include/vqn_chain_desc.h).  Activation-image / A-fragment layouts are those of geo/packing.py.
 
 `ChainBuilder(mode='f16s')` builds the same programs for the split-precision kernel (csrc/mlp_chain_f16s.hip, layouts in
 csrc/mlp_prims_f16s.h): K segments advance in 16-feature steps (row pairs hi / lo), weights are packed as f16 hi / lo

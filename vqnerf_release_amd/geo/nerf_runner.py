@@ -151,7 +151,7 @@ class Runner:
         world = parallel.world_size()
         sums = torch.stack([mask.sum(), torch.tensor(float(mask.numel()), device=data.device)])
         if world > 1:
-            torch.distributed.all_reduce(sums)
+            parallel.all_reduce_sum(sums, what='all_reduce:loss_normalisers')
         mask_sum, n_rays = sums[0] + 1e-5, sums[1]
         if self.bucket is None:
             self.bucket = parallel.FlatBucket(self._dp_params, n_extra=4)

@@ -15,6 +15,19 @@ import torch
 import torch.distributed as dist
 
 
+def _clock(name):
+    """Device-time bracket of a collective (HIP events on the launch stream, `_C.KernelClock`; a no-op unless switched on)."""
+    from vqnerf_release_amd import _C
+    return _C._clock(name)
+
+
+def all_reduce_sum(t, group=None, what='all_reduce:scalars'):
+    """dist.all_reduce(SUM) with the optional device-time bracket (bench.py reports collective time per step)."""
+    with _clock(what):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def is_dist():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
@@ -65,7 +78,7 @@ class FlatBucket:
         batch, as train_nfr.py:571-572 does with `global_batch_size`), or averaged on request."""
         self.gather_grads()
         if is_dist():
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            all_reduce_sum(self.flat, group, 'all_reduce:grad_bucket')
             if average_grads:
                 self.flat[:self.n_grad].div_(dist.get_world_size(group))
         return self.extra
@@ -86,7 +99,7 @@ class VQStatsReducer:
             self._buf = torch.empty(n, dtype=torch.float32, device=counts.device)
         self._buf[:K].copy_(counts.reshape(-1))
         self._buf[K:].copy_(dw.reshape(-1))
-        dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)
+        all_reduce_sum(self._buf, self.group, 'all_reduce:vq_stats')
         return self._buf[:K].clone().view_as(counts), self._buf[K:].clone().view_as(dw)
 
 
