@@ -268,6 +268,7 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     per = lambda k: clk[k][1] / clk[k][0] * 1e-3
     launches_per_call = {k: v[0] // 3 for k, v in clk.items()}
     SHADE_BYTES = 2048 + 36 + 56 + 60      # lvis row + xyz/normal/rayo + two (albedo, spec, rough) sets in; normal + 4 rgb outputs
+    SHADE_FLOP_PER_POINT = 68502            # measured: profiles/r02_pmc_units.json (134 FLOP per point and light, both sets)
     enc_macs, head_macs = model._enc_program().macs_per_point(), 296832 + 297600
     t_chain = sum(v[1] for k, v in clk.items() if k == 'vqn_mlp_chain_fwd') / 3 * 1e-3
     t_shade = per('vqn_brdf_shade_fwd')
@@ -276,9 +277,19 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
         'mlp_chain': {'bound': 'mfma', 'achieved': 2.0 * (enc_macs + head_macs) * N / t_chain / 1e12,
                       'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                       'frac': 2.0 * (enc_macs + head_macs) * N / t_chain / 1e12 / F32_MFMA_PEAK_TFLOPS, 'ms': t_chain * 1e3},
-        'brdf_shade': {'bound': 'hbm', 'achieved': N * SHADE_BYTES / t_shade / 1e9, 'peak': 8000.0,
-                       'unit': 'GB/s', 'frac': N * SHADE_BYTES / t_shade / 1e9 / 8000.0, 'bytes_per_point': SHADE_BYTES,
-                       'ms': t_shade * 1e3, 'note': 'two material sets + diffuse/specular split per pass'},
+        # both rooflines: the 2 KB visibility row per point against HBM, and the per-light arithmetic against the f32
+        # vector pipe.  FLOPs per point are MEASURED (rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 of this kernel on this
+        # workload, profiles/r02_pmc_units.json: 35.07 GFLOP per 512,000-point launch); the same file has its vector-pipe
+        # occupancy (valu_busy_frac 0.60) -- the kernel is vector-issue bound, not HBM bound
+        'brdf_shade': {'bound': 'valu', 'ms': t_shade * 1e3, 'note': 'two material sets + diffuse/specular split per pass',
+                       'hbm': {'achieved': N * SHADE_BYTES / t_shade / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                               'frac': N * SHADE_BYTES / t_shade / 1e9 / 8000.0, 'bytes_per_point': SHADE_BYTES},
+                       'valu': {'achieved': N * SHADE_FLOP_PER_POINT / t_shade / 1e12, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                'frac': N * SHADE_FLOP_PER_POINT / t_shade / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                                'flop_per_point': SHADE_FLOP_PER_POINT,
+                                'peak_note': '157.3 TFLOP/s is the packed-FMA (v_pk_fma_f32) vector peak; scalar v_fma_f32 issue '
+                                             'peaks at half of it, transcendentals (rsq / rcp / sqrt: 9 per light and material '
+                                             'set here) at an eighth'}},
         'kernel_launches_per_call': launches_per_call}
     # ---- the same view on the split-precision MLP kernels (matrix_mode 'f16s': f16 hi/lo operands, 3 f16 MFMAs per product) ----
     with torch.no_grad():

@@ -55,6 +55,21 @@ int64_t vqn_vq_ema_stats_ws_bytes(int64_t N, int D, int K);
 int vqn_vq_ste_loss(const float* x, const float* quant, int64_t numel, float scale, float* ste, float* loss, float* ws,
                     void* stream);
 
+/* Replaces `mathutil.safe_l2_normalize(z, axis=1)` (util/math.py:63-64 = tf.linalg.l2_normalize: x * rsqrt(max(sum x^2, eps))) as
+ * called at vq_nfr.py:575: y [N,D] = x / sqrt(max(sum_d x^2, eps)) row by row, the sum in the defined order of vqn_vq_assign's
+ * |x|^2 and a correctly rounded sqrt / division (oracle/vq_strict.c states it in C).  D % 4 == 0. */
+int vqn_l2_normalize_rows(const float* x, int64_t N, int D, float eps, float* y, void* stream);
+
+/* The inference path of vq_nfr.Model.call / fast_embed / vq_test (vq_nfr.py:575-578 -> vq_layers.py:277-302, :327-330) in ONE pass
+ * over the rows: z [N,D] un-normalised encoder output -> l2-normalise (as vqn_l2_normalize_rows) -> nearest code (as vqn_vq_assign,
+ * incl. the code-dropout mask) -> idx [N], ste [N,D] = z^ + (q - z^) (or NULL), *loss = loss_scale * sum (q - z^)^2 (fixed order
+ * for a given N), counts [K] = code usage.  Bit-identical idx and ste to the sequence vqn_l2_normalize_rows -> vqn_vq_assign ->
+ * vqn_vq_ste_loss; reads N D floats, writes N D floats + N indices (the sequence moves 7 N D).  D <= 256; ws: VQN_QUANT_WS_FLOATS
+ * floats of device scratch. */
+#define VQN_QUANT_WS_FLOATS 4096
+int vqn_vq_quantize_rows(const float* z, int64_t N, int D, const float* codebook, int K, const float* sel_mask, float eps,
+                         float loss_scale, float* ws, int64_t* idx, float* ste, float* loss, float* counts, void* stream);
+
 /* ---- reflectance MLP stacks + shading (decomp/nerfvq_nfr3/nerfactor) ------------------------- */
 
 /* Generic fused Dense-stack evaluator: [posenc ->] Dense -> Dense ... with skip-concats and several
@@ -92,6 +107,16 @@ int vqn_brdf_shade_fwd(const float* xyz, const float* normal, const float* rayo,
                        const float* spec1, const float* rough1, const float* gamma, float* normal_out, float* rgb0,
                        float* rgb1, float* rgb0_diff, float* rgb0_spec, int raw, const float* probes, int n_probes,
                        float* rgb0_probes, void* stream);
+
+/* The same with the foreground gather of the visibility buffer (vq_nfr.py:558-559, tf.boolean_mask(lvis, alpha > 0)) folded in:
+ * lvis_rows [N] int64 (or NULL = identity) names, for each of the N shaded points, its row of the FULL-view lvis [n_view, L];
+ * everything else stays compact [N, .].  Saves the copy the gather makes: 2 KB per foreground point read and written once more. */
+int vqn_brdf_shade_fwd_rows(const int64_t* lvis_rows, const float* xyz, const float* normal, const float* rayo, const float* lvis,
+                            const float* lxyz, const float* lareas, const float* light, int64_t N, int L, int n_sets,
+                            const float* albedo0, const float* spec0, const float* rough0, const float* albedo1,
+                            const float* spec1, const float* rough1, const float* gamma, float* normal_out, float* rgb0,
+                            float* rgb1, float* rgb0_diff, float* rgb0_spec, int raw, const float* probes, int n_probes,
+                            float* rgb0_probes, void* stream);
 
 /* Reverse of vqn_brdf_shade_fwd(raw = 1) (autograd in the reference: tape.gradient through microfacet.py:9-89 and
  * vq_nfr.py:694-723): given g_sum_s = d loss / d (plain sum over lights) [N,3] per material set, returns

@@ -49,6 +49,19 @@ static float x2_strict(const float *x, int D) {
   return (p[0] + p[1]) + (p[2] + p[3]);
 }
 
+/* tf.linalg.l2_normalize over axis 1 (util/math.py:63-64, called at vq_nfr.py:575): y = x * rsqrt(max(sum x^2, eps)).  Pinned order:
+ * sum x^2 = x2_strict above (the order vqn_vq_assign already uses for |x|^2); the scale is 1 / sqrt(max(., eps)) with a
+ * correctly rounded sqrtf and division, then one multiplication per element. */
+int vq_strict_l2_normalize(const float *x, long N, int D, float eps, float *y) {
+  for (long n = 0; n < N; ++n) {
+    const float *xr = x + (size_t)n * D;
+    float x2 = x2_strict(xr, D);
+    float sc = 1.0f / sqrtf(x2 > eps ? x2 : eps);
+    for (int d = 0; d < D; ++d) y[(size_t)n * D + d] = xr[d] * sc;
+  }
+  return 0;
+}
+
 /* x [N,D] row-major, C [D,K] row-major, sel [K] (0/1) or NULL.
  * dist_out [N,K] or NULL, idx_out [N] int64, quant_out [N,D] or NULL.  Returns 0. */
 int vq_strict_assign(const float *x, long N, int D, const float *C, int K, const float *sel,

@@ -53,3 +53,13 @@ def ema_stats(x, idx, K):
     rc = lib().vq_strict_ema_stats(_p(x), _p(idx), ctypes.c_long(N), ctypes.c_int(D), ctypes.c_int(K), _p(counts), _p(dw))
     assert rc == 0, rc
     return counts, dw
+
+
+def l2_normalize(x, eps=1e-6):
+    """vq_strict_l2_normalize: rows of x scaled to unit length in the pinned order (see vq_strict.c)."""
+    x = np.ascontiguousarray(x, np.float32)
+    N, D = x.shape
+    y = np.empty_like(x)
+    rc = lib().vq_strict_l2_normalize(_p(x), ctypes.c_long(N), ctypes.c_int(D), ctypes.c_float(eps), _p(y))
+    assert rc == 0, rc
+    return y

@@ -140,3 +140,27 @@ def test_hdr_probe_reader_and_novel_lights(tmp_path):
     assert float(o[4, 8, 0]) == 200.5 and float(o[0, 0, 0]) == 0.5 and float(o.sum()) == pytest.approx(3 * (200 + 0.5 * 512))
     m2 = m.double()                                                 # _apply reaches the maps
     assert m2.novel_probes['c_big'].dtype == torch.float64
+
+
+def test_check_numerics_guards_are_optional_debug_checks(setup):
+    """The reference's tf.debugging.check_numerics sites (vq_nfr.py:783 "Z", :802 "Albedo", :815, :827, :985 "Loss"): off by
+    default (each is a host sync), on with Model(config, debug=True) or VQN_CHECK_NUMERICS=1, raising like TF does."""
+    from vqnerf_release_amd.decomp.nerfactor.util.math import InvalidArgumentError, check_numerics
+    assert check_numerics(torch.ones(3), 'x') is not None
+    with pytest.raises(InvalidArgumentError, match='Loss : Tensor had NaN'):
+        check_numerics(torch.tensor([1.0, float('nan')]), 'Loss')
+    with pytest.raises(InvalidArgumentError, match='Inf'):
+        check_numerics(torch.tensor([float('inf')]), 'Z')
+    p = setup['p']
+    quiet = load_oracle_params(get_model_class('vq_nfr')(make_config()), p, 'cpu')
+    loud = load_oracle_params(get_model_class('vq_nfr')(make_config(), debug=True), p, 'cpu')
+    assert not quiet.check_numerics and loud.check_numerics
+    xyz = torch.tensor(od.make_points(8, seed=1)['xyz'])
+    for m in (quiet, loud):
+        with torch.no_grad():
+            m.net['fine_enc'].layers[0].kernel[0, 0] = float('nan')
+    assert torch.isnan(quiet._pred_enc_at(xyz)).any()                   # silently propagates, as any torch op would
+    with pytest.raises(InvalidArgumentError, match='^Z : '):
+        loud._pred_enc_at(xyz)
+    with pytest.raises(InvalidArgumentError, match='^Albedo : '):
+        loud._pred_diff_at(torch.full((4, 256), float('nan')))

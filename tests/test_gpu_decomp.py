@@ -150,6 +150,30 @@ def test_shade_kernel_vs_oracle(setup, with_lvis):
     _assert_as_accurate_as_fp32_oracle(_np(got_g['rgb'][0]), g32['rgb'][0].numpy(), g64['rgb'][0].numpy(), 'gamma')
 
 
+def test_shade_reads_visibility_rows_in_place(setup):
+    """vqn_brdf_shade_fwd_rows: the foreground gather of the visibility buffer (vq_nfr.py:558-559) folded into the kernel gives
+    bit for bit what the gathered copy gives; the models use it on the inference path (LazyRows)."""
+    od = setup['od']
+    from vqnerf_release_amd import _C
+    n_view, N = 900, 500
+    pts = od.make_points(n_view, seed=17)
+    rng = np.random.default_rng(18)
+    rows = np.sort(rng.choice(n_view, N, replace=False)).astype(np.int64)
+    c = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32).cuda().contiguous()
+    mats = [(c(rng.uniform(0, 1, (N, 3))), c(rng.uniform(0, 1, (N, 3))), c(rng.uniform(0.02, 1, (N, 1)))) for _ in range(2)]
+    geo = (c(pts['xyz'][rows]), c(pts['normal'][rows]), c(pts['rayo'][rows]))
+    lights = (c(setup['lxyz'].reshape(-1, 3)), c(setup['lareas'].reshape(-1)), c(rng.uniform(0, 1, (512, 3))))
+    full = c(pts['lvis'])
+    a = _C.brdf_shade_fwd(*geo, full[torch.tensor(rows).cuda()].contiguous(), *lights, mats, want_split=True)
+    b = _C.brdf_shade_fwd(*geo, full, *lights, mats, want_split=True, lvis_rows=torch.tensor(rows).cuda())
+    for k in ('rgb_diff', 'rgb_spec', 'normal'):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(a['rgb'][0], b['rgb'][0]) and torch.equal(a['rgb'][1], b['rgb'][1])
+    from vqnerf_release_amd.decomp.nerfactor.models.nfr_unit import LazyRows
+    lz = LazyRows(full, torch.tensor(rows).cuda())
+    assert lz.shape == (N, 512) and torch.equal(lz.dense(), full[torch.tensor(rows).cuda()])
+
+
 def test_shade_known_answers():
     """Analytic pins: a Lambertian point under a white unit sky integrates to ~albedo; a light
     behind the surface contributes nothing; lvis = 0 everywhere gives black."""

@@ -212,3 +212,95 @@ def test_gradient_trained_vector_quantizer():
     np.testing.assert_allclose(cb.grad.cpu().numpy(), want_c.cpu().numpy(), rtol=1e-5, atol=1e-6)
     only = vq(xin.detach(), cb.detach(), False, thres=torch.tensor([1.0] * 4 + [0.0] + [1.0] * 4))
     assert set(only['encoding_indices'].tolist()) == {4}
+
+
+# ---- round 2: defined-order l2-normalise + the fused inference kernel (normalise + assign + straight-through + loss + usage) ----
+@pytest.mark.parametrize('N,D', [(1, 4), (17, 12), (1000, 64), (333, 252), (4097, 256), (50, 512)])
+def test_l2_normalize_rows_is_bit_exact_vs_strict_c(N, D):
+    from oracle import vq_strict
+    from vqnerf_release_amd import _C
+    rng = np.random.default_rng(N + D)
+    x = rng.uniform(0, 1, (N, D)).astype(np.float32)
+    x[0] = 0.0                                                           # the eps floor: 0 / sqrt(1e-6)
+    if N > 2:
+        x[1] *= 1e-4                                                     # sum x^2 below eps
+    y = _C.l2_normalize_rows(torch.tensor(x).cuda())
+    np.testing.assert_array_equal(y.cpu().numpy(), vq_strict.l2_normalize(x))
+    ref = x.astype(np.float64) / np.sqrt(np.maximum((x.astype(np.float64) ** 2).sum(1, keepdims=True), 1e-6))
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=3e-7, atol=0)
+
+
+def test_l2_normalize_rows_backward_matches_autograd():
+    from vqnerf_release_amd.decomp.nerfactor.networks.vq_layers import l2_normalize_rows
+    from vqnerf_release_amd.decomp.nerfactor.util.math import safe_l2_normalize
+    torch.manual_seed(0)
+    x = torch.rand(64, 256, device='cuda')
+    x[0] *= 1e-5                                                         # below the eps floor: gradient g * s only
+    g = torch.randn(64, 256, device='cuda')
+    a = x.clone().requires_grad_(True)
+    b = x.clone().requires_grad_(True)
+    (l2_normalize_rows(a) * g).sum().backward()
+    (safe_l2_normalize(b, axis=1) * g).sum().backward()
+    np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('N,D,K,masked', [(1, 64, 8, False), (17, 256, 15, False), (1000, 256, 15, True), (100003, 256, 64, False),
+                                          (5000, 256, 128, True), (777, 128, 33, False)])
+def test_fused_quantize_equals_the_three_kernel_sequence(N, D, K, masked):
+    """vqn_vq_quantize_rows == vqn_l2_normalize_rows -> vqn_vq_assign -> vqn_vq_ste_loss (+ usage counts): indices and the
+    straight-through rows bit for bit, counts exactly, the commitment term to fp32 rounding (its partial sums are grouped per
+    workgroup in both forms, but the groups differ); indices also against the strict-order C oracle."""
+    from oracle import vq_strict
+    from vqnerf_release_amd import _C
+    rng = np.random.default_rng(N + K)
+    z = rng.uniform(0, 1, (N, D)).astype(np.float32)                      # un-normalised encoder outputs (sigmoid range)
+    C = rng.uniform(0, 1, (D, K)).astype(np.float32)
+    C /= np.linalg.norm(C, axis=0, keepdims=True)
+    sel = (rng.uniform(size=K) > 0.4).astype(np.float32) if masked else None
+    if masked:
+        sel[0] = 1.0
+    zt, Ct = torch.tensor(z).cuda(), torch.tensor(C).cuda()
+    st = None if sel is None else torch.tensor(sel).cuda()
+    idx_f, ste_f, loss_f, counts_f = _C.vq_quantize_rows(zt, Ct, sel_mask=st)
+    zn = _C.l2_normalize_rows(zt)
+    idx_s, quant_s, _ = _C.vq_assign(zn, Ct, sel_mask=st, want_quant=True)
+    ste_s, loss_s = _C.vq_ste_loss(zn, quant_s)
+    counts_s = _C.vq_counts(idx_s, K)
+    assert torch.equal(idx_f, idx_s)
+    assert torch.equal(ste_f, ste_s)
+    assert torch.equal(counts_f, counts_s) and float(counts_f.sum()) == N
+    np.testing.assert_allclose(float(loss_f), float(loss_s), rtol=2e-6)
+    ridx, _, _ = vq_strict.assign(vq_strict.l2_normalize(z), C, sel=sel, want_dist=False, want_quant=False)
+    np.testing.assert_array_equal(idx_f.cpu().numpy(), ridx)
+    # no straight-through output requested: same indices, nothing written
+    idx_n, ste_n, _, _ = _C.vq_quantize_rows(zt, Ct, sel_mask=st, want_ste=False)
+    assert ste_n is None and torch.equal(idx_n, idx_f)
+
+
+@pytest.mark.parametrize('K', [15, 64])
+def test_model_call_is_bit_identical_with_and_without_the_fused_quantiser(K):
+    """vq_nfr.Model.call / fast_render(gen_embed) / vq_test in inference mode: the one-kernel quantiser against the three-kernel
+    sequence -- every output tensor bit for bit (the commitment-loss scalar to fp32 rounding)."""
+    from oracle import decomp as od
+    from tests.decomp_util import make_config, load_oracle_params, make_batch
+    from tests.gpu_util import launches
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    p, specs = od.make_model_params(seed=0, K=K)
+    model = load_oracle_params(get_model_class('vq_nfr')(make_config(num_embed=K)), p, 'cuda')
+    batch = make_batch(od.make_points(5000, seed=4), 'cuda', bg_every=9)
+    out = {}
+    for fused in (True, False):
+        model.fuse_quantise = fused
+        with torch.no_grad(), launches() as rec:
+            pred, gt, lk, _ = model.call(batch, mode='vali', thres=[0.0] * (K - 2) + [1.0, 1.0], roll=torch.full((1, K), 0.5).cuda())
+            emb = model.fast_embed(batch, mode='test')[3]['embed']
+            _, _, lkt, _ = model.vq_test(batch, mode='vali')
+        assert rec.ran('vqn_vq_quantize_rows') == fused and rec.ran('vqn_vq_ste_loss') == (not fused)
+        out[fused] = (pred, lk, emb, lkt)
+    (pa, la, ea, ta), (pb, lb, eb, tb) = out[True], out[False]
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
+    assert torch.equal(la['z'], lb['z']) and torch.equal(la['vqrgb'], lb['vqrgb']) and torch.equal(ea, eb)
+    assert torch.equal(ta['vqrgb'], tb['vqrgb']) and torch.equal(ta['usage'], tb['usage'])
+    np.testing.assert_allclose(float(la['vqloss']), float(lb['vqloss']), rtol=2e-6)
+    assert int(pa['embed'].max()) <= K - 2                                   # the two dropped codes are never chosen

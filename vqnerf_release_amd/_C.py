@@ -168,6 +168,41 @@ def vq_ste_loss(x, quant, want_ste=True):
     _check(rc, 'vqn_vq_ste_loss')
     return ste, loss
 
+def l2_normalize_rows(x, eps=1e-6):
+    """x [N,D] -> x / sqrt(max(sum_d x^2, eps)) row by row, in the defined summation order of vqn_vq_assign's |x|^2."""
+    _f32c(x, 'x')
+    y = torch.empty_like(x)
+    with _clock('vqn_l2_normalize_rows'):
+        rc = lib().vqn_l2_normalize_rows(_ptr(x), ctypes.c_int64(x.shape[0]), ctypes.c_int(x.shape[1]), ctypes.c_float(eps), _ptr(y), _stream())
+    _check(rc, 'vqn_l2_normalize_rows')
+    return y
+
+
+def vq_quantize_rows(z, codebook, sel_mask=None, eps=1e-6, want_ste=True):
+    """Fused inference path: z [N,D] un-normalised, codebook [D,K] -> (idx int64 [N], ste [N,D] | None, mean((q - z^)^2) scalar
+    tensor, counts [K]) in one pass over the rows (l2-normalise, nearest code, straight-through output, commitment term, usage)."""
+    _f32c(z, 'z'); _f32c(codebook, 'codebook')
+    N, D = z.shape
+    K = codebook.shape[1]
+    assert codebook.shape[0] == D
+    dev = z.device
+    idx = torch.empty((N,), dtype=torch.int64, device=dev)
+    ste = torch.empty((N, D), dtype=torch.float32, device=dev) if want_ste else None
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    counts = torch.empty((K,), dtype=torch.float32, device=dev)
+    ws = torch.empty((4096,), dtype=torch.float32, device=dev)
+    if sel_mask is not None:
+        sel_mask = _f32c(sel_mask.reshape(-1).to(torch.float32).contiguous(), 'sel_mask')
+        assert sel_mask.numel() == K
+    n = N * D
+    with _clock('vqn_vq_quantize_rows'):
+        rc = lib().vqn_vq_quantize_rows(_ptr(z), ctypes.c_int64(N), ctypes.c_int(D), _ptr(codebook), ctypes.c_int(K), _ptr(sel_mask),
+                                        ctypes.c_float(eps), ctypes.c_float(1.0 / n if n else 0.0), _ptr(ws), _ptr(idx), _ptr(ste),
+                                        _ptr(loss), _ptr(counts), _stream())
+    _check(rc, 'vqn_vq_quantize_rows')
+    return idx, ste, loss, counts
+
+
 # --------------------------------------------------------------------------------------
 # fused NeuS networks (csrc/neus_mlp.hip)
 _scratch = {}
@@ -335,17 +370,24 @@ def mlp_chain_fwd(desc, wbuf, x, out_widths, mode='f32'):
 
 
 def brdf_shade_fwd(xyz, normal, rayo, lvis, lxyz, lareas, light, materials, gamma=None, want_normal=True,
-                   want_split=False, raw=False, probes=None):
+                   want_split=False, raw=False, probes=None, lvis_rows=None):
     """materials: [(albedo [N,3], spec [N,3], rough [N,1])] (1 or 2 sets).
+    lvis_rows [N] int64 (optional): `lvis` is the FULL-view buffer [n_view, L] and point n reads its row lvis_rows[n].
     -> dict(rgb=[...per set], normal=..., rgb_diff=..., rgb_spec=...)."""
     for n_, t in (('xyz', xyz), ('normal', normal), ('rayo', rayo), ('lxyz', lxyz), ('lareas', lareas), ('light', light)):
         _f32c(t, n_)
-    N = xyz.shape[0]
     L = lareas.numel()
     assert lxyz.numel() == 3 * L and light.numel() == 3 * L
+    N = xyz.shape[0]
+    assert normal.shape[0] == N and rayo.shape[0] == N
+    rows = None
     if lvis is not None:
         _f32c(lvis, 'lvis')
-        assert tuple(lvis.shape) == (N, L)
+        if lvis_rows is not None:
+            rows = lvis_rows
+            assert rows.dtype == torch.int64 and rows.is_contiguous() and rows.is_cuda and rows.numel() == N and lvis.shape[1] == L
+        else:
+            assert tuple(lvis.shape) == (N, L)
     mats = []
     for (a, s, r) in materials:
         _f32c(a, 'albedo'); _f32c(s, 'spec'); _f32c(r, 'rough')
@@ -366,12 +408,12 @@ def brdf_shade_fwd(xyz, normal, rayo, lvis, lxyz, lareas, light, materials, gamm
         n_probes = probes.shape[0]
         rgb_probes = f(N, n_probes, 3)
     with _clock('vqn_brdf_shade_fwd'):
-        rc = lib().vqn_brdf_shade_fwd(_ptr(xyz), _ptr(normal), _ptr(rayo), _ptr(lvis), _ptr(lxyz), _ptr(lareas),
-                                      _ptr(light), ctypes.c_int64(N), ctypes.c_int(L), ctypes.c_int(len(materials)),
-                                      *[_ptr(m) for m in mats], _ptr(gamma), _ptr(nout), _ptr(rgb[0]),
-                                      _ptr(rgb[1] if len(rgb) > 1 else None), _ptr(rd), _ptr(rs), ctypes.c_int(1 if raw else 0),
-                                      _ptr(probes), ctypes.c_int(n_probes), _ptr(rgb_probes), _stream())
-    _check(rc, 'vqn_brdf_shade_fwd')
+        rc = lib().vqn_brdf_shade_fwd_rows(_ptr(rows), _ptr(xyz), _ptr(normal), _ptr(rayo), _ptr(lvis), _ptr(lxyz), _ptr(lareas),
+                                           _ptr(light), ctypes.c_int64(N), ctypes.c_int(L), ctypes.c_int(len(materials)),
+                                           *[_ptr(m) for m in mats], _ptr(gamma), _ptr(nout), _ptr(rgb[0]),
+                                           _ptr(rgb[1] if len(rgb) > 1 else None), _ptr(rd), _ptr(rs), ctypes.c_int(1 if raw else 0),
+                                           _ptr(probes), ctypes.c_int(n_probes), _ptr(rgb_probes), _stream())
+    _check(rc, 'vqn_brdf_shade_fwd_rows')
     return dict(rgb=rgb, normal=nout, rgb_diff=rd, rgb_spec=rs, rgb_probes=rgb_probes)
 
 

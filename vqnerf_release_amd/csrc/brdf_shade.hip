@@ -10,6 +10,7 @@
 // one pass over the geometry and the visibility row.
 // Bound: HBM for data_type == 'nerf' (2 KB of lvis per point) -- VALU otherwise; see DESIGN.md.
 #include "common.h"
+#include "vqnerf_hip.h"
 #include <math.h>
 
 namespace {
@@ -38,17 +39,32 @@ struct ShadeArgs {
   long N;
   int n_sets;
   int raw;                     // 1: write the plain sums over lights (no gamma, no [0,1] clip) -- the training path applies those in torch
+  const long long* rows;       // null, or [N]: point n takes its visibility row from row rows[n] of the FULL-view lvis tensor --
+                               // the tf.boolean_mask gather of vq_nfr.py:558-559 (2 KB per point) without the copy
   const float* probes;         // [P][L][3] novel light probes (vq_nfr.py:724-733) or null
   float* rgb_probes;           // [N][P][3]: material set 0 re-lit by every probe in the same pass
   int n_probes;
 };
 
 struct Material {
-  float a[3], f0[3], a2;       // albedo, spec (f0), alpha^2 with alpha = rough^2 (microfacet.py:24, squared again inside D and G)
-  float g1v;                   // G1(v.n) (per point)
+  float a[3], f0[3], omf0[3];  // albedo / pi, spec (f0), 1 - f0
+  float a2, a2_pi, oma2;       // alpha^2 with alpha = rough^2 (microfacet.py:24, squared again inside D and G), a2 / pi, 1 - a2
+  float kv;                    // G1(v.n) / (2 |v.n|)  (per point; 0 where v.n == 0: divide_no_nan, microfacet.py:33)
 };
 
-template <int LQ>
+// One wave per point, LP lights per lane.  Per (point, light) the arithmetic of microfacet.py:9-89 + vq_nfr.py:694-723 is
+//     rgb_c = sum_l (glossy_c + albedo_c / pi) * vis_l * L_{l,c} * cos_l * area_l,
+//     glossy_c = F_c D G1(l.n) G1(v.n) / (4 |l.n| |v.n|),   G1(c) = 2 c / (c + sqrt|a2 + (1 - a2) c^2|).
+// The kernel is vector-ALU bound (the 2 KB visibility row per point costs 0.6 TB/s of the 8 available), so the inner loop is
+// written for instruction count, algebraically equal to the reference's op sequence where a light contributes at all:
+//   * a light contributes only if it is front-lit (cos_l > 0, vq_nfr.py:704); there 0 < l.n, so
+//     G1(l.n) / (4 |l.n|) = 1 / (2 (cl + sqrt|a2 + (1 - a2) cl^2|)), cl = min(l.n, 1): one reciprocal instead of two and no
+//     2 cl / (4 |l.n|) round trip; G1(v.n) / (2 |v.n|) is a per-point scalar (kv);
+//   * the Lambertian part albedo_c / pi * sum_l w_{l,c} is factored out of the loop (w = vis L cos area is shared by both
+//     material sets and by the diffuse / specular split);
+//   * get_brdf's re-normalisation of the already unit light direction (microfacet.py:13) is dropped (<= 2 ulp).
+// Results move by fp32 rounding only (tests/test_gpu_decomp.py judges them against the float64 oracle).
+template <int LQ, bool PROBES, int NS>
 __global__ __launch_bounds__(256) void brdf_shade_kernel(const ShadeArgs a) {
   constexpr int LP = 4 * LQ;                       // lights per lane
   constexpr int L = 64 * LP;
@@ -57,26 +73,34 @@ __global__ __launch_bounds__(256) void brdf_shade_kernel(const ShadeArgs a) {
   const long n_waves = (long)gridDim.x * 4;
 
   // ---- this lane's lights: light index = 256 g + 4 lane + e ----
-  float lx[LP], ly[LP], lz[LP], area[LP], Lr[LP], Lg[LP], Lb[LP];
+  float lx[LP], ly[LP], lz[LP], Ar[LP], Ag[LP], Ab[LP];      // A_c = radiance_c * solid angle
 #pragma unroll
   for (int g = 0; g < LQ; ++g)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int li = 256 * g + 4 * lane + e, k = 4 * g + e;
       lx[k] = a.lxyz[li * 3 + 0]; ly[k] = a.lxyz[li * 3 + 1]; lz[k] = a.lxyz[li * 3 + 2];
-      area[k] = a.lareas[li];
-      Lr[k] = a.light[li * 3 + 0]; Lg[k] = a.light[li * 3 + 1]; Lb[k] = a.light[li * 3 + 2];
+      const float area = a.lareas[li];
+      Ar[k] = a.light[li * 3 + 0] * area; Ag[k] = a.light[li * 3 + 1] * area; Ab[k] = a.light[li * 3 + 2] * area;
     }
+  float area_k[PROBES ? LP : 1];                    // only the relighting pass needs the bare solid angles
+  if (PROBES) {
+#pragma unroll
+    for (int g = 0; g < LQ; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) area_k[4 * g + e] = a.lareas[256 * g + 4 * lane + e];
+  }
   float gam_b = 1.f, gam_i = 1.f;
   if (a.gamma) { gam_b = a.gamma[0]; gam_i = a.gamma[1]; }
   const bool split = a.rgb_diff != nullptr;
 
   for (long n = wave_id; n < a.N; n += n_waves) {
+    const long m = a.rows ? (long)a.rows[n] : n;   // visibility row (wave-uniform)
     // visibility row first (longest latency)
     f32x4 vis4[LQ];
 #pragma unroll
     for (int g = 0; g < LQ; ++g)
-      vis4[g] = a.lvis ? *reinterpret_cast<const f32x4*>(a.lvis + n * L + 256 * g + 4 * lane) : (f32x4){1.f, 1.f, 1.f, 1.f};
+      vis4[g] = a.lvis ? *reinterpret_cast<const f32x4*>(a.lvis + m * L + 256 * g + 4 * lane) : (f32x4){1.f, 1.f, 1.f, 1.f};
     const float px = a.xyz[n * 3], py = a.xyz[n * 3 + 1], pz = a.xyz[n * 3 + 2];
     // view direction (shape.py:112-119) and camera-facing normal (vq_nfr.py:830-833)
     float vx = a.rayo[n * 3] - px, vy = a.rayo[n * 3 + 1] - py, vz = a.rayo[n * 3 + 2] - pz;
@@ -94,64 +118,61 @@ __global__ __launch_bounds__(256) void brdf_shade_kernel(const ShadeArgs a) {
     Material M[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
-      if (s < a.n_sets) {
+      if (s < NS) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { M[s].a[c] = a.albedo[s][n * 3 + c]; M[s].f0[c] = a.spec[s][n * 3 + c]; }
+        for (int c = 0; c < 3; ++c) {
+          M[s].a[c] = a.albedo[s][n * 3 + c] * (1.f / PI_F);
+          M[s].f0[c] = a.spec[s][n * 3 + c];
+          M[s].omf0[c] = 1.f - M[s].f0[c];
+        }
         const float r = a.rough[s][n];
         const float alpha = r * r;
         M[s].a2 = alpha * alpha;
+        M[s].a2_pi = M[s].a2 * (1.f / PI_F);
+        M[s].oma2 = 1.f - M[s].a2;
         const float c = clip01(v_dot_n);
-        M[s].g1v = div_no_nan(2.f * c, c + sqrtf(fabsf(M[s].a2 + (1.f - M[s].a2) * c * c)));
+        const float g1v = div_no_nan(2.f * c, c + sqrtf(fabsf(M[s].a2 + M[s].oma2 * c * c)));
+        M[s].kv = div_no_nan(g1v, 2.f * fabsf(v_dot_n));
       }
-    float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-    float accd[3] = {0.f, 0.f, 0.f}, accs[3] = {0.f, 0.f, 0.f};
-    float wbr[LP][3];                                // set 0: brdf_c * vis * cos * area per light = contribution per unit radiance
+    float S[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};              // sum_l glossy_c * w_c per material set
+    float W[3] = {0.f, 0.f, 0.f};                                    // sum_l w_c  (Lambertian part, shared)
+    float wsp[PROBES ? LP : 1][3], wgt[PROBES ? LP : 1];             // relighting: set-0 glossy_c * gw and gw = vis cos area per light
 #pragma unroll
     for (int k = 0; k < LP; ++k) {
       // light direction (shape.py:103-110)
       float dx = lx[k] - px, dy = ly[k] - py, dz = lz[k] - pz;
-      float il = inv_norm(dx, dy, dz);
-      dx *= il; dy *= il; dz *= il;                                 // surf2l
+      const float il = inv_norm(dx, dy, dz);
+      dx *= il; dy *= il; dz *= il;                                 // surf2l = l
       const float cosl = dx * nx + dy * ny + dz * nz;               // vq_nfr.py:702 (un-renormalised normal)
-      const float vis = (cosl > 0.f ? 1.f : 0.f) * vis4[k >> 2][k & 3];
-      il = inv_norm(dx, dy, dz);
-      const float wx = dx * il, wy = dy * il, wz = dz * il;          // l (microfacet.py:13)
-      float hx = wx + ux, hy = wy + uy, hz = wz + uz;
+      const float l_dot_n = dx * mx + dy * my + dz * mz;
+      const float cw = (cosl > 0.f && l_dot_n > 0.f) ? cosl * vis4[k >> 2][k & 3] : 0.f;     // vis * cos
+      float hx = dx + ux, hy = dy + uy, hz = dz + uz;
       const float ih = inv_norm(hx, hy, hz);
       hx *= ih; hy *= ih; hz *= ih;
       const float cos_vh = clip01(hx * ux + hy * uy + hz * uz);
       const float om = 1.f - cos_vh, om2 = om * om, om5 = om2 * om2 * om;
       const float cos_m = clip01(hx * mx + hy * my + hz * mz);
-      const float l_dot_n = wx * mx + wy * my + wz * mz;
-      const float cl = clip01(l_dot_n);
-      const float den = 4.f * fabsf(l_dot_n) * fabsf(v_dot_n);
-      const float inv_den = den == 0.f ? 0.f : __builtin_amdgcn_rcpf(den);
-      const float lr = vis * Lr[k], lg = vis * Lg[k], lb = vis * Lb[k];
+      const float cm2 = cos_m * cos_m;
+      const float cl = clip01(l_dot_n), cl2 = cl * cl;
+      const float wr = cw * Ar[k], wg = cw * Ag[k], wb = cw * Ab[k];
+      W[0] += wr; W[1] += wg; W[2] += wb;
 #pragma unroll
       for (int s = 0; s < 2; ++s)
-        if (s < a.n_sets) {
-          const float a2 = M[s].a2;
-          const float t = cos_m * cos_m * (a2 - 1.f) + 1.f;
-          const float D = fdiv_no_nan(a2, PI_F * t * t);
-          const float G = fdiv_no_nan(2.f * cl, cl + __builtin_amdgcn_sqrtf(fabsf(a2 + (1.f - a2) * cl * cl))) * M[s].g1v;
-          const float gd = G * D;
-          float gl[3], df[3];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const float F = M[s].f0[c] + (1.f - M[s].f0[c]) * om5;
-            gl[c] = F * gd * inv_den;
-            df[c] = M[s].a[c] * (1.f / PI_F);
-          }
-          acc[s][0] += (gl[0] + df[0]) * lr * cosl * area[k];
-          acc[s][1] += (gl[1] + df[1]) * lg * cosl * area[k];
-          acc[s][2] += (gl[2] + df[2]) * lb * cosl * area[k];
-          if (s == 0 && a.probes != nullptr) {
-            const float gw = vis * cosl * area[k];
-            wbr[k][0] = (gl[0] + df[0]) * gw; wbr[k][1] = (gl[1] + df[1]) * gw; wbr[k][2] = (gl[2] + df[2]) * gw;
-          }
-          if (split && s == 0) {
-            accd[0] += df[0] * lr * cosl * area[k]; accd[1] += df[1] * lg * cosl * area[k]; accd[2] += df[2] * lb * cosl * area[k];
-            accs[0] += gl[0] * lr * cosl * area[k]; accs[1] += gl[1] * lg * cosl * area[k]; accs[2] += gl[2] * lb * cosl * area[k];
+        if (s < NS) {
+          const float t = fmaf(cm2, -M[s].oma2, 1.f);                // cos_m^2 (a2 - 1) + 1
+          const float t2 = t * t;
+          // divide_no_nan (microfacet.py:57, :71-72): both denominators vanish only together with their numerators (t = 0 needs
+          // a2 = 0; cl + sl = 0 needs cl = 0 and a2 = 0, where D = 0 too), so a floor on the denominator gives the same 0
+          const float D = M[s].a2_pi * __builtin_amdgcn_rcpf(fmaxf(t2, 1e-30f));
+          const float sl = __builtin_amdgcn_sqrtf(fabsf(fmaf(M[s].oma2, cl2, M[s].a2)));
+          const float gdi = D * M[s].kv * __builtin_amdgcn_rcpf(fmaxf(cl + sl, 1e-30f));
+          const float g0 = fmaf(M[s].omf0[0], om5, M[s].f0[0]) * gdi, g1 = fmaf(M[s].omf0[1], om5, M[s].f0[1]) * gdi,
+                      g2 = fmaf(M[s].omf0[2], om5, M[s].f0[2]) * gdi;
+          S[s][0] = fmaf(g0, wr, S[s][0]); S[s][1] = fmaf(g1, wg, S[s][1]); S[s][2] = fmaf(g2, wb, S[s][2]);
+          if (PROBES && s == 0) {
+            const float gw = cw * area_k[k];
+            wgt[k] = gw;
+            wsp[k][0] = g0 * gw; wsp[k][1] = g1 * gw; wsp[k][2] = g2 * gw;
           }
         }
     }
@@ -163,11 +184,12 @@ __global__ __launch_bounds__(256) void brdf_shade_kernel(const ShadeArgs a) {
     };
 #pragma unroll
     for (int s = 0; s < 2; ++s)
-      if (s < a.n_sets) {
-        const float r = finish(acc[s][0]), g = finish(acc[s][1]), b = finish(acc[s][2]);
+      if (s < NS) {
+        const float r = finish(fmaf(M[s].a[0], W[0], S[s][0])), g = finish(fmaf(M[s].a[1], W[1], S[s][1])),
+                    b = finish(fmaf(M[s].a[2], W[2], S[s][2]));
         if (lane < 3) a.rgb[s][n * 3 + lane] = lane == 0 ? r : (lane == 1 ? g : b);
       }
-    if (a.probes != nullptr) {
+    if (PROBES) {
       // all probes against the SAME per-light weights: the [N,L] x [L,3P] contraction of the relighting loop
       for (int pr = 0; pr < a.n_probes; ++pr) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -178,7 +200,9 @@ __global__ __launch_bounds__(256) void brdf_shade_kernel(const ShadeArgs a) {
           const float rad[12] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3], q2[0], q2[1], q2[2], q2[3]};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            s0 += wbr[4 * g + e][0] * rad[3 * e]; s1 += wbr[4 * g + e][1] * rad[3 * e + 1]; s2 += wbr[4 * g + e][2] * rad[3 * e + 2];
+            const int k = 4 * g + e;
+            s0 += fmaf(M[0].a[0], wgt[k], wsp[k][0]) * rad[3 * e]; s1 += fmaf(M[0].a[1], wgt[k], wsp[k][1]) * rad[3 * e + 1];
+            s2 += fmaf(M[0].a[2], wgt[k], wsp[k][2]) * rad[3 * e + 2];
           }
         }
         const float r = finish(s0), gg = finish(s1), b = finish(s2);
@@ -186,9 +210,9 @@ __global__ __launch_bounds__(256) void brdf_shade_kernel(const ShadeArgs a) {
       }
     }
     if (split) {
-      const float r = finish(accd[0]), g = finish(accd[1]), b = finish(accd[2]);
+      const float r = finish(M[0].a[0] * W[0]), g = finish(M[0].a[1] * W[1]), b = finish(M[0].a[2] * W[2]);
       if (lane < 3) a.rgb_diff[n * 3 + lane] = lane == 0 ? r : (lane == 1 ? g : b);
-      const float r2 = finish(accs[0]), g2 = finish(accs[1]), b2 = finish(accs[2]);
+      const float r2 = finish(S[0][0]), g2 = finish(S[0][1]), b2 = finish(S[0][2]);
       if (lane < 3) a.rgb_spec[n * 3 + lane] = lane == 0 ? r2 : (lane == 1 ? g2 : b2);
     }
   }
@@ -342,6 +366,17 @@ extern "C" int vqn_brdf_shade_fwd(const float* xyz, const float* normal, const f
                                   const float* albedo1, const float* spec1, const float* rough1, const float* gamma,
                                   float* normal_out, float* rgb0, float* rgb1, float* rgb0_diff, float* rgb0_spec,
                                   int raw, const float* probes, int n_probes, float* rgb0_probes, void* stream) {
+  return vqn_brdf_shade_fwd_rows(nullptr, xyz, normal, rayo, lvis, lxyz, lareas, light, N, L, n_sets, albedo0, spec0, rough0, albedo1,
+                                 spec1, rough1, gamma, normal_out, rgb0, rgb1, rgb0_diff, rgb0_spec, raw, probes, n_probes, rgb0_probes,
+                                 stream);
+}
+
+extern "C" int vqn_brdf_shade_fwd_rows(const int64_t* lvis_rows, const float* xyz, const float* normal, const float* rayo, const float* lvis,
+                                       const float* lxyz, const float* lareas, const float* light, int64_t N, int L,
+                                       int n_sets, const float* albedo0, const float* spec0, const float* rough0,
+                                       const float* albedo1, const float* spec1, const float* rough1, const float* gamma,
+                                       float* normal_out, float* rgb0, float* rgb1, float* rgb0_diff, float* rgb0_spec,
+                                       int raw, const float* probes, int n_probes, float* rgb0_probes, void* stream) {
   VQN_CHECK_ARG(N >= 0, "N >= 0");
   if (N == 0) return VQN_OK;
   VQN_CHECK_ARG(xyz && normal && rayo && lxyz && lareas && light, "null geometry / light pointer");
@@ -358,6 +393,7 @@ extern "C" int vqn_brdf_shade_fwd(const float* xyz, const float* normal, const f
   a.albedo[1] = albedo1; a.spec[1] = spec1; a.rough[1] = rough1;
   a.normal_out = normal_out; a.rgb[0] = rgb0; a.rgb[1] = rgb1; a.rgb_diff = rgb0_diff; a.rgb_spec = rgb0_spec;
   a.N = N; a.n_sets = n_sets; a.raw = raw;
+  a.rows = lvis ? reinterpret_cast<const long long*>(lvis_rows) : nullptr;
   VQN_CHECK_ARG(probes == nullptr || (n_probes >= 1 && rgb0_probes != nullptr), "probes need n_probes >= 1 and rgb0_probes");
   VQN_CHECK_SHAPE(probes == nullptr || ((uintptr_t)probes & 15) == 0, "probes must be 16-byte aligned");
   a.probes = probes; a.n_probes = probes ? n_probes : 0; a.rgb_probes = rgb0_probes;
@@ -365,9 +401,18 @@ extern "C" int vqn_brdf_shade_fwd(const float* xyz, const float* normal, const f
   const long cap = (long)vqn_num_cus() * 8;
   if (blocks > cap) blocks = cap;
   hipStream_t s = (hipStream_t)stream;
-  if (L == 256) hipLaunchKernelGGL(brdf_shade_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, a);
-  else if (L == 512) hipLaunchKernelGGL(brdf_shade_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(brdf_shade_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  const bool pr = a.probes != nullptr;
+#define VQN_SHADE_LAUNCH(LQ)                                                                                   \
+  do {                                                                                                         \
+    if (pr && n_sets == 1) hipLaunchKernelGGL((brdf_shade_kernel<LQ, true, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a);        \
+    else if (pr) hipLaunchKernelGGL((brdf_shade_kernel<LQ, true, 2>), dim3((unsigned)blocks), dim3(256), 0, s, a);                  \
+    else if (n_sets == 1) hipLaunchKernelGGL((brdf_shade_kernel<LQ, false, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a);        \
+    else hipLaunchKernelGGL((brdf_shade_kernel<LQ, false, 2>), dim3((unsigned)blocks), dim3(256), 0, s, a);                         \
+  } while (0)
+  if (L == 256) VQN_SHADE_LAUNCH(1);
+  else if (L == 512) VQN_SHADE_LAUNCH(2);
+  else VQN_SHADE_LAUNCH(4);
+#undef VQN_SHADE_LAUNCH
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }

@@ -13,6 +13,7 @@
 //     dist      : (x2 - 2 dot) + c2 ; argmin, lowest index wins ties.
 // The codebook lives in LDS already laid out as MFMA B-fragments (one ds_read_b128 per 4 MFMAs).
 #include "common.h"
+#include "vqnerf_hip.h"
 #include <math.h>
 
 namespace {
@@ -23,17 +24,29 @@ __device__ __forceinline__ int f2key(float f) {
 }
 __device__ __forceinline__ float key2f(int k) { return __int_as_float(k >= 0 ? k : (k ^ 0x7fffffff)); }
 
-template <int KT, bool MAXONLY>
+// FUSE (the inference path of vq_nfr.Model: vq_nfr.py:575-578 + vq_layers.py:277-302, :327 in one pass over the rows, D <= 256):
+// the rows arrive UN-normalised and are l2-normalised in registers first (util/math.py:63-64; arithmetic of
+// l2_normalize_rows_kernel below, so that this kernel and the three-kernel sequence normalise -> assign -> ste agree bit for
+// bit); `quant` then receives the straight-through output x^ + (q - x^) instead of q, `loss_part[block]` the block's share of
+// sum (q - x^)^2 (fixed order) and `counts[k]` the code usage (integer adds: exact in any order).
+struct VqFuse {
+  float eps;
+  float* loss_part;
+  float* counts;
+};
+
+template <int KT, bool MAXONLY, bool FUSE>
 __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict__ x, long N, int D,
                                                         const float* __restrict__ C, int K,
                                                         const float* __restrict__ sel, int* __restrict__ gmax_key,
                                                         long long* __restrict__ idx, float* __restrict__ quant,
-                                                        float* __restrict__ dist) {
+                                                        float* __restrict__ dist, const VqFuse fuse) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int D16 = (D + 15) >> 4;
   f32x4* Bf = reinterpret_cast<f32x4*>(smem);             // [KT][D16][64] float4
   float* c2 = smem + (size_t)KT * D16 * 256;              // [KT*16]
   float* selm = c2 + KT * 16;                             // [KT*16]  1 = keep, 0 = dropped
+  int* hist = reinterpret_cast<int*>(selm + KT * 16);     // FUSE: [KT*16] code usage of this workgroup, then 4 floats of wave sums
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, q = lane >> 4;
 
@@ -65,8 +78,10 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
     }
     c2[k] = acc;
     selm[k] = (k < K) ? ((sel != nullptr && !MAXONLY) ? sel[k] : 1.0f) : 0.0f;
+    if (FUSE) hist[k] = 0;
   }
   __syncthreads();
+  float wave_loss = 0.f;                                  // FUSE: this wave's rows, summed group by group
 
   const float gmax = (!MAXONLY && sel != nullptr) ? key2f(*gmax_key) : 0.f;
   float wmax = -INFINITY;
@@ -83,12 +98,26 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
     // unconditionally (clamped offsets, zeroed afterwards where out of range): the stream is HBM-bound, so what matters is how
     // many fetches are in flight -- a guarded fetch per step makes the compiler wait for each one before the next is issued.
     // (Requesting the next group's rows before this group is multiplied was measured: 2x the registers, half the waves, -10 %.)
+    f32x4 av[16];                                        // (FUSE: D16 <= 16, the one chunk stays live for the straight-through output)
     for (int t0 = 0; t0 < D16; t0 += 16) {
-      f32x4 av[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int off = min(16 * (t0 + i) + 4 * q, D - 4);
         av[i] = *reinterpret_cast<const f32x4*>(xr + off);
+      }
+      if (FUSE) {
+        // x^ = x / sqrt(max(sum x^2, eps)) with sum x^2 in the order of x2 below (four chains, then (p0 + p1) + (p2 + p3))
+        float pr = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (!(rvalid && i < D16 && (16 * i + 4 * q) < D)) av[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          pr = fmaf(av[i][0], av[i][0], pr); pr = fmaf(av[i][1], av[i][1], pr); pr = fmaf(av[i][2], av[i][2], pr); pr = fmaf(av[i][3], av[i][3], pr);
+        }
+        pr = pr + __shfl_xor(pr, 16);
+        pr = pr + __shfl_xor(pr, 32);
+        const float sc = 1.0f / sqrtf(fmaxf(pr, fuse.eps));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) av[i] = av[i] * sc;
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -145,7 +174,33 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
         }
         if (col == 0 && (row0 + 4 * q + j) < N) idx[row0 + 4 * q + j] = (long long)best_i[j];
       }
-      if (quant != nullptr) {
+      if (FUSE) {
+        // this lane's row is `col`; its nearest code sits in the lanes of quarter col >> 2, slot col & 3
+        int kr = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int kj = __shfl(best_i[j], (col >> 2) * 16);
+          if ((col & 3) == j) kr = kj;
+        }
+        const int kt_r = kr >> 4, kc_r = kr & 15;
+        float lr = 0.f;                                   // sum over this lane's 64 features of (q - x^)^2, one fmaf chain
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (i < D16 && (16 * i + 4 * q) < D) {
+            const f32x4 cq = Bf[((size_t)kt_r * D16 + i) * 64 + 16 * q + kc_r];        // C[16 i + 4 q + e][kr], e = 0..3
+            const f32x4 dq = cq - av[i];
+            lr = fmaf(dq[0], dq[0], lr); lr = fmaf(dq[1], dq[1], lr); lr = fmaf(dq[2], dq[2], lr); lr = fmaf(dq[3], dq[3], lr);
+            if (rvalid && quant != nullptr) *reinterpret_cast<f32x4*>(quant + (size_t)(row0 + col) * D + 16 * i + 4 * q) = av[i] + dq;
+          }
+        }
+        if (!rvalid) lr = 0.f;
+        lr = lr + __shfl_xor(lr, 16);                     // the row's four quarter sums: (l0 + l1) + (l2 + l3)
+        lr = lr + __shfl_xor(lr, 32);
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) lr += __shfl_xor(lr, m);      // the group's 16 rows, fixed xor tree
+        wave_loss += lr;
+        if (q == 0 && rvalid) atomicAdd(&hist[kr], 1);
+      } else if (quant != nullptr) {
         const int nchunk = (D + 255) >> 8;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -167,6 +222,44 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, m));
     if (lane == 0 && wmax > -INFINITY) atomicMax(gmax_key, f2key(wmax));
+  }
+  if (FUSE && !MAXONLY) {
+    float* wsum = reinterpret_cast<float*>(hist + KT * 16);
+    if (lane == 0) wsum[wave] = wave_loss;
+    __syncthreads();
+    if (tid == 0) fuse.loss_part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    for (int k = tid; k < K; k += 256)
+      if (hist[k]) atomicAdd(&fuse.counts[k], (float)hist[k]);       // integers below 2^24: exact in any order
+  }
+}
+
+// y = x / sqrt(max(sum_d x^2, eps)) row by row (tf.linalg.l2_normalize, util/math.py:63-64), with the sum in the DEFINED order of
+// vq_assign_kernel's x2 (lane (row, q) runs one fmaf chain over d = 16 t + 4 q + e, t outer; then (p0 + p1) + (p2 + p3)) and a
+// correctly rounded sqrt and division: oracle/vq_strict.c states the same in plain C.  16 rows per wave, any D % 4 == 0.
+__global__ __launch_bounds__(256) void l2_normalize_rows_kernel(const float* __restrict__ x, long N, int D, float eps, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
+  const int D16 = (D + 15) >> 4;
+  const long n_groups = (N + 15) >> 4;
+  for (long rg = (long)blockIdx.x * 4 + wave; rg < n_groups; rg += (long)gridDim.x * 4) {
+    const long row = (rg << 4) + col;
+    const bool rvalid = row < N;
+    const float* xr = x + (size_t)(rvalid ? row : N - 1) * D;
+    float p = 0.f;
+    for (int t = 0; t < D16; ++t) {
+      if (16 * t + 4 * q < D) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * t + 4 * q);
+        p = fmaf(a[0], a[0], p); p = fmaf(a[1], a[1], p); p = fmaf(a[2], a[2], p); p = fmaf(a[3], a[3], p);
+      }
+    }
+    p = p + __shfl_xor(p, 16);
+    p = p + __shfl_xor(p, 32);
+    const float sc = 1.0f / sqrtf(fmaxf(p, eps));
+    if (rvalid)
+      for (int t = 0; t < D16; ++t)
+        if (16 * t + 4 * q < D) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * t + 4 * q);       // (L2-resident second read)
+          *reinterpret_cast<f32x4*>(y + (size_t)row * D + 16 * t + 4 * q) = a * sc;
+        }
   }
 }
 
@@ -465,28 +558,33 @@ static long ema_grid(long N, int D, int K) {
   return blocks < 1 ? 1 : blocks;
 }
 
-template <int KT>
-int launch_assign(const float* x, long N, int D, const float* C, int K, const float* sel, float* ws, long long* idx,
-                  float* quant, float* dist, hipStream_t s) {
-  const int D16 = (D + 15) >> 4;
-  const size_t lds = ((size_t)KT * D16 * 256 + 2 * KT * 16) * sizeof(float);
+static long assign_grid(long N) {
   const long n_groups = (N + 15) >> 4;
   long blocks = (n_groups + 3) / 4;
   const long cap = (long)vqn_num_cus() * 8;
   if (blocks > cap) blocks = cap;
+  return blocks < 1 ? 1 : blocks;
+}
+
+template <int KT, bool FUSE>
+int launch_assign(const float* x, long N, int D, const float* C, int K, const float* sel, float* ws, long long* idx,
+                  float* quant, float* dist, const VqFuse fuse, hipStream_t s) {
+  const int D16 = (D + 15) >> 4;
+  const size_t lds = ((size_t)KT * D16 * 256 + 3 * KT * 16 + 4) * sizeof(float);
+  const long blocks = assign_grid(N);
   if (lds > 64 * 1024) {
-    VQN_HIP(hipFuncSetAttribute((const void*)vq_assign_kernel<KT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    VQN_HIP(hipFuncSetAttribute((const void*)vq_assign_kernel<KT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VQN_HIP(hipFuncSetAttribute((const void*)vq_assign_kernel<KT, true, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VQN_HIP(hipFuncSetAttribute((const void*)vq_assign_kernel<KT, false, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   if (sel != nullptr) {
     // distances.max() is taken over the UNMASKED distances (vq_layers.py:285) -> extra pass
     VQN_HIP(hipMemsetD32Async((hipDeviceptr_t)ws, (int)0x807fffff /* key(-inf) */, 1, s));
-    hipLaunchKernelGGL((vq_assign_kernel<KT, true>), dim3((unsigned)blocks), dim3(256), lds, s, x, N, D, C, K, sel,
-                       reinterpret_cast<int*>(ws), idx, quant, dist);
+    hipLaunchKernelGGL((vq_assign_kernel<KT, true, FUSE>), dim3((unsigned)blocks), dim3(256), lds, s, x, N, D, C, K, sel,
+                       reinterpret_cast<int*>(ws), idx, quant, dist, fuse);
     VQN_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL((vq_assign_kernel<KT, false>), dim3((unsigned)blocks), dim3(256), lds, s, x, N, D, C, K, sel,
-                     reinterpret_cast<int*>(ws), idx, quant, dist);
+  hipLaunchKernelGGL((vq_assign_kernel<KT, false, FUSE>), dim3((unsigned)blocks), dim3(256), lds, s, x, N, D, C, K, sel,
+                     reinterpret_cast<int*>(ws), idx, quant, dist, fuse);
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }
@@ -505,15 +603,62 @@ extern "C" int vqn_vq_assign(const float* x, int64_t N, int D, const float* code
   const int D16 = (D + 15) / 16;
   VQN_CHECK_SHAPE(KT <= 8, "K <= 128");
   int KTp = KT <= 1 ? 1 : KT <= 2 ? 2 : KT <= 4 ? 4 : 8;
-  VQN_CHECK_SHAPE(((size_t)KTp * D16 * 256 + 2 * KTp * 16) * 4 <= 160 * 1024, "codebook does not fit in 160 KB of LDS");
+  VQN_CHECK_SHAPE(((size_t)KTp * D16 * 256 + 3 * KTp * 16 + 4) * 4 <= 160 * 1024, "codebook does not fit in 160 KB of LDS");
   hipStream_t s = (hipStream_t)stream;
   long long* idx_ll = reinterpret_cast<long long*>(idx);
+  const VqFuse nf = {0.f, nullptr, nullptr};
   switch (KTp) {
-    case 1: return launch_assign<1>(x, N, D, codebook, K, sel_mask, ws, idx_ll, quant, dist, s);
-    case 2: return launch_assign<2>(x, N, D, codebook, K, sel_mask, ws, idx_ll, quant, dist, s);
-    case 4: return launch_assign<4>(x, N, D, codebook, K, sel_mask, ws, idx_ll, quant, dist, s);
-    default: return launch_assign<8>(x, N, D, codebook, K, sel_mask, ws, idx_ll, quant, dist, s);
+    case 1: return launch_assign<1, false>(x, N, D, codebook, K, sel_mask, ws, idx_ll, quant, dist, nf, s);
+    case 2: return launch_assign<2, false>(x, N, D, codebook, K, sel_mask, ws, idx_ll, quant, dist, nf, s);
+    case 4: return launch_assign<4, false>(x, N, D, codebook, K, sel_mask, ws, idx_ll, quant, dist, nf, s);
+    default: return launch_assign<8, false>(x, N, D, codebook, K, sel_mask, ws, idx_ll, quant, dist, nf, s);
   }
+}
+
+extern "C" int vqn_l2_normalize_rows(const float* x, int64_t N, int D, float eps, float* y, void* stream) {
+  VQN_CHECK_ARG(N >= 0 && D > 0, "N >= 0, D > 0 required");
+  if (N == 0) return VQN_OK;
+  VQN_CHECK_ARG(x && y, "x and y must be non-null");
+  VQN_CHECK_SHAPE(D % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0, "D multiple of 4, x / y 16-byte aligned");
+  hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3((unsigned)assign_grid(N)), dim3(256), 0, (hipStream_t)stream, x, (long)N, D, eps, y);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
+
+extern "C" int vqn_vq_quantize_rows(const float* z, int64_t N, int D, const float* codebook, int K, const float* sel_mask, float eps,
+                                    float loss_scale, float* ws, int64_t* idx, float* ste, float* loss, float* counts, void* stream) {
+  VQN_CHECK_ARG(N >= 0 && D > 0 && K > 0, "N >= 0, D > 0, K > 0 required");
+  VQN_CHECK_ARG(loss && counts && ws, "loss, counts and ws (VQN_QUANT_WS_FLOATS floats) must be non-null");
+  hipStream_t s = (hipStream_t)stream;
+  VQN_HIP(hipMemsetAsync(counts, 0, sizeof(float) * K, s));
+  if (N == 0) {                                         /* mean over nothing: the reference yields NaN (0 / 0) */
+    const float nan = NAN;
+    VQN_HIP(hipMemcpyAsync(loss, &nan, sizeof(float), hipMemcpyHostToDevice, s));
+    return VQN_OK;
+  }
+  VQN_CHECK_ARG(z && codebook && idx, "z, codebook and idx must be non-null");
+  VQN_CHECK_SHAPE(D % 4 == 0 && D <= 256, "D must be a multiple of 4 and <= 256 (the row stays in registers)");
+  VQN_CHECK_SHAPE(((uintptr_t)z % 16) == 0 && (ste == nullptr || ((uintptr_t)ste % 16) == 0), "z / ste must be 16-byte aligned");
+  const int KT = (K + 15) / 16;
+  const int D16 = (D + 15) / 16;
+  VQN_CHECK_SHAPE(KT <= 8, "K <= 128");
+  int KTp = KT <= 1 ? 1 : KT <= 2 ? 2 : KT <= 4 ? 4 : 8;
+  VQN_CHECK_SHAPE(((size_t)KTp * D16 * 256 + 3 * KTp * 16 + 4) * 4 <= 160 * 1024, "codebook does not fit in 160 KB of LDS");
+  long long* idx_ll = reinterpret_cast<long long*>(idx);
+  const long blocks = assign_grid(N);
+  VQN_CHECK_SHAPE(blocks + 1 <= VQN_QUANT_WS_FLOATS, "workspace too small for this device");
+  const VqFuse fz = {eps, ws + 1, counts};             // ws[0]: the code-dropout maximum; ws[1 ..]: per-workgroup loss sums
+  int rc;
+  switch (KTp) {
+    case 1: rc = launch_assign<1, true>(z, N, D, codebook, K, sel_mask, ws, idx_ll, ste, nullptr, fz, s); break;
+    case 2: rc = launch_assign<2, true>(z, N, D, codebook, K, sel_mask, ws, idx_ll, ste, nullptr, fz, s); break;
+    case 4: rc = launch_assign<4, true>(z, N, D, codebook, K, sel_mask, ws, idx_ll, ste, nullptr, fz, s); break;
+    default: rc = launch_assign<8, true>(z, N, D, codebook, K, sel_mask, ws, idx_ll, ste, nullptr, fz, s); break;
+  }
+  if (rc != VQN_OK) return rc;
+  hipLaunchKernelGGL(vq_ste_loss_final_kernel, dim3(1), dim3(64), 0, s, ws + 1, (int)blocks, loss_scale, loss);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
 }
 
 extern "C" int64_t vqn_vq_ema_stats_ws_bytes(int64_t N, int D, int K) {

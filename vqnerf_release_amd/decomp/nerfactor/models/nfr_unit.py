@@ -23,8 +23,10 @@ from vqnerf_release_amd.decomp.nerfactor.util import img as imgutil, io as iouti
 def fg_rows(alpha):
     """Row indices of the foreground rays (alpha > 0), ascending -- what `tf.where(mask)` / `tf.boolean_mask` select.  Taken
     ONCE per call and reused for every gather and scatter: a boolean-mask index costs a `nonzero` (a host sync) each time,
-    twenty of them per rendered view."""
-    return (alpha[:, 0] > 0).nonzero(as_tuple=False).squeeze(1)
+    twenty of them per rendered view.  Returns None when EVERY row is foreground (the index list is on the host after the
+    `nonzero` anyway): `take_rows` / `scatter_rows` are then the identity and no gather or scatter is launched at all."""
+    rows = (alpha[:, 0] > 0).nonzero(as_tuple=False).squeeze(1)
+    return None if rows.numel() == alpha.shape[0] else rows
 
 
 def scatter_rows(mask, x, n):
@@ -42,6 +44,29 @@ def take_rows(mask, *tensors):
     a data-dependent shape (a host sync), which a captured training step cannot have."""
     out = tuple(t if (t is None or mask is None) else t[mask] for t in tensors)
     return out if len(out) > 1 else out[0]
+
+
+class LazyRows:
+    """`full[rows]` not yet gathered: the visibility buffer of a view is 2 KB per pixel, and the fused shading kernel can read the
+    foreground rows in place (`vqn_brdf_shade_fwd_rows`), so the tf.boolean_mask copy of vq_nfr.py:558-559 is only made for the
+    paths that need a dense tensor (`dense()`)."""
+
+    def __init__(self, full, rows):
+        self.full, self.rows = full, rows
+        self._dense = None
+
+    def dense(self):
+        if self._dense is None:
+            self._dense = self.full[self.rows]
+        return self._dense
+
+    @property
+    def shape(self):
+        return (self.rows.numel(),) + tuple(self.full.shape[1:])
+
+
+def dense_rows(t):
+    return t.dense() if isinstance(t, LazyRows) else t
 
 
 class ShadeFunction(torch.autograd.Function):
@@ -98,6 +123,9 @@ class BrdfModel(ShapeModel):
         self.matrix_mode = 'f32'         # 'f16s': inference MLP stacks on the split-precision (f16 hi/lo MFMA) kernel, ~1e-6 relative
         self.assume_foreground = False   # True: callers promise alpha > 0 everywhere (vq_nfr.Model.call skips the boolean gathers)
         self.train_backend = 'hip'       # 'hip': fused shading fwd/bwd kernels under autograd; 'torch': torch statements
+        # the reference's tf.debugging.check_numerics guards (vq_nfr.py:731, :783, :802, :815, :827, :985 and their twins in
+        # nfr_unit.py / ref_nfr.py): optional here -- each is a host sync -- on with `debug=True` or VQN_CHECK_NUMERICS=1
+        self.check_numerics = bool(debug) or os.environ.get('VQN_CHECK_NUMERICS', '0') not in ('', '0')
         self._novel_lights()
 
     def _apply(self, fn, *args, **kwargs):
@@ -291,25 +319,32 @@ class BrdfModel(ShapeModel):
         return self._engines[key]
 
     # ------------------------------------------------------------------ reference-named pieces
+    def _numerics(self, x, message):
+        return mathutil.check_numerics(x, message) if self.check_numerics else x
+
+    _HEAD_MESSAGES = {'diff': 'Albedo', 'spec': 'Specular', 'rough': 'Roughness'}
+
     def _pred_bias_at(self, pts):
         """xyz [N,3] -> z [N,z_dim]  (nfr_unit.py:329-342; vq_nfr.py:771-784 is the same function)."""
         if self._fused(pts):
-            return self._fused_enc(pts)
+            return self._numerics(self._fused_enc(pts), 'Z')
         if self._train_hip(pts):
             from vqnerf_release_amd.decomp.train_programs import EncoderFunction
             layers = list(self.net['fine_enc'].layers) + list(self.net['bottleneck'].layers)
-            return EncoderFunction.apply(self._enc_engine(pts.device), pts, *[l.kernel for l in layers], *[l.bias for l in layers])
-        return self.net['bottleneck'](self.net['fine_enc'](self.embedder['xyz'](pts)))
+            return self._numerics(EncoderFunction.apply(self._enc_engine(pts.device), pts, *[l.kernel for l in layers],
+                                                        *[l.bias for l in layers]), 'Z')
+        return self._numerics(self.net['bottleneck'](self.net['fine_enc'](self.embedder['xyz'](pts))), 'Z')
 
     def _head(self, name, z):
+        msg = self._HEAD_MESSAGES.get(name.split('_')[0], name)
         if self._fused(z):
-            return self._fused_heads(z, [name])[0]
+            return self._numerics(self._fused_heads(z, [name])[0], msg)
         if self._train_hip(z) and z.shape[1] == self.z_dim and any(p.requires_grad for p in self.net[name].parameters()):
             from vqnerf_release_amd.decomp.train_programs import HeadsFunction
             net = self.net[name]
-            return HeadsFunction.apply(self._heads_engine([name], z.device), z, *[l.kernel for l in net.layers],
-                                       *[l.bias for l in net.layers])[0]
-        return self.net[name](z)
+            return self._numerics(HeadsFunction.apply(self._heads_engine([name], z.device), z, *[l.kernel for l in net.layers],
+                                                      *[l.bias for l in net.layers])[0], msg)
+        return self._numerics(self.net[name](z), msg)
 
     def _albedo_affine(self, albedo):
         slope = self.config.getfloat('DEFAULT', 'albedo_slope', fallback=1.0)
@@ -337,7 +372,7 @@ class BrdfModel(ShapeModel):
                                           *[l.bias for n in nets for l in n.layers])
         else:
             d, s, r = (self.net[n](z) for n in names)
-        return self._albedo_affine(d), s, r
+        return self._numerics(self._albedo_affine(d), 'Albedo'), self._numerics(s, 'Specular'), self._numerics(r, 'Roughness')
 
     @staticmethod
     def _normal_correct(normal, surf2c):
@@ -358,6 +393,7 @@ class BrdfModel(ShapeModel):
     def _render(self, brdf, l, n, light_vis=None, relight_olat=False, relight_probes=False, dst_env=None,
                 white_light_override=False, light=None):
         """torch statement of the rendering-equation sum (nfr_unit.py:273-306, vq_nfr.py:694-733)."""
+        light_vis = dense_rows(light_vis)
         if light is None:
             light = self.light if dst_env is None else self.novel_probes[dst_env]
         if white_light_override:
@@ -369,8 +405,16 @@ class BrdfModel(ShapeModel):
         rgb_probes = None
         if relight_probes:                                       # True: the loaded probes; a list: those maps (OLAT and / or probes)
             maps = list(self.novel_probes.values()) if relight_probes is True else list(relight_probes)
-            rgb_probes = torch.stack([self._integrate(brdf, vis, cos, lp) for lp in maps], 1)
+            rgb_probes = self._numerics(torch.stack([self._integrate(brdf, vis, cos, lp) for lp in maps], 1), 'Light Probe Renders')
         return rgb, None, rgb_probes
+
+    def fg_lvis(self, lvis, mask, like):
+        """The foreground rows of the visibility buffer: gathered lazily on the device inference path (see LazyRows)."""
+        if lvis is None or mask is None:
+            return lvis
+        if like.is_cuda and not self._needs_graph(like) and lvis.dtype == torch.float32 and lvis.is_contiguous():
+            return LazyRows(lvis, mask)
+        return take_rows(mask, lvis)
 
     def _shade(self, xyz, normal, rayo, lvis, materials, split=False, light=None, probes=None):
         """Fused directions + BRDF + integral for 1-2 material sets (no graph).  Returns the dict of _C.brdf_shade_fwd."""
@@ -378,16 +422,22 @@ class BrdfModel(ShapeModel):
         gamma = None if self.data_type == 'nerf' else self.gamma.detach()
         mats = [(a.detach().float().contiguous(), s.detach().float().expand(-1, 3).contiguous(),
                  r.detach().float().contiguous()) for a, s, r in materials]
-        return _C.brdf_shade_fwd(xyz.detach().float().contiguous(), normal.detach().float().contiguous(),
-                                 rayo.detach().float().contiguous(),
-                                 None if lvis is None else lvis.detach().float().contiguous(),
-                                 self.lxyz.reshape(-1, 3).contiguous(), self.lareas.reshape(-1).contiguous(),
-                                 light.detach().float().reshape(-1, 3).contiguous(), mats, gamma=gamma,
-                                 want_normal=True, want_split=split, probes=probes)
+        lvis_rows = None
+        if isinstance(lvis, LazyRows):
+            lvis, lvis_rows = lvis.full, lvis.rows.contiguous()
+        out = _C.brdf_shade_fwd(xyz.detach().float().contiguous(), normal.detach().float().contiguous(),
+                                rayo.detach().float().contiguous(),
+                                None if lvis is None else lvis.detach().float().contiguous(),
+                                self.lxyz.reshape(-1, 3).contiguous(), self.lareas.reshape(-1).contiguous(),
+                                light.detach().float().reshape(-1, 3).contiguous(), mats, gamma=gamma,
+                                want_normal=True, want_split=split, probes=probes, lvis_rows=lvis_rows)
+        self._numerics(out.get('rgb_probes'), 'Light Probe Renders')
+        return out
 
     def _shade_train(self, xyz, normal, rayo, lvis, materials, light=None):
         """Shading with gradients (albedo / spec / rough / light) through the fused forward + backward kernels."""
         light = self.light if light is None else light
+        lvis = dense_rows(lvis)
         c = lambda t: t.detach().float().contiguous()
         geom = (c(xyz), c(normal), c(rayo), None if lvis is None else c(lvis), self.lxyz.reshape(-1, 3).contiguous(),
                 self.lareas.reshape(-1).contiguous())
@@ -432,8 +482,8 @@ class Model(BrdfModel):
         gt = {'rgb': rgb, 'normal': normal, 'alpha': alpha, 'xyz': xyz}
         mask = fg_rows(alpha)
         n = alpha.shape[0]
-        rayo, rgb_m, xyz_m, normal_m = rayo[mask], rgb[mask], xyz[mask], normal[mask]
-        lvis_m = lvis[mask] if lvis is not None else None
+        rayo, rgb_m, xyz_m, normal_m = take_rows(mask, rayo), take_rows(mask, rgb), take_rows(mask, xyz), take_rows(mask, normal)
+        lvis_m = self.fg_lvis(lvis, mask, xyz_m)
         z_bias = self._pred_bias_at(xyz_m)
         basecolor, ks, rough = self._all_heads(z_bias, 'out')
         spec = ks * basecolor
@@ -477,4 +527,4 @@ class Model(BrdfModel):
         loss = ((linear_gt - rgb_pred) ** 2).mean(-1)
         if mode != 'train':
             return loss                                     # nfr_unit.py:415 returns the bare tensor in vali mode
-        return loss, {'rgb': loss, 'loss': loss}
+        return self._numerics(loss, 'Loss'), {'rgb': loss, 'loss': loss}

@@ -9,7 +9,7 @@ import torch
 
 from vqnerf_release_amd.decomp import packing
 from vqnerf_release_amd import _C
-from vqnerf_release_amd.decomp.nerfactor.models.nfr_unit import BrdfModel, fg_rows, scatter_rows
+from vqnerf_release_amd.decomp.nerfactor.models.nfr_unit import BrdfModel, fg_rows, scatter_rows, take_rows
 from vqnerf_release_amd.decomp.nerfactor.networks import mlp
 from vqnerf_release_amd.decomp.nerfactor.util import img as imgutil
 
@@ -69,8 +69,8 @@ class Model(BrdfModel):
                 b.mlp('rgb_enc', net.widths, net.act, net.skip_at, b.input, out_slot=0, small_last=False)
                 self._plans['ref'] = b.build()
             wbuf, desc = self._program_pack('ref', self._plans['ref'], ['rgb_enc'])
-            return _C.mlp_chain_fwd(desc, wbuf, ref.detach().float().contiguous(), [self.z_dim])[0]
-        return self.net['rgb_enc'](ref)
+            return self._numerics(_C.mlp_chain_fwd(desc, wbuf, ref.detach().float().contiguous(), [self.z_dim])[0], 'Z_ref')
+        return self._numerics(self.net['rgb_enc'](ref), 'Z_ref')
 
     def call(self, batch, mode='train', relight_olat=False, relight_probes=False, save_z=False, opt_scale=None, bias_weight=None):
         self._validate_mode(mode)
@@ -78,8 +78,8 @@ class Model(BrdfModel):
         lvis = batch[10] if self.data_type == 'nerf' else None
         mask = fg_rows(alpha)
         n = alpha.shape[0]
-        rayo, rgb_m, xyz_m, normal_m, ref_m = rayo[mask], rgb[mask], xyz[mask], normal[mask], ref[mask]
-        lvis_m = lvis[mask] if lvis is not None else None
+        rayo, rgb_m, xyz_m, normal_m, ref_m = take_rows(mask, rayo), take_rows(mask, rgb), take_rows(mask, xyz), take_rows(mask, normal), take_rows(mask, ref)
+        lvis_m = self.fg_lvis(lvis, mask, xyz_m)
         z_xyz = self._pred_bias_at(xyz_m)
         ks = self._head('spec_out', z_xyz)
         z_bias = torch.cat([z_xyz, self._pred_ref_at(ref_m)], -1)
@@ -133,10 +133,10 @@ class Model(BrdfModel):
         lvis = batch[10] if self.data_type == 'nerf' else None
         mask = fg_rows(alpha)
         n = alpha.shape[0]
-        rayo, rgb_m, xyz_m, normal_m, ref_m = rayo[mask], rgb[mask], xyz[mask], normal[mask], ref[mask]
-        lvis_m = lvis[mask] if lvis is not None else None
+        rayo, rgb_m, xyz_m, normal_m, ref_m = take_rows(mask, rayo), take_rows(mask, rgb), take_rows(mask, xyz), take_rows(mask, normal), take_rows(mask, ref)
+        lvis_m = self.fg_lvis(lvis, mask, xyz_m)
         if edit_mask is not None:
-            edit_mask = (edit_mask[mask][..., 0:1] > 0).to(torch.float32)
+            edit_mask = (take_rows(mask, edit_mask)[..., 0:1] > 0).to(torch.float32)
         z_xyz = self._pred_bias_at(xyz_m)
         ks = self._head('spec_out', z_xyz)
         z_bias = torch.cat([z_xyz, self._pred_ref_at(ref_m)], -1)
@@ -189,4 +189,4 @@ class Model(BrdfModel):
         loss = ((linear_gt - rgb_pred) ** 2).mean(-1)
         if mode != 'train':
             return loss                                     # ref_nfr.py:606 returns the bare tensor in vali mode
-        return loss, {'rgb': loss, 'loss': loss}
+        return self._numerics(loss, 'Loss'), {'rgb': loss, 'loss': loss}

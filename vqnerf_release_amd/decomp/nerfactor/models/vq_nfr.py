@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from vqnerf_release_amd.decomp.nerfactor.models.nfr_unit import BrdfModel, fg_rows, scatter_rows, take_rows
 from vqnerf_release_amd.decomp.nerfactor.networks import mlp
-from vqnerf_release_amd.decomp.nerfactor.networks.vq_layers import VectorQuantizerEMA
+from vqnerf_release_amd.decomp.nerfactor.networks.vq_layers import VectorQuantizerEMA, l2_normalize_rows
 from vqnerf_release_amd.decomp.nerfactor.util import img as imgutil, math as mathutil
 
 
@@ -79,17 +79,27 @@ class Model(BrdfModel):
             return None
         return torch.as_tensor(thres, dtype=torch.float32, device=device).reshape(1, self.num_embed)
 
+    fuse_quantise = True       # inference without a graph: normalise + assign + straight-through + loss + usage in one kernel
+
     def _quantise(self, z_enc, mode, thres, roll=None):
-        z_norm = mathutil.safe_l2_normalize(z_enc, axis=1)
+        """vq_nfr.py:575-578: z_norm = l2_normalize(z_enc), vq_layer(z_norm, codebook).  Two device paths with bit-identical
+        `quantize` / indices: the fused kernel when neither a graph nor the EMA statistics are needed, else the sequence
+        vqn_l2_normalize_rows -> vqn_vq_assign -> vqn_vq_ste_loss (-> vqn_vq_ema_stats)."""
         codebook = self.get_codebook()
-        vq = self.vq_layer(z_norm, codebook, is_training=(mode == 'train'), thres=self._thres(thres, z_enc.device), roll=roll)
+        th = self._thres(thres, z_enc.device)
+        on_kernels = z_enc.is_cuda and z_enc.shape[1] % 4 == 0
+        if self.fuse_quantise and on_kernels and mode != 'train' and z_enc.shape[1] <= 256 and not self._needs_graph(z_enc):
+            vq = self.vq_layer.infer_from_raw(z_enc, codebook, thres=th, roll=roll)
+        else:
+            z_norm = l2_normalize_rows(z_enc) if on_kernels else mathutil.safe_l2_normalize(z_enc, axis=1)
+            vq = self.vq_layer(z_norm, codebook, is_training=(mode == 'train'), thres=th, roll=roll)
         return vq, vq['quantize'], vq['loss'], vq['encoding_indices'] + 1
 
     # ------------------------------------------------------------------ entry points
     def init_z(self, batch):
         id_, hw, _, _, _, alpha, pred_alpha, xyz = batch[:8]
         mask = fg_rows(alpha)
-        return {'id': id_, 'hw': hw, 'z_pred': self._pred_enc_at(xyz[mask])}
+        return {'id': id_, 'hw': hw, 'z_pred': self._pred_enc_at(take_rows(mask, xyz))}
 
     def init_mat(self, z_pred):
         basecolor, ks, rough = self._all_heads(z_pred, 'main')
@@ -100,7 +110,7 @@ class Model(BrdfModel):
         id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz = batch[:8]
         mask = fg_rows(alpha)
         n = alpha.shape[0]
-        xyz_m = xyz[mask]
+        xyz_m = take_rows(mask, xyz)
         _, _, _, embed_ind = self._quantise(self._pred_enc_at(xyz_m), mode, thres)
         pred, gt = {'alpha': pred_alpha}, {'alpha': alpha}
         to_vis = {'id': id_, 'hw': hw, 'embed': scatter_rows(mask, embed_ind[:, None], n), 'xyz': scatter_rows(mask, xyz_m, n),
@@ -110,8 +120,8 @@ class Model(BrdfModel):
     def vq_test(self, batch, mode='vali', thres=None):
         id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz, normal, lvis = self._unpack(batch)
         mask = fg_rows(alpha)
-        rayo, rgb_m, xyz_m, normal_m = rayo[mask], rgb[mask], xyz[mask], normal[mask]
-        lvis_m = lvis[mask] if lvis is not None else None
+        rayo, rgb_m, xyz_m, normal_m = take_rows(mask, rayo), take_rows(mask, rgb), take_rows(mask, xyz), take_rows(mask, normal)
+        lvis_m = self.fg_lvis(lvis, mask, xyz_m)
         vq, z_vq, vq_loss, _ = self._quantise(self._pred_enc_at(xyz_m), mode, thres)
         usage = (vq['encodings'].max(0, keepdim=True)[0] > 0).to(torch.float32)
         vq_albedo, vq_spec, vq_rough = self._all_heads(z_vq, 'vq')
@@ -151,7 +161,8 @@ class Model(BrdfModel):
         # gather / scatter -- and no host sync -- is needed
         mask = None if self.assume_foreground else fg_rows(alpha)
         n = alpha.shape[0]
-        rayo, rgb_m, xyz_m, normal_m, lvis_m = take_rows(mask, rayo, rgb, xyz, normal, lvis)
+        rayo, rgb_m, xyz_m, normal_m = take_rows(mask, rayo, rgb, xyz, normal)
+        lvis_m = self.fg_lvis(lvis, mask, xyz_m)
 
         z_enc = self._pred_enc_at(xyz_m)
         vq, z_vq, vq_loss, embed_ind = self._quantise(z_enc, mode, thres, roll=roll)
@@ -199,10 +210,10 @@ class Model(BrdfModel):
         lvis = batch[-1] if self.data_type == 'nerf' else None
         mask = fg_rows(alpha)
         n = alpha.shape[0]
-        rayo, rgb_m, xyz_m, normal_m = rayo[mask], rgb[mask], xyz[mask], normal[mask]
-        lvis_m = lvis[mask] if lvis is not None else None
+        rayo, rgb_m, xyz_m, normal_m = take_rows(mask, rayo), take_rows(mask, rgb), take_rows(mask, xyz), take_rows(mask, normal)
+        lvis_m = self.fg_lvis(lvis, mask, xyz_m)
         if edit_mask is not None:
-            edit_mask = (edit_mask[mask][..., 0:1] > 0).to(torch.float32)
+            edit_mask = (take_rows(mask, edit_mask)[..., 0:1] > 0).to(torch.float32)
         z_enc = self._pred_enc_at(xyz_m)
         if gen_embed:
             _, _, _, embed_ind = self._quantise(z_enc, mode, thres)
@@ -252,7 +263,7 @@ class Model(BrdfModel):
         id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz = batch[:8]
         mask = fg_rows(alpha)
         n = alpha.shape[0]
-        z_enc = self._pred_enc_at(xyz[mask])
+        z_enc = self._pred_enc_at(take_rows(mask, xyz))
         _, _, _, embed_ind = self._quantise(z_enc, mode, thres)
         basecolor, ks, rough = self._all_heads(z_enc, 'main')
         pred = {'alpha': pred_alpha, 'albedo': scatter_rows(mask, (1 - ks) * basecolor, n),
@@ -320,4 +331,4 @@ class Model(BrdfModel):
             ld['lambert'] = cfg('lambert_weight') * spec.max(-1)[0] * r[:, 0]
             loss = loss + ld['lambert']
         ld['loss'] = loss
-        return loss, ld
+        return self._numerics(loss, 'Loss'), ld

@@ -68,6 +68,54 @@ class _SteAndCommitment(torch.autograd.Function):
         return g, None
 
 
+class L2NormalizeRows(torch.autograd.Function):
+    """`safe_l2_normalize(x, axis=1)` (util/math.py:63-64) on `vqn_l2_normalize_rows`: the sum of squares in the DEFINED order the
+    VQ kernels use for |x|^2, so that the fused inference kernel (`vqn_vq_quantize_rows`) and this three-kernel sequence agree bit
+    for bit.  Backward: y = x s, s = max(sum x^2, eps)^(-1/2)  ->  g s - x s^3 (x . g) where sum x^2 > eps, g s elsewhere."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        xd = x.detach().float().contiguous()
+        ctx.save_for_backward(xd)
+        ctx.eps = float(eps)
+        return _C.l2_normalize_rows(xd, ctx.eps)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        x2 = (x * x).sum(1, keepdim=True)
+        s = torch.rsqrt(torch.clamp(x2, min=ctx.eps))
+        gx = g * s - torch.where(x2 > ctx.eps, x * (s * s * s) * (x * g).sum(1, keepdim=True), torch.zeros_like(x))
+        return gx, None
+
+
+def l2_normalize_rows(x, eps=1e-6):
+    """Row-wise l2-normalisation of a [N, D] device tensor on the HIP kernel (D % 4 == 0), differentiable."""
+    return L2NormalizeRows.apply(x, eps)
+
+
+class LazyResult(dict):
+    """The result dict of the VQ layer with some values computed on first access: the model only ever reads `quantize`, `loss`,
+    `encoding_indices` (and `update` in training); `encodings` (an [N, K] one-hot), `distances` ([N, K]) and `perplexity` cost
+    passes over the rows that nobody pays for unless they look."""
+
+    def __init__(self, values, thunks):
+        super().__init__(values)
+        self._thunks = dict(thunks)
+
+    def __missing__(self, key):
+        if key in self._thunks:
+            self[key] = self._thunks.pop(key)()
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._thunks
+
+    def keys(self):
+        return list(dict.keys(self)) + list(self._thunks)
+
+
 class VectorQuantizerEMA(torch.nn.Module):
     def __init__(self, embedding_dim, num_embeddings, commitment_cost, seed, decay=0.999, epsilon=1e-5,
                  dtype=torch.float32, name='vector_quantizer_ema'):
@@ -137,6 +185,34 @@ class VectorQuantizerEMA(torch.nn.Module):
         ret.update({'quantize': quantized, 'loss': loss, 'perplexity': perplexity, 'encodings': encodings,
                     'encoding_indices': encoding_indices, 'distances': dist})
         return ret
+
+    @torch.no_grad()
+    def infer_from_raw(self, z_raw, codebook, thres=None, individual=True, roll=None, eps=1e-6):
+        """Inference-only form taking the UN-normalised encoder output: l2-normalise, nearest code, straight-through output,
+        commitment term and code usage in ONE kernel (`vqn_vq_quantize_rows`; vq_nfr.py:575-578 + :277-302, :327-330 of this
+        file's reference).  Same result keys as `forward(l2_normalize_rows(z_raw), codebook, is_training=False, ...)` and
+        bit-identical `quantize` / `encoding_indices`; `encodings`, `distances`, `perplexity` are computed on first access."""
+        D, K = self.embedding_dim, self.num_embeddings
+        x = z_raw.detach().reshape(-1, D).float().contiguous()
+        cb = codebook.detach().contiguous()
+        sel = None
+        if thres is not None:
+            if roll is None:
+                roll = self.draw_roll(individual, x.device)
+            thres_t = torch.as_tensor(thres, dtype=torch.float32, device=x.device)
+            sel = (roll.to(x.device) >= thres_t).to(torch.float32).expand(1, K).reshape(K).contiguous()
+        idx, ste, e_latent_loss, counts = _C.vq_quantize_rows(x, cb, sel_mask=sel, eps=eps)
+
+        def perplexity():
+            avg = counts / max(idx.numel(), 1)
+            return torch.exp(-torch.sum(avg * torch.log(avg + 1e-10)))
+
+        def distances():
+            return _C.vq_assign(_C.l2_normalize_rows(x, eps), cb, sel_mask=sel, want_quant=False, want_dist=True)[2]
+        return LazyResult({'quantize': ste.reshape(z_raw.shape), 'loss': self.commitment_cost * e_latent_loss,
+                           'encoding_indices': idx.reshape(z_raw.shape[:-1])},
+                          {'perplexity': perplexity, 'distances': distances,
+                           'encodings': lambda: torch.nn.functional.one_hot(idx, K).to(torch.float32)})
 
     def quantize(self, codebook, encoding_indices):
         return codebook.t()[encoding_indices]

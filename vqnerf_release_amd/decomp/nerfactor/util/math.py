@@ -17,3 +17,16 @@ def divide_no_nan(a, b):
     """tf.math.divide_no_nan: 0 where b == 0 (value and gradient)."""
     zero = b == 0
     return torch.where(zero, torch.zeros_like(a * b), a / torch.where(zero, torch.ones_like(b), b))
+
+
+class InvalidArgumentError(ValueError):
+    """What `tf.debugging.check_numerics` raises in the reference (tf.errors.InvalidArgumentError)."""
+
+
+def check_numerics(x, message):
+    """tf.debugging.check_numerics: raise if `x` holds a NaN or an Inf, else return it.  One host sync per call, which is why the
+    models only call it in debug mode (`Model(config, debug=True)` or VQN_CHECK_NUMERICS=1)."""
+    if x is not None and torch.is_tensor(x) and x.numel() and not bool(torch.isfinite(x).all()):
+        bad = 'NaN' if bool(torch.isnan(x).any()) else 'Inf'
+        raise InvalidArgumentError(f'{message} : Tensor had {bad} values')
+    return x
