@@ -10,7 +10,8 @@
 struct ChainLayer {            // 16 ints
   int kind;                    // 0 = GEMM tiles (MFMA) -> LDS rows [dst_row0, +4*n_out_tiles);  1 = <= 4 outputs (VALU dots) -> HBM;
                                // 2 = load the input image again into rows [dst_row0, +in_rows)
-  int act;                     // eng::Act: 0 none, 1 relu, 2 softplus(beta=100), 3 sigmoid
+  int act;                     // bits 0-7 eng::Act: 0 none, 1 relu, 2 softplus(beta=100), 3 sigmoid;  bit 8 (kind 0): the output is written
+                               // in place over one of the layer's own K segments, after a barrier (<= one output tile per wave)
   int n_out_tiles;             // kind 0: ceil(out/32);  kind 1: number of outputs (1..4)
   int kA_row0, kA_rows;        // K segment A: LDS rows
   int kB_row0, kB_rows;        // K segment B (skip-concat input), kB_rows = 0 if none

@@ -56,6 +56,25 @@ def test_chain_ragged_sizes(setup, n):
     np.testing.assert_allclose(_np(z), od.pred_enc(pt, specs, od.T(pts['xyz'])).numpy(), rtol=0, atol=3e-6)
 
 
+def test_chain_outputs_do_not_depend_on_the_launch_size(setup):
+    """A point's encoder / head outputs are the same bits whether it is evaluated in a 5 k-point or a 100 k-point launch (one tile
+    per persistent workgroup pass vs many; ragged last tile): the arithmetic per point has one defined order."""
+    od, model = setup['od'], setup['model']
+    from tests.gpu_util import launches
+    n_big, n_small = 100003, 4999                                        # 3126 tiles (two-image, ragged) / 157 tiles (one-image)
+    xyz = torch.tensor(od.make_points(n_big, seed=77)['xyz']).cuda()
+    with torch.no_grad():
+        z_big = model._pred_enc_at(xyz)
+        z_small = model._pred_enc_at(xyz[:n_small].contiguous())
+        assert torch.equal(z_big[:n_small], z_small)
+        for fam in ('main', 'vq'):
+            big = model._all_heads(z_big, fam)
+            small = model._all_heads(z_big[:n_small].contiguous(), fam)
+            for b, s_ in zip(big, small):
+                assert torch.equal(b[:n_small], s_)
+        assert torch.isfinite(z_big).all() and float(z_big[-1].abs().sum()) > 0
+
+
 @pytest.mark.parametrize('n', [1, 33, 1000])
 def test_split_precision_chain_vs_fp64_oracle(setup, n):
     """matrix_mode = 'f16s' (vqn_mlp_chain_fwd_f16s: f16 hi/lo operands, three f16 MFMAs per product, f32 accumulate) is an

@@ -102,7 +102,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_kernel(con
         load_input(L.dst_row0);
       } else if (L.kind == 0) {
         const f32x4* bp = wbuf + L.b_off;
-        const int act = L.act, dst = L.dst_row0;
+        const int act = L.act & 0xff, dst = L.dst_row0;
+        // bit 8 of `act`: the output goes IN PLACE over one of the layer's own K segments (one output tile per wave at most):
+        // every wave keeps its accumulators across a workgroup barrier that separates the last K read from the first write
+        const bool late = (L.act & 0x100) != 0;
+        f32x16 held;
         // weight fragments run one GEMM layer ahead: the first four of this wave's first tile of the NEXT GEMM layer in which
         // it owns a tile (program order, wrapping into the next point tile) are requested before this layer's epilogue + barrier
         int nl = -1;
@@ -122,6 +126,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_kernel(con
         gemm_tiles_chain<NW>(lds, ks, wbuf + L.w_off, L.n_out_tiles, wave, lane, pre, next_wp,
                        [&](int ot, f32x16& acc) { init_bias(bp, ot, lane, acc); },
                        [&](int ot, const f32x16& acc) {
+                         if (late) { held = acc; return; }
 #pragma unroll
                          for (int rq = 0; rq < 4; ++rq) {
                            f32x4 v = acc_quad(acc, rq);
@@ -130,6 +135,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_kernel(con
                            lds[(dst + ot * 4 + rq) * 64 + lane] = v;
                          }
                        });
+        if (late) {
+          __syncthreads();
+          if (wave < L.n_out_tiles) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+              f32x4 v = acc_quad(held, rq);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = act_rt(act, v[j]);
+              lds[(dst + wave * 4 + rq) * 64 + lane] = v;
+            }
+          }
+        }
         __syncthreads();
         if (L.out_slot >= 0) {                   // image rows -> [N, out_feats] in HBM (16 B per lane)
           float* o = outs.p[L.out_slot];
@@ -217,10 +234,14 @@ int check_desc(const ChainDesc& d) {
     if (L.kind == 0) {
       if (L.n_out_tiles < 1 || L.dst_row0 < 0 || L.dst_row0 + 4 * L.n_out_tiles > d.total_rows) return 14;
       if (L.out_slot >= 0 && (L.out_feats < 1 || L.out_feats > 32 * L.n_out_tiles)) return 15;
-      // a layer must not overwrite its own K rows
+      // a layer must not overwrite its own K rows -- unless it writes after a barrier (bit 8 of act), one tile per wave
       const int d0 = L.dst_row0, d1 = L.dst_row0 + 4 * L.n_out_tiles;
-      if (d0 < L.kA_row0 + L.kA_rows && L.kA_row0 < d1) return 16;
-      if (L.kB_rows > 0 && d0 < L.kB_row0 + L.kB_rows && L.kB_row0 < d1) return 17;
+      if (L.act & 0x100) {
+        if (L.n_out_tiles > d.n_waves) return 22;
+      } else {
+        if (d0 < L.kA_row0 + L.kA_rows && L.kA_row0 < d1) return 16;
+        if (L.kB_rows > 0 && d0 < L.kB_row0 + L.kB_rows && L.kB_row0 < d1) return 17;
+      }
     } else if (L.kind == 1) {
       if (L.n_out_tiles < 1 || L.n_out_tiles > 4 || L.out_slot < 0) return 18;
       if (L.dst_row0 < 0 || L.dst_row0 + L.n_out_tiles * (L.kA_rows + L.kB_rows) * 2 > d.small_w4) return 21;

@@ -258,12 +258,20 @@ class BrdfModel(ShapeModel):
         if key not in self._plans:
             b = packing.ChainBuilder('raw', in_dim, mode=self.matrix_mode)
             x = b.input
+            resident = self.matrix_mode == 'f32' and all(self._is_std_head(self.net[n]) and self.net[n].widths[1] <= 128 for n in names)
             for slot, name in enumerate(names):
                 net = self.net[name]
-                if self._is_std_head(net):
-                    # [w0, w1, c] with the input concatenated into the last layer: the input image is NOT kept in LDS while
-                    # the two wide activations are live -- it is fetched again (L2) for the last layer, and for the next head.
-                    # That keeps the program at 64 rows, i.e. two workgroups per CU instead of one.
+                if resident:
+                    # [w0, w1, c] with the input concatenated into the last layer.  The input image (32 rows at z_dim = 256) stays in
+                    # LDS for the whole program: layer 1's output is written IN PLACE over layer 0's (its own K operand; the kernel
+                    # holds the accumulators across a barrier), so input + one wide activation = 64 rows = two workgroups per CU and
+                    # ONE fetch of the input per point tile instead of two per head.  Same arithmetic and order as the form below.
+                    y0 = b.dense(f'{name}/0', [x], net.widths[0], net.act[0], keep=[x])
+                    y1 = b.dense(f'{name}/1', [y0], net.widths[1], net.act[1], keep=[x], over=y0)
+                    b.dense_small(f'{name}/2', [y1, x], net.widths[2], net.act[2], slot)
+                elif self._is_std_head(net):
+                    # the input image is NOT kept in LDS while the two wide activations are live -- it is fetched again (L2) for
+                    # the last layer, and for the next head.  That keeps the program at 64 rows, i.e. two workgroups per CU.
                     if x is None:
                         x = b.reload_input()
                     y0 = b.dense(f'{name}/0', [x], net.widths[0], net.act[0])

@@ -20,6 +20,7 @@ MAX_OUTS = 4
 LAYER_INTS = 16
 DESC_INTS = 16 + MAX_LAYERS * LAYER_INTS
 ACT = {None: 0, 'none': 0, 'relu': 1, 'softplus100': 2, 'sigmoid': 3}
+LATE_EPILOGUE = 0x100          # ChainLayer.act bit 8: barrier between the K loops and the write-back (in-place output)
 
 
 class Region:
@@ -91,14 +92,20 @@ class ChainBuilder:
         self.total_rows = self.input.rows
         self.n_slots = 0
 
-    def dense(self, key, segs, out_feats, act, keep=(), out_slot=None):
+    def dense(self, key, segs, out_feats, act, keep=(), out_slot=None, over=None):
         """GEMM layer: K = concat of `segs` (1 or 2 Regions, in Keras concat order), -> new Region.
-        `keep`: regions that later layers still read (must not be overwritten).  Rows are assigned in build()."""
+        `keep`: regions that later layers still read (must not be overwritten).  Rows are assigned in build().
+        `over` (one of `segs`): write the output IN PLACE over that K segment -- the kernel then holds every wave's accumulators
+        across a workgroup barrier between the K loops and the write-back (one output tile per wave at most: out_feats <= 128
+        with 4 waves).  Saves the rows of one region, which is what lets the head programs keep their input resident."""
         assert 1 <= len(segs) <= 2
         tiles = (out_feats + 31) // 32
         dst = Region(None, out_feats, alloc_rows=4 * tiles, mode=self.mode)
-        self.layers.append(dict(kind=0, key=key, segs=list(segs), out=out_feats, act=ACT[act], dst=dst, tiles=tiles,
-                                live=list(segs) + list(keep), out_slot=-1 if out_slot is None else out_slot))
+        if over is not None:
+            assert any(over is s_ for s_ in segs) and tiles <= 4 and 4 * tiles <= over.alloc_rows and self.mode == 'f32'
+        self.layers.append(dict(kind=0, key=key, segs=list(segs), out=out_feats, act=ACT[act] | (LATE_EPILOGUE if over is not None else 0),
+                                dst=dst, tiles=tiles, over=over,
+                                live=[s_ for s_ in segs if s_ is not over] + list(keep), out_slot=-1 if out_slot is None else out_slot))
         if out_slot is not None:
             self.n_slots = max(self.n_slots, out_slot + 1)
         return dst
@@ -148,6 +155,8 @@ class ChainBuilder:
             L = gemm[i]
             need = L['dst'].alloc_rows
             cands = sorted({0} | {r.row0 + r.alloc_rows for r in placed})
+            if L.get('over') is not None:
+                cands = [L['over'].row0]                       # in place: over one of its own K segments
             for c in cands:
                 if any(c < r.row0 + r.alloc_rows and r.row0 < c + need for r in L['live']):
                     continue
