@@ -56,6 +56,22 @@ def test_chain_ragged_sizes(setup, n):
     np.testing.assert_allclose(_np(z), od.pred_enc(pt, specs, od.T(pts['xyz'])).numpy(), rtol=0, atol=3e-6)
 
 
+def test_encoder_and_main_heads_in_one_program_are_bit_identical(setup):
+    """`enc_and_heads` (inference path: encoder + the three continuous-branch heads as ONE layer program, z never read back from
+    HBM) against the two separate programs: z and every head output bit for bit."""
+    od, model = setup['od'], setup['model']
+    from tests.gpu_util import launches
+    xyz = torch.tensor(od.make_points(20011, seed=78)['xyz']).cuda()
+    with torch.no_grad():
+        with launches() as rec:
+            z, d, s_, r = model.enc_and_heads(xyz, 'main')
+        assert rec.counts.get('vqn_mlp_chain_fwd') == 1
+        z2 = model._pred_enc_at(xyz)
+        d2, s2, r2 = model._all_heads(z2, 'main')
+    for a, b in ((z, z2), (d, d2), (s_, s2), (r, r2)):
+        assert a.shape == b.shape and torch.equal(a, b)
+
+
 def test_chain_outputs_do_not_depend_on_the_launch_size(setup):
     """A point's encoder / head outputs are the same bits whether it is evaluated in a 5 k-point or a 100 k-point launch (one tile
     per persistent workgroup pass vs many; ragged last tile): the arithmetic per point has one defined order."""

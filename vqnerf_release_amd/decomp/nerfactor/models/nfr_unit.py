@@ -298,6 +298,53 @@ class BrdfModel(ShapeModel):
                 pdict[f'{name}/{i}'] = (layer.kernel.detach(), layer.bias.detach())
         return cache.get(params, lambda: plan.pack(pdict))
 
+    def _enc_heads_program(self, names):
+        """Encoder + the `names` head family in ONE program (f32 kernels, standard heads): z stays in LDS as the heads' input --
+        it is written to HBM once (slot 0, the VQ branch reads it) and never read back for the continuous branch.  Same per-point
+        arithmetic and order as the two separate programs (bit-identical outputs, tests/test_gpu_decomp.py); 16 layers, 64 rows."""
+        key = 'enc+heads:' + ','.join(names)
+        if key not in self._plans:
+            emb = self.embedder['xyz']
+            b = packing.ChainBuilder('posenc', emb.out_dims, n_freqs=emb.n_freqs, mode='f32')
+            fe, bn = self.net['fine_enc'], self.net['bottleneck']
+            y = b.mlp('fine_enc', fe.widths, fe.act, fe.skip_at, b.input)
+            z = b.mlp('bottleneck', bn.widths, bn.act, bn.skip_at, y, out_slot=0, small_last=False)
+            for slot, name in enumerate(names):
+                net = self.net[name]
+                y0 = b.dense(f'{name}/0', [z], net.widths[0], net.act[0], keep=[z])
+                y1 = b.dense(f'{name}/1', [y0], net.widths[1], net.act[1], keep=[z], over=y0)
+                b.dense_small(f'{name}/2', [y1, z], net.widths[2], net.act[2], slot + 1)
+            self._plans[key] = b.build()
+        return self._plans[key]
+
+    def _can_fuse_enc_heads(self, names):
+        fe, bn = self.net['fine_enc'], self.net['bottleneck']
+        n_layers = len(fe.widths) + len(bn.widths) + 3 * len(names)
+        return (self.matrix_mode == 'f32' and len(names) <= 3 and n_layers <= packing.MAX_LAYERS and bn.widths[-1] == self.z_dim
+                and all(self._is_std_head(self.net[n]) and self.net[n].widths[1] <= 128 for n in names))
+
+    def _fused_enc_heads(self, pts, names):
+        """-> (z [N, z_dim], head outputs...) in one launch."""
+        plan = self._enc_heads_program(names)
+        wbuf, desc = self._program_pack('enc+heads:' + ','.join(names), plan, ['fine_enc', 'bottleneck'] + list(names))
+        widths = [self.z_dim] + [self.net[n].widths[-1] for n in names]
+        outs = _C.mlp_chain_fwd(desc, wbuf, pts.detach().float().contiguous(), widths)
+        return outs[0], outs[1:]
+
+    def enc_and_heads(self, pts, suffix):
+        """(z, basecolor | albedo, ks | spec, rough) of `pts`: `_pred_bias_at` followed by `_all_heads(z, suffix)`, as one fused
+        program where the path allows it (no graph, f32 kernels, standard heads)."""
+        names = [h + '_' + suffix for h in self.HEADS]
+        if self._fused(pts) and self._can_fuse_enc_heads(names) and self._plan_fits_two_workgroups(names):
+            z, (d, s_, r) = self._fused_enc_heads(pts, names)
+            return (self._numerics(z, 'Z'), self._numerics(self._albedo_affine(d), 'Albedo'), self._numerics(s_, 'Specular'),
+                    self._numerics(r, 'Roughness'))
+        z = self._pred_bias_at(pts)
+        return (z,) + tuple(self._all_heads(z, suffix))
+
+    def _plan_fits_two_workgroups(self, names):
+        return self._enc_heads_program(names).n_waves == 4
+
     def _fused_enc(self, pts):
         plan = self._enc_program()
         wbuf, desc = self._program_pack('enc:' + self.matrix_mode, plan, ['fine_enc', 'bottleneck'])
@@ -492,8 +539,7 @@ class Model(BrdfModel):
         n = alpha.shape[0]
         rayo, rgb_m, xyz_m, normal_m = take_rows(mask, rayo), take_rows(mask, rgb), take_rows(mask, xyz), take_rows(mask, normal)
         lvis_m = self.fg_lvis(lvis, mask, xyz_m)
-        z_bias = self._pred_bias_at(xyz_m)
-        basecolor, ks, rough = self._all_heads(z_bias, 'out')
+        z_bias, basecolor, ks, rough = self.enc_and_heads(xyz_m, 'out')
         spec = ks * basecolor
         albedo = (1 - ks) * basecolor
         if not self._fused(xyz_m, albedo, spec, rough) and self.train_backend == 'hip' and xyz_m.is_cuda and mode == 'train':

@@ -164,13 +164,12 @@ class Model(BrdfModel):
         rayo, rgb_m, xyz_m, normal_m = take_rows(mask, rayo, rgb, xyz, normal)
         lvis_m = self.fg_lvis(lvis, mask, xyz_m)
 
-        z_enc = self._pred_enc_at(xyz_m)
+        z_enc, basecolor, ks, rough = self.enc_and_heads(xyz_m, 'main')       # (one launch on the inference path)
         vq, z_vq, vq_loss, embed_ind = self._quantise(z_enc, mode, thres, roll=roll)
         if mode == 'train':                                   # codebook is moved by the EMA, outside the optimiser (:582-583)
             with torch.no_grad():
                 self._codebook.copy_(vq['update'])
 
-        basecolor, ks, rough = self._all_heads(z_enc, 'main')
         spec = ks * basecolor
         albedo = (1 - ks) * basecolor
         vq_albedo, vq_spec, vq_rough = self._all_heads(z_vq, 'vq')
@@ -214,10 +213,9 @@ class Model(BrdfModel):
         lvis_m = self.fg_lvis(lvis, mask, xyz_m)
         if edit_mask is not None:
             edit_mask = (take_rows(mask, edit_mask)[..., 0:1] > 0).to(torch.float32)
-        z_enc = self._pred_enc_at(xyz_m)
+        z_enc, basecolor, ks, rough = self.enc_and_heads(xyz_m, 'main')
         if gen_embed:
             _, _, _, embed_ind = self._quantise(z_enc, mode, thres)
-        basecolor, ks, rough = self._all_heads(z_enc, 'main')
         spec = ks * basecolor
         albedo = (1 - ks) * basecolor
         if edit_mask is not None:
