@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void brdf_shade_kernel(const ShadeArgs a) {
       }
     float S[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};              // sum_l glossy_c * w_c per material set
     float W[3] = {0.f, 0.f, 0.f};                                    // sum_l w_c  (Lambertian part, shared)
-    float wsp[PROBES ? LP : 1][3], wgt[PROBES ? LP : 1];             // relighting: set-0 glossy_c * gw and gw = vis cos area per light
+    float wsp[PROBES ? LP : 1][3];                                   // relighting: set-0 brdf_c * vis * cos * area per light (per unit radiance)
 #pragma unroll
     for (int k = 0; k < LP; ++k) {
       // light direction (shape.py:103-110)
@@ -171,49 +171,79 @@ __global__ __launch_bounds__(256) void brdf_shade_kernel(const ShadeArgs a) {
           S[s][0] = fmaf(g0, wr, S[s][0]); S[s][1] = fmaf(g1, wg, S[s][1]); S[s][2] = fmaf(g2, wb, S[s][2]);
           if (PROBES && s == 0) {
             const float gw = cw * area_k[k];
-            wgt[k] = gw;
-            wsp[k][0] = g0 * gw; wsp[k][1] = g1 * gw; wsp[k][2] = g2 * gw;
+            wsp[k][0] = (g0 + M[0].a[0]) * gw; wsp[k][1] = (g1 + M[0].a[1]) * gw; wsp[k][2] = (g2 + M[0].a[2]) * gw;
           }
         }
     }
-    auto finish = [&](float v) {
-      v = wave_sum(v);
-      if (a.raw) return v;
-      if (a.gamma) v = powf(v * gam_b, gam_i);
-      return clip01(v);
-    };
+    {
+      // the (up to) 12 sums over lights of this point -- rgb of each material set, and set 0's diffuse / specular split: each is
+      // reduced over the wave, then lane i takes value i and lanes 0..11 apply the gamma curve / clip to their own value (ONE powf
+      // per wave instead of twelve: the curve of the 'dtu' / 'hw' data types cost half as much as the shading itself) and store it
+      float u[12];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-      if (s < NS) {
-        const float r = finish(fmaf(M[s].a[0], W[0], S[s][0])), g = finish(fmaf(M[s].a[1], W[1], S[s][1])),
-                    b = finish(fmaf(M[s].a[2], W[2], S[s][2]));
-        if (lane < 3) a.rgb[s][n * 3 + lane] = lane == 0 ? r : (lane == 1 ? g : b);
+      for (int c = 0; c < 3; ++c) {
+        u[c] = wave_sum(fmaf(M[0].a[c], W[c], S[0][c]));
+        u[3 + c] = NS > 1 ? wave_sum(fmaf(M[1].a[c], W[c], S[1][c])) : 0.f;
+        u[6 + c] = split ? wave_sum(M[0].a[c] * W[c]) : 0.f;
+        u[9 + c] = split ? wave_sum(S[0][c]) : 0.f;
       }
+      float t = u[0];
+#pragma unroll
+      for (int i = 1; i < 12; ++i) t = lane == i ? u[i] : t;
+      if (!a.raw) {
+        if (a.gamma) t = powf(t * gam_b, gam_i);
+        t = clip01(t);
+      }
+      // (one store per output array, each from a uniform base pointer)
+      if (lane < 3) a.rgb[0][n * 3 + lane] = t;
+      if (NS > 1 && lane >= 3 && lane < 6) a.rgb[1][n * 3 + lane - 3] = t;
+      if (split && lane >= 6 && lane < 9) a.rgb_diff[n * 3 + lane - 6] = t;
+      if (split && lane >= 9 && lane < 12) a.rgb_spec[n * 3 + lane - 9] = t;
+    }
     if (PROBES) {
-      // all probes against the SAME per-light weights: the [N,L] x [L,3P] contraction of the relighting loop
-      for (int pr = 0; pr < a.n_probes; ++pr) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+      // all probes against the SAME per-light weights: the [N,L] x [L,3P] contraction of the relighting loop, 16 probes at a time.
+      // Every lane first sums its own lights into 48 accumulators (probe, channel); the 64-lane reduction of all 48 is then ONE
+      // halving butterfly (64 -> 32 -> ... -> 1 values per lane, 63 shuffles) instead of 48 separate 6-step reductions (288), and it
+      // leaves lane i with the total of value i = 3 probe + channel -- the order they lie in memory: one coalesced 192 B store.
+      for (int pb = 0; pb < a.n_probes; pb += 16) {
+        float v[64];
 #pragma unroll
-        for (int g = 0; g < LQ; ++g) {
-          const f32x4* pp = reinterpret_cast<const f32x4*>(a.probes + ((size_t)pr * L + 256 * g + 4 * lane) * 3);
-          const f32x4 q0 = pp[0], q1 = pp[1], q2 = pp[2];      // 4 lights x rgb, interleaved
-          const float rad[12] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3], q2[0], q2[1], q2[2], q2[3]};
+        for (int i = 0; i < 64; ++i) v[i] = 0.f;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int k = 4 * g + e;
-            s0 += fmaf(M[0].a[0], wgt[k], wsp[k][0]) * rad[3 * e]; s1 += fmaf(M[0].a[1], wgt[k], wsp[k][1]) * rad[3 * e + 1];
-            s2 += fmaf(M[0].a[2], wgt[k], wsp[k][2]) * rad[3 * e + 2];
+        for (int pi = 0; pi < 16; ++pi) {
+          const int pr = min(pb + pi, a.n_probes - 1);         // (clamped: the surplus sums of a ragged last chunk are not stored)
+#pragma unroll
+          for (int g = 0; g < LQ; ++g) {
+            const f32x4* pp = reinterpret_cast<const f32x4*>(a.probes + ((size_t)pr * L + 256 * g + 4 * lane) * 3);
+            const f32x4 q0 = pp[0], q1 = pp[1], q2 = pp[2];      // 4 lights x rgb, interleaved
+            const float rad[12] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3], q2[0], q2[1], q2[2], q2[3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int k = 4 * g + e;
+              v[3 * pi + 0] = fmaf(wsp[k][0], rad[3 * e + 0], v[3 * pi + 0]);
+              v[3 * pi + 1] = fmaf(wsp[k][1], rad[3 * e + 1], v[3 * pi + 1]);
+              v[3 * pi + 2] = fmaf(wsp[k][2], rad[3 * e + 2], v[3 * pi + 2]);
+            }
           }
         }
-        const float r = finish(s0), gg = finish(s1), b = finish(s2);
-        if (lane < 3) a.rgb_probes[((size_t)n * a.n_probes + pr) * 3 + lane] = lane == 0 ? r : (lane == 1 ? gg : b);
+#pragma unroll
+        for (int half = 32; half >= 1; half >>= 1) {
+          const bool up = (lane & half) != 0;                  // this lane keeps the upper / lower half of its values, sends the other
+#pragma unroll
+          for (int i = 0; i < half; ++i) {
+            const float keep = up ? v[i + half] : v[i];
+            const float send = up ? v[i] : v[i + half];
+            v[i] = keep + __shfl_xor(send, half);
+          }
+        }
+        float t = v[0];                                        // total of value `lane`
+        if (!a.raw) {
+          if (a.gamma) t = powf(t * gam_b, gam_i);
+          t = clip01(t);
+        }
+        const int n_here = min(16, a.n_probes - pb) * 3;
+        if (lane < n_here) a.rgb_probes[((size_t)n * a.n_probes + pb) * 3 + lane] = t;
       }
-    }
-    if (split) {
-      const float r = finish(M[0].a[0] * W[0]), g = finish(M[0].a[1] * W[1]), b = finish(M[0].a[2] * W[2]);
-      if (lane < 3) a.rgb_diff[n * 3 + lane] = lane == 0 ? r : (lane == 1 ? g : b);
-      const float r2 = finish(S[0][0]), g2 = finish(S[0][1]), b2 = finish(S[0][2]);
-      if (lane < 3) a.rgb_spec[n * 3 + lane] = lane == 0 ? r2 : (lane == 1 ? g2 : b2);
     }
   }
 }
