@@ -7,7 +7,7 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch tensor.data_ptr());
- *     the library allocates nothing persistent except the weight-pack handles of vqn_neus_pack_create / _destroy
+ *     the library allocates nothing persistent except the weight-pack handles of vqn_{neus,chain}_pack_create / _destroy
  *   - `stream` is a hipStream_t (NULL = default stream); all work is enqueued asynchronously
  *   - return 0 on success; -1 bad argument, -2 unsupported shape, -3 HIP runtime error;
  *     vqn_last_error() returns the thread-local message of the last failure
@@ -204,6 +204,40 @@ int64_t vqn_neus_sdf_pack_plan(const int32_t* dims, int n_lin, int skip, int mul
                                int f16s, int32_t* desc_out, int32_t* words_out, int64_t words_cap);
 int64_t vqn_neus_col_pack_plan(int d_feature, int mode, int d_hidden, int n_layers, int d_out, int multires_view, int squeeze_out,
                                int feat_tiles, int f16s, int32_t* desc_out, int32_t* words_out, int64_t words_cap);
+
+/* ---- layer programs + weight packs of the Dense-stack evaluator, built in C ---------------------------------- */
+
+/* vqn_mlp_chain_fwd takes a layer program (include/vqn_chain_desc.h) and a weight pack.  These entries build both from a
+ * declarative description of the networks -- what vqnerf_release_amd/decomp/packing.py does for the Python host (f32 kernels):
+ *   kind 0: a Dense chain (networks/mlp.py:24-50): `n_layers` layers of `widths[i]` with activations `acts[i]` (0 none, 1 relu,
+ *           2 softplus(beta = 100), 3 sigmoid); after layer `skip_at` (or -1) the output is concat(y, stack input) (mlp.py:47-48)
+ *   kind 1: a reflectance head (nfr_unit.py:110-129 / vq_nfr.py:135-164): three Dense layers, the stack input concatenated into the
+ *           last one (skip_at = [1]), <= 4 outputs, middle width <= 128; built with its input resident in LDS
+ * `input`: -1 = the program input ([N, in_feats] raw rows, or the positional encoding of [N, 3] points, embedder.py:23-47), or the
+ * index of an earlier kind-0 stack whose output it reads from LDS; `out_slot` (0..3, or -1): which output of vqn_mlp_chain_fwd the
+ * stack's result leaves through.  The reference's encoder is {kind 0 fine_enc, kind 0 bottleneck (input 0, slot 0)} on in_mode 1;
+ * a head family is three kind-1 stacks on in_mode 0 -- or stacked after the encoder in the same program (input 1, slots 1..3).
+ * Weights are passed layer by layer in stack order, Keras layout: kernel [in, out], bias [out] (device pointers). */
+#define VQN_CHAIN_MAX_STACKS 8
+typedef struct vqn_chain_stack {
+  int32_t kind, n_layers;
+  int32_t widths[8], acts[8];
+  int32_t skip_at, input, out_slot;
+} vqn_chain_stack;
+typedef struct vqn_chain_pack vqn_chain_pack;
+int vqn_chain_pack_create(int in_mode, int in_feats, int n_freqs, int n_stacks, const vqn_chain_stack* stacks, vqn_chain_pack** out);
+/* Gather the current weights into the pack (one launch) and refresh the descriptor (the <= 4-output layers keep their biases in
+ * it: one small device -> host copy, the call synchronises `stream`).  kernels / biases: host arrays of vqn_chain_pack_n_weights
+ * device pointers. */
+int vqn_chain_pack_update(vqn_chain_pack* pack, const float* const* kernels, const float* const* biases, void* stream);
+int vqn_chain_pack_n_weights(const vqn_chain_pack* pack);
+const int32_t* vqn_chain_pack_desc(const vqn_chain_pack* pack);     /* host, 272 ints: `desc` of vqn_mlp_chain_fwd */
+const float* vqn_chain_pack_wbuf(const vqn_chain_pack* pack);       /* device: `wbuf` */
+int64_t vqn_chain_pack_floats(const vqn_chain_pack* pack);
+void vqn_chain_pack_destroy(vqn_chain_pack* pack);
+/* Host-only half (no device needed): descriptor (without the small layers' biases) and gather table, as vqn_neus_*_pack_plan. */
+int64_t vqn_chain_pack_plan(int in_mode, int in_feats, int n_freqs, int n_stacks, const vqn_chain_stack* stacks, int32_t* desc_out,
+                            int32_t* words_out, int64_t words_cap);
 
 /* ---- per-ray NeuS kernels (geo/NeuS-ours2/models/renderer.py) ------------------------------ */
 

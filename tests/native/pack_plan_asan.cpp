@@ -9,7 +9,11 @@
 
 #include <vector>
 
+struct vqn_chain_stack { int32_t kind, n_layers, widths[8], acts[8], skip_at, input, out_slot; };
+
 extern "C" {
+int64_t vqn_chain_pack_plan(int in_mode, int in_feats, int n_freqs, int n_stacks, const vqn_chain_stack* stacks, int32_t* desc_out,
+                            int32_t* words_out, int64_t words_cap);
 int64_t vqn_neus_sdf_pack_plan(const int32_t* dims, int n_lin, int skip, int multires, float scale, int max_tiles, int with_reverse,
                                int f16s, int32_t* desc_out, int32_t* words_out, int64_t words_cap);
 int64_t vqn_neus_col_pack_plan(int d_feature, int mode, int d_hidden, int n_layers, int d_out, int multires_view, int squeeze_out,
@@ -77,6 +81,28 @@ int main() {
               return fail("colour plan fill");
             ++checked;
           }
+  // the layer-program builder of the Dense-stack kernel: encoder, head families, encoder + heads, odd widths
+  for (int w : {64, 96, 128})
+    for (int z : {128, 160, 256})
+      for (int nf : {4, 10}) {
+        vqn_chain_stack st[5] = {};
+        st[0] = {0, 4, {w, w, w, w}, {1, 1, 1, 1}, 2, -1, -1};
+        st[1] = {0, 3, {w, z, z}, {0, 1, 3}, -1, 0, 0};
+        for (int h = 0; h < 3; ++h) st[2 + h] = {1, 3, {z, z / 2, h == 0 ? 3 : 1}, {1, 1, 3}, 1, 1, h + 1};
+        for (int n_st : {2, 5}) {
+          int32_t desc[16 + 16 * 16];
+          const int64_t n = vqn_chain_pack_plan(1, 3 + 6 * nf, nf, n_st, st, desc, nullptr, 0);
+          if (n <= 0 || n % 4) return fail("chain plan size");
+          std::vector<int32_t> words((size_t)n * 4);
+          if (vqn_chain_pack_plan(1, 3 + 6 * nf, nf, n_st, st, nullptr, words.data(), n) != n) return fail("chain plan fill");
+          if (desc[6] < 1 || desc[6] > 156) return fail("chain plan rows");
+          ++checked;
+        }
+        vqn_chain_stack hd[3];
+        for (int h = 0; h < 3; ++h) hd[h] = {1, 3, {z, z / 2, 3}, {1, 1, 3}, 1, -1, h};
+        if (vqn_chain_pack_plan(0, z, 0, 3, hd, nullptr, nullptr, 0) <= 0) return fail("head program");
+        ++checked;
+      }
   // rejected shapes must fail cleanly, not read out of bounds
   const int32_t bad[] = {39, 64, 64, 65};
   if (vqn_neus_sdf_pack_plan(bad, 3, 2, 6, 1.0f, 0, 1, 0, nullptr, nullptr, 0) != -2) return fail("skip into the last layer accepted");

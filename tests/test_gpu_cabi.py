@@ -23,6 +23,15 @@ def test_render_through_the_c_abi_alone(flag):
     print(r.stdout.strip())
 
 
+def test_reflectance_call_through_the_c_abi_alone():
+    """tests/cabi_reflectance.py in a child process: layer programs + packs from vqn_chain_pack_*, then encoder + heads, the fused
+    quantiser, the VQ heads and the shading kernel -- against oracle/decomp.py, no module of the package imported."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'cabi_reflectance.py')], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'imported package modules: []' in r.stdout
+    print(r.stdout.strip())
+
+
 @pytest.mark.parametrize('mode', ['f32', 'f16s'])
 @pytest.mark.parametrize('name', ['full', 'small'])
 def test_c_packs_equal_python_packs_on_the_device(name, mode):

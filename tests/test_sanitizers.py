@@ -25,7 +25,8 @@ def _run(cmd, exe, tmp_path):
 def test_pack_planner_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / 'pack_plan_asan')
     out = _run(['g++', '-std=c++17'] + SAN + ['-I', 'include', '-I', 'vqnerf_release_amd/csrc', 'tests/native/pack_plan_asan.cpp',
-                                               'vqnerf_release_amd/csrc/neus_pack_plan.cpp', 'vqnerf_release_amd/csrc/error.cpp', '-o', exe],
+                                               'vqnerf_release_amd/csrc/neus_pack_plan.cpp', 'vqnerf_release_amd/csrc/chain_pack_plan.cpp',
+                                               'vqnerf_release_amd/csrc/error.cpp', '-o', exe],
                exe, tmp_path)
     assert 'shapes ok' in out
 
