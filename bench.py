@@ -456,7 +456,7 @@ def geo_train_setup(dev, rank, batch_rays=2560):
     return runner, step
 
 
-def decomp_train_setup(dev, rank, world, batch_points=2048):
+def decomp_train_setup(dev, rank, world, batch_points=2048, graph=False):
     """The VQ-stage trainer (train_nfr.Trainer: n_rays_per_step = 1024 pixel pairs = 2048 surface points per rank, Keras-Adam with
     amsgrad; under N ranks the [counts || dw] codebook statistics are summed in the middle of the forward pass and the gradient
     bucket after the backward pass, the loss normaliser is the global batch)."""
@@ -470,8 +470,12 @@ def decomp_train_setup(dev, rank, world, batch_points=2048):
     model.set_codebook(cb / np.linalg.norm(cb, axis=1, keepdims=True))
     model.set_light(rng.uniform(0, 1, (16, 32, 3)).astype(np.float32))
     model.get_codebook(); _ = model.light
-    opt = torch.optim.Adam(model.trainable_variables, lr=5e-4, eps=1e-7, amsgrad=True)
-    tr = train_nfr.Trainer(model, opt)
+    if graph:
+        opt, _, clip = train_nfr.make_optimizer(config_from_dict(DECOMP_INI), model.trainable_variables, capturable=True)
+        tr = train_nfr.Trainer(model, opt, clip=clip, graph=True)
+    else:
+        opt = torch.optim.Adam(model.trainable_variables, lr=5e-4, eps=1e-7, amsgrad=True)
+        tr = train_nfr.Trainer(model, opt)
     batch = synthetic_points(batch_points, dev, np.random.default_rng(100 + rank))      # this rank's points
     return model, tr, (lambda: tr.train_iter(batch, global_bs=(batch_points // 2) * world))
 
@@ -510,6 +514,18 @@ def dp_train_leg(dev, rank, world, backend, steps=10, warmup=3):
         from vqnerf_release_amd import parallel
         parallel.assert_replicas_identical([model._codebook] + list(model.trainable_variables), 'decomp replicas')
         out['decomp']['replicas_bit_identical_after_steps'] = True
+    del model, tr, dstep
+    # the same step replayed from HIP graphs: under N ranks three graphs with the two all-reduces between them
+    # (parallel.SegmentedCapture); guarded -- a failure here must not cost the run its headline line
+    try:
+        model, tr, gstep2 = decomp_train_setup(dev, rank, world, graph=True)
+        from vqnerf_release_amd.decomp.nerfactor import train_nfr
+        dt, clk = _timed_steps(gstep2, steps, train_nfr.Trainer.GRAPH_WARMUP + 2, dev, world, backend)
+        out['decomp_graph'] = {'points_per_s': 2048 * world * steps / dt, 'ms_per_step': dt / steps * 1e3,
+                               'graph_segments': len(tr._captured.graphs) if tr._captured is not None else 0,
+                               'all_reduce': _collective_report(clk, steps)}
+    except Exception as e:                                      # noqa: BLE001
+        out['decomp_graph'] = {'error': repr(e)[:300]}
     return out
 
 

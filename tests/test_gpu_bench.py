@@ -51,6 +51,8 @@ def test_two_rank_render_line_and_dp_training_legs():
     assert g['grad_bucket_bytes'] > 3_000_000 and d['grad_bucket_bytes'] > 3_000_000           # 0.80 M and 0.78 M fp32 gradients (+ extras)
     assert d['replicas_bit_identical_after_steps'] is True
     assert g['rays_per_s'] > 0 and d['points_per_s'] > 0
+    dg = dp['decomp_graph']
+    assert 'error' not in dg and dg['graph_segments'] == 3 and dg['all_reduce']['vq_stats']['calls_per_step'] == 1
 
 
 def test_two_rank_train_mode_times_the_dp_step():

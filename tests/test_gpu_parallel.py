@@ -163,3 +163,66 @@ def test_decomp_trainer_dp2_shares_codebook_statistics():
     np.testing.assert_array_equal(got['counts'], model.vq_layer.ema_cluster_size.hidden.cpu().numpy())        # integer counts: exact
     np.testing.assert_allclose(got['codebook'], model._codebook.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
     assert abs(got['loss'] - float(wl)) <= 5e-3 * max(1.0, abs(float(wl)))     # batch-level terms (pair similarity, code spread) are per rank
+
+
+def _decomp_graph_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from oracle import decomp as od
+    from tests.decomp_util import make_batch, make_config
+    from vqnerf_release_amd import parallel
+    from vqnerf_release_amd.decomp.nerfactor import train_nfr
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        cfg = make_config(n_rays_per_step=128)
+        batches = []
+        for i in range(6):
+            full = make_batch(od.make_points(256, seed=40 + i), 'cuda')
+            lo, hi = parallel.shard_range(256)
+            batches.append(tuple(t[lo:hi].contiguous() if torch.is_tensor(t) else t for t in full))
+        runs = {}
+        for graph in (False, True):
+            model = _decomp_model()
+            opt, _, clip = train_nfr.make_optimizer(cfg, model.trainable_variables, capturable=True)
+            tr = train_nfr.Trainer(model, opt, clip=clip, graph=graph)
+            losses = [float(tr.train_iter(b, global_bs=256)[0]) for b in batches]
+            parallel.assert_replicas_identical(list(model.trainable_variables) + [model._codebook], 'replicas (graph=%s)' % graph)
+            runs[graph] = (losses, [v.detach().clone() for v in model.trainable_variables], model._codebook.detach().clone(),
+                           None if tr._captured is None else (len(tr._captured.graphs), [w for _, _, w in tr._captured.exchanges]))
+        (l0, w0, c0, _), (l1, w1, c1, segs) = runs[False], runs[True]
+        same = l0 == l1 and all(torch.equal(a, b) for a, b in zip(w0, w1)) and torch.equal(c0, c1)
+        if rank == 0:
+            q.put(dict(same=bool(same), segs=segs, losses=(l0, l1)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_decomp_trainer_graph_replays_the_data_parallel_step():
+    """Trainer(graph=True) under data parallelism: the captured step is three HIP graphs with the two collectives (VQ statistics,
+    gradient bucket) issued eagerly between them -- parameters, codebook and losses after six steps are bit for bit those of the
+    eager data-parallel trainer, on both ranks."""
+    import time
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_decomp_graph_worker, args=(rk, 2, port, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        t0 = time.time()
+        while q.empty():
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), 'a rank died'
+            assert time.time() - t0 < 300, 'ranks did not finish'
+            time.sleep(0.2)
+        got = q.get()
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    assert got['segs'] == (3, ['all_reduce:vq_stats', 'all_reduce:grad_bucket']), got['segs']
+    assert got['same'], got['losses']

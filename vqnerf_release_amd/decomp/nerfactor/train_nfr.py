@@ -41,7 +41,7 @@ def compute_average_loss(per_example_loss, global_batch_size):
 class Trainer:
     """Holds the DP plumbing of one model: flat gradient bucket + VQ statistics reducer.
 
-    `graph=True` (single rank): the step at the reference's batch size (n_rays_per_step = 1024 pairs) is ~150 short
+    `graph=True`: the step at the reference's batch size (n_rays_per_step = 1024 pairs) is ~150 short
     launches, i.e. launch-bound; the whole of it -- forward, loss, backward, EMA codebook move, Adam -- is captured once
     into a HIP graph and replayed on static buffers.  Conditions, all checked: batches of a fixed shape whose rows are all
     foreground (`outer_sample` only yields such rows; sets `model.assume_foreground`), no explicit `roll` (`thres` as a device
@@ -57,8 +57,8 @@ class Trainer:
         self.graph = bool(graph)
         self._calls, self._captured, self._static_in, self._static_out = 0, None, None, None
         if self.graph:
-            if parallel.is_dist():
-                raise RuntimeError('Trainer(graph=True) is single-rank: the captured step holds no collective')
+            # (data parallel: the captured step is cut at its two collectives -- VQ statistics, gradient bucket -- into three
+            # graphs with the eager all-reduces between them: parallel.SegmentedCapture)
             if not all(g.get('capturable', False) for g in optimizer.param_groups):
                 raise ValueError('Trainer(graph=True) needs a capturable optimiser (make_optimizer(..., capturable=True))')
             if sched is not None and not all(torch.is_tensor(g['lr']) for g in optimizer.param_groups):
@@ -92,11 +92,11 @@ class Trainer:
             self._static_in = [t.clone() if torch.is_tensor(t) else t for t in batch]
             self._static_thres = None if thres is None else thres.detach().clone()
             self._global_bs = global_bs
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            cap = parallel.SegmentedCapture()
+            with cap:
                 # (code dropout: the thresholds are a static input, the draw comes from the device generator inside the graph)
                 self._static_out = self._step(tuple(self._static_in), global_bs, self._static_thres, None, sched=False, fresh_leaves=True)
-            self._captured = g
+            self._captured = cap
         if global_bs != self._global_bs:
             raise ValueError('global_bs is baked into the captured step')
         if (thres is None) != (self._static_thres is None):
@@ -382,7 +382,7 @@ def fit(config, outdir, dataset_train, dataset_vali=None, model=None, device='cu
         model.set_codebook(np.zeros((num_embed, model.z_dim), np.float32))      # placeholder: the checkpoint below holds the values
     _ = model.light                                              # lazy variables exist before the optimiser is built
     model.register_trainable()
-    use_graph = bool(graph) and parallel.world_size() == 1        # the captured step holds no collective
+    use_graph = bool(graph)                                       # (data parallel: the captured step is cut at its collectives)
     opt, sched, clip = make_optimizer(config, model.trainable_variables, capturable=use_graph)
     if latest is not None:
         state = torch.load(latest[1], map_location=device, weights_only=False)

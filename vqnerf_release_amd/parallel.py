@@ -21,11 +21,83 @@ def _clock(name):
     return _C._clock(name)
 
 
+_capture = None          # the SegmentedCapture that is recording, if any
+
+
 def all_reduce_sum(t, group=None, what='all_reduce:scalars'):
-    """dist.all_reduce(SUM) with the optional device-time bracket (bench.py reports collective time per step)."""
+    """dist.all_reduce(SUM) with the optional device-time bracket (bench.py reports collective time per step).  While a
+    SegmentedCapture records, the collective is not issued: the graph segment ends here, the tensor is noted as the exchange
+    between this segment and the next, and a new segment begins."""
+    if _capture is not None:
+        _capture.cut(t, group, what)
+        return t
     with _clock(what):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+class SegmentedCapture:
+    """A training step as HIP graphs WITH its collectives: every `all_reduce_sum` met while recording ends the current graph and
+    starts the next, so a step becomes  graph 0 -> all-reduce(buffer 0) -> graph 1 -> all-reduce(buffer 1) -> graph 2 ...  and
+    `replay()` launches the graphs with the eager collectives between them.  The exchanged tensors are static buffers (the flat
+    gradient bucket, the VQ statistics buffer), all segments share one memory pool, and the recording runs on one side stream.
+    With a single rank nothing cuts and the step is one graph.
+
+        cap = SegmentedCapture()
+        with cap:
+            out = step(static_inputs)          # recorded, not executed
+        cap.replay()                           # every later step
+    """
+
+    def __init__(self):
+        self.graphs, self.exchanges = [], []
+        self._pool = None
+        self._stream = None
+        self._ctx = None
+
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()       # one memory pool for every segment: tensors live across the cuts
+        g.capture_begin(pool=self._pool)
+        self.graphs.append(g)
+
+    def __enter__(self):
+        import gc
+        global _capture
+        assert _capture is None, 'captures do not nest'
+        torch.cuda.synchronize()
+        gc.collect()
+        self._stream = torch.cuda.Stream()
+        self._stream.wait_stream(torch.cuda.current_stream())
+        self._ctx = torch.cuda.stream(self._stream)
+        self._ctx.__enter__()
+        self._begin()
+        _capture = self
+        return self
+
+    def cut(self, tensor, group, what):
+        self.graphs[-1].capture_end()
+        self.exchanges.append((tensor, group, what))
+        self._begin()
+
+    def __exit__(self, exc_type, exc, tb):
+        global _capture
+        _capture = None
+        try:
+            self.graphs[-1].capture_end()
+        finally:
+            self._ctx.__exit__(exc_type, exc, tb)
+            torch.cuda.current_stream().wait_stream(self._stream)
+        return False
+
+    def replay(self):
+        for i, g in enumerate(self.graphs):
+            g.replay()
+            if i < len(self.exchanges):
+                t, group, what = self.exchanges[i]
+                with _clock(what):
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
 def is_dist():
