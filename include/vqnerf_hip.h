@@ -35,6 +35,12 @@ const char* vqn_last_error(void);
 int vqn_vq_assign(const float* x, int64_t N, int D, const float* codebook, int K, const float* sel_mask,
                   float* ws, int64_t* idx, float* quant, float* dist, void* stream);
 
+/* Which kernel a vqn_vq_assign / vqn_vq_quantize_rows call of this shape launches: 0 = the f32 kernel (all distances on the f32
+ * matrix pipe), 1 = the prefiltered kernel (K in 17..64, D <= 256, no mask, no distance output: distances first from f16 pairs, the
+ * codes within the error margin of the minimum then evaluated in the defined f32 order -- the same indices bit for bit, see vq.hip).
+ * The environment variable VQN_VQ_SPLIT=0 forces 0. */
+int vqn_vq_assign_variant(int D, int K, int has_sel_mask, int has_dist);
+
 /* Replaces vq_layers.py:304-309 (the two reductions that feed the EMAs):
  *   counts[k] = #{n : idx[n] == k}   (as float),   dw[d,k] = sum_n x[n,d] [idx[n] == k].
  * counts [K], dw [D,K] are overwritten.  dw == NULL: counts only (x is not read). */

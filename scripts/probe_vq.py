@@ -24,3 +24,12 @@ for K in (15, 32, 64):
     ba = N * (4 * D + 8) + 4 * D * K
     be = N * (4 * D + 8) + 4 * K * (D + 1)
     print(f'K={K}: assign {ta*1e3:.3f} ms {ba/ta/1e9:.0f} GB/s   ema {te*1e3:.3f} ms {be/te/1e9:.0f} GB/s', flush=True)
+
+# the fused quantiser (l2-normalise + assign + straight-through + commitment + counts) on encoder-like rows
+z = torch.sigmoid(torch.randn((N, D), device='cuda', generator=g))
+for K in (15, 32, 64):
+    C = torch.rand((D, K), device='cuda', generator=g)
+    C = C / C.norm(dim=0, keepdim=True)
+    tq = t_gpu(lambda: _C.vq_quantize_rows(z, C))
+    bq = N * (8 * D + 8) + 4 * D * K
+    print(f'K={K}: quantize_rows {tq*1e3:.3f} ms {bq/tq/1e9:.0f} GB/s (variant {_C.vq_assign_variant(D, K)})', flush=True)

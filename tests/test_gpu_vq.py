@@ -32,6 +32,63 @@ def test_assign_bit_exact_vs_strict_oracle(N, D, K):
     np.testing.assert_array_equal(quant.cpu().numpy(), rquant)
 
 
+def _adversarial(N, D, K, kind, seed):
+    """Inputs that stress the candidate filter of vq_assign_split_kernel (K in 17..64, indices only)."""
+    rng = np.random.default_rng(seed)
+    x, C = _data(N, D, K, seed)
+    if kind == 'duplicates':                       # exact ties between code k and k + K/2 -> the lowest index, through the exact passes
+        C[:, K // 2:2 * (K // 2)] = C[:, :K // 2]
+    elif kind == 'clusters':                       # 6 codes within an ulp or two of each other: more than 4 candidates -> plain f32 path
+        for j in range(1, 6):
+            C[:, j] = C[:, 0] * np.float32(1.0 + j * 2.0 ** -23)
+        x[::3] = C[:, 0][None] * rng.uniform(0.5, 1.5, (len(x[::3]), 1)).astype(np.float32)
+    elif kind == 'midpoints':                      # rows half way between two codes (and exactly ON a code)
+        a, b = rng.integers(0, K, N), rng.integers(0, K, N)
+        x = (0.5 * (C[:, a] + C[:, b])).T.astype(np.float32).copy()
+        x[::5] = C[:, a[::5]].T
+    elif kind == 'scaled':                         # unnormalised rows and codes over six decades
+        x = x * (10.0 ** rng.uniform(-3, 3, (N, 1))).astype(np.float32)
+        C = C * (10.0 ** rng.uniform(-1, 1, (1, K))).astype(np.float32)
+    elif kind == 'tiny':                           # rows far below the f16 range (an f16 pair has an ABSOLUTE floor): exact passes decide
+        x = x * (10.0 ** rng.uniform(-12, -4, (N, 1))).astype(np.float32)
+    elif kind == 'huge':                           # elements beyond the f16 range in the rows (some) and in the codebook (all groups)
+        x[::4] *= np.float32(3.0e5)
+        C = C * np.float32(1.0e5)
+    elif kind == 'zeros':
+        x[::2] = 0.0
+        C[:, 3] = 0.0
+    elif kind == 'signed':
+        x = rng.normal(size=(N, D)).astype(np.float32)
+        C = rng.normal(size=(D, K)).astype(np.float32)
+    return np.ascontiguousarray(x, np.float32), np.ascontiguousarray(C, np.float32)
+
+
+@pytest.mark.parametrize('kind', ['plain', 'duplicates', 'clusters', 'midpoints', 'scaled', 'tiny', 'huge', 'zeros', 'signed'])
+@pytest.mark.parametrize('N,D,K', [(3000, 256, 64), (1000, 256, 33), (1000, 256, 17), (2049, 64, 32), (500, 20, 40), (333, 252, 64)])
+def test_prefiltered_assign_is_bit_exact_vs_strict_oracle(N, D, K, kind):
+    """K in 17..64 without a distance output runs vq_assign_split_kernel (f16-pair prefilter + exact evaluation of the candidates):
+    the indices and the gathered rows must be those of the defined arithmetic, including exact ties (lowest index)."""
+    from oracle import vq_strict as vs
+    from vqnerf_release_amd import _C
+    x, C = _adversarial(N, D, K, kind, seed=N + K)
+    assert _C.vq_assign_variant(D, K) == 1 and _C.vq_assign_variant(D, K, has_dist=True) == 0
+    idx, quant, _ = _C.vq_assign(torch.tensor(x).cuda(), torch.tensor(C).cuda(), want_quant=True, want_dist=False)
+    ridx, _, rquant = vs.assign(x, C)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    np.testing.assert_array_equal(quant.cpu().numpy(), rquant)
+
+
+def test_prefiltered_assign_agrees_with_the_f32_kernel_on_non_finite_rows():
+    """NaN / Inf rows send the group down the plain f32 path: same indices as the f32 kernel (which the distance output selects)."""
+    from vqnerf_release_amd import _C
+    x, C = _data(1000, 256, 64, seed=3)
+    x[5, 7] = np.inf; x[40] = np.nan; x[77, 0] = -np.inf; x[300, 100] = 3e38; x[301] = 1e-30
+    xt, Ct = torch.tensor(x).cuda(), torch.tensor(C).cuda()
+    a, _, _ = _C.vq_assign(xt, Ct, want_quant=False, want_dist=False)
+    b, _, _ = _C.vq_assign(xt, Ct, want_quant=False, want_dist=True)
+    np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+
+
 def test_assign_matches_fp64_where_gap_is_clear_and_reports_near_ties():
     from oracle import decomp as od
     from vqnerf_release_amd import _C

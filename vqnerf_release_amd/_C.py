@@ -124,6 +124,11 @@ def vq_assign(x, codebook, sel_mask=None, want_quant=True, want_dist=False):
     return idx, quant, dist
 
 
+def vq_assign_variant(D, K, has_sel_mask=False, has_dist=False):
+    """0: the f32 kernel, 1: the prefiltered kernel (vqn_vq_assign_variant)."""
+    return int(lib().vqn_vq_assign_variant(ctypes.c_int(D), ctypes.c_int(K), ctypes.c_int(bool(has_sel_mask)), ctypes.c_int(bool(has_dist))))
+
+
 def vq_ema_stats(x, idx, K):
     """x [N,D], idx [N] int64 -> (counts [K], dw [D,K])."""
     _f32c(x, 'x')

@@ -233,6 +233,368 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
   }
 }
 
+// ---- K in 17..64: the f32 matrix pipe, not HBM, bounds vq_assign_kernel (2 D K FLOP per 4 D bytes: 164 TFLOP/s at 5 TB/s for K = 64).
+// This kernel gets the SAME indices (and straight-through rows) from 1/5 of the matrix-pipe time:
+//   1. approximate distances on the f16 pipe with f32-level accuracy: every operand as an f16 pair (hi = f16(v), lo = f16((v - hi) 2^11)),
+//      dot ~ hi.hi + 2^-11 (hi.lo + lo.hi) on v_mfma_f32_16x16x32_f16 with f32 accumulation -- |error| <= 3.3e-5 sqrt(|x|^2 |c|^2)
+//      (operand split 2^-22 per factor, the dropped lo.lo term, two f32 summations of D <= 256 terms);
+//   2. every code whose approximate distance lies within a margin M of the row's minimum is a CANDIDATE, M = twice the largest
+//      possible |approximate - defined| distance error: no other code can be the argmin (or tie with it) in the defined arithmetic;
+//   3. a row with one candidate is decided; otherwise the candidates are evaluated EXACTLY, in the defined order (the f32 MFMA chain
+//      of vq_assign_kernel: one 16x16x4 pass per candidate rank, B operand column n = the candidate of row n, result on the diagonal),
+//      and compared as (distance, index) -- ties to the lowest index, as tf.argmax(-d).  More than 4 candidates in a row (or
+//      non-finite inputs): the whole group takes the plain f32 path.
+// Bit-identical to vq_assign_kernel / oracle/vq_strict.c by construction; D <= 256, no code-dropout mask, no distance output
+// (those calls keep the f32 kernel).  One 512-thread workgroup per CU (codebook as f32 + f16 hi / lo fragments: 32 KB per 16 codes).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// DPP lane exchanges inside a row of 16 lanes (no LDS round trip, unlike ds_bpermute): xor 1, xor 2, mirror of 8, mirror of 16 --
+// applied in this order they leave the reduction over the 16 lanes in every lane.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+__device__ __forceinline__ float row16_min(float v) {
+  v = fminf(v, dpp_f<0xB1>(v)); v = fminf(v, dpp_f<0x4E>(v)); v = fminf(v, dpp_f<0x141>(v)); v = fminf(v, dpp_f<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = v + dpp_f<0xB1>(v); v = v + dpp_f<0x4E>(v); v = v + dpp_f<0x141>(v); v = v + dpp_f<0x140>(v);
+  return v;
+}
+
+template <int KT, bool FUSE>
+__global__ __launch_bounds__(512, 1) void vq_assign_split_kernel(const float* __restrict__ x, long N, int D, const float* __restrict__ C,
+                                                                 int K, long long* __restrict__ idx, float* __restrict__ quant,
+                                                                 const VqFuse fuse) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int D16 = (D + 15) >> 4;                                  // <= 16
+  f32x4* Bf = reinterpret_cast<f32x4*>(smem);                     // [KT][D16][64] float4: the f32 fragments of vq_assign_kernel
+  f16x8* Bh = reinterpret_cast<f16x8*>(Bf + (size_t)KT * D16 * 64);   // [KT][8][64] x 8 halves: code 16 kt + (l & 15), d = 32 m + 16 (jj >> 2) + 4 (l >> 4) + (jj & 3)
+  f16x8* Bl = Bh + KT * 8 * 64;
+  float* c2 = reinterpret_cast<float*>(Bl + KT * 8 * 64);         // [KT*16] + [1] max
+  int* hist = reinterpret_cast<int*>(c2 + KT * 16 + 4);           // [KT*16], then 8 floats of wave sums
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, q = lane >> 4;
+
+  for (int i = tid; i < KT * D16 * 64; i += 512) {
+    const int l = i & 63, t = (i >> 6) % D16, kt = (i >> 6) / D16;
+    const int code = 16 * kt + (l & 15);
+    f32x4 v;
+    for (int e = 0; e < 4; ++e) {
+      const int d = 16 * t + 4 * (l >> 4) + e;
+      v[e] = (d < D && code < K) ? C[(size_t)d * K + code] : 0.0f;
+    }
+    Bf[i] = v;
+  }
+  for (int i = tid; i < KT * 8 * 64; i += 512) {
+    const int l = i & 63, m = (i >> 6) & 7, kt = i >> 9;
+    const int code = 16 * kt + (l & 15);
+    f16x8 hi, lo;
+    for (int jj = 0; jj < 8; ++jj) {
+      const int d = 32 * m + 16 * (jj >> 2) + 4 * (l >> 4) + (jj & 3);
+      const float c = (d < D && code < K) ? C[(size_t)d * K + code] : 0.0f;
+      hi[jj] = (_Float16)c;
+      lo[jj] = (_Float16)((c - (float)hi[jj]) * 2048.0f);
+    }
+    Bh[i] = hi; Bl[i] = lo;
+  }
+  __syncthreads();
+  for (int k = tid; k < KT * 16; k += 512) {
+    float acc = 0.f;
+    if (k < K) {
+      const f32x4* col_k = Bf + (size_t)(k >> 4) * D16 * 64 + (k & 15);
+      for (int d4 = 0; 4 * d4 < D; ++d4) {
+        const f32x4 c = col_k[(d4 >> 2) * 64 + (d4 & 3) * 16];
+        acc = fmaf(c[0], c[0], acc);
+        if (4 * d4 + 1 < D) acc = fmaf(c[1], c[1], acc);
+        if (4 * d4 + 2 < D) acc = fmaf(c[2], c[2], acc);
+        if (4 * d4 + 3 < D) acc = fmaf(c[3], c[3], acc);
+      }
+    }
+    c2[k] = k < K ? acc : INFINITY;                                 // padding codes: never a candidate, never the minimum
+    if (FUSE) hist[k] = 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float mx = 0.f, ok = 1.f;
+    for (int k = 0; k < K; ++k) {
+      mx = fmaxf(mx, c2[k]);
+      if (!(c2[k] < 4.0e9f)) ok = 0.f;                                // NaN / Inf / beyond f16 range (|c| may exceed 65504): no prefilter
+    }
+    c2[KT * 16] = mx;
+    c2[KT * 16 + 1] = ok;
+  }
+  __syncthreads();
+  const float c2max = c2[KT * 16];
+  const bool cb_ok = c2[KT * 16 + 1] != 0.f;
+  const float sc2max = __builtin_amdgcn_sqrtf(c2max) * 1.000001f;
+  float c2r[KT];                                                    // |c|^2 of this lane's code in each tile
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) c2r[kt] = c2[16 * kt + col];
+  float wave_loss = 0.f;
+
+  // PRE (the index-only form): the rows of the NEXT group are requested as soon as this group's rows are converted to f16 pairs, so
+  // every wave keeps 16 KB in flight while it computes (two waves per SIMD cannot hide HBM latency otherwise); the rare groups
+  // that need the f32 rows again (exact passes, plain f32 path) re-read them (L2 / MALL hits).
+  constexpr bool PRE = !FUSE;
+  const long n_groups = (N + 15) >> 4;
+  const long rg_step = (long)gridDim.x * 8;
+  auto load_rows = [&](long g, f32x4 (&r)[16]) {
+    const long r0 = g << 4;
+    const float* xr = x + (size_t)((r0 + col) < N ? r0 + col : N - 1) * D;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = *reinterpret_cast<const f32x4*>(xr + min(16 * i + 4 * q, D - 4));
+  };
+  auto mask_rows = [&](long g, f32x4 (&r)[16]) {
+    const bool ok = ((g << 4) + col) < N;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (!(ok && i < D16 && (16 * i + 4 * q) < D)) r[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  // |x|^2 of row `col` in the DEFINED order: four chains over d = 16 t + 4 q + e, then (p0 + p1) + (p2 + p3)
+  auto strict_x2 = [&](const f32x4 (&r)[16]) -> float {
+    float pp = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      pp = fmaf(r[i][0], r[i][0], pp); pp = fmaf(r[i][1], r[i][1], pp); pp = fmaf(r[i][2], r[i][2], pp); pp = fmaf(r[i][3], r[i][3], pp);
+    }
+    pp = pp + __shfl_xor(pp, 16);
+    pp = pp + __shfl_xor(pp, 32);
+    return pp;
+  };
+  f32x4 av[16];
+  long rg = (long)blockIdx.x * 8 + wave;
+  if (PRE && rg < n_groups) load_rows(rg, av);
+  for (; rg < n_groups; rg += rg_step) {
+    const long row0 = rg << 4;
+    const bool rvalid = (row0 + col) < N;
+    const bool ragged = (row0 + 16 > N) || D != 256;                // wave-uniform: only then are there registers to blank
+    if (!PRE) load_rows(rg, av);
+    if (ragged) mask_rows(rg, av);
+    float x2b;                                                      // an upper estimate of |x|^2 (the margin and the range checks only)
+    if (FUSE) {
+      const float pr = strict_x2(av);
+      const float sc = 1.0f / sqrtf(fmaxf(pr, fuse.eps));
+#pragma unroll
+      for (int i = 0; i < 16; ++i) av[i] = av[i] * sc;
+      x2b = (pr * sc) * sc;
+    } else {
+      f32x2 pb = {0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const f32x2 lo2 = {av[i][0], av[i][1]}, hi2 = {av[i][2], av[i][3]};
+        pb = __builtin_elementwise_fma(lo2, lo2, pb);
+        pb = __builtin_elementwise_fma(hi2, hi2, pb);
+      }
+      x2b = pb[0] + pb[1];
+      x2b = x2b + __shfl_xor(x2b, 16);
+      x2b = x2b + __shfl_xor(x2b, 32);
+    }
+    x2b *= 1.00002f;
+    // the margin of row `col` (see 2. below); NaN marks a row the prefilter must not decide
+    const float sx = __builtin_amdgcn_sqrtf(x2b);
+    float mrow = 1.72e-4f * (sx * sc2max) + 1.2e-6f * (x2b + c2max) + 1.0e-9f * (sx + sc2max);
+    if (!(x2b < 4.0e9f)) mrow = NAN;                                // NaN / Inf rows, elements beyond the f16 range
+
+    // ---- 1. approximate dot products on the f16 pipe
+    // (the fragment loads are loop-invariant per lane: without the opaque offset the compiler hoists all 64 KT of them out of the
+    //  group loop -- 256 VGPRs at KT = 4 -- and spills them to scratch)
+    int lofs = lane;
+    asm volatile("" : "+v"(lofs));
+    f16x8 hv[8], lv[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const float v = av[2 * m + (jj >> 2)][jj & 3];
+        const _Float16 h = (_Float16)v;
+        hv[m][jj] = h;
+        lv[m][jj] = (_Float16)fmaf((float)h, -2048.0f, v * 2048.0f);         // (v - hi) 2^11, exactly (one mixed-precision fma)
+      }
+    if (PRE && rg + rg_step < n_groups) load_rows(rg + rg_step, av);          // av now belongs to the next group
+    f32x4 ahh[KT], axx[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) { ahh[kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; axx[kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const f16x8 bh = Bh[(kt * 8 + m) * 64 + lofs], bl = Bl[(kt * 8 + m) * 64 + lofs];
+        ahh[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv[m], bh, ahh[kt], 0, 0, 0);
+        axx[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv[m], bl, axx[kt], 0, 0, 0);
+        axx[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lv[m], bh, axx[kt], 0, 0, 0);
+      }
+    }
+    // ---- 2. candidates: |c|^2 - 2 x.c (the row's |x|^2 is common to its codes) within the margin of the row's minimum.
+    // Margin = 2 x the largest |approximate - defined| difference: the f32 summations of both (3.3e-5 sqrt(|x|^2 |c|^2), which also
+    // covers the 2^-22 relative split error), the two roundings of the distance formula (1.2e-6 (|x|^2 + |c|^2)), and the ABSOLUTE
+    // floor of an f16 pair, 2^-36 per element (1e-9 (|x| + |c|)): tiny rows are decided by the exact passes, not by noise.
+    unsigned rm_lo[4], rm_hi[4];                                    // candidate codes of row 4 q + j, bit = code
+    bool bad = !cb_ok, multi = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float margin = __shfl(mrow, 4 * q + j);                 // accumulator register j of this lane is row 4 q + j
+      float dt[KT], vmin = INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const float dot = fmaf(axx[kt][j], 1.0f / 2048.0f, ahh[kt][j]);
+        dt[kt] = fmaf(-2.0f, dot, c2r[kt]);
+        vmin = fminf(vmin, dt[kt]);
+      }
+      vmin = row16_min(vmin);
+      const float thr = vmin + margin;
+      bad = bad || !(fabsf(thr) < INFINITY);
+      unsigned f[KT];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const unsigned long long bl64 = __ballot(dt[kt] <= thr);    // bit (16 q' + c): code 16 kt + c is a candidate of row 4 q' + j
+        const unsigned half = (q & 2) ? (unsigned)(bl64 >> 32) : (unsigned)bl64;
+        f[kt] = (half >> (16 * (q & 1))) & 0xffffu;
+      }
+      rm_lo[j] = f[0] | (f[1] << 16);
+      rm_hi[j] = KT > 2 ? (f[2] | (f[KT > 2 ? 3 : 0] << 16)) : 0u;
+      multi = multi || (__popc(rm_lo[j]) + __popc(rm_hi[j])) != 1;
+    }
+    const bool any_bad = __ballot(bad) != 0ull;
+    const bool any_multi = __ballot(multi) != 0ull;
+    int best_i[4];
+    if (!any_bad && !any_multi) {
+      // every row is decided by the margin alone
+#pragma unroll
+      for (int j = 0; j < 4; ++j) best_i[j] = rm_lo[j] ? __builtin_ctz(rm_lo[j]) : 32 + __builtin_ctz(rm_hi[j]);
+    } else {
+      f32x4 aw[16];
+      if (PRE) { load_rows(rg, aw); mask_rows(rg, aw); }
+      else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) aw[i] = av[i];
+      }
+      const float p = strict_x2(aw);
+      // this lane's row in the exact passes is row `col`: its mask sits in lane 16 (col >> 2) as entry col & 3
+      unsigned long long my_mask = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned lo = __shfl(rm_lo[j], (col >> 2) * 16), hi = __shfl(rm_hi[j], (col >> 2) * 16);
+        if ((col & 3) == j) my_mask = ((unsigned long long)hi << 32) | lo;
+      }
+      int maxc = __popcll(my_mask);
+#pragma unroll
+      for (int mm = 1; mm < 16; mm <<= 1) maxc = max(maxc, __shfl_xor(maxc, mm));
+      if (!any_bad && maxc <= 4) {
+        // ---- 3. exact evaluation of the candidates, one rank per pass: column n of the B operand is the pass's candidate of row n
+        float bd = INFINITY;
+        int bk = 0;
+        for (int ps = 0; ps < maxc; ++ps) {
+          unsigned long long mk = my_mask;
+          for (int i = 0; i < ps; ++i) mk &= mk - 1;
+          if (mk == 0ull) mk = my_mask;                              // fewer candidates than passes: the first one again
+          const int k = __builtin_ctzll(mk);
+          const f32x4* bp = Bf + ((size_t)(k >> 4) * D16) * 64 + 16 * q + (k & 15);
+          f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < 16; ++t)
+            if (t < D16) {
+              const f32x4 b = bp[t * 64];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t][e], b[e], acc, 0, 0, 0);
+            }
+          // the dot of row r with ITS candidate sits on the diagonal: lane (col = r, q = r >> 2), register r & 3
+          const float dot = (col & 3) == 0 ? acc[0] : ((col & 3) == 1 ? acc[1] : ((col & 3) == 2 ? acc[2] : acc[3]));
+          const float dv = (p - 2.0f * dot) + c2[k];
+          if (dv < bd) { bd = dv; bk = k; }                          // candidates come in increasing code order: ties keep the lowest
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) best_i[j] = __shfl(bk, 20 * q + j);     // row 4 q + j was decided in lane (col = 4 q + j, quarter q)
+      } else {
+        // ---- plain f32 path for this group (vq_assign_kernel's arithmetic)
+        f32x4 acc[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) acc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          if (t < D16) {
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+              const f32x4 b = Bf[((size_t)kt * D16 + t) * 64 + lofs];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t][e], b[e], acc[kt], 0, 0, 0);
+            }
+          }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x2 = __shfl(p, 4 * q + j);
+          float bv = INFINITY;
+          int bi = 0x7fffffff;
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) {
+            const int code = 16 * kt + col;
+            const float dv = (x2 - 2.0f * acc[kt][j]) + c2r[kt];
+            if (code < K && (dv < bv || bi == 0x7fffffff)) { bv = dv; bi = code; }
+          }
+#pragma unroll
+          for (int mm = 1; mm < 16; mm <<= 1) {
+            const float ov = __shfl_xor(bv, mm);
+            const int oi = __shfl_xor(bi, mm);
+            const bool take = (oi != 0x7fffffff) && (bi == 0x7fffffff || ov < bv || (ov == bv && oi < bi));
+            if (take) { bv = ov; bi = oi; }
+          }
+          best_i[j] = bi;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (col == 0 && (row0 + 4 * q + j) < N) idx[row0 + 4 * q + j] = (long long)best_i[j];
+    if (FUSE) {
+      int kr = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kj = __shfl(best_i[j], (col >> 2) * 16);
+        if ((col & 3) == j) kr = kj;
+      }
+      const int kt_r = kr >> 4, kc_r = kr & 15;
+      float lr = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i < D16 && (16 * i + 4 * q) < D) {
+          const f32x4 cq = Bf[((size_t)kt_r * D16 + i) * 64 + 16 * q + kc_r];
+          const f32x4 dq = cq - av[i];
+          lr = fmaf(dq[0], dq[0], lr); lr = fmaf(dq[1], dq[1], lr); lr = fmaf(dq[2], dq[2], lr); lr = fmaf(dq[3], dq[3], lr);
+          if (rvalid && quant != nullptr) *reinterpret_cast<f32x4*>(quant + (size_t)(row0 + col) * D + 16 * i + 4 * q) = av[i] + dq;
+        }
+      }
+      if (!rvalid) lr = 0.f;
+      lr = lr + __shfl_xor(lr, 16);
+      lr = lr + __shfl_xor(lr, 32);
+      lr = row16_sum(lr);
+      wave_loss += lr;
+      if (q == 0 && rvalid) atomicAdd(&hist[kr], 1);
+    } else if (quant != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (row0 + r >= N) continue;                                // wave-uniform
+        const int k = __shfl(best_i[r & 3], (r >> 2) * 16);
+        const int d4 = lane;                                        // float4 index along D (D <= 256)
+        if (4 * d4 < D) {
+          const f32x4 v = Bf[((size_t)(k >> 4) * D16 + (d4 >> 2)) * 64 + (d4 & 3) * 16 + (k & 15)];
+          *reinterpret_cast<f32x4*>(quant + (size_t)(row0 + r) * D + 4 * d4) = v;
+        }
+      }
+    }
+  }
+  if (FUSE) {
+    float* wsum = reinterpret_cast<float*>(hist + KT * 16);
+    if (lane == 0) wsum[wave] = wave_loss;
+    __syncthreads();
+    // (the loss partial of a workgroup: its eight waves in wave order, two by two -- a fixed order, as in vq_assign_kernel)
+    if (tid == 0) fuse.loss_part[blockIdx.x] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + ((wsum[4] + wsum[5]) + (wsum[6] + wsum[7]));
+    for (int k = tid; k < K; k += 512)
+      if (hist[k]) atomicAdd(&fuse.counts[k], (float)hist[k]);
+  }
+}
+
 // y = x / sqrt(max(sum_d x^2, eps)) row by row (tf.linalg.l2_normalize, util/math.py:63-64), with the sum in the DEFINED order of
 // vq_assign_kernel's x2 (lane (row, q) runs one fmaf chain over d = 16 t + 4 q + e, t outer; then (p0 + p1) + (p2 + p3)) and a
 // correctly rounded sqrt and division: oracle/vq_strict.c states the same in plain C.  16 rows per wave, any D % 4 == 0.
@@ -589,7 +951,38 @@ int launch_assign(const float* x, long N, int D, const float* C, int K, const fl
   return VQN_OK;
 }
 
+// The prefiltered kernel (vq_assign_split_kernel) serves K in 17..64 without a code-dropout mask or a distance output; VQN_VQ_SPLIT=0
+// keeps the f32 kernel (A/B measurements, bisecting).
+static bool split_ok(int K, int D, const float* sel, const float* dist) {
+  static const int on = [] { const char* e = getenv("VQN_VQ_SPLIT"); return (e == nullptr || atoi(e) != 0) ? 1 : 0; }();
+  return on && K > 16 && K <= 64 && D <= 256 && sel == nullptr && dist == nullptr;
+}
+
+static long split_grid(long N) {
+  const long n_groups = (N + 15) >> 4;
+  long blocks = (n_groups + 7) / 8;
+  const long cap = (long)vqn_num_cus();
+  if (blocks > cap) blocks = cap;
+  return blocks < 1 ? 1 : blocks;
+}
+
+template <int KT, bool FUSE>
+int launch_split(const float* x, long N, int D, const float* C, int K, long long* idx, float* quant, const VqFuse fuse, hipStream_t s) {
+  const int D16 = (D + 15) >> 4;
+  const size_t lds = (size_t)KT * D16 * 1024 + (size_t)2 * KT * 8 * 1024 + ((size_t)2 * KT * 16 + 4 + 8) * sizeof(float);
+  VQN_CHECK_SHAPE(lds <= 160 * 1024, "codebook does not fit in 160 KB of LDS");
+  VQN_HIP(hipFuncSetAttribute((const void*)vq_assign_split_kernel<KT, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((vq_assign_split_kernel<KT, FUSE>), dim3((unsigned)split_grid(N)), dim3(512), lds, s, x, N, D, C, K, idx, quant, fuse);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
+
 }  // namespace
+
+extern "C" int vqn_vq_assign_variant(int D, int K, int has_sel_mask, int has_dist) {
+  static const float one = 1.f;
+  return split_ok(K, D, has_sel_mask ? &one : nullptr, has_dist ? &one : nullptr) ? 1 : 0;
+}
 
 extern "C" int vqn_vq_assign(const float* x, int64_t N, int D, const float* codebook, int K, const float* sel_mask,
                              float* ws, int64_t* idx, float* quant, float* dist, void* stream) {
@@ -607,6 +1000,9 @@ extern "C" int vqn_vq_assign(const float* x, int64_t N, int D, const float* code
   hipStream_t s = (hipStream_t)stream;
   long long* idx_ll = reinterpret_cast<long long*>(idx);
   const VqFuse nf = {0.f, nullptr, nullptr};
+  if (split_ok(K, D, sel_mask, dist))
+    return KTp == 2 ? launch_split<2, false>(x, N, D, codebook, K, idx_ll, quant, nf, s)
+                    : launch_split<4, false>(x, N, D, codebook, K, idx_ll, quant, nf, s);
   switch (KTp) {
     case 1: return launch_assign<1, false>(x, N, D, codebook, K, sel_mask, ws, idx_ll, quant, dist, nf, s);
     case 2: return launch_assign<2, false>(x, N, D, codebook, K, sel_mask, ws, idx_ll, quant, dist, nf, s);
@@ -645,11 +1041,14 @@ extern "C" int vqn_vq_quantize_rows(const float* z, int64_t N, int D, const floa
   int KTp = KT <= 1 ? 1 : KT <= 2 ? 2 : KT <= 4 ? 4 : 8;
   VQN_CHECK_SHAPE(((size_t)KTp * D16 * 256 + 3 * KTp * 16 + 4) * 4 <= 160 * 1024, "codebook does not fit in 160 KB of LDS");
   long long* idx_ll = reinterpret_cast<long long*>(idx);
-  const long blocks = assign_grid(N);
+  const bool split = split_ok(K, D, sel_mask, nullptr);
+  const long blocks = split ? split_grid(N) : assign_grid(N);
   VQN_CHECK_SHAPE(blocks + 1 <= VQN_QUANT_WS_FLOATS, "workspace too small for this device");
   const VqFuse fz = {eps, ws + 1, counts};             // ws[0]: the code-dropout maximum; ws[1 ..]: per-workgroup loss sums
   int rc;
-  switch (KTp) {
+  if (split)
+    rc = KTp == 2 ? launch_split<2, true>(z, N, D, codebook, K, idx_ll, ste, fz, s) : launch_split<4, true>(z, N, D, codebook, K, idx_ll, ste, fz, s);
+  else switch (KTp) {
     case 1: rc = launch_assign<1, true>(z, N, D, codebook, K, sel_mask, ws, idx_ll, ste, nullptr, fz, s); break;
     case 2: rc = launch_assign<2, true>(z, N, D, codebook, K, sel_mask, ws, idx_ll, ste, nullptr, fz, s); break;
     case 4: rc = launch_assign<4, true>(z, N, D, codebook, K, sel_mask, ws, idx_ll, ste, nullptr, fz, s); break;
