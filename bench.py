@@ -268,7 +268,7 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     per = lambda k: clk[k][1] / clk[k][0] * 1e-3
     launches_per_call = {k: v[0] // 3 for k, v in clk.items()}
     SHADE_BYTES = 2048 + 36 + 56 + 60      # lvis row + xyz/normal/rayo + two (albedo, spec, rough) sets in; normal + 4 rgb outputs
-    SHADE_FLOP_PER_POINT = 68502            # measured: profiles/r02_pmc_units.json (134 FLOP per point and light, both sets)
+    SHADE_FLOP_PER_POINT = 54165            # measured: profiles/r02_pmc_units.json (27.73 GFLOP per 512,000-point launch = 106 FLOP per point and light, both sets; valu_busy_frac 0.77)
     enc_macs, head_macs = model._enc_program().macs_per_point(), 296832 + 297600
     t_chain = sum(v[1] for k, v in clk.items() if k == 'vqn_mlp_chain_fwd') / 3 * 1e-3
     t_shade = per('vqn_brdf_shade_fwd')
@@ -288,8 +288,8 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
                                 'frac': N * SHADE_FLOP_PER_POINT / t_shade / 1e12 / F32_MFMA_PEAK_TFLOPS,
                                 'flop_per_point': SHADE_FLOP_PER_POINT,
                                 'peak_note': '157.3 TFLOP/s is the packed-FMA (v_pk_fma_f32) vector peak; scalar v_fma_f32 issue '
-                                             'peaks at half of it, transcendentals (rsq / rcp / sqrt: 9 per light and material '
-                                             'set here) at an eighth'}},
+                                             'peaks at half of it, transcendentals (rsq / rcp / sqrt: 9 per light for the two '
+                                             'material sets together, counted) at an eighth; counters: valu_busy_frac 0.77'}},
         'kernel_launches_per_call': launches_per_call}
     # ---- the same view on the split-precision MLP kernels (matrix_mode 'f16s': f16 hi/lo operands, 3 f16 MFMAs per product) ----
     with torch.no_grad():
