@@ -14,7 +14,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 - <<PY
 import csv, glob, json, collections, re
-pat = re.compile(r'(mlp_chain_kernel<\d+>|brdf_shade_kernel<\d+>|vq_assign_kernel<\d+, \w+>|vq_ema_mfma_kernel<\d+, \d+>|vq_ema_reduce2_kernel|vq_ste_loss_kernel|vq_counts_kernel)')
+pat = re.compile(r'(mlp_chain_kernel<[^>]*>|brdf_shade_kernel<[^>]*>|vq_assign_kernel<[^>]*>|vq_assign_split_kernel<[^>]*>|l2_normalize_rows_kernel|vq_ema_mfma_kernel<[^>]*>|vq_ema_reduce2_kernel|vq_ste_loss_kernel|vq_counts_kernel)')
 out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), MI355X (scripts/pmc_decomp.sh)",
        "units": "KB per launch as reported; gfx950 corrections of MI355X_MICROARCH.md (HBM section): FETCH_SIZE x2 for 16 B/lane coalesced reads, WRITE_SIZE exact; fabric-side requests, Infinity-Cache hits included",
        "workloads": {}}
@@ -34,7 +34,10 @@ for wl, rows, note in (("call", 512000, "one vq_nfr.call(mode='vali') on a 640,0
             e["traffic_bytes_per_launch"] = (2.0 * e["FETCH_SIZE_KB_mean_per_launch"] + e["WRITE_SIZE_KB_mean_per_launch"]) * 1024.0
             e["traffic_bytes_per_row"] = e["traffic_bytes_per_launch"] / rows
         ks[k] = e
-    out["workloads"][wl] = {"note": note, "rows": rows, "kernels": ks}
+    entry = {"note": note, "rows": rows, "kernels": ks}
+    if wl == "call":                                  # 3 calls per pass: everything the call's kernels move, per foreground row
+        entry["traffic_bytes_per_row_whole_call"] = sum(e.get("traffic_bytes_per_launch", 0.0) * e["launches"] for e in ks.values()) / 3.0 / rows
+    out["workloads"][wl] = entry
 json.dump(out, open("$OUT/pmc_decomp.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:6000])
 PY

@@ -27,6 +27,28 @@ __device__ __forceinline__ float act_rt(int act, float x) {
   }
 }
 
+// One output tile through its activation into the LDS image.  The activation is a run-time field of the layer record, but it is
+// resolved ONCE per tile here: with the switch inside the element loops every accumulator element went through its own chain of
+// scalar compares and branches.
+template <int ACT>
+__device__ __forceinline__ void store_tile_act(f32x4* lds, int row0, int lane, const f32x16& acc) {
+#pragma unroll
+  for (int rq = 0; rq < 4; ++rq) {
+    f32x4 v = acc_quad(acc, rq);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = act_fwd<ACT>(v[j]);
+    lds[(row0 + rq) * 64 + lane] = v;
+  }
+}
+__device__ __forceinline__ void store_tile(int act, f32x4* lds, int row0, int lane, const f32x16& acc) {
+  switch (act) {
+    case ACT_RELU: store_tile_act<ACT_RELU>(lds, row0, lane, acc); break;
+    case ACT_SIGMOID: store_tile_act<ACT_SIGMOID>(lds, row0, lane, acc); break;
+    case ACT_SOFTPLUS100: store_tile_act<ACT_SOFTPLUS100>(lds, row0, lane, acc); break;
+    default: store_tile_act<ACT_NONE>(lds, row0, lane, acc); break;
+  }
+}
+
 struct OutPtrs {
   float* p[VQN_CHAIN_MAX_OUTS];
   int ld[VQN_CHAIN_MAX_OUTS];
@@ -127,25 +149,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_kernel(con
                        [&](int ot, f32x16& acc) { init_bias(bp, ot, lane, acc); },
                        [&](int ot, const f32x16& acc) {
                          if (late) { held = acc; return; }
-#pragma unroll
-                         for (int rq = 0; rq < 4; ++rq) {
-                           f32x4 v = acc_quad(acc, rq);
-#pragma unroll
-                           for (int j = 0; j < 4; ++j) v[j] = act_rt(act, v[j]);
-                           lds[(dst + ot * 4 + rq) * 64 + lane] = v;
-                         }
+                         store_tile(act, lds, dst + ot * 4, lane, acc);
                        });
         if (late) {
           __syncthreads();
-          if (wave < L.n_out_tiles) {
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-              f32x4 v = acc_quad(held, rq);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = act_rt(act, v[j]);
-              lds[(dst + wave * 4 + rq) * 64 + lane] = v;
-            }
-          }
+          if (wave < L.n_out_tiles) store_tile(act, lds, dst + wave * 4, lane, held);
         }
         __syncthreads();
         if (L.out_slot >= 0) {                   // image rows -> [N, out_feats] in HBM (16 B per lane)

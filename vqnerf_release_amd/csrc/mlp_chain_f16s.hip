@@ -4,6 +4,7 @@
 // with the f32 kernel to ~1e-6 relative, not bitwise.  Row counts of every K segment are even (16 features per step);
 // the host builds programs and packs for it with ChainBuilder(mode='f16s').
 #include "mlp_prims_f16s.h"
+#include <type_traits>
 #include "vqn_chain_desc.h"
 
 using namespace eng;
@@ -135,8 +136,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_f16s_kerne
 #pragma unroll
                               for (int s = 0; s < 2; ++s) {
                                 float x[8];
+                                // the activation is resolved once per half tile, not once per element (scalar branch chains)
+                                auto fill = [&](auto act_c) {
 #pragma unroll
-                                for (int jj = 0; jj < 8; ++jj) x[jj] = act_rt(act, fmaf(acc2[8 * s + jj], LO_INV, acc1[8 * s + jj]));
+                                  for (int jj = 0; jj < 8; ++jj) x[jj] = act_fwd<decltype(act_c)::value>(fmaf(acc2[8 * s + jj], LO_INV, acc1[8 * s + jj]));
+                                };
+                                switch (act) {
+                                  case ACT_RELU: fill(std::integral_constant<int, ACT_RELU>{}); break;
+                                  case ACT_SIGMOID: fill(std::integral_constant<int, ACT_SIGMOID>{}); break;
+                                  case ACT_SOFTPLUS100: fill(std::integral_constant<int, ACT_SOFTPLUS100>{}); break;
+                                  default: fill(std::integral_constant<int, ACT_NONE>{}); break;
+                                }
                                 f32x4 hi, lo;
                                 split8(x, hi, lo);
                                 lds[(dst + ot * 4 + 2 * s) * 64 + lane] = hi;

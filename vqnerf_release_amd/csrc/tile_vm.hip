@@ -86,55 +86,83 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void tile_vm_kernel(const
         const int tf1 = ia1 >= 0 ? tab.t[ia1].ld : 0, tf2 = ia2 >= 0 ? tab.t[ia2].ld : 0;
         const int tfs = ist >= 0 ? tab.t[ist].ld : 0, tfs2 = ist2 >= 0 ? tab.t[ist2].ld : 0;
         const f32x4* bp = wbuf + b_off;
-        // epilogue operands of a tile, fetched before its K loop so that their latency hides under it; two sets: a wave's second
-        // tile is set up while the epilogue of its first one is still being issued (gemm_tiles_sw)
-        float r1[2][16], r2[2][16];
-        auto g_init = [&](int ot, auto slot, f32x16& acc) {
-          constexpr int S = decltype(slot)::value;
+        // The op body is instantiated per (epilogue, activation) pair that the shipped programs use: with both as run-time values
+        // every accumulator element went through a chain of scalar compares / branches (1,500 branches in the kernel, each
+        // epilogue element 6-10 of them with waits inside); a pair not in the table runs the generic form (EPI = ACT = -1).
+        auto run_gemm = [&](auto epi_c, auto act_c) {
+          constexpr int EPI_C = decltype(epi_c)::value, ACT_C = decltype(act_c)::value;
+          const int epi_ = EPI_C >= 0 ? EPI_C : epi, act_ = ACT_C >= 0 ? ACT_C : act;
+          // epilogue operands of a tile, fetched before its K loop so that their latency hides under it; two sets: a wave's second
+          // tile is set up while the epilogue of its first one is still being issued (gemm_tiles_sw)
+          float r1[2][16], r2[2][16];
+          auto g_init = [&](int ot, auto slot, f32x16& acc) {
+            constexpr int S = decltype(slot)::value;
 #ifdef VQN_DIAG_VM_NO_AUX
-          for (int e = 0; e < 16; ++e) { r1[S][e] = 0.5f; r2[S][e] = 0.25f; }
+            for (int e = 0; e < 16; ++e) { r1[S][e] = 0.5f; r2[S][e] = 0.25f; }
 #else
-          if (epi != VM_EPI_ACT) {
+            if (epi_ != VM_EPI_ACT) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) r1[S][e] = a1[tf_off(tile, tf1, ot, 8 * (e >> 2) + 2 * (e & 3) + h, p)];
-            if (epi != VM_EPI_MUL_DACT) {
+              for (int e = 0; e < 16; ++e) r1[S][e] = a1[tf_off(tile, tf1, ot, 8 * (e >> 2) + 2 * (e & 3) + h, p)];
+              if (epi_ != VM_EPI_MUL_DACT) {
 #pragma unroll
-              for (int e = 0; e < 16; ++e) r2[S][e] = a2[tf_off(tile, tf2, ot, 8 * (e >> 2) + 2 * (e & 3) + h, p)];
+                for (int e = 0; e < 16; ++e) r2[S][e] = a2[tf_off(tile, tf2, ot, 8 * (e >> 2) + 2 * (e & 3) + h, p)];
+              }
             }
-          }
 #endif
-          if (accum) init_rows(lds + (dst + ot * 4) * 64, lane, acc);
-          else if (b_off >= 0) init_bias(bp, ot, lane, acc);
-          else init_zero(acc);
-        };
-        auto g_epi = [&](int ot, auto slot, int rq, const f32x16& acc) {
-          constexpr int S = decltype(slot)::value;
-          f32x4 y;
+            if (accum) init_rows(lds + (dst + ot * 4) * 64, lane, acc);
+            else if (b_off >= 0) init_bias(bp, ot, lane, acc);
+            else init_zero(acc);
+          };
+          auto g_epi = [&](int ot, auto slot, int rq, const f32x16& acc) {
+            constexpr int S = decltype(slot)::value;
+            f32x4 y, y2;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float a = acc[4 * rq + j];
-            const int fi = 8 * rq + 2 * j + h;
-            float v;
-            if (epi == VM_EPI_ACT) v = vm_act(act, a);
-            else {
-              const float o1 = r1[S][4 * rq + j];
-              const float d1 = vm_dact(act, o1);
-              if (epi == VM_EPI_MUL_DACT) v = a * d1;
-              else if (epi == VM_EPI_TANGENT) {
-                v = a * d1;
-                if (st2) st2[tf_off(tile, tfs2, ot, fi, p)] = pvalid ? r2[S][4 * rq + j] * a * vm_d2ratio(act, o1) : 0.f;
-              } else v = a * d1 + r2[S][4 * rq + j];
+            for (int j = 0; j < 4; ++j) {
+              const float a = acc[4 * rq + j];
+              float v, v2 = 0.f;
+              if (epi_ == VM_EPI_ACT) v = vm_act(act_, a);
+              else {
+                const float o1 = r1[S][4 * rq + j];
+                const float d1 = vm_dact(act_, o1);
+                if (epi_ == VM_EPI_MUL_DACT) v = a * d1;
+                else if (epi_ == VM_EPI_TANGENT) {
+                  v = a * d1;
+                  v2 = r2[S][4 * rq + j] * a * vm_d2ratio(act_, o1);
+                } else v = a * d1 + r2[S][4 * rq + j];
+              }
+              y[j] = v;
+              y2[j] = v2;
             }
-            y[j] = v;
-            if (st) st[tf_off(tile, tfs, ot, fi, p)] = pvalid ? v : 0.f;
-          }
-          if (dst >= 0) lds[(dst + ot * 4 + rq) * 64 + lane] = y;
+            if (st) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) st[tf_off(tile, tfs, ot, 8 * rq + 2 * j + h, p)] = pvalid ? y[j] : 0.f;
+            }
+            if (epi_ == VM_EPI_TANGENT && st2) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) st2[tf_off(tile, tfs2, ot, 8 * rq + 2 * j + h, p)] = pvalid ? y2[j] : 0.f;
+            }
+            if (dst >= 0) lds[(dst + ot * 4 + rq) * 64 + lane] = y;
+          };
+          using S0 = std::integral_constant<int, 0>;
+          using S1 = std::integral_constant<int, 1>;
+          gemm_tiles_sw<NW>(lds, ks, wbuf + w_off, n_out_tiles, wave, lane,
+                            [&](int ot, int slot, f32x16& acc) { if (slot == 0) g_init(ot, S0{}, acc); else g_init(ot, S1{}, acc); },
+                            [&](int ot, int slot, int rq, const f32x16& acc) { if (slot == 0) g_epi(ot, S0{}, rq, acc); else g_epi(ot, S1{}, rq, acc); });
         };
-        using S0 = std::integral_constant<int, 0>;
-        using S1 = std::integral_constant<int, 1>;
-        gemm_tiles_sw<NW>(lds, ks, wbuf + w_off, n_out_tiles, wave, lane,
-                          [&](int ot, int slot, f32x16& acc) { if (slot == 0) g_init(ot, S0{}, acc); else g_init(ot, S1{}, acc); },
-                          [&](int ot, int slot, int rq, const f32x16& acc) { if (slot == 0) g_epi(ot, S0{}, rq, acc); else g_epi(ot, S1{}, rq, acc); });
+#define VM_PAIR(E, A) case (E) * 8 + (A): run_gemm(std::integral_constant<int, (E)>{}, std::integral_constant<int, (A)>{}); break;
+        switch (epi * 8 + act) {
+          VM_PAIR(VM_EPI_ACT, ACT_NONE)
+          VM_PAIR(VM_EPI_ACT, ACT_RELU)
+          VM_PAIR(VM_EPI_ACT, ACT_SOFTPLUS100)
+          VM_PAIR(VM_EPI_ACT, ACT_SIGMOID)
+          VM_PAIR(VM_EPI_MUL_DACT, ACT_RELU)
+          VM_PAIR(VM_EPI_MUL_DACT, ACT_SOFTPLUS100)
+          VM_PAIR(VM_EPI_MUL_DACT, ACT_SIGMOID)
+          VM_PAIR(VM_EPI_TANGENT, ACT_SOFTPLUS100)
+          VM_PAIR(VM_EPI_BWD2, ACT_SOFTPLUS100)
+          default: run_gemm(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{}); break;
+        }
+#undef VM_PAIR
         __syncthreads();
       } else if (kind == VM_LD_POSENC || kind == VM_LD_POSENC_JVP) {
         const bool jvp = kind == VM_LD_POSENC_JVP;
