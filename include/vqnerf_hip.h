@@ -298,9 +298,15 @@ int vqn_neus_composite_bwd(const float* rays_o, const float* rays_d, const float
  * programs (vqnerf_release_amd/geo/train_programs.py): forward with saved activations, colour-net reverse
  * sweep, SDF tangent pass + reverse sweep with second-order source terms.
  *   desc_dev / desc_host: the same descriptor in device and host memory (the host copy is validated);
- *   tensors[i] / tensor_ld[i]: device pointers and leading dims (VEC: row stride, TFMT: feature tiles). */
+ *   tensors[i] / tensor_ld[i]: device pointers and leading dims (VEC: row stride, TFMT: feature tiles; negative: see
+ *   vqn_tile_program_grid). */
 int vqn_tile_program(const void* desc_dev, const int32_t* desc_host, const float* wbuf, float* const* tensors,
                      const int32_t* tensor_ld, int n_tensors, int64_t N, void* stream);
+/* Number of workgroups vqn_tile_program launches for this program and N points.  A tensor passed with a NEGATIVE tensor_ld
+ * (-feature_tiles) is a per-workgroup temporary of the program: written and read back for the same tile by the same workgroup
+ * (GEMM aux / store operands only), it is addressed by workgroup instead of by tile and needs only [grid][tiles][32][32] floats --
+ * small enough to stay in L2 / Infinity Cache instead of streaming [n_tiles] images to HBM and back. */
+int64_t vqn_tile_program_grid(const int32_t* desc_host, int64_t N);
 
 /* Weight normalisation of all layers of a network in one launch and its backward in another (the geo trainer's per-step
  * chain rule through nn.utils.weight_norm, fields.py:65-66 / :139-140: w = g * v / ||v||_row).  Host arrays of n_layers

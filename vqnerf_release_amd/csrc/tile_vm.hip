@@ -10,6 +10,7 @@
 // saved TFMT tensors by csrc/wgrad.hip.  Formats: include/vqn_vm_desc.h.
 #include "mlp_prims.h"
 #include <type_traits>
+#include <vector>
 #include "vqn_vm_desc.h"
 
 using namespace eng;
@@ -85,6 +86,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void tile_vm_kernel(const
 #endif
         const int tf1 = ia1 >= 0 ? tab.t[ia1].ld : 0, tf2 = ia2 >= 0 ? tab.t[ia2].ld : 0;
         const int tfs = ist >= 0 ? tab.t[ist].ld : 0, tfs2 = ist2 >= 0 ? tab.t[ist2].ld : 0;
+        // a tensor flagged per-workgroup (pad != 0) is a temporary of THIS program: written and read back by the same workgroup for
+        // the same tile, so it is addressed by workgroup, not by tile -- [grid] images that stay in L2 / Infinity Cache instead of
+        // [n_tiles] images streamed to HBM and back
+        const long tl1 = (ia1 >= 0 && tab.t[ia1].pad) ? (long)blockIdx.x : tile, tl2 = (ia2 >= 0 && tab.t[ia2].pad) ? (long)blockIdx.x : tile;
+        const long tls = (ist >= 0 && tab.t[ist].pad) ? (long)blockIdx.x : tile, tls2 = (ist2 >= 0 && tab.t[ist2].pad) ? (long)blockIdx.x : tile;
         const f32x4* bp = wbuf + b_off;
         // The op body is instantiated per (epilogue, activation) pair that the shipped programs use: with both as run-time values
         // every accumulator element went through a chain of scalar compares / branches (1,500 branches in the kernel, each
@@ -102,10 +108,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void tile_vm_kernel(const
 #else
             if (epi_ != VM_EPI_ACT) {
 #pragma unroll
-              for (int e = 0; e < 16; ++e) r1[S][e] = a1[tf_off(tile, tf1, ot, 8 * (e >> 2) + 2 * (e & 3) + h, p)];
+              for (int e = 0; e < 16; ++e) r1[S][e] = a1[tf_off(tl1, tf1, ot, 8 * (e >> 2) + 2 * (e & 3) + h, p)];
               if (epi_ != VM_EPI_MUL_DACT) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) r2[S][e] = a2[tf_off(tile, tf2, ot, 8 * (e >> 2) + 2 * (e & 3) + h, p)];
+                for (int e = 0; e < 16; ++e) r2[S][e] = a2[tf_off(tl2, tf2, ot, 8 * (e >> 2) + 2 * (e & 3) + h, p)];
               }
             }
 #endif
@@ -135,11 +141,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void tile_vm_kernel(const
             }
             if (st) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) st[tf_off(tile, tfs, ot, 8 * rq + 2 * j + h, p)] = pvalid ? y[j] : 0.f;
+              for (int j = 0; j < 4; ++j) st[tf_off(tls, tfs, ot, 8 * rq + 2 * j + h, p)] = pvalid ? y[j] : 0.f;
             }
             if (epi_ == VM_EPI_TANGENT && st2) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) st2[tf_off(tile, tfs2, ot, 8 * rq + 2 * j + h, p)] = pvalid ? y2[j] : 0.f;
+              for (int j = 0; j < 4; ++j) st2[tf_off(tls2, tfs2, ot, 8 * rq + 2 * j + h, p)] = pvalid ? y2[j] : 0.f;
             }
             if (dst >= 0) lds[(dst + ot * 4 + rq) * 64 + lane] = y;
           };
@@ -365,6 +371,15 @@ extern "C" int vqn_tfmt_unpack(const float* t, int tiles_f, int64_t N, int F, fl
   return VQN_OK;
 }
 
+extern "C" int64_t vqn_tile_program_grid(const int32_t* desc_host, int64_t N) {
+  if (desc_host == nullptr || N <= 0) return 0;
+  const VmDesc* d = reinterpret_cast<const VmDesc*>(desc_host);
+  const size_t lds = (size_t)d->total_rows * 1024;
+  const long n_tiles = (N + 31) / 32;
+  long grid = (long)vqn_num_cus() * ((d->n_waves == 4 && 2 * lds <= 160 * 1024) ? 2 : 1);
+  return grid > n_tiles ? n_tiles : grid;
+}
+
 extern "C" int vqn_tile_program(const void* desc_dev, const int32_t* desc_host, const float* wbuf,
                                 float* const* tensors, const int32_t* tensor_ld, int n_tensors, int64_t N,
                                 void* stream) {
@@ -377,6 +392,9 @@ extern "C" int vqn_tile_program(const void* desc_dev, const int32_t* desc_host, 
   const size_t lds = (size_t)d->total_rows * 1024;
   VQN_CHECK_SHAPE(d->total_rows >= 1 && lds <= 160 * 1024, "program does not fit in 160 KB of LDS");
   // validate every op against the row budget and the tensor table before anything is launched
+  std::vector<int32_t> ld_abs(tensor_ld, tensor_ld + n_tensors);
+  for (int i = 0; i < n_tensors; ++i) ld_abs[i] = tensor_ld[i] < 0 ? -tensor_ld[i] : tensor_ld[i];
+  { const int32_t* tensor_ld = ld_abs.data();
   for (int i = 0; i < d->n_ops; ++i) {
     const VmOp& op = d->ops[i];
     auto row_ok = [&](int r0, int n) { return r0 >= 0 && n >= 0 && r0 + n <= d->total_rows; };
@@ -406,9 +424,21 @@ extern "C" int vqn_tile_program(const void* desc_dev, const int32_t* desc_host, 
       return VQN_ESHAPE;
     }
   }
+  }
+  // per-workgroup tensors (negative ld) are understood by the GEMM op's aux / store operands only
+  for (int i = 0; i < d->n_ops; ++i) {
+    const VmOp& op = d->ops[i];
+    const int nongemm[3] = {op.kind == VM_LD_T ? op.p[0] : -1, op.kind == VM_LD_VEC ? op.p[4] : -1,
+                            op.kind == VM_LD_POSENC ? op.p[4] : (op.kind == VM_LD_POSENC_JVP ? op.p[5] : (op.kind == VM_LD_EXTRAS ? op.p[5] : -1))};
+    for (int k = 0; k < 3; ++k)
+      if (nongemm[k] >= 0 && nongemm[k] < n_tensors && tensor_ld[nongemm[k]] < 0) {
+        vqn_set_error("vqn_tile_program: bad argument: op %d addresses a per-workgroup tensor (negative ld) outside a GEMM aux / store operand", i);
+        return VQN_EARG;
+      }
+  }
   VmTable tab;
   memset(&tab, 0, sizeof(tab));
-  for (int i = 0; i < n_tensors; ++i) { tab.t[i].ptr = tensors[i]; tab.t[i].ld = tensor_ld[i]; }
+  for (int i = 0; i < n_tensors; ++i) { tab.t[i].ptr = tensors[i]; tab.t[i].ld = tensor_ld[i] < 0 ? -tensor_ld[i] : tensor_ld[i]; tab.t[i].pad = tensor_ld[i] < 0; }
   const long n_tiles = (N + 31) / 32;
   hipStream_t s = (hipStream_t)stream;
   const VmDesc* dd = reinterpret_cast<const VmDesc*>(desc_dev);

@@ -445,12 +445,23 @@ class NeusTrainEngine:
         return L.flatten(src)[gidx], descs
 
     # launches --------------------------------------------------------------------------------------
+    def _scratch_names(self):
+        """Temporaries of ONE program (the tangent pass's second-order sources, consumed by the reverse sweep of the same prog_sbwd
+        program for the same tile): per-workgroup images that stay cache-resident (vqn_tile_program_grid, negative ld)."""
+        return {'S%d' % l for l in range(self.nL)}
+
     def alloc_tensors(self, P, device):
         nt = (P + 31) // 32
+        L = _C.lib()
+        L.vqn_tile_program_grid.restype = ctypes.c_int64
+        scratch, n_wg = self._scratch_names(), nt
+        if scratch:
+            d_host = self._static(device)[2]['prog_sbwd'][0]
+            n_wg = int(L.vqn_tile_program_grid(d_host.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(P)))
         out = {}
         for name, (kind, w) in self._tensor_specs().items():
             out[name] = torch.empty((P, w), dtype=torch.float32, device=device) if kind == 'vec' \
-                else torch.empty((nt, w, 32, 32), dtype=torch.float32, device=device)
+                else torch.empty((n_wg if name in scratch else nt, w, 32, 32), dtype=torch.float32, device=device)
         out['ONES'].fill_(1.0)
         return out
 
@@ -459,8 +470,8 @@ class NeusTrainEngine:
         d_host, d_dev = descs[which]
         names = list(prog.tn.keys())
         ptrs = (ctypes.c_void_p * len(names))(*[tensors[n].data_ptr() for n in names])
-        specs = self._tensor_specs()
-        lds = np.array([specs[n][1] for n in names], np.int32)
+        specs, scratch = self._tensor_specs(), self._scratch_names()
+        lds = np.array([-specs[n][1] if n in scratch else specs[n][1] for n in names], np.int32)
         with _C._clock('vqn_tile_program:' + which):
             rc = _C.lib().vqn_tile_program(ctypes.c_void_p(d_dev.data_ptr()), d_host.ctypes.data_as(ctypes.c_void_p),
                                            _C._ptr(wbuf), ptrs, lds.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(len(names)),
