@@ -100,43 +100,55 @@ __device__ __forceinline__ void gemm_tiles(const f32x4* __restrict__ lds, const 
 // output tiles; a wave owns two at 256 outputs and 4 waves).  init(ot, slot, acc) / epi_rq(ot, slot, rq, acc): `slot` (0 / 1,
 // compile-time at every call) tells the caller which of two sets of per-tile epilogue operands to use -- tile B's are fetched
 // while tile A's are still needed.  Same arithmetic and order as gemm_tiles.
-template <int NW = 4, class Init, class EpiRq>
+// aux(ot, slot): issue the loads of a tile's epilogue operands.  Tile B's are issued together with tile A's, a whole K loop before
+// they are used (the vector-memory counter is in order: a load requested at the start of its own tile's K loop is waited for at that
+// loop's first weight-fragment wait).  NB: weight-fragment buffers of four K groups each; fragments run NB - 1 blocks ahead of the
+// multiplies (NB = 2: the scheme of gemm_tiles).
+template <int NW = 4, int NB = 2, class Aux, class Init, class EpiRq>
 __device__ __forceinline__ void gemm_tiles_sw(const f32x4* __restrict__ lds, const KSegs ks, const f32x4* __restrict__ w,
-                                              const int n_out_tiles, const int wave, const int lane, Init init, EpiRq epi_rq) {
+                                              const int n_out_tiles, const int wave, const int lane, Aux aux, Init init, EpiRq epi_rq) {
   const int ng = ks.nA + ks.nB;
   auto brow = [&](int g) { g = min(g, ng - 1); return ((g < ks.nA) ? (ks.rowA + g) : (ks.rowB + (g - ks.nA))) * 64 + lane; };
   for (int base = wave; base < n_out_tiles; base += 2 * NW) {
     f32x16 accA, accB;
-    f32x4 a0[4], a1[4], bc, bn;
-    auto group = [&](const f32x4& a, f32x16& acc) {
+    f32x4 a[NB][4], bc, bn;
+    auto group = [&](const f32x4& af, f32x16& acc) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bc[j], acc, 0, 0, 0);
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bc[j], acc, 0, 0, 0);
     };
-    auto block = [&](const f32x4 (&a)[4], int g0, f32x16& acc) {
+    auto block = [&](const f32x4 (&af)[4], int g0, f32x16& acc) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         bn = lds[brow(g0 + i + 1)];
-        if (g0 + i < ng) group(a[i], acc);
+        if (g0 + i < ng) group(af[i], acc);
         bc = bn;
+      }
+    };
+    auto fill = [&](const f32x4* __restrict__ wp, f32x4 (&af)[4], int g0) {          // unconditional, clamped (see gemm_tiles)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = wp[min(g0 + i, ng - 1) * 64];
+    };
+    // one round of NB blocks starting at group g: block b multiplies buffer b while the buffer block b - 1 used is refilled
+    auto round = [&](const f32x4* __restrict__ wp, int g, int b_first, f32x16& acc) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (b < b_first) continue;
+        fill(wp, a[(b + NB - 1) % NB], g + 4 * (b + NB - 1));
+        block(a[b], g + 4 * b, acc);
       }
     };
     // ---- tile A
     {
       const f32x4* __restrict__ wp = w + (size_t)base * ng * 64 + lane;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a0[i] = wp[min(i, ng - 1) * 64];
+      for (int b = 0; b < NB - 1; ++b) fill(wp, a[b], 4 * b);
       bc = lds[brow(0)];
       __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) only (see gemm_tiles)
+      aux(base, 0);
+      if (base + NW < n_out_tiles) aux(base + NW, 1);
       init(base, 0, accA);
       __builtin_amdgcn_s_setprio(1);
-      for (int g = 0; g < ng; g += 8) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a1[i] = wp[min(g + 4 + i, ng - 1) * 64];
-        block(a0, g, accA);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a0[i] = wp[min(g + 8 + i, ng - 1) * 64];
-        block(a1, g + 4, accA);
-      }
+      for (int g = 0; g < ng; g += 4 * NB) round(wp, g, 0, accA);
       __builtin_amdgcn_s_setprio(0);
     }
     const int otB = base + NW;
@@ -149,31 +161,21 @@ __device__ __forceinline__ void gemm_tiles_sw(const f32x4* __restrict__ lds, con
     {
       const f32x4* __restrict__ wp = w + (size_t)otB * ng * 64 + lane;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a0[i] = wp[min(i, ng - 1) * 64];
+      for (int b = 0; b < NB - 1; ++b) fill(wp, a[b], 4 * b);
       bc = lds[brow(0)];
       __builtin_amdgcn_s_waitcnt(0x0F70);
       init(otB, 1, accB);
       __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a1[i] = wp[min(4 + i, ng - 1) * 64];
+      fill(wp, a[NB - 1], 4 * (NB - 1));
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         bn = lds[brow(i + 1)];
-        if (i < ng) group(a0[i], accB);
+        if (i < ng) group(a[0][i], accB);
         bc = bn;
         epi_rq(base, 0, i, accA);
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a0[i] = wp[min(8 + i, ng - 1) * 64];
-      block(a1, 4, accB);
-      for (int g = 8; g < ng; g += 8) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a1[i] = wp[min(g + 4 + i, ng - 1) * 64];
-        block(a0, g, accB);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a0[i] = wp[min(g + 8 + i, ng - 1) * 64];
-        block(a1, g + 4, accB);
-      }
+      round(wp, 0, 1, accB);
+      for (int g = 4 * NB; g < ng; g += 4 * NB) round(wp, g, 0, accB);
       __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) epi_rq(otB, 1, rq, accB);

@@ -13,7 +13,31 @@
 #include <vector>
 #include "vqn_vm_desc.h"
 
+#ifndef VQN_VM_NB
+#define VQN_VM_NB 2          // weight-fragment buffers of the K loops (mlp_prims.h, gemm_tiles_sw)
+#endif
+
 using namespace eng;
+
+// In-kernel phase stamps of the DIAGNOSTIC build (make stamps; never shipped): wave 0 of every workgroup accumulates shader-clock
+// cycles: [0] op decode + non-GEMM ops, [1] GEMM tile set-up (epilogue-operand fetches issued, accumulators initialised),
+// [2] K loops (operand waits included), [3] epilogues (activation derivative, stash stores, LDS write), [4] barrier waits,
+// [5] total, [6] workgroups.
+#ifdef VQN_STAMPS
+__device__ unsigned long long g_stamps_vm[8];
+#define VS_DECL unsigned long long vs_[6] = {0, 0, 0, 0, 0, 0}; unsigned long long vs_prev = __builtin_amdgcn_s_memtime(); const unsigned long long vs_begin = vs_prev;
+#define VS(i) { const unsigned long long vs_now = __builtin_amdgcn_s_memtime(); vs_[i] += vs_now - vs_prev; vs_prev = vs_now; }
+#define VS_FLUSH if (threadIdx.x == 0) { vs_[5] = __builtin_amdgcn_s_memtime() - vs_begin; for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&g_stamps_vm[i_], vs_[i_]); atomicAdd(&g_stamps_vm[6], 1ull); }
+extern "C" int vqn_debug_read_stamps_vm(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_vm), sizeof(unsigned long long) * 8) != hipSuccess) return -3;
+  if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_vm), z, sizeof(z)) != hipSuccess) return -3; }
+  return 0;
+}
+#else
+#define VS_DECL
+#define VS(i)
+#define VS_FLUSH
+#endif
 
 namespace {
 
@@ -64,6 +88,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void tile_vm_kernel(const
   const long n_tiles = (N + 31) >> 5;
   const int n_ops = dp->n_ops;
   float* ldsf = reinterpret_cast<float*>(lds);
+  VS_DECL
 
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long p0 = tile << 5;
@@ -72,6 +97,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void tile_vm_kernel(const
     for (int oi = 0; oi < n_ops; ++oi) {
       const VmOp* op = &dp->ops[oi];
       const int kind = op->kind;
+      VS(0)
       if (kind == VM_GEMM) {
         const int n_out_tiles = op->p[0];
         const KSegs ks{op->p[1], op->p[2], op->p[3], op->p[4]};
@@ -101,8 +127,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void tile_vm_kernel(const
           // epilogue operands of a tile, fetched before its K loop so that their latency hides under it; two sets: a wave's second
           // tile is set up while the epilogue of its first one is still being issued (gemm_tiles_sw)
           float r1[2][16], r2[2][16];
-          auto g_init = [&](int ot, auto slot, f32x16& acc) {
+          auto g_aux = [&](int ot, auto slot) {
             constexpr int S = decltype(slot)::value;
+            VS(2)
 #ifdef VQN_DIAG_VM_NO_AUX
             for (int e = 0; e < 16; ++e) { r1[S][e] = 0.5f; r2[S][e] = 0.25f; }
 #else
@@ -115,12 +142,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void tile_vm_kernel(const
               }
             }
 #endif
+            VS(1)
+          };
+          auto g_init = [&](int ot, f32x16& acc) {
+            VS(2)
             if (accum) init_rows(lds + (dst + ot * 4) * 64, lane, acc);
             else if (b_off >= 0) init_bias(bp, ot, lane, acc);
             else init_zero(acc);
+            VS(1)
           };
           auto g_epi = [&](int ot, auto slot, int rq, const f32x16& acc) {
             constexpr int S = decltype(slot)::value;
+            VS(2)
             f32x4 y, y2;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -148,11 +181,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void tile_vm_kernel(const
               for (int j = 0; j < 4; ++j) st2[tf_off(tls2, tfs2, ot, 8 * rq + 2 * j + h, p)] = pvalid ? y2[j] : 0.f;
             }
             if (dst >= 0) lds[(dst + ot * 4 + rq) * 64 + lane] = y;
+            VS(3)
           };
           using S0 = std::integral_constant<int, 0>;
           using S1 = std::integral_constant<int, 1>;
-          gemm_tiles_sw<NW>(lds, ks, wbuf + w_off, n_out_tiles, wave, lane,
-                            [&](int ot, int slot, f32x16& acc) { if (slot == 0) g_init(ot, S0{}, acc); else g_init(ot, S1{}, acc); },
+          gemm_tiles_sw<NW, VQN_VM_NB>(lds, ks, wbuf + w_off, n_out_tiles, wave, lane,
+                            [&](int ot, int slot) { if (slot == 0) g_aux(ot, S0{}); else g_aux(ot, S1{}); },
+                            [&](int ot, int slot, f32x16& acc) { g_init(ot, acc); },
                             [&](int ot, int slot, int rq, const f32x16& acc) { if (slot == 0) g_epi(ot, S0{}, rq, acc); else g_epi(ot, S1{}, rq, acc); });
         };
 #define VM_PAIR(E, A) case (E) * 8 + (A): run_gemm(std::integral_constant<int, (E)>{}, std::integral_constant<int, (A)>{}); break;
@@ -169,7 +204,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void tile_vm_kernel(const
           default: run_gemm(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{}); break;
         }
 #undef VM_PAIR
+        VS(2)
         __syncthreads();
+        VS(4)
       } else if (kind == VM_LD_POSENC || kind == VM_LD_POSENC_JVP) {
         const bool jvp = kind == VM_LD_POSENC_JVP;
         const float* x = tab.t[op->p[0]].ptr;
@@ -310,6 +347,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void tile_vm_kernel(const
       }
     }
   }
+  VS(0)
+  VS_FLUSH
 }
 
 // ---- row-major [N, F] <-> TFMT: one 32 x 32 transpose per (point tile, feature tile) through LDS ------------------
