@@ -14,6 +14,9 @@
 namespace {
 
 // NOT: output tiles per wave (1: a_nt <= 4, 2: a_nt <= 8); BT: B tiles held (4 or 8); D: operand buffers = steps in flight.
+#ifndef VQN_WGRAD_D
+#define VQN_WGRAD_D 2          // operand ring depth of the 256 x 256 form (see the experiments table of DESIGN.md)
+#endif
 template <int NOT, int BT, int D>
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__ A, int a_tiles, int a_t0, int a_nt,
                                                        const float* __restrict__ B, int b_tiles, int b_t0, int b_nt,
@@ -152,7 +155,7 @@ extern "C" int vqn_wgrad_partials(const float* A, int a_tiles, int a_t0, int a_n
                      b_tiles, b_t0, b_nt, (long)n_point_tiles, ws, rowsum_ws)
   if (a_nt <= 4 && b_nt <= 4) VQN_WGRAD(1, 4, 6);
   else if (a_nt <= 4) VQN_WGRAD(1, 8, 4);
-  else VQN_WGRAD(2, 8, 2);
+  else VQN_WGRAD(2, 8, VQN_WGRAD_D);
 #undef VQN_WGRAD
   VQN_LAUNCH_CHECK();
   return (int)grid;      // number of partial blocks written (>= 1)
