@@ -211,6 +211,23 @@ int64_t vqn_neus_sdf_pack_plan(const int32_t* dims, int n_lin, int skip, int mul
 int64_t vqn_neus_col_pack_plan(int d_feature, int mode, int d_hidden, int n_layers, int d_out, int multires_view, int squeeze_out,
                                int feat_tiles, int f16s, int32_t* desc_out, int32_t* words_out, int64_t words_cap);
 
+/* The whole inference path of vq_nfr.Model.call up to the shading (vq_nfr.py:534-692: encoder -> z -> continuous heads; l2-normalise
+ * -> nearest code -> straight-through rows -> VQ heads) in ONE launch for K <= 16, z_dim = 256: program A (desc_a / wbuf_a: positional
+ * encoding -> fine_enc -> bottleneck -> heads, z through output slot 0) leaves z in LDS, the VQ step runs on it with the arithmetic
+ * of vqn_vq_quantize_rows (bit-identical indices and straight-through rows), program B (desc_b / wbuf_b: a head family on a raw
+ * 256-feature input kept resident) reads the straight-through rows from LDS.  z and the quantised rows never reach HBM
+ * (outs_a[0] may be NULL; pass a pointer to get z as well).  outs_* / ld_*: VQN_CHAIN_MAX_OUTS (4) pointers / leading dimensions per
+ * program; cb_frags: vqn_vq_codebook_frags of the codebook; idx [N] int64, ste [N, 256] (or NULL: the straight-through rows stay on
+ * the chip), *loss = loss_scale * sum (q - z^)^2, counts [K] as vqn_vq_quantize_rows; ws: VQN_QUANT_WS_FLOATS floats of device scratch. */
+int vqn_mlp_chain_vq_fwd(const int32_t* desc_a, const float* wbuf_a, const int32_t* desc_b, const float* wbuf_b, const float* in,
+                         int64_t N, float* const* outs_a, const int32_t* ld_a, float* const* outs_b, const int32_t* ld_b,
+                         const float* cb_frags, int K, float eps, float loss_scale, int64_t* idx, float* ste, float* loss,
+                         float* counts, float* ws, void* stream);
+/* Codebook [256, K] (K <= 16) -> the MFMA B fragments + |c|^2 the fused kernel reads (VQN_VQ_FRAGS_FLOATS floats, device);
+ * call again whenever the codebook changes. */
+#define VQN_VQ_FRAGS_FLOATS (16 * 64 * 4 + 16)
+int vqn_vq_codebook_frags(const float* codebook, int D, int K, float* frags, void* stream);
+
 /* ---- layer programs + weight packs of the Dense-stack evaluator, built in C ---------------------------------- */
 
 /* vqn_mlp_chain_fwd takes a layer program (include/vqn_chain_desc.h) and a weight pack.  These entries build both from a

@@ -14,7 +14,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 - <<PY
 import csv, glob, json, collections, re
-pat = re.compile(r'(mlp_chain_kernel<[^>]*>|brdf_shade_kernel<[^>]*>|vq_assign_kernel<[^>]*>|vq_assign_split_kernel<[^>]*>|l2_normalize_rows_kernel|vq_ema_mfma_kernel<[^>]*>|vq_ema_reduce2_kernel|vq_ste_loss_kernel|vq_counts_kernel)')
+pat = re.compile(r'(mlp_chain_vq_kernel|mlp_chain_kernel<[^>]*>|brdf_shade_kernel<[^>]*>|vq_assign_kernel<[^>]*>|vq_assign_split_kernel<[^>]*>|l2_normalize_rows_kernel|vq_ema_mfma_kernel<[^>]*>|vq_ema_reduce2_kernel|vq_ste_loss_kernel|vq_counts_kernel)')
 out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), MI355X (scripts/pmc_decomp.sh)",
        "units": "KB per launch as reported; gfx950 corrections of MI355X_MICROARCH.md (HBM section): FETCH_SIZE x2 for 16 B/lane coalesced reads, WRITE_SIZE exact; fabric-side requests, Infinity-Cache hits included",
        "workloads": {}}

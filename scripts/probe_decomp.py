@@ -22,13 +22,13 @@ batch = (['v'], torch.zeros(N, 2, device=dev), T(np.tile(np.array([[0, 0, 4.0]],
          torch.rand(N, 3, device=dev), one, one.clone(), T(xyz * 0.8), T(xyz.copy()), (torch.rand(N, 512, device=dev) < 0.7).float())
 with torch.no_grad():
     for _ in range(2):
-        model.call(batch, mode='vali')
+        model.call(batch, mode=os.environ.get('VQN_MODE', 'test'))
     torch.cuda.synchronize()
     _C.KernelClock.reset(True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(3):
-        model.call(batch, mode='vali')
+        model.call(batch, mode=os.environ.get('VQN_MODE', 'test'))
     e1.record(); torch.cuda.synchronize()
 print(f'N={N}: {e0.elapsed_time(e1)/3:.2f} ms per call')
 for k, v in _C.KernelClock.pairs.items():

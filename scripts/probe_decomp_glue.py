@@ -1,4 +1,5 @@
-"""Dev probe: per-kernel time of one full-view vq_nfr.call(mode='vali') (rocprofv3 --kernel-trace --stats around it)."""
+"""Dev probe: per-kernel time of one full-view vq_nfr.call (mode from VQN_MODE, default 'test': a render) -- rocprofv3
+--kernel-trace --stats around it."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -22,6 +23,6 @@ batch = (['v'], torch.zeros(n, 2, device=dev), torch.tensor([[0, 0, 4.0]], devic
          torch.rand(n, 3, device=dev), one, one.clone(), xyz, nrm, (torch.rand(n, 512, device=dev) < 0.7).float())
 with torch.no_grad():
     for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
-        model.call(batch, mode='vali')
+        model.call(batch, mode=os.environ.get('VQN_MODE', 'test'))
 torch.cuda.synchronize()
 print('done')

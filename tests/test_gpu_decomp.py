@@ -471,3 +471,37 @@ def test_ref_nfr_training_grads_vs_oracle(setup, data_type):
     if data_type != 'nerf':
         np.testing.assert_allclose(_np(m._gamma_bias.grad), gb.grad.numpy(), rtol=2e-3)
         np.testing.assert_allclose(_np(m._gamma_index.grad), gi.grad.numpy(), rtol=2e-3)
+
+
+@pytest.mark.parametrize('mode,full_vis', [('test', False), ('vali', False), ('vali', True)])
+@pytest.mark.parametrize('n', [5000, 31, 4097])
+def test_fused_front_is_bit_identical_to_the_separate_launches(mode, full_vis, n):
+    """vq_nfr.Model.call in inference mode, K = 15: encoder -> heads -> VQ step -> VQ heads as ONE launch (vqn_mlp_chain_vq_fwd, z
+    and the quantised rows never leave LDS) against the four-launch path (enc + heads program, vqn_vq_quantize_rows, VQ-heads
+    program): every output tensor, the indices and the lazily produced rows bit for bit; the commitment term to fp32 rounding
+    (different grouping of its partial sums)."""
+    from oracle import decomp as od
+    from tests.decomp_util import make_config, load_oracle_params, make_batch
+    from tests.gpu_util import launches
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    p, specs = od.make_model_params(seed=0, K=15)
+    model = load_oracle_params(get_model_class('vq_nfr')(make_config(num_embed=15)), p, 'cuda')
+    batch = make_batch(od.make_points(n, seed=6), 'cuda', bg_every=7)
+    out = {}
+    for fused in (True, False):
+        model.fuse_front = fused
+        with torch.no_grad(), launches() as rec:
+            pred, gt, lk, tv = model.call(batch, mode=mode, full_vis=full_vis)
+        assert rec.ran('vqn_mlp_chain_vq_fwd') == fused, rec.counts
+        if fused:
+            assert not rec.ran('vqn_vq_quantize_rows') and rec.counts.get('vqn_mlp_chain_fwd', 0) == 0, rec.counts
+        out[fused] = (pred, lk, tv)
+    (pa, la, ta), (pb, lb, tb) = out[True], out[False]
+    assert set(pa) == set(pb)
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
+    assert torch.equal(la['vqrgb'], lb['vqrgb']) and torch.equal(la['rgb'], lb['rgb'])
+    np.testing.assert_allclose(float(la['vqloss']), float(lb['vqloss']), rtol=2e-6)
+    assert torch.equal(la['z'], lb['z'])                                      # materialised (vali) or recomputed on access (test)
+    if full_vis:
+        assert torch.equal(ta['enc_z'], tb['enc_z'])

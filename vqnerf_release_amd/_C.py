@@ -374,6 +374,45 @@ def mlp_chain_fwd(desc, wbuf, x, out_widths, mode='f32'):
     return outs
 
 
+def vq_codebook_frags(codebook):
+    """codebook [256, K <= 16] -> the B-fragment + |c|^2 image the fused reflectance kernel reads (vqn_vq_codebook_frags)."""
+    _f32c(codebook, 'codebook')
+    D, K = codebook.shape
+    frags = torch.empty((16 * 64 * 4 + 16,), dtype=torch.float32, device=codebook.device)
+    with _clock('vqn_vq_codebook_frags'):
+        rc = lib().vqn_vq_codebook_frags(_ptr(codebook), ctypes.c_int(D), ctypes.c_int(K), _ptr(frags), _stream())
+    _check(rc, 'vqn_vq_codebook_frags')
+    return frags
+
+
+def mlp_chain_vq_fwd(desc_a, wbuf_a, widths_a, desc_b, wbuf_b, widths_b, x, frags, K, eps=1e-6, want_z=False, want_ste=False):
+    """Program A (encoder + heads, z through slot 0) -> VQ step on z in LDS -> program B (heads on the straight-through rows) in one
+    launch (vqn_mlp_chain_vq_fwd).  Returns (outs_a, outs_b, idx, ste, loss, counts); outs_a[0] (z) is None unless want_z, ste
+    (the straight-through rows [N, 256]) None unless want_ste."""
+    _f32c(wbuf_a, 'wbuf_a'); _f32c(wbuf_b, 'wbuf_b'); _f32c(x, 'x'); _f32c(frags, 'frags')
+    da, dpa = _i32(desc_a)
+    db, dpb = _i32(desc_b)
+    N = x.shape[0]
+    dev = x.device
+    assert x.shape[1] == int(da[8]), (x.shape, int(da[8]))
+    outs_a = [torch.empty((N, w), dtype=torch.float32, device=dev) if (i > 0 or want_z) else None for i, w in enumerate(widths_a)]
+    outs_b = [torch.empty((N, w), dtype=torch.float32, device=dev) for w in widths_b]
+    tab = lambda ts: (ctypes.c_void_p * 4)(*[(0 if (i >= len(ts) or ts[i] is None) else ts[i].data_ptr()) for i in range(4)])
+    lds = lambda ws: (ctypes.c_int32 * 4)(*[(ws[i] if i < len(ws) else 0) for i in range(4)])
+    idx = torch.empty((N,), dtype=torch.int64, device=dev)
+    ste = torch.empty((N, 256), dtype=torch.float32, device=dev) if want_ste else None
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    counts = torch.empty((K,), dtype=torch.float32, device=dev)
+    ws = torch.empty((4096,), dtype=torch.float32, device=dev)
+    n = N * 256
+    with _clock('vqn_mlp_chain_vq_fwd'):
+        rc = lib().vqn_mlp_chain_vq_fwd(dpa, _ptr(wbuf_a), dpb, _ptr(wbuf_b), _ptr(x), ctypes.c_int64(N), tab(outs_a), lds(widths_a),
+                                        tab(outs_b), lds(widths_b), _ptr(frags), ctypes.c_int(K), ctypes.c_float(eps),
+                                        ctypes.c_float(1.0 / n if n else 0.0), _ptr(idx), _ptr(ste), _ptr(loss), _ptr(counts), _ptr(ws), _stream())
+    _check(rc, 'vqn_mlp_chain_vq_fwd')
+    return outs_a, outs_b, idx, ste, loss, counts
+
+
 def brdf_shade_fwd(xyz, normal, rayo, lvis, lxyz, lareas, light, materials, gamma=None, want_normal=True,
                    want_split=False, raw=False, probes=None, lvis_rows=None):
     """materials: [(albedo [N,3], spec [N,3], rough [N,1])] (1 or 2 sets).

@@ -9,8 +9,12 @@
 // on the host (vqnerf_release_amd/decomp/packing.py) -- the kernel is a small interpreter over it.
 #include "mlp_prims.h"
 #include "vqn_chain_desc.h"
+#include "vqnerf_hip.h"
+#include <math.h>
 
 using namespace eng;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -54,29 +58,27 @@ struct OutPtrs {
   int ld[VQN_CHAIN_MAX_OUTS];
 };
 
+// the <= 4-output layers' weight images are tiny and the same for every point tile: one LDS copy per workgroup (their
+// VALU dots would otherwise wait on an L2 round trip per row)
 template <int NW>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_kernel(const ChainDesc d,
-                                                                             const f32x4* __restrict__ wbuf,
-                                                                             const float* __restrict__ in, const long N,
-                                                                             const OutPtrs outs) {
-  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
-  ChainSmalls* sm = reinterpret_cast<ChainSmalls*>(lds + (size_t)d.total_rows * 64);
-  f32x4* smallw = lds + (size_t)d.total_rows * 64 + sizeof(ChainSmalls) / sizeof(f32x4);
-  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: let the compiler know
-  const long n_tiles = (N + 31) >> 5;
-  // the <= 4-output layers' weight images are tiny and the same for every point tile: one LDS copy per workgroup (their
-  // VALU dots would otherwise wait on an L2 round trip per row)
+__device__ __forceinline__ void chain_stage_smalls(const ChainDesc& d, const f32x4* __restrict__ wbuf, f32x4* smallw) {
+  const int tid = threadIdx.x;
   for (int l = 0; l < d.n_layers; ++l)
     if (d.layers[l].kind == 1) {
       const int n4 = d.layers[l].n_out_tiles * (d.layers[l].kA_rows + d.layers[l].kB_rows) * 2;
       for (int i = tid; i < n4; i += NW * 64) smallw[d.layers[l].dst_row0 + i] = wbuf[d.layers[l].w_off + i];
     }
-  __syncthreads();
+}
 
-  f32x4 pre[4];                    // first weight fragments of this wave's next GEMM tile (see the GEMM layers)
-  int pre_for = -1;                // layer they belong to
-  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+// One point tile through one layer program.  `resident`: the input image already stands in rows [in_row0, +in_rows) (written by the
+// caller: the fused kernel below puts the straight-through rows there); an output slot whose pointer is null is not written.
+template <int NW>
+__device__ __forceinline__ void chain_tile(const ChainDesc& d, const f32x4* __restrict__ wbuf, const float* __restrict__ in, const long N,
+                                           const OutPtrs& outs, f32x4* lds, ChainSmalls* sm, f32x4* smallw, const long tile,
+                                           const bool resident, f32x4 (&pre)[4], int& pre_for) {
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: let the compiler know
+  {
     const long p0 = tile << 5;
     const long pt = (p0 + p < N) ? p0 + p : N - 1;
     // ---------------- input image (also re-loadable later in the program: kind 2) ----------------
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_kernel(con
       }
       __syncthreads();
     };
-    load_input(d.in_row0);
+    if (!resident) load_input(d.in_row0);
 
     // ---------------- layer program ----------------
     for (int l = 0; l < d.n_layers; ++l) {
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_kernel(con
           if (wave < L.n_out_tiles) store_tile(act, lds, dst + wave * 4, lane, held);
         }
         __syncthreads();
-        if (L.out_slot >= 0) {                   // image rows -> [N, out_feats] in HBM (16 B per lane)
+        if (L.out_slot >= 0 && outs.p[L.out_slot] != nullptr) {      // image rows -> [N, out_feats] in HBM (16 B per lane)
           float* o = outs.p[L.out_slot];
           const int ld = outs.ld[L.out_slot];
           const bool vec_ok = (ld & 3) == 0;
@@ -222,6 +224,181 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_kernel(con
   }
 }
 
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_kernel(const ChainDesc d,
+                                                                             const f32x4* __restrict__ wbuf,
+                                                                             const float* __restrict__ in, const long N,
+                                                                             const OutPtrs outs) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+  ChainSmalls* sm = reinterpret_cast<ChainSmalls*>(lds + (size_t)d.total_rows * 64);
+  f32x4* smallw = lds + (size_t)d.total_rows * 64 + sizeof(ChainSmalls) / sizeof(f32x4);
+  const long n_tiles = (N + 31) >> 5;
+  chain_stage_smalls<NW>(d, wbuf, smallw);
+  __syncthreads();
+  f32x4 pre[4];                    // first weight fragments of this wave's next GEMM tile (see the GEMM layers)
+  int pre_for = -1;                // layer they belong to
+  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
+    chain_tile<NW>(d, wbuf, in, N, outs, lds, sm, smallw, tile, false, pre, pre_for);
+}
+
+// ---- encoder + continuous heads -> VQ step -> VQ heads in ONE launch (vq_nfr.py:534-692, inference, K <= 16, z_dim = 256) --------
+// Program A leaves z in LDS rows [z_row0, +32); waves 0 / 1 each take 16 of the tile's 32 points through EXACTLY the arithmetic of
+// vq_assign_kernel<1, false, FUSE> (csrc/vq.hip; oracle/vq_strict.c): the A operand of the 16x16x4 MFMA chain is gathered from the
+// image (feature f of point p: row f >> 3, lane p + 32 (f & 1), component (f & 7) >> 1), rows are l2-normalised in registers, the
+// codebook comes as B fragments + |c|^2 from vqn_vq_codebook_frags (global, L2-resident: 16 KB), and the straight-through rows
+// x^ + (q - x^) go back into the image where program B expects its input.  z and the quantised rows never leave the chip; indices,
+// the commitment term and the code usage leave as in vqn_vq_quantize_rows.  Bit-identical outputs to the four-launch path (tested).
+struct VqTail {
+  const f32x4* frags;          // [16][64] float4: frags[t][l][e] = C[16 t + 4 (l >> 4) + e][l & 15]
+  const float* c2;             // [16]
+  int K;
+  float eps;
+  long long* idx;
+  float* loss_part;            // [grid]
+  float* counts;               // [K]
+  float* ste_out;              // [N, 256] straight-through rows for HBM as well, or null
+};
+
+__device__ __forceinline__ void vq_tail(f32x4* lds, const int z_row0, const int dst_row0, const VqTail& vq, const long p0, const long N,
+                                        int* hist, float& wave_loss) {
+  const int lane = threadIdx.x & 63, col = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* ldsf = reinterpret_cast<float*>(lds);
+  const bool active = wave < 2;
+  const int pp = 16 * (wave & 1) + col;                            // this lane's point in the tile (rows of the MFMA: col)
+  const bool rvalid = active && (p0 + pp) < N;
+  f32x4 av[16];
+  int kr = 0;
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      // features 16 t + 4 q + e, e = 0..3: e & 1 picks the half-wave (lane pp / pp + 32), e >> 1 the component 2 (q & 1) + (e >> 1)
+      const int row = z_row0 + (t >> 1) * 4 + 2 * (t & 1) + (q >> 1);
+      const float* b = ldsf + ((size_t)row * 64 + pp) * 4 + 2 * (q & 1);
+      const f32x2 lo = *reinterpret_cast<const f32x2*>(b), hi = *reinterpret_cast<const f32x2*>(b + 32 * 4);
+      av[t] = (f32x4){lo[0], hi[0], lo[1], hi[1]};
+    }
+    // x^ = x / sqrt(max(sum x^2, eps)): the arithmetic of vq_assign_kernel's FUSE path
+    float pr = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (!rvalid) av[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      pr = fmaf(av[i][0], av[i][0], pr); pr = fmaf(av[i][1], av[i][1], pr); pr = fmaf(av[i][2], av[i][2], pr); pr = fmaf(av[i][3], av[i][3], pr);
+    }
+    pr = pr + __shfl_xor(pr, 16);
+    pr = pr + __shfl_xor(pr, 32);
+    const float sc = 1.0f / sqrtf(fmaxf(pr, vq.eps));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) av[i] = av[i] * sc;
+    float p = 0.f;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const f32x4 a = av[t];
+      p = fmaf(a[0], a[0], p); p = fmaf(a[1], a[1], p); p = fmaf(a[2], a[2], p); p = fmaf(a[3], a[3], p);
+      const f32x4 b = vq.frags[t * 64 + lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+    }
+    p = p + __shfl_xor(p, 16);
+    p = p + __shfl_xor(p, 32);
+    const float c2c = vq.c2[col];
+    float best_v[4];
+    int best_i[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x2 = __shfl(p, 4 * q + j);
+      best_v[j] = INFINITY;
+      best_i[j] = 0x7fffffff;
+      const float t1 = x2 - 2.0f * acc[j];
+      const float dv = t1 + c2c;
+      if (col < vq.K) {
+        if (dv < best_v[j] || best_i[j] == 0x7fffffff) { best_v[j] = dv; best_i[j] = col; }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) {
+        const float ov = __shfl_xor(best_v[j], m);
+        const int oi = __shfl_xor(best_i[j], m);
+        const bool take = (oi != 0x7fffffff) && (best_i[j] == 0x7fffffff || ov < best_v[j] || (ov == best_v[j] && oi < best_i[j]));
+        if (take) { best_v[j] = ov; best_i[j] = oi; }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kj = __shfl(best_i[j], (col >> 2) * 16);
+      if ((col & 3) == j) kr = kj;
+    }
+    float lr = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const f32x4 cq = vq.frags[i * 64 + 16 * q + kr];               // C[16 i + 4 q + e][kr], e = 0..3
+      const f32x4 dq = cq - av[i];
+      lr = fmaf(dq[0], dq[0], lr); lr = fmaf(dq[1], dq[1], lr); lr = fmaf(dq[2], dq[2], lr); lr = fmaf(dq[3], dq[3], lr);
+      av[i] = av[i] + dq;                                            // the straight-through row
+    }
+    if (!rvalid) lr = 0.f;
+    lr = lr + __shfl_xor(lr, 16);
+    lr = lr + __shfl_xor(lr, 32);
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) lr += __shfl_xor(lr, m);
+    wave_loss += lr;
+    if (q == 0 && rvalid) {
+      vq.idx[p0 + pp] = (long long)kr;
+      atomicAdd(&hist[kr], 1);
+    }
+    if (vq.ste_out != nullptr && rvalid) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4*>(vq.ste_out + (size_t)(p0 + pp) * 256 + 16 * t + 4 * q) = av[t];
+    }
+  }
+  __syncthreads();                                                   // every read of z is done: the rows may be overwritten
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int row = dst_row0 + (t >> 1) * 4 + 2 * (t & 1) + (q >> 1);
+      float* b = ldsf + ((size_t)row * 64 + pp) * 4 + 2 * (q & 1);
+      *reinterpret_cast<f32x2*>(b) = (f32x2){av[t][0], av[t][2]};
+      *reinterpret_cast<f32x2*>(b + 32 * 4) = (f32x2){av[t][1], av[t][3]};
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256, 2) void mlp_chain_vq_kernel(const ChainDesc da, const f32x4* __restrict__ wa, const ChainDesc db,
+                                                              const f32x4* __restrict__ wb, const float* __restrict__ in, const long N,
+                                                              const OutPtrs oa, const OutPtrs ob, const int z_row0, const VqTail vq) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+  const int rows = max(da.total_rows, db.total_rows);
+  ChainSmalls* sm = reinterpret_cast<ChainSmalls*>(lds + (size_t)rows * 64);
+  // ONE region for the <= 4-output layers' weight images, re-staged before each program of each tile (11 KB from L2): with a copy
+  // per program the workgroup needs 90 KB of LDS and the CU holds one workgroup instead of two.  A program's first layer is a GEMM
+  // layer, whose barrier orders the staging before the first use; the last reader of the previous image ended with a barrier.
+  f32x4* smallw = lds + (size_t)rows * 64 + sizeof(ChainSmalls) / sizeof(f32x4);
+  int* hist = reinterpret_cast<int*>(smallw + max(da.small_w4, db.small_w4));        // [16] code usage of this workgroup, then 4 floats of wave sums
+  const long n_tiles = (N + 31) >> 5;
+  if (threadIdx.x < 16) hist[threadIdx.x] = 0;
+  __syncthreads();
+  f32x4 pre_a[4], pre_b[4];
+  int pre_for_a = -1, pre_for_b = -1;
+  float wave_loss = 0.f;
+  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    chain_stage_smalls<4>(da, wa, smallw);
+    chain_tile<4>(da, wa, in, N, oa, lds, sm, smallw, tile, false, pre_a, pre_for_a);
+    chain_stage_smalls<4>(db, wb, smallw);
+    vq_tail(lds, z_row0, db.in_row0, vq, tile << 5, N, hist, wave_loss);
+    chain_tile<4>(db, wb, nullptr, N, ob, lds, sm, smallw, tile, true, pre_b, pre_for_b);
+  }
+  float* wsum = reinterpret_cast<float*>(hist + 16);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wsum[wave] = wave_loss;
+  __syncthreads();
+  if (threadIdx.x == 0) vq.loss_part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  if ((int)threadIdx.x < vq.K && hist[threadIdx.x]) atomicAdd(&vq.counts[threadIdx.x], (float)hist[threadIdx.x]);
+}
+
 int check_desc(const ChainDesc& d) {
   if (d.n_layers < 1 || d.n_layers > VQN_CHAIN_MAX_LAYERS) return 1;
   if (d.n_waves != 4 && d.n_waves != 8) return 2;
@@ -259,6 +436,95 @@ int check_desc(const ChainDesc& d) {
 }
 
 }  // namespace
+
+int vqn_internal_finish_loss(const float* part, int n, float scale, float* loss, hipStream_t s);      // csrc/vq.hip
+
+extern "C" int vqn_mlp_chain_vq_fwd(const int32_t* desc_a, const float* wbuf_a, const int32_t* desc_b, const float* wbuf_b,
+                                    const float* in, int64_t N, float* const* outs_a, const int32_t* ld_a, float* const* outs_b,
+                                    const int32_t* ld_b, const float* cb_frags, int K, float eps, float loss_scale, int64_t* idx,
+                                    float* ste, float* loss, float* counts, float* ws, void* stream) {
+  VQN_CHECK_ARG(desc_a && wbuf_a && desc_b && wbuf_b && outs_a && ld_a && outs_b && ld_b, "descriptors, packs and output tables must be non-null");
+  VQN_CHECK_ARG(cb_frags && idx && loss && counts && ws, "cb_frags, idx, loss, counts and ws must be non-null");
+  VQN_CHECK_ARG(N >= 0 && K >= 1, "N >= 0, K >= 1");
+  VQN_CHECK_SHAPE(K <= 16, "K <= 16 (one code tile; larger codebooks run the separate launches)");
+  hipStream_t s = (hipStream_t)stream;
+  VQN_HIP(hipMemsetAsync(counts, 0, sizeof(float) * K, s));
+  if (N == 0) {                                         /* mean over nothing: the reference yields NaN (0 / 0) */
+    const float nan = NAN;
+    VQN_HIP(hipMemcpyAsync(loss, &nan, sizeof(float), hipMemcpyHostToDevice, s));
+    return VQN_OK;
+  }
+  VQN_CHECK_ARG(in != nullptr, "in must be non-null");
+  VQN_CHECK_ARG(ste == nullptr || ((uintptr_t)ste & 15) == 0, "ste must be 16-byte aligned");
+  ChainDesc da, db;
+  memcpy(&da, desc_a, sizeof(ChainDesc));
+  memcpy(&db, desc_b, sizeof(ChainDesc));
+  int bad = check_desc(da);
+  if (!bad) bad = check_desc(db) ? 100 + check_desc(db) : 0;
+  if (bad) {
+    vqn_set_error("vqn_mlp_chain_vq_fwd: unsupported shape: invalid chain descriptor (check %d)", bad);
+    return VQN_ESHAPE;
+  }
+  VQN_CHECK_SHAPE(da.n_waves == 4 && db.n_waves == 4, "both programs must be 4-wave programs");
+  int z_row0 = -1;
+  for (int l = 0; l < da.n_layers; ++l)
+    if (da.layers[l].kind == 0 && da.layers[l].out_slot == 0 && da.layers[l].out_feats == 256) z_row0 = da.layers[l].dst_row0;
+  VQN_CHECK_SHAPE(z_row0 >= 0, "program A must leave a 256-feature z in LDS through output slot 0");
+  VQN_CHECK_SHAPE(db.in_mode == 0 && db.in_feats == 256 && db.in_rows == 32, "program B must take a raw 256-feature input");
+  for (int l = 0; l < db.n_layers; ++l) VQN_CHECK_SHAPE(db.layers[l].kind != 2, "program B must keep its input resident");
+  VQN_CHECK_SHAPE(da.layers[0].kind == 0 && db.layers[0].kind == 0, "both programs must start with a GEMM layer");
+  // z must survive program A to its end: no later layer of A may write over it
+  {
+    bool seen = false;
+    for (int l = 0; l < da.n_layers; ++l) {
+      const ChainLayer& L = da.layers[l];
+      if (seen && L.kind == 0) {
+        const int d0 = L.dst_row0, d1 = L.dst_row0 + 4 * L.n_out_tiles;
+        VQN_CHECK_SHAPE(!(d0 < z_row0 + 32 && z_row0 < d1), "a layer of program A overwrites z before the VQ step");
+      }
+      if (L.kind == 2) VQN_CHECK_SHAPE(!seen || !(L.dst_row0 < z_row0 + 32 && z_row0 < L.dst_row0 + da.in_rows), "program A reloads its input over z");
+      if (L.kind == 0 && L.out_slot == 0) seen = true;
+    }
+  }
+  OutPtrs oa, ob;
+  for (int i = 0; i < VQN_CHAIN_MAX_OUTS; ++i) { oa.p[i] = outs_a[i]; oa.ld[i] = ld_a[i]; ob.p[i] = outs_b[i]; ob.ld[i] = ld_b[i]; }
+  for (int which = 0; which < 2; ++which) {
+    const ChainDesc& d = which ? db : da;
+    const OutPtrs& o = which ? ob : oa;
+    for (int l = 0; l < d.n_layers; ++l) {
+      const int sl = d.layers[l].out_slot;
+      if (sl < 0) continue;
+      if (which == 0 && sl == 0 && o.p[0] == nullptr) continue;                 // z stays on the chip
+      VQN_CHECK_ARG(o.p[sl] != nullptr, "an output a descriptor writes is null");
+      VQN_CHECK_ARG(o.ld[sl] >= (d.layers[l].kind == 0 ? d.layers[l].out_feats : d.layers[l].n_out_tiles),
+                    "output leading dimension smaller than the layer's width");
+      if (d.layers[l].kind == 0 && (o.ld[sl] & 3) == 0)
+        VQN_CHECK_ARG(((uintptr_t)o.p[sl] & 15) == 0, "outputs with ld % 4 == 0 must be 16-byte aligned");
+    }
+  }
+  const int rows = da.total_rows > db.total_rows ? da.total_rows : db.total_rows;
+  const size_t lds = (size_t)rows * 1024 + sizeof(ChainSmalls) + (size_t)(da.small_w4 > db.small_w4 ? da.small_w4 : db.small_w4) * 16 + 16 * 4 + 4 * 4;
+  VQN_CHECK_SHAPE(lds <= 160 * 1024, "the two programs do not fit in 160 KB of LDS");
+  const long n_tiles = (N + 31) / 32;
+  if (lds > 64 * 1024)
+    VQN_HIP(hipFuncSetAttribute((const void*)mlp_chain_vq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int per_cu = (2 * lds <= 160 * 1024) ? 2 : 1;
+  long grid = (long)vqn_num_cus() * per_cu;
+  if (grid > n_tiles) grid = n_tiles;
+  VQN_CHECK_SHAPE(grid + 1 <= VQN_QUANT_WS_FLOATS, "workspace too small for this device");
+  VqTail vq;
+  vq.frags = reinterpret_cast<const f32x4*>(cb_frags);
+  vq.c2 = cb_frags + 16 * 64 * 4;
+  vq.K = K; vq.eps = eps;
+  vq.idx = reinterpret_cast<long long*>(idx);
+  vq.loss_part = ws + 1;
+  vq.counts = counts;
+  vq.ste_out = ste;
+  hipLaunchKernelGGL(mlp_chain_vq_kernel, dim3((unsigned)grid), dim3(256), lds, s, da, reinterpret_cast<const f32x4*>(wbuf_a), db,
+                     reinterpret_cast<const f32x4*>(wbuf_b), in, (long)N, oa, ob, z_row0, vq);
+  VQN_LAUNCH_CHECK();
+  return vqn_internal_finish_loss(ws + 1, (int)grid, loss_scale, loss, s);
+}
 
 extern "C" int vqn_mlp_chain_fwd(const int32_t* desc, const float* wbuf, const float* in, int64_t N, float* out0,
                                  int ld0, float* out1, int ld1, float* out2, int ld2, float* out3, int ld3,

@@ -977,7 +977,44 @@ int launch_split(const float* x, long N, int D, const float* C, int K, long long
   return VQN_OK;
 }
 
+// B fragments + |c|^2 of a codebook of <= 16 codes, D = 256, as the fused reflectance kernel (csrc/mlp_chain.hip) reads them:
+// exactly what vq_assign_kernel<1, ...> stages into LDS (same element order, the same fmaf chain over d for |c|^2).
+__global__ __launch_bounds__(256) void vq_codebook_frags_kernel(const float* __restrict__ C, int D, int K, float* __restrict__ out) {
+  const int D16 = (D + 15) >> 4;
+  f32x4* Bf = reinterpret_cast<f32x4*>(out);
+  for (int i = threadIdx.x; i < D16 * 64; i += 256) {
+    const int l = i & 63, t = i >> 6, code = l & 15;
+    f32x4 v;
+    for (int e = 0; e < 4; ++e) {
+      const int d = 16 * t + 4 * (l >> 4) + e;
+      v[e] = (d < D && code < K) ? C[(size_t)d * K + code] : 0.0f;
+    }
+    Bf[i] = v;
+  }
+  if (threadIdx.x < 16) {
+    const int k = threadIdx.x;
+    float acc = 0.f;
+    if (k < K)
+      for (int d = 0; d < D; ++d) { const float c = C[(size_t)d * K + k]; acc = fmaf(c, c, acc); }
+    out[(size_t)D16 * 256 + k] = acc;
+  }
+}
+
 }  // namespace
+
+int vqn_internal_finish_loss(const float* part, int n, float scale, float* loss, hipStream_t s) {
+  hipLaunchKernelGGL(vq_ste_loss_final_kernel, dim3(1), dim3(64), 0, s, part, n, scale, loss);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
+
+extern "C" int vqn_vq_codebook_frags(const float* codebook, int D, int K, float* frags, void* stream) {
+  VQN_CHECK_ARG(codebook && frags, "codebook and frags must be non-null");
+  VQN_CHECK_SHAPE(D == 256 && K >= 1 && K <= 16, "D = 256, K <= 16");
+  hipLaunchKernelGGL(vq_codebook_frags_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, codebook, D, K, frags);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
 
 extern "C" int vqn_vq_assign_variant(int D, int K, int has_sel_mask, int has_dist) {
   static const float one = 1.f;

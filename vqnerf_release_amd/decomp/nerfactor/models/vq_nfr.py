@@ -14,7 +14,8 @@ import torch.nn as nn
 
 from vqnerf_release_amd.decomp.nerfactor.models.nfr_unit import BrdfModel, fg_rows, scatter_rows, take_rows
 from vqnerf_release_amd.decomp.nerfactor.networks import mlp
-from vqnerf_release_amd.decomp.nerfactor.networks.vq_layers import VectorQuantizerEMA, l2_normalize_rows
+from vqnerf_release_amd import _C
+from vqnerf_release_amd.decomp.nerfactor.networks.vq_layers import LazyKwargs, LazyResult, VectorQuantizerEMA, l2_normalize_rows
 from vqnerf_release_amd.decomp.nerfactor.util import img as imgutil, math as mathutil
 
 
@@ -95,6 +96,64 @@ class Model(BrdfModel):
             vq = self.vq_layer(z_norm, codebook, is_training=(mode == 'train'), thres=th, roll=roll)
         return vq, vq['quantize'], vq['loss'], vq['encoding_indices'] + 1
 
+    fuse_front = True          # inference, K <= 16, no code dropout: encoder -> heads -> VQ step -> VQ heads in ONE launch
+
+    def _cb_frags(self, cb):
+        """MFMA fragments + |c|^2 of the (clipped) codebook for the fused front kernel, rebuilt when the parameter changes."""
+        key = (self._codebook.data_ptr(), self._codebook._version, cb.device)
+        if getattr(self, '_frags_key', None) != key:
+            self._frags, self._frags_key = _C.vq_codebook_frags(cb), key
+        return self._frags
+
+    def _fused_front(self, pts, mode, thres, full_vis):
+        """Everything of `call` between the inputs and the shading in one launch (`vqn_mlp_chain_vq_fwd`): z and the quantised rows
+        stay in LDS.  Returns None when the path does not apply (training, code dropout, K > 16, split-precision mode, non-standard
+        heads), else (z_enc | None, basecolor, ks, rough, vq, z_vq | None, vq_loss, embed_ind, (vq_albedo, vq_spec, vq_rough), redo)
+        with `redo()` -> (z_enc, z_vq) through the separate launches (bit-identical) for whoever asks for the rows later."""
+        names_m = [h + '_main' for h in self.HEADS]
+        names_v = [h + '_vq' for h in self.HEADS]
+        if not (self.fuse_front and self.fuse_quantise and mode != 'train' and thres is None and self.num_embed <= 16
+                and self.z_dim == 256 and self.matrix_mode == 'f32' and pts.is_cuda):
+            return None
+        if not (self._fused(pts) and self._can_fuse_enc_heads(names_m) and self._plan_fits_two_workgroups(names_m)
+                and all(self._is_std_head(self.net[n]) and self.net[n].widths[1] <= 128 for n in names_v)):
+            return None
+        plan_b = self._head_program(names_v, self.z_dim)
+        if plan_b.n_waves != 4:
+            return None
+        plan_a = self._enc_heads_program(names_m)
+        wa, da = self._program_pack('enc+heads:' + ','.join(names_m), plan_a, ['fine_enc', 'bottleneck'] + names_m)
+        wb, db = self._program_pack('heads:%s:%d:' % (self.matrix_mode, self.z_dim) + ','.join(names_v), plan_b, names_v)
+        cb = self.get_codebook().detach().contiguous()
+        want_z = bool(full_vis or self.check_numerics)
+        want_ste = bool(self.check_numerics or (mode == 'vali' and self.config.getfloat('DEFAULT', 'mat_sloss_weight', fallback=0.0) > 0))
+        x = pts.detach().float().contiguous()
+        (z, d, s_, r), (vd, vs, vr), idx, ste, e_latent, counts = _C.mlp_chain_vq_fwd(
+            da, wa, [self.z_dim] + [self.net[n].widths[-1] for n in names_m], db, wb, [self.net[n].widths[-1] for n in names_v],
+            x, self._cb_frags(cb), self.num_embed, want_z=want_z, want_ste=want_ste)
+        K = self.num_embed
+        redo_box = {}
+
+        def redo():
+            if not redo_box:
+                ze = self._fused_enc(x)
+                redo_box['z'] = ze
+                redo_box['zq'] = self.vq_layer.infer_from_raw(ze, cb)['quantize']
+            return redo_box['z'], redo_box['zq']
+
+        def perplexity():
+            avg = counts / max(idx.numel(), 1)
+            return torch.exp(-torch.sum(avg * torch.log(avg + 1e-10)))
+        vq = LazyResult({'loss': self.vq_layer.commitment_cost * e_latent, 'encoding_indices': idx},
+                        {'quantize': (lambda: ste if ste is not None else redo()[1]), 'perplexity': perplexity,
+                         'encodings': lambda: torch.nn.functional.one_hot(idx, K).to(torch.float32),
+                         'distances': lambda: _C.vq_assign(_C.l2_normalize_rows(redo()[0]), cb, want_quant=False, want_dist=True)[2]})
+        num = self._numerics
+        if z is not None:
+            z = num(z, 'Z')
+        return (z, num(self._albedo_affine(d), 'Albedo'), num(s_, 'Specular'), num(r, 'Roughness'), vq, ste, vq['loss'], idx + 1,
+                (num(self._albedo_affine(vd), 'Albedo'), num(vs, 'Specular'), num(vr, 'Roughness')), redo)
+
     # ------------------------------------------------------------------ entry points
     def init_z(self, batch):
         id_, hw, _, _, _, alpha, pred_alpha, xyz = batch[:8]
@@ -164,21 +223,29 @@ class Model(BrdfModel):
         rayo, rgb_m, xyz_m, normal_m = take_rows(mask, rayo, rgb, xyz, normal)
         lvis_m = self.fg_lvis(lvis, mask, xyz_m)
 
-        z_enc, basecolor, ks, rough = self.enc_and_heads(xyz_m, 'main')       # (one launch on the inference path)
-        vq, z_vq, vq_loss, embed_ind = self._quantise(z_enc, mode, thres, roll=roll)
-        if mode == 'train':                                   # codebook is moved by the EMA, outside the optimiser (:582-583)
-            with torch.no_grad():
-                self._codebook.copy_(vq['update'])
+        front = self._fused_front(xyz_m, mode, thres, full_vis)
+        redo = None
+        if front is not None:                                 # inference: encoder, heads, VQ step and VQ heads in ONE launch
+            z_enc, basecolor, ks, rough, vq, z_vq, vq_loss, embed_ind, (vq_albedo, vq_spec, vq_rough), redo = front
+        else:
+            z_enc, basecolor, ks, rough = self.enc_and_heads(xyz_m, 'main')       # (one launch on the inference path)
+            vq, z_vq, vq_loss, embed_ind = self._quantise(z_enc, mode, thres, roll=roll)
+            if mode == 'train':                               # codebook is moved by the EMA, outside the optimiser (:582-583)
+                with torch.no_grad():
+                    self._codebook.copy_(vq['update'])
+            vq_albedo, vq_spec, vq_rough = self._all_heads(z_vq, 'vq')
 
         spec = ks * basecolor
         albedo = (1 - ks) * basecolor
-        vq_albedo, vq_spec, vq_rough = self._all_heads(z_vq, 'vq')
         sh = self._shade_or_render(xyz_m, normal_m, rayo, lvis_m, [(albedo, spec, rough), (vq_albedo, vq_spec, vq_rough)],
                                    split=(mode != 'train'))
         rgb_pred, vq_rgb, normal_pred = sh['rgb'][0], sh['rgb'][1], sh['normal']
 
         loss_kwargs = {'vqloss': vq_loss, 'vqrgb': vq_rgb, 'mode': mode, 'gtc': rgb_m, 'rgb': rgb_pred, 'spec': spec,
                        'rough': rough, 'z': z_vq, 'embed': self._codebook}
+        if z_vq is None:              # the fused launch kept the quantised rows on the chip: produced on first access (never by `**`)
+            del loss_kwargs['z']
+            loss_kwargs = LazyKwargs(loss_kwargs, {'z': lambda: redo()[1]})
         srgb = (lambda t: imgutil.linear2srgb(t)) if self.data_type == 'nerf' else (lambda t: t)
         pred = {'rgb': scatter_rows(mask, srgb(rgb_pred), n), 'normal': scatter_rows(mask, normal_pred, n),
                 'albedo': scatter_rows(mask, albedo, n), 'alpha': pred_alpha, 'spec': scatter_rows(mask, spec, n),
@@ -189,7 +256,7 @@ class Model(BrdfModel):
         gt = {'rgb': scatter_rows(mask, rgb_m, n), 'normal': scatter_rows(mask, normal_m, n), 'alpha': alpha}
         to_vis = {'id': id_, 'hw': hw}
         if full_vis:
-            to_vis['enc_z'] = scatter_rows(mask, z_enc, n)
+            to_vis['enc_z'] = scatter_rows(mask, z_enc if z_enc is not None else redo()[0], n)
         if mode != 'train':
             pred['embed'] = scatter_rows(mask, embed_ind[:, None], n)
             pred['vq_rgb'] = scatter_rows(mask, srgb(vq_rgb), n)

@@ -116,6 +116,19 @@ class LazyResult(dict):
         return list(dict.keys(self)) + list(self._thunks)
 
 
+class LazyKwargs(LazyResult):
+    """A keyword dict with values that exist only if somebody indexes them: `d['z']` computes, `f(**d)` / iteration / `keys()` see the
+    materialised entries only (a consumer that never names the key never pays for it)."""
+
+    def keys(self):
+        return list(dict.keys(self))
+
+    def pop(self, key, *default):
+        if not dict.__contains__(self, key) and key in self._thunks:
+            return self._thunks.pop(key)()
+        return dict.pop(self, key, *default)
+
+
 class VectorQuantizerEMA(torch.nn.Module):
     def __init__(self, embedding_dim, num_embeddings, commitment_cost, seed, decay=0.999, epsilon=1e-5,
                  dtype=torch.float32, name='vector_quantizer_ema'):
