@@ -212,7 +212,7 @@ int64_t vqn_neus_col_pack_plan(int d_feature, int mode, int d_hidden, int n_laye
                                int feat_tiles, int f16s, int32_t* desc_out, int32_t* words_out, int64_t words_cap);
 
 /* The whole inference path of vq_nfr.Model.call up to the shading (vq_nfr.py:534-692: encoder -> z -> continuous heads; l2-normalise
- * -> nearest code -> straight-through rows -> VQ heads) in ONE launch for K <= 16, z_dim = 256: program A (desc_a / wbuf_a: positional
+ * -> nearest code -> straight-through rows -> VQ heads) in ONE launch for K <= 64, z_dim = 256: program A (desc_a / wbuf_a: positional
  * encoding -> fine_enc -> bottleneck -> heads, z through output slot 0) leaves z in LDS, the VQ step runs on it with the arithmetic
  * of vqn_vq_quantize_rows (bit-identical indices and straight-through rows), program B (desc_b / wbuf_b: a head family on a raw
  * 256-feature input kept resident) reads the straight-through rows from LDS.  z and the quantised rows never reach HBM
@@ -223,9 +223,9 @@ int vqn_mlp_chain_vq_fwd(const int32_t* desc_a, const float* wbuf_a, const int32
                          int64_t N, float* const* outs_a, const int32_t* ld_a, float* const* outs_b, const int32_t* ld_b,
                          const float* cb_frags, int K, float eps, float loss_scale, int64_t* idx, float* ste, float* loss,
                          float* counts, float* ws, void* stream);
-/* Codebook [256, K] (K <= 16) -> the MFMA B fragments + |c|^2 the fused kernel reads (VQN_VQ_FRAGS_FLOATS floats, device);
- * call again whenever the codebook changes. */
-#define VQN_VQ_FRAGS_FLOATS (16 * 64 * 4 + 16)
+/* Codebook [256, K] (K <= 64: 1, 2 or 4 tiles of 16 codes) -> the MFMA B fragments + |c|^2 the fused kernel reads
+ * (VQN_VQ_FRAGS_FLOATS(K) floats, device); call again whenever the codebook changes. */
+#define VQN_VQ_FRAGS_FLOATS(K) (((K) <= 16 ? 1 : ((K) <= 32 ? 2 : 4)) * (16 * 64 * 4 + 16))
 int vqn_vq_codebook_frags(const float* codebook, int D, int K, float* frags, void* stream);
 
 /* ---- layer programs + weight packs of the Dense-stack evaluator, built in C ---------------------------------- */

@@ -99,7 +99,24 @@ rgb0, rgb1, rd, rs, nout = E(N, 3), E(N, 3), E(N, 3), E(N, 3), E(N, 3)
 ok(lib.vqn_brdf_shade_fwd(P(xyz), P(normal), P(rayo), P(lvis), P(T(lxyz.reshape(-1, 3))), P(T(lareas.reshape(-1))), P(light), ctypes.c_int64(N), 512, 2,
                           P(albedo), P(spec), P(rough), P(vq_albedo), P(vq_spec), P(vq_rough), None, P(nout), P(rgb0), P(rgb1), P(rd), P(rs), 0,
                           None, 0, None, STREAM), 'vqn_brdf_shade_fwd')
+# ---- the same front end as ONE launch: encoder + heads -> VQ step on z in LDS -> VQ heads (vqn_mlp_chain_vq_fwd) ----
+frags = E(16 * 64 * 4 + 16)
+ok(lib.vqn_vq_codebook_frags(P(cb), 256, K, P(frags), STREAM), 'vqn_vq_codebook_frags')
+f_base, f_ks, f_rough, f_va, f_vs, f_vr = E(N, 3), E(N, 1), E(N, 1), E(N, 3), E(N, 3), E(N, 1)
+f_idx = torch.empty(N, dtype=torch.int64, device=dev)
+f_loss, f_counts = E(1), E(K)
+tab = lambda ts: (ctypes.c_void_p * 4)(*[(0 if t is None else t.data_ptr()) for t in ts])
+i4 = lambda v: (ctypes.c_int32 * 4)(*v)
+ok(lib.vqn_mlp_chain_vq_fwd(ctypes.c_void_p(lib.vqn_chain_pack_desc(enc_main)), ctypes.c_void_p(lib.vqn_chain_pack_wbuf(enc_main)),
+                            ctypes.c_void_p(lib.vqn_chain_pack_desc(vq_heads)), ctypes.c_void_p(lib.vqn_chain_pack_wbuf(vq_heads)),
+                            P(xyz), ctypes.c_int64(N), tab([None, f_base, f_ks, f_rough]), i4([0, 3, 1, 1]),
+                            tab([f_va, f_vs, f_vr, None]), i4([3, 3, 1, 0]), P(frags), K, ctypes.c_float(1e-6),
+                            ctypes.c_float(1.0 / (N * 256)), P(f_idx), None, P(f_loss), P(f_counts), P(ws), STREAM), 'vqn_mlp_chain_vq_fwd')
 torch.cuda.synchronize()
+for a, b, what in ((f_base, base, 'basecolor'), (f_ks, ks, 'ks'), (f_rough, rough, 'rough'), (f_va, vq_albedo, 'vq_albedo'),
+                   (f_vs, vq_spec, 'vq_spec'), (f_vr, vq_rough, 'vq_rough'), (f_idx, idx, 'indices'), (f_counts, counts, 'counts')):
+    assert torch.equal(a, b), 'one-launch front differs from the separate launches: ' + what
+np.testing.assert_allclose(float(f_loss), float(loss), rtol=2e-6)
 for h in (enc_main, vq_heads):
     lib.vqn_chain_pack_destroy(h)
 

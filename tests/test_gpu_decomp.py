@@ -474,9 +474,9 @@ def test_ref_nfr_training_grads_vs_oracle(setup, data_type):
 
 
 @pytest.mark.parametrize('mode,full_vis', [('test', False), ('vali', False), ('vali', True)])
-@pytest.mark.parametrize('n', [5000, 31, 4097])
-def test_fused_front_is_bit_identical_to_the_separate_launches(mode, full_vis, n):
-    """vq_nfr.Model.call in inference mode, K = 15: encoder -> heads -> VQ step -> VQ heads as ONE launch (vqn_mlp_chain_vq_fwd, z
+@pytest.mark.parametrize('n,K', [(5000, 15), (31, 15), (4097, 15), (3000, 64), (2000, 33), (1000, 16), (1500, 17)])
+def test_fused_front_is_bit_identical_to_the_separate_launches(mode, full_vis, n, K):
+    """vq_nfr.Model.call in inference mode, K <= 64: encoder -> heads -> VQ step -> VQ heads as ONE launch (vqn_mlp_chain_vq_fwd, z
     and the quantised rows never leave LDS) against the four-launch path (enc + heads program, vqn_vq_quantize_rows, VQ-heads
     program): every output tensor, the indices and the lazily produced rows bit for bit; the commitment term to fp32 rounding
     (different grouping of its partial sums)."""
@@ -484,8 +484,8 @@ def test_fused_front_is_bit_identical_to_the_separate_launches(mode, full_vis, n
     from tests.decomp_util import make_config, load_oracle_params, make_batch
     from tests.gpu_util import launches
     from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
-    p, specs = od.make_model_params(seed=0, K=15)
-    model = load_oracle_params(get_model_class('vq_nfr')(make_config(num_embed=15)), p, 'cuda')
+    p, specs = od.make_model_params(seed=0, K=K)
+    model = load_oracle_params(get_model_class('vq_nfr')(make_config(num_embed=K)), p, 'cuda')
     batch = make_batch(od.make_points(n, seed=6), 'cuda', bg_every=7)
     out = {}
     for fused in (True, False):

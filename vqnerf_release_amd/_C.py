@@ -375,10 +375,10 @@ def mlp_chain_fwd(desc, wbuf, x, out_widths, mode='f32'):
 
 
 def vq_codebook_frags(codebook):
-    """codebook [256, K <= 16] -> the B-fragment + |c|^2 image the fused reflectance kernel reads (vqn_vq_codebook_frags)."""
+    """codebook [256, K <= 64] -> the B-fragment + |c|^2 image the fused reflectance kernel reads (vqn_vq_codebook_frags)."""
     _f32c(codebook, 'codebook')
     D, K = codebook.shape
-    frags = torch.empty((16 * 64 * 4 + 16,), dtype=torch.float32, device=codebook.device)
+    frags = torch.empty(((1 if K <= 16 else (2 if K <= 32 else 4)) * (16 * 64 * 4 + 16),), dtype=torch.float32, device=codebook.device)
     with _clock('vqn_vq_codebook_frags'):
         rc = lib().vqn_vq_codebook_frags(_ptr(codebook), ctypes.c_int(D), ctypes.c_int(K), _ptr(frags), _stream())
     _check(rc, 'vqn_vq_codebook_frags')

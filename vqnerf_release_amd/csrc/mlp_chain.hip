@@ -249,8 +249,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mlp_chain_kernel(con
 // x^ + (q - x^) go back into the image where program B expects its input.  z and the quantised rows never leave the chip; indices,
 // the commitment term and the code usage leave as in vqn_vq_quantize_rows.  Bit-identical outputs to the four-launch path (tested).
 struct VqTail {
-  const f32x4* frags;          // [16][64] float4: frags[t][l][e] = C[16 t + 4 (l >> 4) + e][l & 15]
-  const float* c2;             // [16]
+  const f32x4* frags;          // [KT][16][64] float4: frags[kt][t][l][e] = C[16 t + 4 (l >> 4) + e][16 kt + (l & 15)]
+  const float* c2;             // [16 KT]
   int K;
   float eps;
   long long* idx;
@@ -259,8 +259,12 @@ struct VqTail {
   float* ste_out;              // [N, 256] straight-through rows for HBM as well, or null
 };
 
-__device__ __forceinline__ void vq_tail(f32x4* lds, const int z_row0, const int dst_row0, const VqTail& vq, const long p0, const long N,
-                                        int* hist, float& wave_loss) {
+// (not inlined: the step is 1 % of a tile's time but holds a whole row per lane in registers; as a real call it has its own register
+//  allocation and the layer programs' loops keep theirs)
+template <int KT>
+__device__ __noinline__ float vq_tail(f32x4* lds, const int z_row0, const int dst_row0, const VqTail vq, const long p0, const long N,
+                                      int* hist) {
+  float wave_loss = 0.f;
   const int lane = threadIdx.x & 63, col = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* ldsf = reinterpret_cast<float*>(lds);
@@ -291,18 +295,27 @@ __device__ __forceinline__ void vq_tail(f32x4* lds, const int z_row0, const int 
 #pragma unroll
     for (int i = 0; i < 16; ++i) av[i] = av[i] * sc;
     float p = 0.f;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) acc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const f32x4 a = av[t];
       p = fmaf(a[0], a[0], p); p = fmaf(a[1], a[1], p); p = fmaf(a[2], a[2], p); p = fmaf(a[3], a[3], p);
-      const f32x4 b = vq.frags[t * 64 + lane];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+      for (int kt = 0; kt < KT; ++kt) {
+        const f32x4 b = vq.frags[(kt * 16 + t) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc[kt], 0, 0, 0);
+      }
+      // (this step is 1 % of a tile's time: keep the compiler from hoisting all 16 KT fragment loads -- 64 KT registers, spilled)
+      if (KT > 1 || (t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     p = p + __shfl_xor(p, 16);
     p = p + __shfl_xor(p, 32);
-    const float c2c = vq.c2[col];
+    float c2c[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) c2c[kt] = vq.c2[16 * kt + col];
     float best_v[4];
     int best_i[4];
 #pragma unroll
@@ -310,10 +323,14 @@ __device__ __forceinline__ void vq_tail(f32x4* lds, const int z_row0, const int 
       const float x2 = __shfl(p, 4 * q + j);
       best_v[j] = INFINITY;
       best_i[j] = 0x7fffffff;
-      const float t1 = x2 - 2.0f * acc[j];
-      const float dv = t1 + c2c;
-      if (col < vq.K) {
-        if (dv < best_v[j] || best_i[j] == 0x7fffffff) { best_v[j] = dv; best_i[j] = col; }
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const int code = 16 * kt + col;
+        const float t1 = x2 - 2.0f * acc[kt][j];
+        const float dv = t1 + c2c[kt];
+        if (code < vq.K) {
+          if (dv < best_v[j] || best_i[j] == 0x7fffffff) { best_v[j] = dv; best_i[j] = code; }
+        }
       }
     }
 #pragma unroll
@@ -331,13 +348,15 @@ __device__ __forceinline__ void vq_tail(f32x4* lds, const int z_row0, const int 
       const int kj = __shfl(best_i[j], (col >> 2) * 16);
       if ((col & 3) == j) kr = kj;
     }
+    const int kt_r = kr >> 4, kc_r = kr & 15;
     float lr = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const f32x4 cq = vq.frags[i * 64 + 16 * q + kr];               // C[16 i + 4 q + e][kr], e = 0..3
+      const f32x4 cq = vq.frags[(kt_r * 16 + i) * 64 + 16 * q + kc_r];       // C[16 i + 4 q + e][kr], e = 0..3
       const f32x4 dq = cq - av[i];
       lr = fmaf(dq[0], dq[0], lr); lr = fmaf(dq[1], dq[1], lr); lr = fmaf(dq[2], dq[2], lr); lr = fmaf(dq[3], dq[3], lr);
       av[i] = av[i] + dq;                                            // the straight-through row
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     if (!rvalid) lr = 0.f;
     lr = lr + __shfl_xor(lr, 16);
@@ -365,8 +384,10 @@ __device__ __forceinline__ void vq_tail(f32x4* lds, const int z_row0, const int 
     }
   }
   __syncthreads();
+  return wave_loss;
 }
 
+template <int KT>
 __global__ __launch_bounds__(256, 2) void mlp_chain_vq_kernel(const ChainDesc da, const f32x4* __restrict__ wa, const ChainDesc db,
                                                               const f32x4* __restrict__ wb, const float* __restrict__ in, const long N,
                                                               const OutPtrs oa, const OutPtrs ob, const int z_row0, const VqTail vq) {
@@ -377,9 +398,9 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_vq_kernel(const ChainDesc da
   // per program the workgroup needs 90 KB of LDS and the CU holds one workgroup instead of two.  A program's first layer is a GEMM
   // layer, whose barrier orders the staging before the first use; the last reader of the previous image ended with a barrier.
   f32x4* smallw = lds + (size_t)rows * 64 + sizeof(ChainSmalls) / sizeof(f32x4);
-  int* hist = reinterpret_cast<int*>(smallw + max(da.small_w4, db.small_w4));        // [16] code usage of this workgroup, then 4 floats of wave sums
+  int* hist = reinterpret_cast<int*>(smallw + max(da.small_w4, db.small_w4));        // [16 KT] code usage of this workgroup, then 4 floats of wave sums
   const long n_tiles = (N + 31) >> 5;
-  if (threadIdx.x < 16) hist[threadIdx.x] = 0;
+  if (threadIdx.x < 16 * KT) hist[threadIdx.x] = 0;
   __syncthreads();
   f32x4 pre_a[4], pre_b[4];
   int pre_for_a = -1, pre_for_b = -1;
@@ -388,10 +409,10 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_vq_kernel(const ChainDesc da
     chain_stage_smalls<4>(da, wa, smallw);
     chain_tile<4>(da, wa, in, N, oa, lds, sm, smallw, tile, false, pre_a, pre_for_a);
     chain_stage_smalls<4>(db, wb, smallw);
-    vq_tail(lds, z_row0, db.in_row0, vq, tile << 5, N, hist, wave_loss);
+    wave_loss += vq_tail<KT>(lds, z_row0, db.in_row0, vq, tile << 5, N, hist);
     chain_tile<4>(db, wb, nullptr, N, ob, lds, sm, smallw, tile, true, pre_b, pre_for_b);
   }
-  float* wsum = reinterpret_cast<float*>(hist + 16);
+  float* wsum = reinterpret_cast<float*>(hist + 16 * KT);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) wsum[wave] = wave_loss;
   __syncthreads();
@@ -446,7 +467,8 @@ extern "C" int vqn_mlp_chain_vq_fwd(const int32_t* desc_a, const float* wbuf_a, 
   VQN_CHECK_ARG(desc_a && wbuf_a && desc_b && wbuf_b && outs_a && ld_a && outs_b && ld_b, "descriptors, packs and output tables must be non-null");
   VQN_CHECK_ARG(cb_frags && idx && loss && counts && ws, "cb_frags, idx, loss, counts and ws must be non-null");
   VQN_CHECK_ARG(N >= 0 && K >= 1, "N >= 0, K >= 1");
-  VQN_CHECK_SHAPE(K <= 16, "K <= 16 (one code tile; larger codebooks run the separate launches)");
+  VQN_CHECK_SHAPE(K <= 64, "K <= 64 (larger codebooks run the separate launches)");
+  const int KT = K <= 16 ? 1 : (K <= 32 ? 2 : 4);
   hipStream_t s = (hipStream_t)stream;
   VQN_HIP(hipMemsetAsync(counts, 0, sizeof(float) * K, s));
   if (N == 0) {                                         /* mean over nothing: the reference yields NaN (0 / 0) */
@@ -503,25 +525,30 @@ extern "C" int vqn_mlp_chain_vq_fwd(const int32_t* desc_a, const float* wbuf_a, 
     }
   }
   const int rows = da.total_rows > db.total_rows ? da.total_rows : db.total_rows;
-  const size_t lds = (size_t)rows * 1024 + sizeof(ChainSmalls) + (size_t)(da.small_w4 > db.small_w4 ? da.small_w4 : db.small_w4) * 16 + 16 * 4 + 4 * 4;
+  const size_t lds = (size_t)rows * 1024 + sizeof(ChainSmalls) + (size_t)(da.small_w4 > db.small_w4 ? da.small_w4 : db.small_w4) * 16 + (size_t)KT * 16 * 4 + 4 * 4;
   VQN_CHECK_SHAPE(lds <= 160 * 1024, "the two programs do not fit in 160 KB of LDS");
   const long n_tiles = (N + 31) / 32;
-  if (lds > 64 * 1024)
-    VQN_HIP(hipFuncSetAttribute((const void*)mlp_chain_vq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const void* kern = KT == 1 ? (const void*)mlp_chain_vq_kernel<1> : (KT == 2 ? (const void*)mlp_chain_vq_kernel<2> : (const void*)mlp_chain_vq_kernel<4>);
+  if (lds > 64 * 1024) VQN_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int per_cu = (2 * lds <= 160 * 1024) ? 2 : 1;
   long grid = (long)vqn_num_cus() * per_cu;
   if (grid > n_tiles) grid = n_tiles;
   VQN_CHECK_SHAPE(grid + 1 <= VQN_QUANT_WS_FLOATS, "workspace too small for this device");
   VqTail vq;
   vq.frags = reinterpret_cast<const f32x4*>(cb_frags);
-  vq.c2 = cb_frags + 16 * 64 * 4;
+  vq.c2 = cb_frags + (size_t)KT * 16 * 64 * 4;
   vq.K = K; vq.eps = eps;
   vq.idx = reinterpret_cast<long long*>(idx);
   vq.loss_part = ws + 1;
   vq.counts = counts;
   vq.ste_out = ste;
-  hipLaunchKernelGGL(mlp_chain_vq_kernel, dim3((unsigned)grid), dim3(256), lds, s, da, reinterpret_cast<const f32x4*>(wbuf_a), db,
-                     reinterpret_cast<const f32x4*>(wbuf_b), in, (long)N, oa, ob, z_row0, vq);
+#define VQN_FRONT(KT_)                                                                                                              \
+  hipLaunchKernelGGL(mlp_chain_vq_kernel<KT_>, dim3((unsigned)grid), dim3(256), lds, s, da, reinterpret_cast<const f32x4*>(wbuf_a), db, \
+                     reinterpret_cast<const f32x4*>(wbuf_b), in, (long)N, oa, ob, z_row0, vq)
+  if (KT == 1) VQN_FRONT(1);
+  else if (KT == 2) VQN_FRONT(2);
+  else VQN_FRONT(4);
+#undef VQN_FRONT
   VQN_LAUNCH_CHECK();
   return vqn_internal_finish_loss(ws + 1, (int)grid, loss_scale, loss, s);
 }

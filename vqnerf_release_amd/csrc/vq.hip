@@ -977,13 +977,14 @@ int launch_split(const float* x, long N, int D, const float* C, int K, long long
   return VQN_OK;
 }
 
-// B fragments + |c|^2 of a codebook of <= 16 codes, D = 256, as the fused reflectance kernel (csrc/mlp_chain.hip) reads them:
+// B fragments + |c|^2 of a codebook of <= 64 codes (1, 2 or 4 tiles of 16), D = 256, as the fused reflectance kernel (csrc/mlp_chain.hip) reads them:
 // exactly what vq_assign_kernel<1, ...> stages into LDS (same element order, the same fmaf chain over d for |c|^2).
-__global__ __launch_bounds__(256) void vq_codebook_frags_kernel(const float* __restrict__ C, int D, int K, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void vq_codebook_frags_kernel(const float* __restrict__ C, int D, int K, int KT, float* __restrict__ out) {
   const int D16 = (D + 15) >> 4;
   f32x4* Bf = reinterpret_cast<f32x4*>(out);
-  for (int i = threadIdx.x; i < D16 * 64; i += 256) {
-    const int l = i & 63, t = i >> 6, code = l & 15;
+  for (int i = threadIdx.x; i < KT * D16 * 64; i += 256) {
+    const int l = i & 63, t = (i >> 6) % D16, kt = (i >> 6) / D16;
+    const int code = 16 * kt + (l & 15);
     f32x4 v;
     for (int e = 0; e < 4; ++e) {
       const int d = 16 * t + 4 * (l >> 4) + e;
@@ -991,12 +992,12 @@ __global__ __launch_bounds__(256) void vq_codebook_frags_kernel(const float* __r
     }
     Bf[i] = v;
   }
-  if (threadIdx.x < 16) {
+  if ((int)threadIdx.x < 16 * KT) {
     const int k = threadIdx.x;
     float acc = 0.f;
     if (k < K)
       for (int d = 0; d < D; ++d) { const float c = C[(size_t)d * K + k]; acc = fmaf(c, c, acc); }
-    out[(size_t)D16 * 256 + k] = acc;
+    out[(size_t)KT * D16 * 256 + k] = acc;
   }
 }
 
@@ -1010,8 +1011,8 @@ int vqn_internal_finish_loss(const float* part, int n, float scale, float* loss,
 
 extern "C" int vqn_vq_codebook_frags(const float* codebook, int D, int K, float* frags, void* stream) {
   VQN_CHECK_ARG(codebook && frags, "codebook and frags must be non-null");
-  VQN_CHECK_SHAPE(D == 256 && K >= 1 && K <= 16, "D = 256, K <= 16");
-  hipLaunchKernelGGL(vq_codebook_frags_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, codebook, D, K, frags);
+  VQN_CHECK_SHAPE(D == 256 && K >= 1 && K <= 64, "D = 256, K <= 64");
+  hipLaunchKernelGGL(vq_codebook_frags_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, codebook, D, K, K <= 16 ? 1 : (K <= 32 ? 2 : 4), frags);
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }

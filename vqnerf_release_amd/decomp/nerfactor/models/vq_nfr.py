@@ -96,7 +96,7 @@ class Model(BrdfModel):
             vq = self.vq_layer(z_norm, codebook, is_training=(mode == 'train'), thres=th, roll=roll)
         return vq, vq['quantize'], vq['loss'], vq['encoding_indices'] + 1
 
-    fuse_front = True          # inference, K <= 16, no code dropout: encoder -> heads -> VQ step -> VQ heads in ONE launch
+    fuse_front = True          # inference, K <= 64, no code dropout: encoder -> heads -> VQ step -> VQ heads in ONE launch
 
     def _cb_frags(self, cb):
         """MFMA fragments + |c|^2 of the (clipped) codebook for the fused front kernel, rebuilt when the parameter changes."""
@@ -112,7 +112,7 @@ class Model(BrdfModel):
         with `redo()` -> (z_enc, z_vq) through the separate launches (bit-identical) for whoever asks for the rows later."""
         names_m = [h + '_main' for h in self.HEADS]
         names_v = [h + '_vq' for h in self.HEADS]
-        if not (self.fuse_front and self.fuse_quantise and mode != 'train' and thres is None and self.num_embed <= 16
+        if not (self.fuse_front and self.fuse_quantise and mode != 'train' and thres is None and self.num_embed <= 64
                 and self.z_dim == 256 and self.matrix_mode == 'f32' and pts.is_cuda):
             return None
         if not (self._fused(pts) and self._can_fuse_enc_heads(names_m) and self._plan_fits_two_workgroups(names_m)
