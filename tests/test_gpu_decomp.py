@@ -505,3 +505,19 @@ def test_fused_front_is_bit_identical_to_the_separate_launches(mode, full_vis, n
     assert torch.equal(la['z'], lb['z'])                                      # materialised (vali) or recomputed on access (test)
     if full_vis:
         assert torch.equal(ta['enc_z'], tb['enc_z'])
+
+
+def test_fused_front_with_no_foreground_rows():
+    """A view without a single foreground pixel: the one-launch front returns empty tensors (no kernel is launched), the commitment
+    term is NaN like the reference's mean over nothing."""
+    from oracle import decomp as od
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    p, specs = od.make_model_params(seed=0, K=15)
+    model = load_oracle_params(get_model_class('vq_nfr')(make_config(num_embed=15)), p, 'cuda')
+    batch = list(make_batch(od.make_points(64, seed=2), 'cuda'))
+    batch[5] = torch.zeros_like(batch[5])                                     # alpha = 0 everywhere
+    with torch.no_grad(), launches() as rec:
+        pred, gt, lk, _ = model.call(tuple(batch), mode='test')
+    assert rec.ran('vqn_mlp_chain_vq_fwd')
+    assert pred['rgb'].shape == (64, 3) and float(pred['rgb'].abs().max()) == 0.0 and float(pred['embed'].abs().max()) == 0.0
+    assert np.isnan(float(lk['vqloss']))

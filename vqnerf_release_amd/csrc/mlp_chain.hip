@@ -465,7 +465,7 @@ extern "C" int vqn_mlp_chain_vq_fwd(const int32_t* desc_a, const float* wbuf_a, 
                                     const int32_t* ld_b, const float* cb_frags, int K, float eps, float loss_scale, int64_t* idx,
                                     float* ste, float* loss, float* counts, float* ws, void* stream) {
   VQN_CHECK_ARG(desc_a && wbuf_a && desc_b && wbuf_b && outs_a && ld_a && outs_b && ld_b, "descriptors, packs and output tables must be non-null");
-  VQN_CHECK_ARG(cb_frags && idx && loss && counts && ws, "cb_frags, idx, loss, counts and ws must be non-null");
+  VQN_CHECK_ARG(cb_frags && loss && counts && ws, "cb_frags, loss, counts and ws must be non-null");
   VQN_CHECK_ARG(N >= 0 && K >= 1, "N >= 0, K >= 1");
   VQN_CHECK_SHAPE(K <= 64, "K <= 64 (larger codebooks run the separate launches)");
   const int KT = K <= 16 ? 1 : (K <= 32 ? 2 : 4);
@@ -476,7 +476,7 @@ extern "C" int vqn_mlp_chain_vq_fwd(const int32_t* desc_a, const float* wbuf_a, 
     VQN_HIP(hipMemcpyAsync(loss, &nan, sizeof(float), hipMemcpyHostToDevice, s));
     return VQN_OK;
   }
-  VQN_CHECK_ARG(in != nullptr, "in must be non-null");
+  VQN_CHECK_ARG(in != nullptr && idx != nullptr, "in and idx must be non-null");
   VQN_CHECK_ARG(ste == nullptr || ((uintptr_t)ste & 15) == 0, "ste must be 16-byte aligned");
   ChainDesc da, db;
   memcpy(&da, desc_a, sizeof(ChainDesc));
