@@ -25,4 +25,11 @@ with torch.no_grad():
     for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
         model.call(batch, mode=os.environ.get('VQN_MODE', 'test'))
 torch.cuda.synchronize()
-print('done')
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+with torch.no_grad():
+    e0.record()
+    for _ in range(5):
+        model.call(batch, mode=os.environ.get('VQN_MODE', 'test'))
+    e1.record()
+torch.cuda.synchronize()
+print('done: %.3f ms per call (640,000 rows, 512,000 foreground)' % (e0.elapsed_time(e1) / 5))
