@@ -521,6 +521,12 @@ def dp_train_leg(dev, rank, world, backend, steps=10, warmup=3):
     del model, tr, dstep
     # the same step replayed from HIP graphs: under N ranks three graphs with the two all-reduces between them
     # (parallel.SegmentedCapture); guarded -- a failure here must not cost the run its headline line
+    # Under RCCL with more than one rank it runs only on request (VQN_BENCH_DP_GRAPH=1): it was validated on two gloo ranks sharing
+    # one card (tests/test_gpu_parallel.py, tests/test_gpu_bench.py) but never on a multi-GPU node, and a rank that hangs inside a
+    # collective here would take the whole line with it.
+    if world > 1 and backend != 'gloo' and os.environ.get('VQN_BENCH_DP_GRAPH') != '1':
+        out['decomp_graph'] = {'skipped': 'multi-rank RCCL: set VQN_BENCH_DP_GRAPH=1 to time the graph-segment replay of the DP step'}
+        return out
     try:
         model, tr, gstep2 = decomp_train_setup(dev, rank, world, graph=True)
         from vqnerf_release_amd.decomp.nerfactor import train_nfr
