@@ -521,3 +521,26 @@ def test_fused_front_with_no_foreground_rows():
     assert rec.ran('vqn_mlp_chain_vq_fwd')
     assert pred['rgb'].shape == (64, 3) and float(pred['rgb'].abs().max()) == 0.0 and float(pred['embed'].abs().max()) == 0.0
     assert np.isnan(float(lk['vqloss']))
+
+
+def test_fused_front_random_shapes():
+    """A sweep over point counts (tile boundaries, single rows) and codebook sizes: one-launch front == separate launches, bit for bit."""
+    from oracle import decomp as od
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    rng = np.random.default_rng(123)
+    for K in (2, 9, 16, 31, 48, 64):
+        p, specs = od.make_model_params(seed=int(rng.integers(100)), K=K)
+        model = load_oracle_params(get_model_class('vq_nfr')(make_config(num_embed=K)), p, 'cuda')
+        for n in [1, 32, 33, 63, 64, 65] + [int(v) for v in rng.integers(2, 20000, 3)]:
+            batch = make_batch(od.make_points(n, seed=int(rng.integers(1000))), 'cuda', bg_every=int(rng.integers(2, 9)))
+            res = {}
+            for fused in (True, False):
+                model.fuse_front = fused
+                with torch.no_grad():
+                    pred, _, lk, _ = model.call(batch, mode='test')
+                res[fused] = (pred, lk)
+            for k in res[True][0]:
+                assert torch.equal(res[True][0][k], res[False][0][k]), (K, n, k)
+            assert torch.equal(res[True][1]['vqrgb'], res[False][1]['vqrgb']), (K, n)
+            a, b = float(res[True][1]['vqloss']), float(res[False][1]['vqloss'])
+            assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 2e-6 * max(abs(b), 1e-30), (K, n, a, b)
