@@ -347,6 +347,12 @@ int vqn_tfmt_unpack(const float* t, int tiles_f, int64_t N, int F, float* x, int
 int vqn_wgrad_partials(const float* A, int a_tiles, int a_t0, int a_nt, const float* B, int b_tiles, int b_t0, int b_nt,
                        int64_t n_point_tiles, int n_split, float* ws, float* rowsum_ws, void* stream);
 
+/* The same contraction with every f32 operand split exactly into three bf16 pieces and the six cross terms down to 2^-24 of |a||b|
+ * kept (csrc/wgrad_x3.hip): f32-level products on the bf16 matrix pipe, 2.7x less matrix time for the 256 x 256 blocks (blocks of
+ * <= 4 output tiles run the f32 kernel).  Same arguments, workspace and return value. */
+int vqn_wgrad_partials_x3(const float* A, int a_tiles, int a_t0, int a_nt, const float* B, int b_tiles, int b_t0, int b_nt,
+                          int64_t n_point_tiles, int n_split, float* ws, float* rowsum_ws, void* stream);
+
 /* The ordered sum of those partial blocks: out[r][c] (+)= sum_s ws[s][r][c], s = 0 .. n-1 (fixed order: deterministic),
  * written into a [rows, cols] window of a matrix with row stride out_ld.  cols, out_ld multiples of 4. */
 int vqn_reduce_partials(const float* ws, int n, int rows, int cols, float* out, int64_t out_ld, int accumulate, void* stream);

@@ -372,3 +372,34 @@ def test_fused_weight_norm_matches_torch_autograd():
         for a, b in zip(g, want):
             scale = float(b.abs().max())
             np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-6 * scale)
+
+
+@pytest.mark.parametrize('a_nt,b_nt,n_tiles', [(8, 8, 300), (8, 3, 77), (5, 8, 40), (8, 8, 1)])
+def test_bf16x3_weight_gradient_contraction_matches_the_f32_one(a_nt, b_nt, n_tiles):
+    """vqn_wgrad_partials_x3 (every operand split exactly into three bf16 pieces, six MFMAs per product) against
+    vqn_wgrad_partials and against the float64 contraction: f32-level agreement over eight decades of operand scale (no range
+    caveat, unlike an f16 split), bias-gradient row sums identical."""
+    import ctypes
+    from vqnerf_release_amd import _C
+    lib = _C.lib()
+    g = torch.Generator(device='cuda'); g.manual_seed(a_nt * 100 + b_nt)
+    A = torch.randn((n_tiles, a_nt, 32, 32), device='cuda', generator=g) * torch.exp(torch.randn((n_tiles, 1, 1, 32), device='cuda', generator=g) * 4.0) * 1e-6
+    B = torch.randn((n_tiles, b_nt, 32, 32), device='cuda', generator=g)
+    n_split = 64
+    outs = {}
+    for entry in ('vqn_wgrad_partials', 'vqn_wgrad_partials_x3'):
+        ws = torch.zeros((n_split, a_nt * 32, b_nt * 32), device='cuda')
+        rs = torch.zeros((n_split, a_nt * 32), device='cuda')
+        n = getattr(lib, entry)(_C._ptr(A), a_nt, 0, a_nt, _C._ptr(B), b_nt, 0, b_nt, ctypes.c_int64(n_tiles), n_split, _C._ptr(ws),
+                                _C._ptr(rs), _C._stream())
+        assert n > 0, lib.vqn_last_error()
+        torch.cuda.synchronize()
+        outs[entry] = (ws[:n].double().sum(0), rs[:n].double().sum(0))
+    Ad, Bd = A.double().permute(1, 2, 0, 3).reshape(a_nt * 32, -1), B.double().permute(1, 2, 0, 3).reshape(b_nt * 32, -1)
+    want = Ad @ Bd.T
+    scale = (Ad.abs() @ Bd.abs().T).max()                     # the sum of |terms|: what fp32 rounding is relative to
+    e32 = float((outs['vqn_wgrad_partials'][0] - want).abs().max() / scale)
+    ex3 = float((outs['vqn_wgrad_partials_x3'][0] - want).abs().max() / scale)
+    assert ex3 <= max(2.0 * e32, 2e-7), (ex3, e32)
+    assert torch.equal(outs['vqn_wgrad_partials'][1], outs['vqn_wgrad_partials_x3'][1]) or \
+        float((outs['vqn_wgrad_partials'][1] - outs['vqn_wgrad_partials_x3'][1]).abs().max()) <= 1e-6 * float(Ad.abs().sum(1).max())

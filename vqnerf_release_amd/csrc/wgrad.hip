@@ -140,8 +140,16 @@ extern "C" int vqn_reduce_partials(const float* ws, int n, int rows, int cols, f
   return VQN_OK;
 }
 
+int vqn_wgrad_partials_f32_internal(const float* A, int a_tiles, int a_t0, int a_nt, const float* B, int b_tiles, int b_t0, int b_nt,
+                                    int64_t n_point_tiles, int n_split, float* ws, float* rowsum_ws, void* stream);      // below
+
 extern "C" int vqn_wgrad_partials(const float* A, int a_tiles, int a_t0, int a_nt, const float* B, int b_tiles, int b_t0,
                                   int b_nt, int64_t n_point_tiles, int n_split, float* ws, float* rowsum_ws, void* stream) {
+  return vqn_wgrad_partials_f32_internal(A, a_tiles, a_t0, a_nt, B, b_tiles, b_t0, b_nt, n_point_tiles, n_split, ws, rowsum_ws, stream);
+}
+
+int vqn_wgrad_partials_f32_internal(const float* A, int a_tiles, int a_t0, int a_nt, const float* B, int b_tiles, int b_t0, int b_nt,
+                                    int64_t n_point_tiles, int n_split, float* ws, float* rowsum_ws, void* stream) {
   VQN_CHECK_ARG(A && B && ws, "null pointer");
   VQN_CHECK_ARG(n_point_tiles >= 1 && n_split >= 1, "n_point_tiles >= 1, n_split >= 1");
   VQN_CHECK_SHAPE(a_nt >= 1 && a_nt <= 8 && b_nt >= 1 && b_nt <= 8, "1..8 feature tiles per operand and call");

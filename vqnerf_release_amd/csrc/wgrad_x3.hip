@@ -1,0 +1,162 @@
+// Weight-gradient contraction (see csrc/wgrad.hip) on the bf16 matrix pipe at f32 accuracy: every f32 operand is split EXACTLY into
+// three bf16 pieces (8 + 8 + 8 significant bits, by truncation: x = p0 + p1 + p2 with no rounding anywhere), and a product keeps
+// the six cross terms down to 2^-24 of |a||b|:
+//     a b = a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0)      [dropped: a1 b2 + a2 b1 + a2 b2 <= 2^-23 |a b|]
+// i.e. what an f32 multiply rounds away, accumulated in f32 like the f32-input MFMA does.  Unlike an f16 split the pieces have the
+// f32 exponent range: adjoints of 1e-9 need no scaling.  Six v_mfma_f32_32x32x16_bf16 (32 cycles each) cover the K = 16 that takes
+// eight v_mfma_f32_32x32x2_f32 (64 cycles each): 2.7x less matrix-pipe time, which puts the 256 x 256 blocks of the NeuS nets at the
+// HBM rate of their operand stream instead of the f32 pipe's.  Same workspace / reduction contract as vqn_wgrad_partials
+// (deterministic: fixed order, no atomics).
+#include "common.h"
+
+int vqn_wgrad_partials_f32_internal(const float* A, int a_tiles, int a_t0, int a_nt, const float* B, int b_tiles, int b_t0, int b_nt,
+                                    int64_t n_point_tiles, int n_split, float* ws, float* rowsum_ws, void* stream);
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct Pieces {
+  u32x4 p0, p1, p2;          // bf16x8 each: elements j = 0..7 <-> points 8 kk + j of the step
+};
+
+// eight consecutive f32 -> three exact bf16x8 pieces (truncation: the high half of the word IS the bf16)
+__device__ __forceinline__ void split3(const f32x4 lo4, const f32x4 hi4, Pieces& o) {
+  const float x[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned u0 = __float_as_uint(x[2 * i]), u1 = __float_as_uint(x[2 * i + 1]);
+    o.p0[i] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = x[2 * i] - __uint_as_float(u0 & 0xffff0000u), r1 = x[2 * i + 1] - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    o.p1[i] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    o.p2[i] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+  }
+}
+
+__device__ __forceinline__ f32x16 mma(const u32x4 a, const u32x4 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// wave w owns output tiles (w, w + 4) x (0..7); step q = (point tile, half u): 16 points
+template <bool FULL>          // FULL: a_nt == b_nt == 8 -- no guards in the instruction stream
+__global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(const float* __restrict__ A, int a_tiles, int a_t0, int a_nt,
+                                                          const float* __restrict__ B, int b_tiles, int b_t0, int b_nt,
+                                                          long n_ptiles, float* __restrict__ ws, float* __restrict__ rowsum_ws) {
+  constexpr int NOT = 2, BT = 8;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fi = lane & 31, kk = lane >> 5;
+  f32x16 acc[NOT][BT];
+#pragma unroll
+  for (int a = 0; a < NOT; ++a)
+#pragma unroll
+    for (int b = 0; b < BT; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  f32x4 rs[NOT];
+#pragma unroll
+  for (int a = 0; a < NOT; ++a) rs[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const long my_tiles = (n_ptiles - blockIdx.x + gridDim.x - 1) / gridDim.x, n_q = 2 * my_tiles;
+  // unconditional clamped fetches, one step ahead (two register buffers): see wgrad.hip
+  auto fetch = [&](long q, f32x4 (&af)[NOT][2], f32x4 (&bf)[BT][2]) {
+    long t = blockIdx.x + (q >> 1) * (long)gridDim.x;
+    if (t >= n_ptiles) t = n_ptiles - 1;
+    const int u = (int)(q & 1);
+    const float* At = A + ((t * a_tiles + a_t0) * 32 + fi) * 32 + 8 * kk + 16 * u;
+    const float* Bt = B + ((t * b_tiles + b_t0) * 32 + fi) * 32 + 8 * kk + 16 * u;
+#pragma unroll
+    for (int a = 0; a < NOT; ++a) {
+      const float* p = At + (long)min(wave + 4 * a, a_nt - 1) * 1024;
+      af[a][0] = *reinterpret_cast<const f32x4*>(p);
+      af[a][1] = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      const float* p = Bt + (long)min(b, b_nt - 1) * 1024;
+      bf[b][0] = *reinterpret_cast<const f32x4*>(p);
+      bf[b][1] = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+  };
+  auto multiply = [&](const f32x4 (&af)[NOT][2], const f32x4 (&bf)[BT][2]) {
+    Pieces pa[NOT];
+#pragma unroll
+    for (int a = 0; a < NOT; ++a) {
+      rs[a] += af[a][0] + af[a][1];
+      split3(af[a][0], af[a][1], pa[a]);
+    }
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      if (!FULL && b >= b_nt) continue;
+      Pieces pb;
+      split3(bf[b][0], bf[b][1], pb);
+#pragma unroll
+      for (int a = 0; a < NOT; ++a)
+        if (FULL || wave + 4 * a < a_nt) {
+          f32x16 c = acc[a][b];
+          c = mma(pa[a].p2, pb.p0, c);            // smallest terms first
+          c = mma(pa[a].p1, pb.p1, c);
+          c = mma(pa[a].p0, pb.p2, c);
+          c = mma(pa[a].p1, pb.p0, c);
+          c = mma(pa[a].p0, pb.p1, c);
+          c = mma(pa[a].p0, pb.p0, c);
+          acc[a][b] = c;
+        }
+    }
+  };
+  f32x4 af[2][NOT][2], bf[2][BT][2];
+  fetch(0, af[0], bf[0]);
+  for (long q = 0; q < n_q; q += 2) {
+    fetch(q + 1, af[1], bf[1]);
+    multiply(af[0], bf[0]);
+    fetch(q + 2, af[0], bf[0]);
+    if (q + 1 < n_q) multiply(af[1], bf[1]);
+  }
+  const int cols = b_nt * 32;
+  float* w = ws + (size_t)blockIdx.x * (size_t)(a_nt * 32) * cols;
+#pragma unroll
+  for (int a = 0; a < NOT; ++a) {
+    const int ot = wave + 4 * a;
+    if (ot >= a_nt) continue;
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      if (b >= b_nt) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * kk;
+        w[(size_t)(ot * 32 + row) * cols + b * 32 + fi] = acc[a][b][e];
+      }
+    }
+    if (rowsum_ws != nullptr) {
+      float r = (rs[a][0] + rs[a][1]) + (rs[a][2] + rs[a][3]);
+      r += __shfl_xor(r, 32);
+      if (kk == 0) rowsum_ws[(size_t)blockIdx.x * (a_nt * 32) + ot * 32 + fi] = r;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vqn_wgrad_partials_x3(const float* A, int a_tiles, int a_t0, int a_nt, const float* B, int b_tiles, int b_t0,
+                                     int b_nt, int64_t n_point_tiles, int n_split, float* ws, float* rowsum_ws, void* stream) {
+  VQN_CHECK_ARG(A && B && ws, "null pointer");
+  VQN_CHECK_ARG(n_point_tiles >= 1 && n_split >= 1, "n_point_tiles >= 1, n_split >= 1");
+  VQN_CHECK_SHAPE(a_nt >= 1 && a_nt <= 8 && b_nt >= 1 && b_nt <= 8, "1..8 feature tiles per operand and call");
+  VQN_CHECK_SHAPE(a_t0 >= 0 && a_t0 + a_nt <= a_tiles && b_t0 >= 0 && b_t0 + b_nt <= b_tiles, "feature-tile range outside the tensor");
+  VQN_CHECK_SHAPE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "operands must be 16-byte aligned");
+  if (a_nt <= 4)               // small blocks are latency-, not matrix-bound: the f32 kernels with their deeper rings
+    return vqn_wgrad_partials_f32_internal(A, a_tiles, a_t0, a_nt, B, b_tiles, b_t0, b_nt, n_point_tiles, n_split, ws, rowsum_ws, stream);
+  long grid = n_split;
+  if (grid > n_point_tiles) grid = n_point_tiles;
+  if (a_nt == 8 && b_nt == 8)
+    hipLaunchKernelGGL(wgrad_x3_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, A, a_tiles, a_t0, a_nt, B, b_tiles,
+                       b_t0, b_nt, (long)n_point_tiles, ws, rowsum_ws);
+  else
+    hipLaunchKernelGGL(wgrad_x3_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, A, a_tiles, a_t0, a_nt, B, b_tiles,
+                       b_t0, b_nt, (long)n_point_tiles, ws, rowsum_ws);
+  VQN_LAUNCH_CHECK();
+  return (int)grid;
+}

@@ -13,7 +13,7 @@ import torch
 
 from vqnerf_release_amd import _C
 from vqnerf_release_amd.geo.train_programs import (Program, _ident, _f2i, DESC_INTS, K_LD_POSENC, K_LD_T, EPI_ACT, EPI_MUL_DACT,
-                                                   ACT_NONE, ACT_RELU, ACT_SIGMOID, FlatLayout, build_static_packs)
+                                                   ACT_NONE, ACT_RELU, ACT_SIGMOID, FlatLayout, build_static_packs, WGRAD_ENTRY, wgrad_mode)
 
 ACTS = {None: ACT_NONE, 'relu': ACT_RELU, 'sigmoid': ACT_SIGMOID}
 
@@ -94,7 +94,7 @@ class _Engine:
             self._rs_ws = torch.empty(self.n_split * 256, dtype=torch.float32, device=A.device)
         lib = _C.lib()
         with _C._clock('vqn_wgrad_partials'):
-            n = lib.vqn_wgrad_partials(_C._ptr(A), ctypes.c_int(at), ctypes.c_int(0), ctypes.c_int(an), _C._ptr(B), ctypes.c_int(bt),
+            n = getattr(lib, WGRAD_ENTRY[wgrad_mode()])(_C._ptr(A), ctypes.c_int(at), ctypes.c_int(0), ctypes.c_int(an), _C._ptr(B), ctypes.c_int(bt),
                                        ctypes.c_int(0), ctypes.c_int(bn), ctypes.c_int64(nt), ctypes.c_int(self.n_split),
                                        _C._ptr(ws), _C._ptr(self._rs_ws if rowsum else None), _C._stream())
         if n <= 0:

@@ -15,12 +15,27 @@ so that the eikonal term and the normal-dependent colour differentiate through d
 (the adjoint of the tangent stream IS the forward's reverse sweep, which is why g^_l is saved rather than recomputed).
 """
 import ctypes
+import os
 import math
 
 import numpy as np
 import torch
 
 from vqnerf_release_amd import _C
+
+# Weight-gradient contraction: 'f32' = the f32-input MFMA (bit-for-bit a k-ordered fmaf chain); 'bf16x3' = every operand split
+# exactly into three bf16 pieces, six MFMAs per product down to 2^-24 (csrc/wgrad_x3.hip): f32-level results, 2.7x less matrix time.
+WGRAD_ENTRY = {'f32': 'vqn_wgrad_partials', 'bf16x3': 'vqn_wgrad_partials_x3'}
+_wgrad_mode = [os.environ.get('VQN_WGRAD', 'f32')]
+
+
+def wgrad_mode(new=None):
+    """Get (or set) the contraction used by every training engine of the process."""
+    if new is not None:
+        assert new in WGRAD_ENTRY, new
+        _wgrad_mode[0] = new
+    return _wgrad_mode[0]
+
 from vqnerf_release_amd.geo.packing import gemm_index, bias_index, _take
 
 K_LD_POSENC, K_LD_POSENC_JVP, K_LD_T, K_LD_VEC, K_LD_EXTRAS, K_GEMM, K_ST_VEC, K_POSENC_VJP = 1, 2, 3, 4, 5, 6, 7, 8
@@ -498,7 +513,7 @@ class NeusTrainEngine:
                     bn = min(8, b_nt_all - b0)
                     want_rs = rowsum and pi == 0 and b0 == 0
                     with _C._clock('vqn_wgrad_partials'):
-                        n = lib.vqn_wgrad_partials(_C._ptr(A_), ctypes.c_int(at), ctypes.c_int(a0), ctypes.c_int(an), _C._ptr(B_),
+                        n = getattr(lib, WGRAD_ENTRY[wgrad_mode()])(_C._ptr(A_), ctypes.c_int(at), ctypes.c_int(a0), ctypes.c_int(an), _C._ptr(B_),
                                                    ctypes.c_int(bt), ctypes.c_int(b0), ctypes.c_int(bn), ctypes.c_int64(nt),
                                                    ctypes.c_int(self.n_split), _C._ptr(ws), _C._ptr(self._rs_ws if want_rs else None),
                                                    _C._stream())
