@@ -8,6 +8,8 @@
 // HBM rate of their operand stream instead of the f32 pipe's.  Same workspace / reduction contract as vqn_wgrad_partials
 // (deterministic: fixed order, no atomics).
 #include "common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 int vqn_wgrad_partials_f32_internal(const float* A, int a_tiles, int a_t0, int a_nt, const float* B, int b_tiles, int b_t0, int b_nt,
                                     int64_t n_point_tiles, int n_split, float* ws, float* rowsum_ws, void* stream);
@@ -138,6 +140,131 @@ __global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(const float* __restric
   }
 }
 
+// The 256 x 256 form with the B operand cut into pieces ONCE per workgroup: wave w fetches and splits B tiles 2 w and 2 w + 1 of
+// the step and parks the pieces in LDS (3 KB per tile, two step buffers), every wave then reads all eight tiles' pieces from there
+// (24 ds_read_b128 per step and wave).  Without it each wave fetches all of B itself, half a 128-byte line per instruction, and the
+// L2 -> L1 traffic (B four times over) binds the launch at 2.5x its matrix time.  One barrier per step.
+template <bool FULL>          // FULL: a_nt == b_nt == 8 -- no guards in the instruction stream
+__global__ __launch_bounds__(256, 1) void wgrad_x3_lds_kernel(const float* __restrict__ A, int a_tiles, int a_t0, int a_nt,
+                                                              const float* __restrict__ B, int b_tiles, int b_t0, int b_nt, long n_ptiles,
+                                                              float* __restrict__ ws, float* __restrict__ rowsum_ws) {
+  const bool two = FULL || (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + 4 < a_nt);      // this wave owns a second output tile
+  constexpr int NOT = 2, BT = 8;
+  __shared__ u32x4 pieces[2][BT][3][64];                       // 48 KB
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fi = lane & 31, kk = lane >> 5;
+  f32x16 acc[NOT][BT];
+#pragma unroll
+  for (int a = 0; a < NOT; ++a)
+#pragma unroll
+    for (int b = 0; b < BT; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  f32x4 rs[NOT];
+#pragma unroll
+  for (int a = 0; a < NOT; ++a) rs[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const long my_tiles = (n_ptiles - blockIdx.x + gridDim.x - 1) / gridDim.x, n_q = 2 * my_tiles;
+  auto fetch = [&](long q, f32x4 (&af)[NOT][2], f32x4 (&bf)[2][2]) {
+    long t = blockIdx.x + (q >> 1) * (long)gridDim.x;
+    if (t >= n_ptiles) t = n_ptiles - 1;
+    const int u = (int)(q & 1);
+    const float* At = A + ((t * a_tiles + a_t0) * 32 + fi) * 32 + 8 * kk + 16 * u;
+    const float* Bt = B + ((t * b_tiles + b_t0) * 32 + fi) * 32 + 8 * kk + 16 * u;
+#pragma unroll
+    for (int a = 0; a < NOT; ++a) {
+      const float* p = At + (long)(FULL ? wave + 4 * a : min(wave + 4 * a, a_nt - 1)) * 1024;
+      af[a][0] = *reinterpret_cast<const f32x4*>(p);
+      af[a][1] = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float* p = Bt + (long)(FULL ? 2 * wave + i : min(2 * wave + i, b_nt - 1)) * 1024;
+      bf[i][0] = *reinterpret_cast<const f32x4*>(p);
+      bf[i][1] = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+  };
+  auto park = [&](int buf, const f32x4 (&bf)[2][2]) {          // this wave's two B tiles -> pieces in LDS
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      Pieces pb;
+      split3(bf[i][0], bf[i][1], pb);
+      pieces[buf][2 * wave + i][0][lane] = pb.p0;
+      pieces[buf][2 * wave + i][1][lane] = pb.p1;
+      pieces[buf][2 * wave + i][2][lane] = pb.p2;
+    }
+  };
+  // operand fetches run R - 1 steps ahead (a step multiplies for ~1.3 us; an HBM round trip under load is several times that)
+  constexpr int R = 4;
+  f32x4 af[R][NOT][2], bf[R][2][2];
+#pragma unroll
+  for (int i = 0; i < R - 1; ++i) fetch(i, af[i], bf[i]);
+  park(0, bf[0]);
+  __syncthreads();
+  auto step = [&](long q, auto slot_c) {                       // slot = q % R, compile-time at the call sites; LDS buffer q & 1
+    constexpr int slot = decltype(slot_c)::value, cur = slot & 1;
+    fetch(q + R - 1, af[(slot + R - 1) % R], bf[(slot + R - 1) % R]);
+    if (q < n_q) {
+      Pieces pa[NOT];
+#pragma unroll
+      for (int a = 0; a < NOT; ++a) {
+        rs[a] += af[slot][a][0] + af[slot][a][1];
+        split3(af[slot][a][0], af[slot][a][1], pa[a]);
+      }
+      u32x4 n0 = pieces[cur][0][0][lane], n1 = pieces[cur][0][1][lane], n2 = pieces[cur][0][2][lane];
+#pragma unroll
+      for (int b = 0; b < BT; ++b) {
+        if (!FULL && b >= b_nt) break;
+        const u32x4 b0 = n0, b1 = n1, b2 = n2;
+        if (b + 1 < BT) { n0 = pieces[cur][b + 1][0][lane]; n1 = pieces[cur][b + 1][1][lane]; n2 = pieces[cur][b + 1][2][lane]; }   // one tile ahead of the MFMAs
+        // the wave's two output tiles alternate MFMA by MFMA (one wave per SIMD: nothing else covers a dependent chain)
+        f32x16 c0 = acc[0][b], c1 = acc[1][b];
+        if (FULL || two) {
+          c0 = mma(pa[0].p2, b0, c0); c1 = mma(pa[1].p2, b0, c1);
+          c0 = mma(pa[0].p1, b1, c0); c1 = mma(pa[1].p1, b1, c1);
+          c0 = mma(pa[0].p0, b2, c0); c1 = mma(pa[1].p0, b2, c1);
+          c0 = mma(pa[0].p1, b0, c0); c1 = mma(pa[1].p1, b0, c1);
+          c0 = mma(pa[0].p0, b1, c0); c1 = mma(pa[1].p0, b1, c1);
+          c0 = mma(pa[0].p0, b0, c0); c1 = mma(pa[1].p0, b0, c1);
+        } else {
+          c0 = mma(pa[0].p2, b0, c0); c0 = mma(pa[0].p1, b1, c0); c0 = mma(pa[0].p0, b2, c0);
+          c0 = mma(pa[0].p1, b0, c0); c0 = mma(pa[0].p0, b1, c0); c0 = mma(pa[0].p0, b0, c0);
+        }
+        acc[0][b] = c0; acc[1][b] = c1;
+      }
+    }
+    park(cur ^ 1, bf[(slot + 1) % R]);
+    __syncthreads();
+  };
+  for (long q = 0; q < n_q; q += R) {                          // n_q is even; R = 4: the tail steps beyond n_q only keep the barriers uniform
+    step(q, std::integral_constant<int, 0>{});
+    step(q + 1, std::integral_constant<int, 1>{});
+    step(q + 2, std::integral_constant<int, 2>{});
+    step(q + 3, std::integral_constant<int, 3>{});
+  }
+  const int cols = b_nt * 32;
+  float* w = ws + (size_t)blockIdx.x * (size_t)(a_nt * 32) * cols;
+#pragma unroll
+  for (int a = 0; a < NOT; ++a) {
+    const int ot = wave + 4 * a;
+    if (ot >= a_nt) continue;
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      if (b >= b_nt) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * kk;
+        w[(size_t)(ot * 32 + row) * cols + b * 32 + fi] = acc[a][b][e];
+      }
+    }
+    if (rowsum_ws != nullptr) {
+      float r = (rs[a][0] + rs[a][1]) + (rs[a][2] + rs[a][3]);
+      r += __shfl_xor(r, 32);
+      if (kk == 0) rowsum_ws[(size_t)blockIdx.x * (a_nt * 32) + ot * 32 + fi] = r;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int vqn_wgrad_partials_x3(const float* A, int a_tiles, int a_t0, int a_nt, const float* B, int b_tiles, int b_t0,
@@ -151,7 +278,14 @@ extern "C" int vqn_wgrad_partials_x3(const float* A, int a_tiles, int a_t0, int 
     return vqn_wgrad_partials_f32_internal(A, a_tiles, a_t0, a_nt, B, b_tiles, b_t0, b_nt, n_point_tiles, n_split, ws, rowsum_ws, stream);
   long grid = n_split;
   if (grid > n_point_tiles) grid = n_point_tiles;
-  if (a_nt == 8 && b_nt == 8)
+  static const int no_lds = [] { const char* e = getenv("VQN_WGRAD_X3_NO_LDS"); return (e != nullptr && atoi(e) != 0) ? 1 : 0; }();
+  if (a_nt == 8 && b_nt == 8 && !no_lds)
+    hipLaunchKernelGGL(wgrad_x3_lds_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, A, a_tiles, a_t0, a_nt, B, b_tiles,
+                       b_t0, b_nt, (long)n_point_tiles, ws, rowsum_ws);
+  else if (!no_lds)
+    hipLaunchKernelGGL(wgrad_x3_lds_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, A, a_tiles, a_t0, a_nt, B, b_tiles,
+                       b_t0, b_nt, (long)n_point_tiles, ws, rowsum_ws);
+  else if (a_nt == 8 && b_nt == 8)
     hipLaunchKernelGGL(wgrad_x3_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, A, a_tiles, a_t0, a_nt, B, b_tiles,
                        b_t0, b_nt, (long)n_point_tiles, ws, rowsum_ws);
   else
