@@ -38,6 +38,17 @@ __device__ __forceinline__ void split3(const f32x4 lo4, const f32x4 hi4, Pieces&
   }
 }
 
+// one pair of elements (slot i of the fragments) -- the unit in which the splits are dealt out between the MFMAs below
+__device__ __forceinline__ void split_pair(const float e0, const float e1, unsigned& q0, unsigned& q1, unsigned& q2) {
+  const unsigned u0 = __float_as_uint(e0), u1 = __float_as_uint(e1);
+  q0 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+  const float r0 = e0 - __uint_as_float(u0 & 0xffff0000u), r1 = e1 - __uint_as_float(u1 & 0xffff0000u);
+  const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+  q1 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+  const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+  q2 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+
 __device__ __forceinline__ f32x16 mma(const u32x4 a, const u32x4 b, const f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -201,6 +212,69 @@ __global__ __launch_bounds__(256, 1) void wgrad_x3_lds_kernel(const float* __res
   for (int i = 0; i < R - 1; ++i) fetch(i, af[i], bf[i]);
   park(0, bf[0]);
   __syncthreads();
+  // FULL form: step q multiplies with the A pieces cut during step q - 1 and the B pieces parked during step q - 1 while it cuts
+  // A (q + 1) and parks B (q + 1) -- one pair of A and one pair of B elements (22 vector instructions) per B tile, dealt out between
+  // that tile's twelve MFMAs by the group barriers of its (small) scheduling region.  One wave per SIMD issues strictly in order: left
+  // to itself the compiler emits the MFMA block and the splits one after the other.  Steps beyond n_q multiply zero pieces.
+  Pieces pa[NOT];
+  if (FULL) {
+#pragma unroll
+    for (int a = 0; a < NOT; ++a) {
+      rs[a] += af[0][a][0] + af[0][a][1];
+      split3(af[0][a][0], af[0][a][1], pa[a]);
+    }
+  }
+  auto step_full = [&](long q, auto slot_c) {
+    constexpr int slot = decltype(slot_c)::value, cur = slot & 1, nxt = (slot + 1) % R;
+    fetch(q + R - 1, af[(slot + R - 1) % R], bf[(slot + R - 1) % R]);
+    const bool live = q + 1 < n_q;                              // wave-uniform; applied as a select, not a branch
+    Pieces pn[NOT], pk[2];
+    u32x4 n0 = pieces[cur][0][0][lane], n1 = pieces[cur][0][1][lane], n2 = pieces[cur][0][2][lane];
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      const u32x4 b0 = n0, b1 = n1, b2 = n2;
+      if (b + 1 < BT) { n0 = pieces[cur][b + 1][0][lane]; n1 = pieces[cur][b + 1][1][lane]; n2 = pieces[cur][b + 1][2][lane]; }
+      f32x16 c0 = acc[0][b], c1 = acc[1][b];
+      c0 = mma(pa[0].p2, b0, c0); c1 = mma(pa[1].p2, b0, c1);
+      c0 = mma(pa[0].p1, b1, c0); c1 = mma(pa[1].p1, b1, c1);
+      c0 = mma(pa[0].p0, b2, c0); c1 = mma(pa[1].p0, b2, c1);
+      c0 = mma(pa[0].p1, b0, c0); c1 = mma(pa[1].p1, b0, c1);
+      c0 = mma(pa[0].p0, b1, c0); c1 = mma(pa[1].p0, b1, c1);
+      c0 = mma(pa[0].p0, b0, c0); c1 = mma(pa[1].p0, b0, c1);
+      acc[0][b] = c0; acc[1][b] = c1;
+      {   // this tile's share of the next step's splits: pair i of A tile ta and of this wave's B tile tb
+        constexpr int dummy = 0; (void)dummy;
+        const int ta = b >> 2, i = b & 3;
+        const f32x4 xa = af[nxt][ta][i >> 1];
+        float e0 = xa[2 * (i & 1)], e1 = xa[2 * (i & 1) + 1];
+        if (!live) { e0 = 0.f; e1 = 0.f; }
+        rs[ta][2 * (i & 1)] += e0; rs[ta][2 * (i & 1) + 1] += e1;
+        unsigned q0, q1, q2, k0, k1, k2;
+        split_pair(e0, e1, q0, q1, q2);
+        const f32x4 xb = bf[nxt][ta][i >> 1];
+        split_pair(xb[2 * (i & 1)], xb[2 * (i & 1) + 1], k0, k1, k2);
+        // (anchors: without them the optimiser sinks all sixteen pair splits below the tile loop, next to their first use)
+        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(k0), "+v"(k1), "+v"(k2));
+        pn[ta].p0[i] = q0; pn[ta].p1[i] = q1; pn[ta].p2[i] = q2;
+        pk[ta].p0[i] = k0; pk[ta].p1[i] = k1; pk[ta].p2[i] = k2;
+      }
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);         // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);         // two vector instructions of the splits
+      }
+      __builtin_amdgcn_sched_barrier(0);                         // regions of one tile: keeps the scheduler's problem small
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      pieces[cur ^ 1][2 * wave + i][0][lane] = pk[i].p0;
+      pieces[cur ^ 1][2 * wave + i][1][lane] = pk[i].p1;
+      pieces[cur ^ 1][2 * wave + i][2][lane] = pk[i].p2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NOT; ++a) pa[a] = pn[a];
+  };
   auto step = [&](long q, auto slot_c) {                       // slot = q % R, compile-time at the call sites; LDS buffer q & 1
     constexpr int slot = decltype(slot_c)::value, cur = slot & 1;
     fetch(q + R - 1, af[(slot + R - 1) % R], bf[(slot + R - 1) % R]);
@@ -236,6 +310,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_x3_lds_kernel(const float* __res
     park(cur ^ 1, bf[(slot + 1) % R]);
     __syncthreads();
   };
+  if (FULL) {
+    for (long q = 0; q < n_q; q += R) {
+      step_full(q, std::integral_constant<int, 0>{});
+      step_full(q + 1, std::integral_constant<int, 1>{});
+      step_full(q + 2, std::integral_constant<int, 2>{});
+      step_full(q + 3, std::integral_constant<int, 3>{});
+    }
+  } else
   for (long q = 0; q < n_q; q += R) {                          // n_q is even; R = 4: the tail steps beyond n_q only keep the barriers uniform
     step(q, std::integral_constant<int, 0>{});
     step(q + 1, std::integral_constant<int, 1>{});
