@@ -24,7 +24,7 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIV
 done
 python3 - <<PY
 import csv, glob, json, collections, re
-pat = re.compile(r'(mlp_chain_kernel<[^>]*>|brdf_shade_kernel<[^>]*>|brdf_shade_bwd_kernel<[^>]*>|vq_assign_kernel<[^>]*>|tile_vm_kernel<[^>]*>|wgrad_kernel<[^>]*>|neus_points2?_kernel<\w+>|composite_\w+_kernel)')
+pat = re.compile(r'(mlp_chain_vq_kernel<[^>]*>|mlp_chain_kernel<[^>]*>|brdf_shade_kernel<[^>]*>|brdf_shade_bwd_kernel<[^>]*>|vq_assign_kernel<[^>]*>|tile_vm_kernel<[^>]*>|wgrad_kernel<[^>]*>|neus_points2?_kernel<\w+>|composite_\w+_kernel)')
 out = {"source": "rocprofv3 --kernel-trace --pmc <set> (4 separate passes each) -- python3 scripts/probe_decomp_glue.py 3 / python3 scripts/probe_train.py 2560, MI355X (scripts/pmc_units.sh)",
        "units": "counter means per launch; SQ_* summed over all SIMDs; SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles, GRBM_GUI_ACTIVE summed over the 8 XCDs (MI355X_MICROARCH.md)",
        "workloads": {}}
