@@ -431,9 +431,10 @@ extern "C" int vqn_tile_program(const void* desc_dev, const int32_t* desc_host, 
   const size_t lds = (size_t)d->total_rows * 1024;
   VQN_CHECK_SHAPE(d->total_rows >= 1 && lds <= 160 * 1024, "program does not fit in 160 KB of LDS");
   // validate every op against the row budget and the tensor table before anything is launched
-  std::vector<int32_t> ld_abs(tensor_ld, tensor_ld + n_tensors);
-  for (int i = 0; i < n_tensors; ++i) ld_abs[i] = tensor_ld[i] < 0 ? -tensor_ld[i] : tensor_ld[i];
-  { const int32_t* tensor_ld = ld_abs.data();
+  const int32_t* const tensor_ld_arg = tensor_ld;         // negative entries flag per-workgroup tensors (vqn_tile_program_grid)
+  std::vector<int32_t> ld_abs(n_tensors);
+  for (int i = 0; i < n_tensors; ++i) ld_abs[i] = tensor_ld_arg[i] < 0 ? -tensor_ld_arg[i] : tensor_ld_arg[i];
+  tensor_ld = ld_abs.data();                              // the checks below are about sizes
   for (int i = 0; i < d->n_ops; ++i) {
     const VmOp& op = d->ops[i];
     auto row_ok = [&](int r0, int n) { return r0 >= 0 && n >= 0 && r0 + n <= d->total_rows; };
@@ -463,7 +464,7 @@ extern "C" int vqn_tile_program(const void* desc_dev, const int32_t* desc_host, 
       return VQN_ESHAPE;
     }
   }
-  }
+  tensor_ld = tensor_ld_arg;
   // per-workgroup tensors (negative ld) are understood by the GEMM op's aux / store operands only
   for (int i = 0; i < d->n_ops; ++i) {
     const VmOp& op = d->ops[i];
