@@ -228,6 +228,10 @@ int vqn_mlp_chain_vq_fwd(const int32_t* desc_a, const float* wbuf_a, const int32
 #define VQN_VQ_FRAGS_FLOATS(K) (((K) <= 16 ? 1 : ((K) <= 32 ? 2 : 4)) * (16 * 64 * 4 + 16))
 int vqn_vq_codebook_frags(const float* codebook, int D, int K, float* frags, void* stream);
 
+/* Replaces `linear2srgb` (nerfactor/util/img.py:142-186) as applied to the rendered colours (vq_nfr.py:736-745, nfr_unit.py:302-306):
+ * y = clip(x, 0, 1) through the piecewise sRGB curve, one pass over n floats. */
+int vqn_linear2srgb(const float* x, int64_t n, float* y, void* stream);
+
 /* ---- layer programs + weight packs of the Dense-stack evaluator, built in C ---------------------------------- */
 
 /* vqn_mlp_chain_fwd takes a layer program (include/vqn_chain_desc.h) and a weight pack.  These entries build both from a

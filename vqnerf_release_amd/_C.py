@@ -374,6 +374,17 @@ def mlp_chain_fwd(desc, wbuf, x, out_widths, mode='f32'):
     return outs
 
 
+def linear2srgb(x):
+    """clip to [0, 1] + the sRGB transfer curve in one pass (vqn_linear2srgb)."""
+    x = x.contiguous()
+    _f32c(x, 'x')
+    y = torch.empty_like(x)
+    with _clock('vqn_linear2srgb'):
+        rc = lib().vqn_linear2srgb(_ptr(x), ctypes.c_int64(x.numel()), _ptr(y), _stream())
+    _check(rc, 'vqn_linear2srgb')
+    return y
+
+
 def vq_codebook_frags(codebook):
     """codebook [256, K <= 64] -> the B-fragment + |c|^2 image the fused reflectance kernel reads (vqn_vq_codebook_frags)."""
     _f32c(codebook, 'codebook')

@@ -484,3 +484,26 @@ extern "C" int vqn_brdf_shade_bwd(const float* xyz, const float* normal, const f
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }
+
+// ---- display transfer of the rendered colours (nerfactor/util/img.py:142-186: clip to [0, 1], then the piecewise sRGB curve) as one
+// pass instead of the seven elementwise framework launches of its torch statement (clamp, compare, mul, pow, mul, sub, where)
+namespace {
+__global__ __launch_bounds__(256) void linear2srgb_kernel(const float* __restrict__ x, const long n, float* __restrict__ y) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float t = fminf(fmaxf(x[i], 0.0f), 1.0f);
+    y[i] = t <= 0.0031308f ? t * 12.92f : 1.055f * powf(t, 1.0f / 2.4f) - (1.055f - 1.0f);
+  }
+}
+}  // namespace
+
+extern "C" int vqn_linear2srgb(const float* x, int64_t n, float* y, void* stream) {
+  VQN_CHECK_ARG(n >= 0, "n >= 0");
+  if (n == 0) return VQN_OK;
+  VQN_CHECK_ARG(x && y, "x and y must be non-null");
+  long blocks = (n + 255) / 256;
+  const long cap = (long)vqn_num_cus() * 16;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(linear2srgb_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)n, y);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
