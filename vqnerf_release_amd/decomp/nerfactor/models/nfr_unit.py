@@ -8,6 +8,7 @@
     on the GPU.  There is no CPU fallback: the fused path raises if the HIP library is missing.
 """
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -25,8 +26,26 @@ def fg_rows(alpha):
     ONCE per call and reused for every gather and scatter: a boolean-mask index costs a `nonzero` (a host sync) each time,
     twenty of them per rendered view.  Returns None when EVERY row is foreground (the index list is on the host after the
     `nonzero` anyway): `take_rows` / `scatter_rows` are then the identity and no gather or scatter is launched at all."""
+    # The device-resident loaders hand the SAME alpha tensor to every call on a view (epochs, probes, validation): its index list is
+    # remembered per tensor object (weakly: the entry dies with the tensor; an in-place write bumps `_version` and invalidates it),
+    # so only the first call on a view pays the `nonzero` -- a host sync that otherwise leaves the GPU idle while the next call's
+    # launches are prepared.
+    key = id(alpha)
+    hit = _FG_CACHE.get(key)
+    if hit is not None and hit[0]() is alpha and hit[1] == alpha._version:
+        return hit[2]
     rows = (alpha[:, 0] > 0).nonzero(as_tuple=False).squeeze(1)
-    return None if rows.numel() == alpha.shape[0] else rows
+    rows = None if rows.numel() == alpha.shape[0] else rows
+    if len(_FG_CACHE) > 4096:
+        _FG_CACHE.clear()
+    try:
+        _FG_CACHE[key] = (weakref.ref(alpha, lambda _r, k=key: _FG_CACHE.pop(k, None)), alpha._version, rows)
+    except TypeError:
+        pass
+    return rows
+
+
+_FG_CACHE = {}
 
 
 def scatter_rows(mask, x, n):
