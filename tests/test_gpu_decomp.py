@@ -334,23 +334,26 @@ def test_full_image_properties(setup):
         assert torch.equal(pred3['vq_rgb'], pred['vq_rgb'][:100001])
 
 
-def test_relight_16_probes_single_pass(setup):
-    """fast_render(relight_probes=True) (test.py:254-266 -> vq_nfr.py:724-733): all 16 probes in ONE shading pass must equal
-    16 separate passes (to rounding: the radiance is multiplied in last instead of first) and the oracle within the shading tolerance."""
+@pytest.mark.parametrize('n_probes', [16, 5, 20, 30])
+def test_relight_16_probes_single_pass(setup, n_probes):
+    """fast_render(relight_probes=True) (test.py:254-266 -> vq_nfr.py:724-733): all probes in ONE shading pass must equal
+    separate passes (to rounding: the radiance is multiplied in last instead of first) and the oracle within the shading tolerance.
+    16 / 5 / 20 probes: the probe table staged in LDS (one chunk, a ragged chunk, two chunks); 30: beyond the LDS budget, read from
+    global memory."""
     od, model, pt, specs = setup['od'], setup['model'], setup['pt'], setup['specs']
     rng = np.random.default_rng(2)
-    model.novel_probes = {f'probe{i:02d}': torch.tensor(rng.uniform(0, 2, (16, 32, 3)).astype(np.float32)).cuda() for i in range(16)}
+    model.novel_probes = {f'probe{i:02d}': torch.tensor(rng.uniform(0, 2, (16, 32, 3)).astype(np.float32)).cuda() for i in range(n_probes)}
     N = 300
     pts = od.make_points(N, seed=12)
     batch = make_batch(pts, 'cuda', bg_every=5)
     with torch.no_grad():
         pred, gt, lk, to_vis = model.fast_render(batch, mode='test', relight_probes=True)
-        assert pred['rgb_probes'].shape == (N, 16, 3)
+        assert pred['rgb_probes'].shape == (N, n_probes, 3)
         keep = np.ones(N, bool); keep[::5] = False
         m = torch.tensor(keep).cuda()
         assert float(pred['rgb_probes'][~m].abs().max()) == 0.0
         # one probe at a time through dst_env
-        for i, name in enumerate(list(model.novel_probes)[:4]):
+        for i, name in [(j, list(model.novel_probes)[j]) for j in (0, 1, n_probes // 2, n_probes - 1)]:
             one, _, _, _ = model.fast_render(batch, mode='test', dst_env=name)
             np.testing.assert_allclose(_np(one['rgb'][m]), _np(pred['rgb_probes'][m][:, i]), rtol=0, atol=3e-6)
     # oracle
@@ -361,7 +364,7 @@ def test_relight_16_probes_single_pass(setup):
     z = od.pred_enc(pt, specs, ob['xyz'])
     base, ks, rough = od.heads(pt, specs, z, False)
     brdf, _, _ = od.get_brdf(surf2l, surf2c, n_pred, (1 - ks) * base, rough, ks * base)
-    for i, lp in enumerate(list(model.novel_probes.values())[:3]):
+    for i, lp in [(j, list(model.novel_probes.values())[j]) for j in (0, 2, n_probes - 1)]:
         want = od.linear2srgb(od.render_integrate(brdf, surf2l, n_pred, setup['lareas'], lp.cpu(), ob['lvis']))
         np.testing.assert_allclose(_np(pred['rgb_probes'][m][:, i]), want.numpy(), rtol=0, atol=2e-4)
     model.novel_probes = {}

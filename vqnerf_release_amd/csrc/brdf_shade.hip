@@ -10,6 +10,7 @@
 // one pass over the geometry and the visibility row.
 // Bound: HBM for data_type == 'nerf' (2 KB of lvis per point) -- VALU otherwise; see DESIGN.md.
 #include "common.h"
+#include <stdlib.h>
 #include "vqnerf_hip.h"
 #include <math.h>
 
@@ -64,13 +65,26 @@ struct Material {
 //     material sets and by the diffuse / specular split);
 //   * get_brdf's re-normalisation of the already unit light direction (microfacet.py:13) is dropped (<= 2 ulp).
 // Results move by fp32 rounding only (tests/test_gpu_decomp.py judges them against the float64 oracle).
-template <int LQ, bool PROBES, int NS>
-__global__ __launch_bounds__(256) void brdf_shade_kernel(const ShadeArgs a) {
+// PLDS (relighting, <= 24 probes): the probe table lives in LDS, laid out [probe][g][q][lane] float4 -- one copy per 768-thread
+// (1024 lights: 512-thread) workgroup, staged once.  Without it every wave re-reads the whole table (6 KB per probe) for every point through the L1: 63 GB per
+// 640,000-point view under 16 probes, and that traffic, not the arithmetic, paced the relighting pass.
+template <int LQ, bool PROBES, int NS, bool PLDS = false>
+__global__ __launch_bounds__(PLDS ? (LQ == 4 ? 512 : 768) : 256) void brdf_shade_kernel(const ShadeArgs a) {
   constexpr int LP = 4 * LQ;                       // lights per lane
   constexpr int L = 64 * LP;
+  constexpr int WPB = PLDS ? (LQ == 4 ? 8 : 12) : 4;      // waves per workgroup (PLDS: as many as the registers allow -- 168 at L <= 512)
+  extern __shared__ __attribute__((aligned(16))) f32x4 ptab[];
   const int lane = threadIdx.x & 63;
-  const long wave_id = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: per-point scalars by scalar loads
-  const long n_waves = (long)gridDim.x * 4;
+  const long wave_id = (long)blockIdx.x * WPB + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: per-point scalars by scalar loads
+  const long n_waves = (long)gridDim.x * WPB;
+  if (PROBES && PLDS) {
+    const int n4 = a.n_probes * LQ * 3 * 64;
+    for (int i = threadIdx.x; i < n4; i += 64 * WPB) {
+      const int l = i & 63, q = (i >> 6) % 3, g = ((i >> 6) / 3) % LQ, pr = (i >> 6) / (3 * LQ);
+      ptab[i] = reinterpret_cast<const f32x4*>(a.probes + ((size_t)pr * L + 256 * g + 4 * l) * 3)[q];
+    }
+    __syncthreads();
+  }
 
   // ---- this lane's lights: light index = 256 g + 4 lane + e ----
   float lx[LP], ly[LP], lz[LP], Ar[LP], Ag[LP], Ab[LP];      // A_c = radiance_c * solid angle
@@ -214,8 +228,14 @@ __global__ __launch_bounds__(256) void brdf_shade_kernel(const ShadeArgs a) {
           const int pr = min(pb + pi, a.n_probes - 1);         // (clamped: the surplus sums of a ragged last chunk are not stored)
 #pragma unroll
           for (int g = 0; g < LQ; ++g) {
-            const f32x4* pp = reinterpret_cast<const f32x4*>(a.probes + ((size_t)pr * L + 256 * g + 4 * lane) * 3);
-            const f32x4 q0 = pp[0], q1 = pp[1], q2 = pp[2];      // 4 lights x rgb, interleaved
+            f32x4 q0, q1, q2;                                    // 4 lights x rgb, interleaved
+            if (PLDS) {
+              const f32x4* pt = ptab + (size_t)(pr * LQ + g) * 3 * 64 + lane;
+              q0 = pt[0]; q1 = pt[64]; q2 = pt[128];
+            } else {
+              const f32x4* pp = reinterpret_cast<const f32x4*>(a.probes + ((size_t)pr * L + 256 * g + 4 * lane) * 3);
+              q0 = pp[0]; q1 = pp[1]; q2 = pp[2];
+            }
             const float rad[12] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3], q2[0], q2[1], q2[2], q2[3]};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -432,9 +452,23 @@ extern "C" int vqn_brdf_shade_fwd_rows(const int64_t* lvis_rows, const float* xy
   if (blocks > cap) blocks = cap;
   hipStream_t s = (hipStream_t)stream;
   const bool pr = a.probes != nullptr;
+  // relighting with the probe table in LDS: one 768-thread workgroup per CU (three waves per SIMD at 168 registers)
+  const size_t plds = pr ? (size_t)n_probes * (L / 256) * 3 * 1024 : 0;
+  static const int no_plds = [] { const char* e = getenv("VQN_SHADE_NO_PLDS"); return (e != nullptr && atoi(e) != 0) ? 1 : 0; }();
+  const bool use_plds = pr && plds <= 144 * 1024 && !no_plds && !(L == 1024 && n_sets == 2);      // (that one form would spill)
+  const int plds_waves = L == 1024 ? 8 : 12;
+  long blocks8 = (N + plds_waves - 1) / plds_waves;
+  if (blocks8 > (long)vqn_num_cus()) blocks8 = vqn_num_cus();
+#define VQN_SHADE_PLDS(LQ, NS_)                                                                                                    \
+  do {                                                                                                                             \
+    VQN_HIP(hipFuncSetAttribute((const void*)brdf_shade_kernel<LQ, true, NS_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds)); \
+    hipLaunchKernelGGL((brdf_shade_kernel<LQ, true, NS_, true>), dim3((unsigned)blocks8), dim3(64 * plds_waves), plds, s, a);                    \
+  } while (0)
 #define VQN_SHADE_LAUNCH(LQ)                                                                                   \
   do {                                                                                                         \
-    if (pr && n_sets == 1) hipLaunchKernelGGL((brdf_shade_kernel<LQ, true, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a);        \
+    if (use_plds && n_sets == 1) VQN_SHADE_PLDS(LQ, 1);                                                        \
+    else if (use_plds) VQN_SHADE_PLDS(LQ, 2);                                                                  \
+    else if (pr && n_sets == 1) hipLaunchKernelGGL((brdf_shade_kernel<LQ, true, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a);   \
     else if (pr) hipLaunchKernelGGL((brdf_shade_kernel<LQ, true, 2>), dim3((unsigned)blocks), dim3(256), 0, s, a);                  \
     else if (n_sets == 1) hipLaunchKernelGGL((brdf_shade_kernel<LQ, false, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a);        \
     else hipLaunchKernelGGL((brdf_shade_kernel<LQ, false, 2>), dim3((unsigned)blocks), dim3(256), 0, s, a);                         \
@@ -443,6 +477,7 @@ extern "C" int vqn_brdf_shade_fwd_rows(const int64_t* lvis_rows, const float* xy
   else if (L == 512) VQN_SHADE_LAUNCH(2);
   else VQN_SHADE_LAUNCH(4);
 #undef VQN_SHADE_LAUNCH
+#undef VQN_SHADE_PLDS
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }
