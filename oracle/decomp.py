@@ -16,7 +16,9 @@ text, the arithmetic of
     .../util/img.py:142-186                                    -> linear2srgb / srgb2linear
     .../models/shape.py:103-119                                -> calc_ldir / calc_vdir
     .../models/vq_nfr.py:534-692                               -> model_call
-    .../models/vq_nfr.py:262-398                               -> fast_render
+    .../models/vq_nfr.py:262-398                               -> fast_render (incl. edit_mask / edit_material / gen_embed / relight_olat)
+    .../models/vq_nfr.py:183-207, :209-256, :400-465, :467-532  -> init_z / init_mat, fast_embed, vis_mat, vq_test
+    .../models/vq_nfr.py:88-103                                -> novel_olat
     .../models/vq_nfr.py:694-733                               -> render_integrate
     .../models/vq_nfr.py:736-745                               -> gamma_param (data types 'dtu' / 'hw')
     .../models/vq_nfr.py:761-769                               -> get_codebook
@@ -332,25 +334,66 @@ def displayed(rgb, data_type):
     return linear2srgb(rgb) if data_type == 'nerf' else rgb
 
 
+def _vq_step(p, specs, z_enc, mode, thres, roll, commitment_cost=0.1):
+    """The quantiser block every inference entry point repeats (vq_nfr.py:226-233, :300-308, :425-433, :495-504):
+    thres -> (1, K); z_norm = safe_l2_normalize(z_enc, 1); vq_layer(z_norm, get_codebook(), is_training=(mode == 'train')).
+    `roll` stands in for the layer's tf.random.uniform((1, K)) (vq_layers.py:287); for thresholds in {0, 1} -- what the
+    drop-ranking validation feeds (train_nfr.py:292-301, test.py:285) -- any draw of U[0, 1) gives the same mask, so
+    `roll=None` then means a constant 0.5."""
+    K = p['codebook_raw'].shape[1]
+    if thres is not None:
+        thres = torch.as_tensor(np.asarray(thres), dtype=torch.float32).reshape(1, K)
+        if roll is None:
+            assert bool(((thres == 0) | (thres == 1)).all()), 'a roll is needed for thresholds strictly inside (0, 1)'
+            roll = torch.full((1, K), 0.5)
+    C = get_codebook(p['codebook_raw'])
+    z_norm = safe_l2_normalize(z_enc, 1)
+    assert mode != 'train', 'inference entry points only (no EMA state here)'
+    return vq_ema_call(z_norm, C, None, None, is_training=False, thres=thres, roll=roll, commitment_cost=commitment_cost)
+
+
+def update_material(src, mask, update):
+    """vq_nfr.py:258-260."""
+    return src * (1.0 - mask) + mask * torch.as_tensor([list(update)], dtype=torch.float32)
+
+
 def fast_render(p, specs, batch, lxyz, lareas, data_type='nerf', gamma=None, probes=(), dst_env=None, opt_scale=None,
-                vis_scale=False):
-    """vq_nfr.Model.fast_render (vq_nfr.py:262-398) on already-masked foreground points: main heads only, optional
-    albedo / spec scale (:332-335), one render under the model light or `dst_env` (:340-343, :694-699) and one per probe
-    (:724-733).  Returns the `pred`-level values (sRGB for 'nerf', see `displayed`)."""
+                vis_scale=False, edit_mask=None, edit_material=None, gen_embed=False, thres=None, roll=None, mode='test',
+                relight_olat=False, olat_maps=()):
+    """vq_nfr.Model.fast_render (vq_nfr.py:262-398) on already-masked foreground points: main heads only, optional material
+    edit under a mask (:289-291, :320-326), optional albedo / spec scale (:332-335), one render under the model light or
+    `dst_env` (:340-343, :694-699) and one per probe (:724-733), optional code indices (`gen_embed`, :300-308, :373-375).
+    Returns the `pred`-level values (sRGB for 'nerf', see `displayed`).
+
+    `relight_olat`: the reference ACCEPTS the flag and its `_render` ignores it -- `return rgb, None, rgb_probes` at :733 (the
+    same in nfr_unit.py:306 and ref_nfr.py:458) -- so `pred` never holds 'rgb_olat' there (:349, :385 are dead).  That is what
+    this statement returns with the default `olat_maps=()`.  `olat_maps` states the build's opt-in extension
+    (`model.render_olat = True`): the OLAT maps of :93-103 integrated exactly like the probes."""
     xyz, normal, rayo = batch['xyz'], batch['normal'], batch['rayo']
     lvis = batch.get('lvis') if data_type == 'nerf' else None
     surf2l = calc_ldir(lxyz, xyz)
     surf2c = calc_vdir(rayo, xyz)
     n_pred = normal_correct(normal, surf2c)
     z_enc = pred_enc(p, specs, xyz)
+    out = {}
+    if gen_embed:
+        out['embed'] = _vq_step(p, specs, z_enc, mode, thres, roll)['encoding_indices'] + 1
     basecolor, ks, rough = heads(p, specs, z_enc, vq=False)
     spec = ks * basecolor
     albedo = (1 - ks) * basecolor
+    if edit_mask is not None:
+        em = (edit_mask[..., 0:1] > 0).to(torch.float32)                       # :289-291 (already foreground rows here)
+        if not edit_material['diff'][0] < 0:
+            albedo = update_material(albedo, em, edit_material['diff'])
+        if not edit_material['spec'][0] < 0:
+            spec = update_material(spec, em, edit_material['spec'])
+        if not edit_material['rough'][0] < 0:
+            rough = update_material(rough, em, edit_material['rough'])
     scaled = (opt_scale is not None) and (not vis_scale)
     s_albedo, s_spec = (albedo * opt_scale, spec * opt_scale) if scaled else (albedo, spec)
     brdf, _, _ = get_brdf(surf2l, surf2c, n_pred, s_albedo, rough, s_spec)
     light = p['light'].clamp(min=0.0) if dst_env is None else dst_env
-    out = dict(albedo=albedo, spec=spec, rough=rough, basecolor=basecolor, normal=n_pred)
+    out.update(albedo=albedo, spec=spec, rough=rough, basecolor=basecolor, normal=n_pred)
     rgb = render_integrate(brdf, surf2l, n_pred, lareas, light, lvis, gamma)
     if (opt_scale is not None) and vis_scale:                                  # :360-364
         out['basecolor'] = linear2srgb(basecolor) * opt_scale
@@ -360,7 +403,67 @@ def fast_render(p, specs, batch, lxyz, lareas, data_type='nerf', gamma=None, pro
     if len(probes):
         out['rgb_probes'] = displayed(torch.stack([render_integrate(brdf, surf2l, n_pred, lareas, lp, lvis, gamma)
                                                    for lp in probes], 1), data_type)
+    if relight_olat and len(olat_maps):
+        out['rgb_olat'] = displayed(torch.stack([render_integrate(brdf, surf2l, n_pred, lareas, lp, lvis, gamma)
+                                                 for lp in olat_maps], 1), data_type)
     return out
+
+
+def novel_olat(light_res=(16, 32), olat_inten=200.0, ambient_inten=0.0, white_bg=True):
+    """vq_nfr.py:88-103: one-hot maps at row 4, columns 0 / 8 / 16 / 24 (`tutil.one_hot_img`, tensor.py:57-64) times
+    `olat_inten`, over an `ambient_inten` floor when the background is white.  Ordered as the reference's OrderedDict."""
+    maps = {}
+    amb = (ambient_inten if white_bg else 0.0) * torch.ones(light_res + (3,))
+    for i in [4]:
+        for j in [0, 8, 16, 24]:
+            one_hot = torch.zeros(light_res + (3,))
+            one_hot[i, j, :] = 1.0
+            maps['%04d-%04d' % (i, j)] = olat_inten * one_hot + amb
+    return maps
+
+
+def init_z(p, specs, batch):
+    """vq_nfr.Model.init_z (vq_nfr.py:183-195) on foreground points: `z_pred = _pred_enc_at(xyz)` (NOT normalised)."""
+    return pred_enc(p, specs, batch['xyz'])
+
+
+def init_mat(p, specs, z_pred):
+    """vq_nfr.Model.init_mat (vq_nfr.py:197-207): concat([albedo, spec, rough], -1) from the main heads -> [N, 7]."""
+    basecolor, ks, rough = heads(p, specs, z_pred, vq=False)
+    return torch.cat([(1 - ks) * basecolor, ks * basecolor, rough], -1)
+
+
+def fast_embed(p, specs, batch, mode='vali', thres=None, roll=None):
+    """vq_nfr.Model.fast_embed (vq_nfr.py:209-256) on foreground points -> `embed` = encoding_indices + 1 (0 is what the
+    scatter leaves on background rows, :247) and the xyz rows it scatters back."""
+    z_enc = pred_enc(p, specs, batch['xyz'])
+    return dict(embed=_vq_step(p, specs, z_enc, mode, thres, roll)['encoding_indices'] + 1, xyz=batch['xyz'])
+
+
+def vis_mat(p, specs, batch, mode='vali', thres=None, roll=None):
+    """vq_nfr.Model.vis_mat (vq_nfr.py:400-465) on foreground points: code indices + the CONTINUOUS-branch materials
+    (`_pred_*_at(z_enc)`, :436-441 -- not the VQ heads)."""
+    z_enc = pred_enc(p, specs, batch['xyz'])
+    embed = _vq_step(p, specs, z_enc, mode, thres, roll)['encoding_indices'] + 1
+    basecolor, ks, rough = heads(p, specs, z_enc, vq=False)
+    return dict(albedo=(1 - ks) * basecolor, spec=ks * basecolor, rough=rough, embed=embed)
+
+
+def vq_test(p, specs, batch, lxyz, lareas, mode='vali', thres=None, roll=None, data_type='nerf', gamma=None):
+    """vq_nfr.Model.vq_test (vq_nfr.py:467-532) on foreground points: VQ branch only.  `usage` [1, K] = 1 where a code won at
+    least one row (:505); loss_kwargs carries vqloss / vqrgb / rgb (= vqrgb, :525) / gtc / usage."""
+    xyz, normal, rayo = batch['xyz'], batch['normal'], batch['rayo']
+    lvis = batch.get('lvis') if data_type == 'nerf' else None
+    surf2l, surf2c = calc_ldir(lxyz, xyz), calc_vdir(rayo, xyz)
+    n_pred = normal_correct(normal, surf2c)
+    vq = _vq_step(p, specs, pred_enc(p, specs, xyz), mode, thres, roll)
+    usage = torch.where(vq['encodings'].max(0, keepdim=True)[0] > 0, 1.0, 0.0)
+    vq_albedo, vq_spec, vq_rough = heads(p, specs, vq['quantize'], vq=True)
+    vq_brdf, _, _ = get_brdf(surf2l, surf2c, n_pred, vq_albedo, vq_rough, vq_spec)
+    light = p['light'].clamp(min=0.0)
+    vq_rgb = render_integrate(vq_brdf, surf2l, n_pred, lareas, light, lvis, gamma)
+    return dict(vq=vq, vqloss=vq['loss'], vq_rgb=vq_rgb, rgb=vq_rgb, usage=usage, embed=vq['encoding_indices'] + 1,
+                vq_albedo=vq_albedo, vq_spec=vq_spec, vq_rough=vq_rough)
 
 
 def _mse(a, b):

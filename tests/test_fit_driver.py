@@ -87,6 +87,13 @@ def test_fit_trains_checkpoints_resumes_and_validates(tmp_path):
     model2.config.set('DEFAULT', 'test_envmap_dir', str(tmp_path / 'probes'))
     model2._novel_lights()
     model2.to('cuda')
+    # (reference behaviour: `relight_olat` is accepted and ignored, vq_nfr.py:733 -- no OLAT files)
+    w, n = train_nfr.render_views(model2, va, str(tmp_path / 'pd_relit_ref'), relight_olat=True, relight_probes=True)
+    w.flush()
+    files = set(os.listdir(tmp_path / 'pd_relit_ref' / ('batch%09d' % 0)))
+    assert n == 1 and {'pred_rgb_probes_city.png', 'pred_rgb_probes_forest.png', 'metadata.json'} <= files
+    assert not any(f.startswith('pred_rgb_olat') for f in files)
+    model2.render_olat = True                                 # the build's opt-in: OLAT maps in the same shading pass
     w, n = train_nfr.render_views(model2, va, str(tmp_path / 'pd_relit'), relight_olat=True, relight_probes=True)
     w.flush()
     files = set(os.listdir(tmp_path / 'pd_relit' / ('batch%09d' % 0)))

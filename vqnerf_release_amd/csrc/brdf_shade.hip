@@ -525,8 +525,10 @@ extern "C" int vqn_brdf_shade_bwd(const float* xyz, const float* normal, const f
 namespace {
 __global__ __launch_bounds__(256) void linear2srgb_kernel(const float* __restrict__ x, const long n, float* __restrict__ y) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const float t = fminf(fmaxf(x[i], 0.0f), 1.0f);
-    y[i] = t <= 0.0031308f ? t * 12.92f : 1.055f * powf(t, 1.0f / 2.4f) - (1.055f - 1.0f);
+    const float v = x[i];
+    const float t = fminf(fmaxf(v, 0.0f), 1.0f);         // fminf / fmaxf drop a NaN: put it back, as the clip of the statement does
+    const float r = t <= 0.0031308f ? t * 12.92f : 1.055f * powf(t, 1.0f / 2.4f) - (1.055f - 1.0f);
+    y[i] = (v != v) ? v : r;
   }
 }
 }  // namespace

@@ -472,8 +472,7 @@ extern "C" int vqn_mlp_chain_vq_fwd(const int32_t* desc_a, const float* wbuf_a, 
   hipStream_t s = (hipStream_t)stream;
   VQN_HIP(hipMemsetAsync(counts, 0, sizeof(float) * K, s));
   if (N == 0) {                                         /* mean over nothing: the reference yields NaN (0 / 0) */
-    const float nan = NAN;
-    VQN_HIP(hipMemcpyAsync(loss, &nan, sizeof(float), hipMemcpyHostToDevice, s));
+    VQN_HIP(hipMemsetD32Async((hipDeviceptr_t)loss, 0x7fc00000, 1, s));     // quiet NaN, written on the device (capturable)
     return VQN_OK;
   }
   VQN_CHECK_ARG(in != nullptr && idx != nullptr, "in and idx must be non-null");

@@ -1066,8 +1066,7 @@ extern "C" int vqn_vq_quantize_rows(const float* z, int64_t N, int D, const floa
   hipStream_t s = (hipStream_t)stream;
   VQN_HIP(hipMemsetAsync(counts, 0, sizeof(float) * K, s));
   if (N == 0) {                                         /* mean over nothing: the reference yields NaN (0 / 0) */
-    const float nan = NAN;
-    VQN_HIP(hipMemcpyAsync(loss, &nan, sizeof(float), hipMemcpyHostToDevice, s));
+    VQN_HIP(hipMemsetD32Async((hipDeviceptr_t)loss, 0x7fc00000, 1, s));     // quiet NaN, written on the device (capturable)
     return VQN_OK;
   }
   VQN_CHECK_ARG(z && codebook && idx, "z, codebook and idx must be non-null");
@@ -1187,8 +1186,7 @@ extern "C" int vqn_vq_ste_loss(const float* x, const float* quant, int64_t numel
   VQN_CHECK_ARG(numel >= 0 && loss && ws, "numel >= 0, loss and ws (VQN_STE_WS_FLOATS floats) must be non-null");
   hipStream_t s = (hipStream_t)stream;
   if (numel == 0) {                                     /* mean over nothing: the reference yields NaN (0 / 0) */
-    const float nan = NAN;
-    VQN_HIP(hipMemcpyAsync(loss, &nan, sizeof(float), hipMemcpyHostToDevice, s));
+    VQN_HIP(hipMemsetD32Async((hipDeviceptr_t)loss, 0x7fc00000, 1, s));     // quiet NaN, written on the device (capturable)
     return VQN_OK;
   }
   VQN_CHECK_ARG(x && quant, "x and quant must be non-null");

@@ -30,19 +30,31 @@ def fg_rows(alpha):
     # remembered per tensor object (weakly: the entry dies with the tensor; an in-place write bumps `_version` and invalidates it),
     # so only the first call on a view pays the `nonzero` -- a host sync that otherwise leaves the GPU idle while the next call's
     # launches are prepared.
+    # A writer torch does not see (a raw-pointer kernel through the C ABI, a DLPack peer) bumps no `_version`: such callers must
+    # call `invalidate_fg_cache()` after rewriting an alpha buffer in place.
     key = id(alpha)
+    sig = (alpha.data_ptr(), alpha._version, tuple(alpha.shape), alpha.device)
     hit = _FG_CACHE.get(key)
-    if hit is not None and hit[0]() is alpha and hit[1] == alpha._version:
+    if hit is not None and hit[0]() is alpha and hit[1] == sig:
         return hit[2]
     rows = (alpha[:, 0] > 0).nonzero(as_tuple=False).squeeze(1)
     rows = None if rows.numel() == alpha.shape[0] else rows
     if len(_FG_CACHE) > 4096:
         _FG_CACHE.clear()
     try:
-        _FG_CACHE[key] = (weakref.ref(alpha, lambda _r, k=key: _FG_CACHE.pop(k, None)), alpha._version, rows)
+        _FG_CACHE[key] = (weakref.ref(alpha, lambda _r, k=key: _FG_CACHE.pop(k, None)), sig, rows)
     except TypeError:
         pass
     return rows
+
+
+def invalidate_fg_cache(alpha=None):
+    """Forget the remembered foreground rows of `alpha` (all tensors when None).  For callers that rewrite an alpha buffer
+    behind torch's back (ctypes kernels, DLPack peers): torch's `_version` counter does not see such writes."""
+    if alpha is None:
+        _FG_CACHE.clear()
+    else:
+        _FG_CACHE.pop(id(alpha), None)
 
 
 _FG_CACHE = {}
@@ -120,8 +132,10 @@ class _PackCache:
     def __init__(self):
         self.key, self.value = None, None
 
-    def get(self, params, build):
-        key = tuple((id(p), p._version, str(p.device)) for p in params)
+    def get(self, params, build, epoch=0):
+        # `epoch`: the owning model's `_weights_epoch` -- writes torch's `_version` counter cannot see (a replayed HIP graph
+        # runs Adam and the EMA codebook move without bumping any version) advance it instead: `BrdfModel.weights_changed()`
+        key = (epoch,) + tuple((id(p), p._version, str(p.device)) for p in params)
         if key != self.key:
             with torch.no_grad():
                 self.value = build()
@@ -139,6 +153,7 @@ class BrdfModel(ShapeModel):
         self._light = None
         self._gamma_index, self._gamma_bias = None, None
         self._plans, self._packs, self._engines = {}, {}, {}
+        self._weights_epoch = 0
         self.matrix_mode = 'f32'         # 'f16s': inference MLP stacks on the split-precision (f16 hi/lo MFMA) kernel, ~1e-6 relative
         self.assume_foreground = False   # True: callers promise alpha > 0 everywhere (vq_nfr.Model.call skips the boolean gathers)
         self.train_backend = 'hip'       # 'hip': fused shading fwd/bwd kernels under autograd; 'torch': torch statements
@@ -146,6 +161,11 @@ class BrdfModel(ShapeModel):
         # nfr_unit.py / ref_nfr.py): optional here -- each is a host sync -- on with `debug=True` or VQN_CHECK_NUMERICS=1
         self.check_numerics = bool(debug) or os.environ.get('VQN_CHECK_NUMERICS', '0') not in ('', '0')
         self._novel_lights()
+
+    def weights_changed(self):
+        """Tell the inference-side caches (weight packs, codebook fragments) that parameters were rewritten in a way torch's
+        `_version` counters do not record: a replayed HIP graph (`Trainer(graph=True)`), a raw-pointer writer through the C ABI."""
+        self._weights_epoch += 1
 
     def _apply(self, fn, *args, **kwargs):
         """.to(device) / .float() also move the relighting maps (plain tensors in dicts, not buffers)."""
@@ -315,7 +335,7 @@ class BrdfModel(ShapeModel):
             for i, layer in enumerate(self.net[name].layers):
                 params += [layer.kernel, layer.bias]
                 pdict[f'{name}/{i}'] = (layer.kernel.detach(), layer.bias.detach())
-        return cache.get(params, lambda: plan.pack(pdict))
+        return cache.get(params, lambda: plan.pack(pdict), self._weights_epoch)
 
     def _enc_heads_program(self, names):
         """Encoder + the `names` head family in ONE program (f32 kernels, standard heads): z stays in LDS as the heads' input --

@@ -100,7 +100,7 @@ class Model(BrdfModel):
 
     def _cb_frags(self, cb):
         """MFMA fragments + |c|^2 of the (clipped) codebook for the fused front kernel, rebuilt when the parameter changes."""
-        key = (self._codebook.data_ptr(), self._codebook._version, cb.device)
+        key = (self._codebook.data_ptr(), self._codebook._version, cb.device, self._weights_epoch)
         if getattr(self, '_frags_key', None) != key:
             self._frags, self._frags_key = _C.vq_codebook_frags(cb), key
         return self._frags
@@ -269,9 +269,16 @@ class Model(BrdfModel):
             to_vis['gt_' + k] = v
         return pred, gt, loss_kwargs, to_vis
 
+    # The reference ACCEPTS `relight_olat` and then never renders the OLAT maps: its `_render` ends in
+    # `return rgb, None, rgb_probes` (vq_nfr.py:733), so `pred` holds no 'rgb_olat' there whatever the flag says (:349, :385).
+    # That is the default here.  `render_olat = True` opts into rendering them (upstream NeRFactor's behaviour) in the same
+    # shading pass as the probes.
+    render_olat = False
+
     def fast_render(self, batch, mode='train', relight_olat=False, relight_probes=False, opt_scale=None, edit_mask=None,
                     edit_material=None, ref_batch=False, dst_env=None, gen_embed=False, thres=None, vis_scale=False):
         self._validate_mode(mode)
+        relight_olat = bool(relight_olat and self.render_olat)
         id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz, normal = batch[:9]
         lvis = batch[-1] if self.data_type == 'nerf' else None
         mask = fg_rows(alpha)

@@ -109,6 +109,7 @@ class Trainer:
                     raise ValueError(f'captured step takes batches of shape {tuple(dst.shape)}, got {tuple(src.shape)}')
                 dst.copy_(src)
         self._captured.replay()
+        self.model.weights_changed()       # a replay moves weights and codebook without bumping any tensor `_version`
         if self.sched is not None:
             self.sched.step()
         return self._static_out
@@ -383,6 +384,12 @@ def fit(config, outdir, dataset_train, dataset_vali=None, model=None, device='cu
     _ = model.light                                              # lazy variables exist before the optimiser is built
     model.register_trainable()
     use_graph = bool(graph)                                       # (data parallel: the captured step is cut at its collectives)
+    if use_graph and parallel.world_size() > 1 and parallel.backend() != 'gloo' and not config.getboolean('DEFAULT', 'dp_graph', fallback=False) \
+            and os.environ.get('VQN_DP_GRAPH', '0') in ('', '0'):
+        # the graph-segment replay of the DP step has been validated bit-identical to the eager one on two gloo ranks sharing a
+        # card, never on a multi-GPU RCCL node: explicit opt-in there (`dp_graph = True` in the config or VQN_DP_GRAPH=1)
+        log('graph=True under multi-rank RCCL needs dp_graph=True / VQN_DP_GRAPH=1: running the eager data-parallel step')
+        use_graph = False
     opt, sched, clip = make_optimizer(config, model.trainable_variables, capturable=use_graph)
     if latest is not None:
         state = torch.load(latest[1], map_location=device, weights_only=False)

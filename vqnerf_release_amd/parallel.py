@@ -85,7 +85,16 @@ class SegmentedCapture:
         global _capture
         _capture = None
         try:
-            self.graphs[-1].capture_end()
+            if exc_type is None:
+                self.graphs[-1].capture_end()
+            else:
+                # the body raised: end the capture only to leave the stream usable, and never let a failure of THAT mask the
+                # original error
+                try:
+                    self.graphs[-1].capture_end()
+                except Exception:
+                    pass
+                self.graphs = []
         finally:
             self._ctx.__exit__(exc_type, exc, tb)
             torch.cuda.current_stream().wait_stream(self._stream)
@@ -106,6 +115,11 @@ def is_dist():
 
 def world_size():
     return dist.get_world_size() if is_dist() else 1
+
+
+def backend():
+    """'nccl' (= RCCL on ROCm) / 'gloo' of the default process group, None without one."""
+    return dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None
 
 
 def rank():
