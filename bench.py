@@ -161,7 +161,7 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
         _C.KernelClock.reset(False)
         out['geo_train_wgrad_bf16x3'] = {'rays_per_s': B / dt3, 'ms_per_step': dt3 * 1e3, 'achieved_tflops': flop / dt3 / 1e12,
                                          'frac_of_f32_mfma_peak': flop / dt3 / 1e12 / F32_MFMA_PEAK_TFLOPS,
-                                         'wgrad_ms_per_step': clk3['vqn_wgrad_partials'][1] / 6,
+                                         'wgrad_ms_per_step': clk3['vqn_wgrad_partials_x3'][1] / 6,
                                          'wgrad_ms_per_step_f32': clk['vqn_wgrad_partials'][1] / 6,
                                          'note': 'opt-in contraction mode: exact three-way bf16 split of every f32 operand, products '
                                                  'carried to 2^-24 (f32-level gradients: 2e-6 of max|g| from the f32 contraction); '

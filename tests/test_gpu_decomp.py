@@ -562,3 +562,11 @@ def test_fused_srgb_transfer_matches_the_torch_statement():
         want = imgutil.linear2srgb(x.clone().requires_grad_(True)).detach()     # the torch statement (autograd path)
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=2e-7)
     assert torch.equal(imgutil.linear2srgb(x), got)                              # the inference path dispatches to the kernel
+    # NaN in -> NaN out, like the clip of the statement (a rendered NaN must not turn into a black pixel); +-inf clip to 1 / 0
+    bad = torch.tensor([float('nan'), 0.5, float('inf'), -float('inf'), float('nan'), 0.25], device='cuda')
+    got_b = _C.linear2srgb(bad)
+    with torch.enable_grad():
+        want_b = imgutil.linear2srgb(bad.clone().requires_grad_(True)).detach()
+    assert torch.isnan(got_b[0]) and torch.isnan(got_b[4]) and torch.equal(torch.isnan(got_b), torch.isnan(want_b))
+    ok = ~torch.isnan(want_b)
+    np.testing.assert_allclose(got_b[ok].cpu().numpy(), want_b[ok].cpu().numpy(), rtol=0, atol=2e-7)

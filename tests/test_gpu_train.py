@@ -214,6 +214,47 @@ def test_decomp_trainer_graph_replays_the_eager_step():
         train_nfr.Trainer(model, torch.optim.Adam(model.trainable_variables, lr=1e-3), graph=True)
 
 
+def test_inference_after_graph_replays_sees_the_moved_weights():
+    """a replayed HIP graph runs Adam and the EMA codebook move without bumping any tensor `_version`, so
+    inference-side caches keyed on `_version` (weight packs, codebook fragments) would serve STALE weights to every validation
+    after the first capture.  Graph-train, validate, graph-train more, validate again: both validations must equal those of an
+    eager-trained model bit for bit (`Trainer._replay` -> `model.weights_changed()`)."""
+    from oracle import decomp as od
+    from vqnerf_release_amd.decomp.nerfactor import train_nfr
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    p, specs = od.make_model_params(seed=0, K=15)
+    cfg = make_config(n_rays_per_step=128, lr=5e-3)
+    batches = [make_batch(od.make_points(256, seed=40 + i), 'cuda') for i in range(10)]
+    view = make_batch(od.make_points(300, seed=99), 'cuda', bg_every=5)
+    runs = {}
+    for graph in (False, True):
+        model = load_oracle_params(get_model_class('vq_nfr')(cfg), p, 'cuda')
+        model.get_codebook(); _ = model.light
+        opt, _, clip = train_nfr.make_optimizer(cfg, model.trainable_variables, capturable=True)
+        tr = train_nfr.Trainer(model, opt, clip=clip, graph=graph)
+        valis = []
+        for i, b in enumerate(batches):
+            tr.train_iter(b, global_bs=256)
+            if i in (4, 9):                                   # after replays 3..5 and again after replays 6..10
+                model.assume_foreground = False               # a validation view has background rows
+                with torch.no_grad(), launches() as rec:
+                    pred, gt, lk, _ = model.call(view, mode='vali')
+                    emb = model.fast_embed(view, mode='vali')[3]['embed']
+                    test = model.vq_test(view, mode='vali')[2]
+                assert rec.ran('vqn_mlp_chain_vq_fwd')        # the fused front: weight packs AND codebook fragments are cached
+                valis.append({k: pred[k].clone() for k in ('rgb', 'albedo', 'vq_rgb', 'vq_albedo', 'embed')}
+                             | {'fe': emb.clone(), 'vt': test['vqrgb'].clone()})
+                model.assume_foreground = graph
+        assert (tr._captured is not None) == graph
+        runs[graph] = valis
+    for a, b in zip(runs[False], runs[True]):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    # and the two validations differ from each other (the weights did move between them)
+    assert not torch.equal(runs[True][0]['albedo'], runs[True][1]['albedo'])
+    assert not torch.equal(runs[True][0]['vq_albedo'], runs[True][1]['vq_albedo'])
+
+
 def test_decomp_trains_from_geometry_buffers_on_disk(tmp_path):
     """The whole hand-off of the pipeline: per-view buffers in the layout gen_geo writes -> datasets.shape_unit (device-resident
     views) -> outer_sample pairs -> Trainer.train_iter (eager, then replayed from the captured HIP graph)."""

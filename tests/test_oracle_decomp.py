@@ -213,3 +213,78 @@ def test_fast_render_probe_loop_is_dst_env_per_probe(data_type):
     mc = od.model_call(pt, specs, ob, od.T(lxyz), od.T(lareas), None, None, mode='vali', data_type=data_type, gamma=gamma)
     np.testing.assert_allclose(fr2['rgb_probes'][:, 0].numpy(), od.displayed(mc['rgb'], data_type).numpy(), rtol=0, atol=1e-6)
     assert 'rgb' not in fr2
+
+
+def _toy(K=8, n=60, data_type='nerf'):
+    p, specs = od.make_model_params(seed=0, K=K)
+    W, b = p['bottleneck'][-1]
+    p['bottleneck'][-1] = (W * 25.0, b)
+    pt = {k: ([(od.T(W), od.T(b)) for W, b in v] if isinstance(v, list) else od.T(v)) for k, v in p.items()}
+    zc = od.pred_enc(pt, specs, od.T(od.make_points(K, seed=77)['xyz']))
+    pt['codebook_raw'] = zc.t().contiguous()
+    lxyz, lareas = od.gen_light_xyz(16, 32)
+    ob = {k: od.T(v) for k, v in od.make_points(n, seed=5, lvis=(data_type == 'nerf')).items()}
+    return pt, specs, ob, od.T(lxyz), od.T(lareas)
+
+
+def test_remaining_entry_points_known_answers():
+    """Known answers for the statements of vq_nfr.py:183-532 added in round 3 (the reference holds no fixtures for them)."""
+    K = 8
+    pt, specs, ob, lxyz, lareas = _toy(K)
+    # init_z feeds init_mat; init_mat = [albedo | spec | rough] of the main heads, albedo + spec = basecolor
+    z = od.init_z(pt, specs, ob)
+    mat = od.init_mat(pt, specs, z)
+    base, ks, rough = od.heads(pt, specs, z, vq=False)
+    assert mat.shape == (60, 7)
+    np.testing.assert_allclose((mat[:, :3] + mat[:, 3:6]).numpy(), base.numpy(), atol=1e-7)
+    np.testing.assert_array_equal(mat[:, 6:].numpy(), rough.numpy())
+    # a point's own encoder output as a code: that point is assigned to it, distance ~ 0
+    pt['codebook_raw'] = z[:K].t().contiguous()
+    emb = od.fast_embed(pt, specs, ob)['embed']
+    assert emb[:K].tolist() == list(range(1, K + 1))
+    # dropping a code (threshold 1) hands its rows to other codes; kept codes keep theirs
+    thres = np.array([0, 0, 0, 0, 1, 1, 1, 1], np.float32)
+    emb_d = od.fast_embed(pt, specs, ob, thres=thres)['embed']
+    assert emb_d.max() <= 4 and torch.equal(emb_d[emb <= 4], emb[emb <= 4])
+    # vis_mat: same indices, CONTINUOUS-branch materials (not the VQ heads)
+    vm = od.vis_mat(pt, specs, ob, thres=thres)
+    assert torch.equal(vm['embed'], emb_d)
+    np.testing.assert_array_equal(vm['albedo'].numpy(), mat[:, :3].numpy())
+    # vq_test: usage marks exactly the codes that won rows; rgb IS vqrgb; with every row on its own code the commitment term is ~0
+    vt = od.vq_test(pt, specs, ob, lxyz, lareas, thres=thres)
+    assert vt['usage'].shape == (1, K) and vt['usage'][0, 4:].sum() == 0
+    assert set((vt['usage'][0].nonzero()[:, 0] + 1).tolist()) == set(emb_d.unique().tolist())
+    assert vt['rgb'] is vt['vq_rgb']
+    pt['codebook_raw'] = z[:K].t().contiguous()
+    first = {k: v[:K] for k, v in ob.items()}
+    assert float(od.vq_test(pt, specs, first, lxyz, lareas)['vqloss']) < 1e-12
+    # thresholds strictly inside (0, 1) need the draw
+    with pytest.raises(AssertionError):
+        od.fast_embed(pt, specs, ob, thres=np.full(K, 0.5, np.float32))
+
+
+def test_fast_render_edit_and_olat_statement():
+    pt, specs, ob, lxyz, lareas = _toy(8)
+    base = od.fast_render(pt, specs, ob, lxyz, lareas)
+    em = torch.zeros(60, 3)
+    em[:20, 0] = 1.0
+    em[:, 2] = 1.0                                                        # only channel 0 counts (:290)
+    ed = od.fast_render(pt, specs, ob, lxyz, lareas, edit_mask=em,
+                        edit_material={'diff': [0.5, 0.4, 0.3], 'spec': [-1, 0, 0], 'rough': [0.9]})
+    assert torch.equal(ed['albedo'][:20], torch.tensor([[0.5, 0.4, 0.3]]).expand(20, 3))
+    assert torch.equal(ed['albedo'][20:], base['albedo'][20:]) and torch.equal(ed['spec'], base['spec'])
+    assert torch.equal(ed['rough'][:20], torch.full((20, 1), 0.9)) and torch.equal(ed['basecolor'], base['basecolor'])
+    # the reference never renders OLAT maps (vq_nfr.py:733): flag without maps -> no key
+    assert 'rgb_olat' not in od.fast_render(pt, specs, ob, lxyz, lareas, relight_olat=True)
+    olat = od.novel_olat(olat_inten=200.0, ambient_inten=0.5, white_bg=True)
+    assert list(olat) == ['0004-0000', '0004-0008', '0004-0016', '0004-0024']
+    m = olat['0004-0008']
+    assert m.shape == (16, 32, 3) and float(m[4, 8, 0]) == 200.5 and float(m[0, 0, 0]) == 0.5 and float(m.sum()) == 3 * (200 + 0.5 * 512)
+    assert float(od.novel_olat(ambient_inten=0.5, white_bg=False)['0004-0000'][0, 0, 0]) == 0.0
+    # an OLAT map rendered as `olat_maps` equals the same map rendered as a probe
+    r1 = od.fast_render(pt, specs, ob, lxyz, lareas, relight_olat=True, olat_maps=[m])
+    r2 = od.fast_render(pt, specs, ob, lxyz, lareas, probes=[m])
+    assert torch.equal(r1['rgb_olat'], r2['rgb_probes'])
+    # gen_embed adds the indices and nothing else changes
+    ge = od.fast_render(pt, specs, ob, lxyz, lareas, gen_embed=True)
+    assert torch.equal(ge['embed'], od.fast_embed(pt, specs, ob)['embed']) and torch.equal(ge['albedo'], base['albedo'])

@@ -93,7 +93,7 @@ class _Engine:
         if rowsum and (getattr(self, '_rs_ws', None) is None or self._rs_ws.device != A.device):
             self._rs_ws = torch.empty(self.n_split * 256, dtype=torch.float32, device=A.device)
         lib = _C.lib()
-        with _C._clock('vqn_wgrad_partials'):
+        with _C._clock(WGRAD_ENTRY[wgrad_mode()]):
             n = getattr(lib, WGRAD_ENTRY[wgrad_mode()])(_C._ptr(A), ctypes.c_int(at), ctypes.c_int(0), ctypes.c_int(an), _C._ptr(B), ctypes.c_int(bt),
                                        ctypes.c_int(0), ctypes.c_int(bn), ctypes.c_int64(nt), ctypes.c_int(self.n_split),
                                        _C._ptr(ws), _C._ptr(self._rs_ws if rowsum else None), _C._stream())

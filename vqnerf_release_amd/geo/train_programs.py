@@ -512,7 +512,7 @@ class NeusTrainEngine:
                 for b0 in range(0, b_nt_all, 8):
                     bn = min(8, b_nt_all - b0)
                     want_rs = rowsum and pi == 0 and b0 == 0
-                    with _C._clock('vqn_wgrad_partials'):
+                    with _C._clock(WGRAD_ENTRY[wgrad_mode()]):
                         n = getattr(lib, WGRAD_ENTRY[wgrad_mode()])(_C._ptr(A_), ctypes.c_int(at), ctypes.c_int(a0), ctypes.c_int(an), _C._ptr(B_),
                                                    ctypes.c_int(bt), ctypes.c_int(b0), ctypes.c_int(bn), ctypes.c_int64(nt),
                                                    ctypes.c_int(self.n_split), _C._ptr(ws), _C._ptr(self._rs_ws if want_rs else None),
