@@ -204,3 +204,32 @@ def test_background_branch_runs_where_the_reference_raises():
     assert r['weights'].shape == (24, n + 8) and r['gradients'].shape == (24, n, 3) and r['color_fine'].shape == (24, 3)
     assert all(torch.isfinite(v).all() for v in r.values() if torch.is_tensor(v))
     assert float(r['weights'].min()) >= 0 and float(r['weights'].sum(-1).max()) <= 1 + 1e-5
+
+
+def test_render_after_a_fused_adam_step_uses_the_new_weights():
+    """`torch._fused_adam_` moves the parameters without bumping their `_version` (measured): the weight packs of the render
+    kernels key on the process-wide weights epoch as well (global optimiser post-step hook), so a render after such a step equals
+    the render of a FRESH renderer loaded from the stepped parameters."""
+    from oracle import geo as og
+    _, sdf, col, var, ren = _build('small')
+    o, d, near, far = [torch.tensor(a).cuda() for a in og.make_rays(64, 5)]
+    kw = dict(perturb_overwrite=0, background_rgb=torch.ones(1, 3).cuda(), cos_anneal_ratio=1.0)
+    params = list(sdf.parameters()) + list(col.parameters()) + list(var.parameters())
+    opt = torch.optim.Adam(params, lr=1e-2, fused=True)
+    with torch.no_grad():
+        before = ren.render(o, d, near, far, 2.0, **kw)['color_fine'].clone()          # fills the pack caches
+    v0 = [p._version for p in params]
+    rr = ren.render(o, d, near, far, 2.0, **kw)
+    (rr['color_fine'].sum() + rr['gradient_error']).backward()
+    opt.step()
+    if [p._version for p in params] != v0:
+        pytest.skip('this torch bumps _version in the fused Adam: nothing to guard')
+    with torch.no_grad():
+        after = ren.render(o, d, near, far, 2.0, **kw)['color_fine'].clone()
+    _, sdf2, col2, var2, ren2 = _build('small')
+    for dst, src in ((sdf2, sdf), (col2, col), (var2, var)):
+        dst.load_state_dict(src.state_dict())
+    with torch.no_grad():
+        fresh = ren2.render(o, d, near, far, 2.0, **kw)['color_fine']
+    assert not torch.equal(before, after)
+    assert torch.equal(after, fresh)

@@ -215,10 +215,11 @@ def test_decomp_trainer_graph_replays_the_eager_step():
 
 
 def test_inference_after_graph_replays_sees_the_moved_weights():
-    """a replayed HIP graph runs Adam and the EMA codebook move without bumping any tensor `_version`, so
-    inference-side caches keyed on `_version` (weight packs, codebook fragments) would serve STALE weights to every validation
-    after the first capture.  Graph-train, validate, graph-train more, validate again: both validations must equal those of an
-    eager-trained model bit for bit (`Trainer._replay` -> `model.weights_changed()`)."""
+    """ADVICE r02 (medium), and wider than reported: a replayed HIP graph runs Adam and the EMA codebook move without bumping any
+    tensor `_version` -- and so does the EAGER fused / capturable Adam (`torch._fused_adam_` leaves `_version` alone, measured).
+    Inference-side caches keyed on `_version` alone (weight packs, codebook fragments) would serve STALE weights to every
+    validation after the first one.  Train (eager and graph), validate, train more, validate again: each validation must equal
+    (a) the other trainer's, bit for bit, and (b) a FRESH model loaded from the trained parameters (no caches at all)."""
     from oracle import decomp as od
     from vqnerf_release_amd.decomp.nerfactor import train_nfr
     from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
@@ -226,6 +227,16 @@ def test_inference_after_graph_replays_sees_the_moved_weights():
     cfg = make_config(n_rays_per_step=128, lr=5e-3)
     batches = [make_batch(od.make_points(256, seed=40 + i), 'cuda') for i in range(10)]
     view = make_batch(od.make_points(300, seed=99), 'cuda', bg_every=5)
+    keys = ('rgb', 'albedo', 'vq_rgb', 'vq_albedo', 'embed')
+
+    def validate(model):
+        with torch.no_grad(), launches() as rec:
+            pred, gt, lk, _ = model.call(view, mode='vali')
+            emb = model.fast_embed(view, mode='vali')[3]['embed']
+            test = model.vq_test(view, mode='vali')[2]
+        assert rec.ran('vqn_mlp_chain_vq_fwd')            # the fused front: weight packs AND codebook fragments are cached
+        return {k: pred[k].clone() for k in keys} | {'fe': emb.clone(), 'vt': test['vqrgb'].clone()}
+
     runs = {}
     for graph in (False, True):
         model = load_oracle_params(get_model_class('vq_nfr')(cfg), p, 'cuda')
@@ -237,13 +248,14 @@ def test_inference_after_graph_replays_sees_the_moved_weights():
             tr.train_iter(b, global_bs=256)
             if i in (4, 9):                                   # after replays 3..5 and again after replays 6..10
                 model.assume_foreground = False               # a validation view has background rows
-                with torch.no_grad(), launches() as rec:
-                    pred, gt, lk, _ = model.call(view, mode='vali')
-                    emb = model.fast_embed(view, mode='vali')[3]['embed']
-                    test = model.vq_test(view, mode='vali')[2]
-                assert rec.ran('vqn_mlp_chain_vq_fwd')        # the fused front: weight packs AND codebook fragments are cached
-                valis.append({k: pred[k].clone() for k in ('rgb', 'albedo', 'vq_rgb', 'vq_albedo', 'embed')}
-                             | {'fe': emb.clone(), 'vt': test['vqrgb'].clone()})
+                got = validate(model)
+                fresh = load_oracle_params(get_model_class('vq_nfr')(cfg), p, 'cuda')
+                fresh.get_codebook()
+                fresh.load_state_dict(model.state_dict())
+                want = validate(fresh)
+                for k in got:
+                    assert torch.equal(got[k], want[k]), (graph, i, k)
+                valis.append(got)
                 model.assume_foreground = graph
         assert (tr._captured is not None) == graph
         runs[graph] = valis

@@ -10,6 +10,8 @@
 import os
 import weakref
 
+import vqnerf_release_amd
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -132,10 +134,10 @@ class _PackCache:
     def __init__(self):
         self.key, self.value = None, None
 
-    def get(self, params, build, epoch=0):
-        # `epoch`: the owning model's `_weights_epoch` -- writes torch's `_version` counter cannot see (a replayed HIP graph
-        # runs Adam and the EMA codebook move without bumping any version) advance it instead: `BrdfModel.weights_changed()`
-        key = (epoch,) + tuple((id(p), p._version, str(p.device)) for p in params)
+    def get(self, params, build):
+        # besides the tensors' `_version`s the process-wide weights epoch: a fused / capturable Adam step and a replayed HIP graph
+        # move the weights without bumping any version (vqnerf_release_amd/__init__.py)
+        key = (vqnerf_release_amd.weights_epoch(),) + tuple((id(p), p._version, str(p.device)) for p in params)
         if key != self.key:
             with torch.no_grad():
                 self.value = build()
@@ -153,7 +155,6 @@ class BrdfModel(ShapeModel):
         self._light = None
         self._gamma_index, self._gamma_bias = None, None
         self._plans, self._packs, self._engines = {}, {}, {}
-        self._weights_epoch = 0
         self.matrix_mode = 'f32'         # 'f16s': inference MLP stacks on the split-precision (f16 hi/lo MFMA) kernel, ~1e-6 relative
         self.assume_foreground = False   # True: callers promise alpha > 0 everywhere (vq_nfr.Model.call skips the boolean gathers)
         self.train_backend = 'hip'       # 'hip': fused shading fwd/bwd kernels under autograd; 'torch': torch statements
@@ -165,7 +166,7 @@ class BrdfModel(ShapeModel):
     def weights_changed(self):
         """Tell the inference-side caches (weight packs, codebook fragments) that parameters were rewritten in a way torch's
         `_version` counters do not record: a replayed HIP graph (`Trainer(graph=True)`), a raw-pointer writer through the C ABI."""
-        self._weights_epoch += 1
+        vqnerf_release_amd.weights_changed()
 
     def _apply(self, fn, *args, **kwargs):
         """.to(device) / .float() also move the relighting maps (plain tensors in dicts, not buffers)."""
@@ -335,7 +336,7 @@ class BrdfModel(ShapeModel):
             for i, layer in enumerate(self.net[name].layers):
                 params += [layer.kernel, layer.bias]
                 pdict[f'{name}/{i}'] = (layer.kernel.detach(), layer.bias.detach())
-        return cache.get(params, lambda: plan.pack(pdict), self._weights_epoch)
+        return cache.get(params, lambda: plan.pack(pdict))
 
     def _enc_heads_program(self, names):
         """Encoder + the `names` head family in ONE program (f32 kernels, standard heads): z stays in LDS as the heads' input --

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import vqnerf_release_amd
 from vqnerf_release_amd import _C
 from vqnerf_release_amd.geo import packing
 from vqnerf_release_amd.geo.models.embedder import get_embedder
@@ -118,7 +119,8 @@ class _PackCache:
         self.value = None
 
     def get(self, params, device, build):
-        key = (str(device),) + tuple((id(p), p._version) for p in params)
+        # (the process-wide weights epoch: writes `_version` does not see -- fused Adam, graph replays; vqnerf_release_amd/__init__.py)
+        key = (str(device), vqnerf_release_amd.weights_epoch()) + tuple((id(p), p._version) for p in params)
         if key != self.key:
             with torch.no_grad():
                 self.value = build()
