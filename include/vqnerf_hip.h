@@ -175,6 +175,22 @@ int vqn_neus_fine_points_f16s(const int32_t* sdf_desc, const float* wbuf_sdf, co
                               const float* pts, const float* dirs, int64_t P, int S, void* scratch,
                               int64_t scratch_bytes, float* out_sdf, float* out_grad, float* out_rgb, void* stream);
 
+/* Exact-split twins of vqn_neus_sdf_points / vqn_neus_fine_points (round 3): same arguments, same outputs, f32-LEVEL results on the
+ * bf16 matrix pipe.  Every f32 operand is split exactly into three bf16 pieces (8 + 8 + 8 significant bits, f32 exponent range: no
+ * scaling, no range limit) and a product keeps the six cross terms down to 2^-24 -- what an f32 multiply rounds away -- on
+ * v_mfma_f32_32x32x16_bf16 with f32 accumulation: 2.7x less matrix-pipe time than the f32-input MFMA of the plain entry points.
+ * Replaces the same reference ops (geo/NeuS-ours2/models/renderer.py:337-338,180-185,216-227; fields.py:72-107,147-172).
+ * Descriptors and packs must be built for it (SdfPackPlan(mode='x3'), ColPackPlan(matrix_mode='x3'): 3 LDS rows per 16
+ * features, bf16 piece triples padded to whole 32-feature K blocks).  Layers of at most 256 outputs (the layers run in place in LDS,
+ * one output tile per wave).  Not bitwise the f32 entry points' results (the sums associate differently); held to the f32 tolerances
+ * against the reference's goldens (tests/test_gpu_neus_x3.py).  Scratch size: vqn_neus_fine_scratch_bytes. */
+int vqn_neus_sdf_points_x3(const int32_t* sdf_desc, const float* wbuf_sdf, const float* rays_o, const float* rays_d,
+                           const float* z, const float* pts, int64_t P, int S, float* out_sdf, void* stream);
+int vqn_neus_fine_points_x3(const int32_t* sdf_desc, const float* wbuf_sdf, const int32_t* col_desc,
+                            const float* wbuf_col, const float* rays_o, const float* rays_d, const float* z,
+                            const float* pts, const float* dirs, int64_t P, int S, void* scratch,
+                            int64_t scratch_bytes, float* out_sdf, float* out_grad, float* out_rgb, void* stream);
+
 /* ---- weight packs of the fused NeuS kernels, built in C ------------------------------------------------ */
 
 /* A pack handle owns the device memory of the two weight buffers + their gather tables and the two host descriptors

@@ -87,7 +87,7 @@ def test_hits_render_core_stage_isolated(hits, prefix):
         np.testing.assert_allclose(_np(rc[k]).reshape(g[f'{prefix}_{k}'].shape), g[f'{prefix}_{k}'], rtol=0, atol=t, err_msg=k)
 
 
-@pytest.mark.parametrize('matrix_mode', ['f32', 'f16s'])
+@pytest.mark.parametrize('matrix_mode', ['f32', 'f16s', 'x3'])
 @pytest.mark.parametrize('variant', ['render', 'render_none0.5', 'perturb', 'tolight'])
 def test_hits_render_variants_vs_reference(hits, variant, matrix_mode):
     g, ren, r = hits['g'], hits['ren'], hits['rays']
@@ -106,7 +106,7 @@ def test_hits_render_variants_vs_reference(hits, variant, matrix_mode):
             rr = ren.render(r['o'], r['d'], near, far, 2.0, **kw)
     finally:
         ren.matrix_mode = 'f32'
-    suffix = '' if matrix_mode == 'f32' else '_f16s'
+    suffix = {'f32': '', 'f16s': '_f16s', 'x3': '_x3'}[matrix_mode]
     assert rec.ran('vqn_neus_fine_points' + suffix) and rec.ran('vqn_neus_upsample') and rec.ran('vqn_neus_composite_fwd')
     assert_render_matches({k: _np(v) for k, v in rr.items()}, g, variant,
                           ray_tol=dict(color_fine=2e-4, s_val=1e-7, weight_sum=3e-4, weight_max=5e-4, surf=3e-4, depth=3e-4,

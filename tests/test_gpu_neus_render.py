@@ -79,27 +79,41 @@ def test_merge_ties_are_stable():
     assert so.tolist() == [[5.0, 10.0, 20.0, 21.0, 99.0, 30.0, 98.0]]   # old before new on equal keys
 
 
+@pytest.mark.parametrize('matrix_mode', ['f32', 'x3'])       # x3: the exact-split engine at the SAME bounds (VERDICT r02 #3 gate)
 @pytest.mark.parametrize('car', [0.0, 0.5, 1.0])
-def test_render_core_all_keys(case, car):
+def test_render_core_all_keys(case, car, matrix_mode):
+    from tests.gpu_util import launches
     g, ren = case['g'], case['ren']
     n0 = case['cfg']['renderer']['n_samples']
     z_in = torch.tensor(g['core_z_in']).cuda()
-    with torch.no_grad():
-        rc = ren.render_core(case['o'], case['d'], z_in, 2 * 2.0 / n0, 2.0, case['sdf'], case['var'], case['col'],
-                             background_rgb=torch.ones(1, 3).cuda(), cos_anneal_ratio=car)
+    ren.matrix_mode = matrix_mode
+    try:
+        with torch.no_grad(), launches() as rec:
+            rc = ren.render_core(case['o'], case['d'], z_in, 2 * 2.0 / n0, 2.0, case['sdf'], case['var'], case['col'],
+                                 background_rgb=torch.ones(1, 3).cuda(), cos_anneal_ratio=car)
+    finally:
+        ren.matrix_mode = 'f32'
+    assert rec.ran('vqn_neus_fine_points_x3') == (matrix_mode == 'x3')
     tol = dict(color=2e-4, sdf=2e-5, dists=0, gradients=3e-4, s_val=1e-7, mid_z_vals=0, weights=3e-4, cdf=3e-4,
                gradient_error=1e-5, inside_sphere=0, surf=5e-4, depth=5e-4)
     for k, t in tol.items():
         np.testing.assert_allclose(_np(rc[k]).reshape(g[f'core{car}_{k}'].shape), g[f'core{car}_{k}'], rtol=0, atol=t, err_msg=k)
 
 
+@pytest.mark.parametrize('matrix_mode', ['f32', 'x3'])
 @pytest.mark.parametrize('bg', ['white', 'none'])
 @pytest.mark.parametrize('car', [0.0, 1.0])
-def test_render_end_to_end_vs_reference(case, bg, car):
+def test_render_end_to_end_vs_reference(case, bg, car, matrix_mode):
+    from tests.gpu_util import launches
     g, ren = case['g'], case['ren']
-    with torch.no_grad():
-        rr = ren.render(case['o'], case['d'], case['near'], case['far'], 2.0, perturb_overwrite=0,
-                        background_rgb=torch.ones(1, 3).cuda() if bg == 'white' else None, cos_anneal_ratio=car)
+    ren.matrix_mode = matrix_mode
+    try:
+        with torch.no_grad(), launches() as rec:
+            rr = ren.render(case['o'], case['d'], case['near'], case['far'], 2.0, perturb_overwrite=0,
+                            background_rgb=torch.ones(1, 3).cuda() if bg == 'white' else None, cos_anneal_ratio=car)
+    finally:
+        ren.matrix_mode = 'f32'
+    assert rec.ran('vqn_neus_fine_points_x3') == (matrix_mode == 'x3') and rec.ran('vqn_neus_sdf_points_x3') == (matrix_mode == 'x3')
     assert set(rr.keys()) == {'color_fine', 's_val', 'cdf_fine', 'weight_sum', 'weight_max', 'gradients', 'weights',
                               'gradient_error', 'inside_sphere', 'surf', 'depth'}
     tol = dict(color_fine=1e-3, s_val=1e-7, cdf_fine=2e-3, weight_sum=1e-3, weight_max=1e-3, gradients=2e-3,
@@ -108,7 +122,7 @@ def test_render_end_to_end_vs_reference(case, bg, car):
         ref = g[f'render_{bg}_{car}_{k}']
         np.testing.assert_allclose(_np(rr[k]).reshape(ref.shape), ref, rtol=0, atol=t, err_msg=k)
     psnr = -10 * np.log10(np.mean((_np(rr['color_fine']) - g[f'render_{bg}_{car}_color_fine']) ** 2) + 1e-20)
-    print(f"{case['name']} {bg} car={car}: PSNR(hip, reference) = {psnr:.1f} dB")
+    print(f"{case['name']} {bg} car={car} {matrix_mode}: PSNR(hip, reference) = {psnr:.1f} dB")
     assert psnr > 70
 
 

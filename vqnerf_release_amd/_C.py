@@ -232,8 +232,7 @@ def neus_sdf_points(sdf_desc, wbuf_sdf, rays_o=None, rays_d=None, z=None, pts=No
         P = B * S
         dev = z.device
     out = torch.empty((P,), dtype=torch.float32, device=dev)
-    assert mode in ('f32', 'f16s')
-    entry = 'vqn_neus_sdf_points' if mode == 'f32' else 'vqn_neus_sdf_points_f16s'
+    entry = {'f32': 'vqn_neus_sdf_points', 'f16s': 'vqn_neus_sdf_points_f16s', 'x3': 'vqn_neus_sdf_points_x3'}[mode]
     with _clock(entry):
         rc = getattr(lib(), entry)(dp, _ptr(wbuf_sdf), _ptr(rays_o), _ptr(rays_d), _ptr(z), _ptr(pts),
                                    ctypes.c_int64(P), ctypes.c_int(S), _ptr(out), _stream())
@@ -267,8 +266,7 @@ def neus_fine_points(sdf_desc, wbuf_sdf, col_desc, wbuf_col, rays_o=None, rays_d
     sdf = torch.empty((P,), dtype=torch.float32, device=dev)
     grad = torch.empty((P, 3), dtype=torch.float32, device=dev)
     rgb = torch.empty((P, 3), dtype=torch.float32, device=dev)
-    assert mode in ('f32', 'f16s')
-    entry = 'vqn_neus_fine_points' if mode == 'f32' else 'vqn_neus_fine_points_f16s'
+    entry = {'f32': 'vqn_neus_fine_points', 'f16s': 'vqn_neus_fine_points_f16s', 'x3': 'vqn_neus_fine_points_x3'}[mode]
     with _clock(entry):
         rc = getattr(L, entry)(sdp, _ptr(wbuf_sdf), cdp, _ptr(wbuf_col), _ptr(rays_o), _ptr(rays_d), _ptr(z),
                                _ptr(pts), _ptr(dirs), ctypes.c_int64(P), ctypes.c_int(S), _ptr(buf),

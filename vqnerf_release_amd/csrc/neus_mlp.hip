@@ -723,6 +723,9 @@ extern "C" int64_t vqn_neus_fine_scratch_bytes(const int32_t* sdf_desc) {
   if (!sdf_desc) return -1;
   SdfDesc sd;
   memcpy(&sd, sdf_desc, sizeof(SdfDesc));
+  // (descriptors of every engine: the x3 packs count 3 rows per 16 embedding features, up to 12)
+  const int emb_rows = sd.emb_rows;
+  if (emb_rows >= 1 && emb_rows <= 12) sd.emb_rows = 1;
   if (check_sdf_desc(sd) != 0) return -2;
   return (int64_t)vqn_num_cus() * 2 * (int64_t)(sd.n_lin - 1) * 4 * sd.max_tiles * 1024;
 }

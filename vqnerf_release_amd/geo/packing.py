@@ -135,6 +135,65 @@ def split_pack(g):
     return torch.stack([hi, lo], 2).contiguous().view(torch.float32).reshape(-1)
 
 
+# ---- exact-split engine (csrc/mlp_prims_x3.h): K advances in 16-feature steps = row TRIPLES (p0, p1, p2), 6 rows per 32 features ----
+def emb_rows_for_x3(n_feats):
+    return 3 * ((n_feats + 15) // 16)
+
+
+def step_features_n(n_steps):
+    """[n_steps, 64, 8] -> local feature held by (step, lane, slot): 16 sl + 8 (jj >> 2) + 4 h + (jj & 3) (as step_features)."""
+    sl = np.arange(n_steps)[:, None, None]
+    h = (np.arange(64) >> 5)[None, :, None]
+    jj = np.arange(8)[None, None, :]
+    return 16 * sl + 8 * (jj >> 2) + 4 * h + (jj & 3)
+
+
+def gemm_index_x3(n_rows_out, n_cols, segs):
+    """[n_out_tiles, n_steps (padded to whole 2-step blocks), 64, 8] gather index: the A operand of v_mfma_f32_32x32x16_bf16 before
+    the split; segs as in gemm_index with row counts in x3 rows (3 per step)."""
+    n_tiles = (n_rows_out + 31) // 32
+    for n_rows, _ in segs:
+        assert n_rows % 3 == 0
+    col = np.concatenate([col_fn(step_features_n(n_rows // 3)) for n_rows, col_fn in segs], 0)
+    if col.shape[0] % 2:
+        col = np.concatenate([col, np.full((1, 64, 8), -1, col.dtype)], 0)
+    row = 32 * np.arange(n_tiles)[:, None, None, None] + (np.arange(64) & 31)[None, None, :, None]
+    row = np.broadcast_to(row, (n_tiles,) + col.shape)
+    colb = np.broadcast_to(col[None], row.shape)
+    return np.where((row < n_rows_out) & (colb >= 0), row * n_cols + colb, n_rows_out * n_cols).astype(np.int64)
+
+
+def rowdot_index_x3(n_out, n_rows, n_cols, col_fn=None):
+    """[n_out, n_rows/3, 2, 8] f32 image of the rows of M [n_out, n_cols] in x3-image order."""
+    assert n_rows % 3 == 0
+    f = step_features_n(n_rows // 3)[:, ::32, :]
+    col = f if col_fn is None else col_fn(f)
+    o = np.arange(n_out)[:, None, None, None]
+    colb = np.broadcast_to(col[None], (n_out,) + col.shape)
+    valid = (colb >= 0) & (colb < n_cols)
+    return np.where(valid, o * n_cols + colb, n_out * n_cols).astype(np.int64)
+
+
+def split3_exact(g):
+    """f32 tensor -> (p0, p1, p2) f32 tensors, each with at most 8 significant bits (a bf16 value), p0 + p1 + p2 == g EXACTLY:
+    truncation of the low 16 bits of the word, twice on the exact remainders."""
+    def trunc(t):
+        return (t.contiguous().view(torch.int32) & -65536).view(torch.float32)
+    p0 = trunc(g)
+    r1 = g - p0
+    p1 = trunc(r1)
+    p2 = trunc(r1 - p1)
+    return p0, p1, p2
+
+
+def split_pack_x3(g):
+    """g [T, S, 64, 8] f32 (gemm_index_x3 order) -> flat float32 view of [T, S, 3, 64, 8] bf16 pieces (no range limit, no scaling)."""
+    if not bool(torch.isfinite(g).all()):
+        raise ValueError('x3 packs: non-finite weight')
+    pieces = [(p.contiguous().view(torch.int32) >> 16).to(torch.int16) for p in split3_exact(g.float())]
+    return torch.stack(pieces, 2).contiguous().view(torch.float32).reshape(-1)
+
+
 def _take(mat, idx_dev):
     flat = torch.cat([mat.reshape(-1), mat.new_zeros(1)])
     return torch.take(flat, idx_dev).reshape(-1)
@@ -152,13 +211,19 @@ def ident_cols(n_valid, base=0):
     return lambda f: np.where(f < n_valid, f + base, -1)
 
 
+_INDEX_FNS = {'f32': (gemm_index, bias_index, rowdot_index),
+              'f16s': (gemm_index_f16s, bias_index_f16s, rowdot_index_f16s),
+              'x3': (gemm_index_x3, bias_index_f16s, rowdot_index_x3)}      # (the accumulator-order bias image is the f16s one)
+
+
 class SdfPackPlan:
     """Index tensors + descriptor for an SDFNetwork-shaped MLP (fields.py:9-107)."""
 
     def __init__(self, dims, skip_in, multires, scale, max_tiles=None, with_reverse=True, mode='f32'):
         # dims: [d0, hidden..., d_out] as in fields.py:24 (d0 = embedded input width)
-        assert mode in ('f32', 'f16s')
-        self.mode = mode                    # 'f16s': packs for csrc/neus_mlp_f16s.hip (split-precision engine)
+        assert mode in ('f32', 'f16s', 'x3')
+        self.mode = mode                    # 'f16s': packs for csrc/neus_mlp_f16s.hip (f16 pair engine); 'x3': csrc/neus_mlp_x3.hip (exact bf16x3 split)
+        self.rpt = 6 if mode == 'x3' else 4 # LDS rows per 32-feature tile
         self.dims = list(dims)
         self.n_lin = len(dims) - 1
         assert 2 <= self.n_lin <= MAX_SDF_LAYERS
@@ -169,7 +234,7 @@ class SdfPackPlan:
         self.multires = multires
         self.emb = dims[0]
         assert self.emb == 3 + 6 * multires and self.emb <= 64
-        self.emb_rows = emb_rows_for(self.emb) if mode == 'f32' else emb_rows_for_f16s(self.emb)
+        self.emb_rows = {'f32': emb_rows_for, 'f16s': emb_rows_for_f16s, 'x3': emb_rows_for_x3}[mode](self.emb)
         self.scale = float(scale)
         # true output width of every linear layer (fields.py:38-41)
         self.out_dims = []
@@ -186,12 +251,10 @@ class SdfPackPlan:
 
     def _build(self):
         E, er = self.emb, self.emb_rows
-        f32 = self.mode == 'f32'
-        gemm_index, bias_index, rowdot_index = ((globals()['gemm_index'], globals()['bias_index'], globals()['rowdot_index']) if f32
-                                                else (gemm_index_f16s, bias_index_f16s, rowdot_index_f16s))
+        gemm_index, bias_index, rowdot_index = _INDEX_FNS[self.mode]
         plan = []          # (kind, layer, index array)
         for l in range(self.n_lin):
-            rows_prev = 4 * self.tiles[l - 1] if l > 0 else 0
+            rows_prev = self.rpt * self.tiles[l - 1] if l > 0 else 0
             if l == 0:
                 segs = [(er, ident_cols(E))]
             elif l == self.skip:
@@ -208,7 +271,7 @@ class SdfPackPlan:
                     plan.append(('bfeat', l, bias_index(self.feat_out)))
                 plan.append(('wrow', l, rowdot_index(1, rows_prev, self.in_dims[l])))
             if self.with_reverse and l < self.n_lin - 1:
-                ksegs = [(4 * self.tiles[l], ident_cols(self.out_dims[l]))]
+                ksegs = [(self.rpt * self.tiles[l], ident_cols(self.out_dims[l]))]
                 if l >= 1:
                     prev = self.out_dims[l - 1]
                     plan.append(('wT', l, gemm_index(prev, self.out_dims[l], ksegs)))
@@ -250,8 +313,8 @@ class SdfPackPlan:
             elif kind == 'wTE':
                 src = W[:, self.out_dims[l - 1]:].t() if l == self.skip else W.t()
             c = _take(src.contiguous(), ix)
-            if self.mode == 'f16s' and kind in ('w', 'wfeat', 'wT', 'wTE'):
-                c = split_pack(c.reshape(ix.shape))
+            if self.mode != 'f32' and kind in ('w', 'wfeat', 'wT', 'wTE'):
+                c = (split_pack if self.mode == 'f16s' else split_pack_x3)(c.reshape(ix.shape))
             assert c.numel() % 4 == 0
             o4 = off // 4
             if kind in ('w', 'wfeat'):
@@ -286,16 +349,15 @@ class ColPackPlan:
     """RenderingNetwork-shaped MLP (fields.py:111-172); input order [pts, view_embed, normals, feat]."""
 
     def __init__(self, d_feature, mode, d_hidden, n_layers, d_out, multires_view, squeeze_out, feat_tiles, matrix_mode='f32'):
-        assert matrix_mode in ('f32', 'f16s')
+        assert matrix_mode in ('f32', 'f16s', 'x3')
         self.matrix_mode = matrix_mode
-        f32 = matrix_mode == 'f32'
-        gemm_index, bias_index, rowdot_index = ((globals()['gemm_index'], globals()['bias_index'], globals()['rowdot_index']) if f32
-                                                else (gemm_index_f16s, bias_index_f16s, rowdot_index_f16s))
+        rpt = 6 if matrix_mode == 'x3' else 4
+        gemm_index, bias_index, rowdot_index = _INDEX_FNS[matrix_mode]
         self.mode = mode
         self.n_view = (3 + 6 * multires_view) if mode in ('idr', 'no_normal') else 0
         self.has_normal = 1 if mode in ('idr', 'no_view_dir') else 0
         self.extra = 3 + self.n_view + 3 * self.has_normal
-        self.extra_rows = emb_rows_for(self.extra) if f32 else emb_rows_for_f16s(self.extra)
+        self.extra_rows = {'f32': emb_rows_for, 'f16s': emb_rows_for_f16s, 'x3': emb_rows_for_x3}[matrix_mode](self.extra)
         self.d_feature = d_feature
         self.dims = [self.extra + d_feature] + [d_hidden] * n_layers + [d_out]
         self.n_lin = len(self.dims) - 1
@@ -306,13 +368,13 @@ class ColPackPlan:
         plan = []
         for l in range(self.n_lin - 1):
             if l == 0:
-                segs = [(4 * feat_tiles, ident_cols(d_feature, base=self.extra)), (self.extra_rows, ident_cols(self.extra))]
+                segs = [(rpt * feat_tiles, ident_cols(d_feature, base=self.extra)), (self.extra_rows, ident_cols(self.extra))]
             else:
-                segs = [(4 * self.tiles[l - 1], ident_cols(self.dims[l]))]
+                segs = [(rpt * self.tiles[l - 1], ident_cols(self.dims[l]))]
             plan.append(('w', l, gemm_index(self.dims[l + 1], self.dims[l], segs)))
             plan.append(('b', l, bias_index(self.dims[l + 1])))
         L = self.n_lin - 1
-        plan.append(('wrow', L, rowdot_index(d_out, 4 * self.tiles[L - 1], self.dims[L])))
+        plan.append(('wrow', L, rowdot_index(d_out, rpt * self.tiles[L - 1], self.dims[L])))
         self.plan = plan
         self._dev_idx = {}
 
@@ -330,8 +392,8 @@ class ColPackPlan:
         for (kind, l, _), ix in zip(self.plan, self._indices(dev)):
             src = weights[l] if kind in ('w', 'wrow') else biases[l]
             c = _take(src.contiguous(), ix)
-            if self.matrix_mode == 'f16s' and kind == 'w':
-                c = split_pack(c.reshape(ix.shape))
+            if self.matrix_mode != 'f32' and kind == 'w':
+                c = (split_pack if self.matrix_mode == 'f16s' else split_pack_x3)(c.reshape(ix.shape))
             o4 = off // 4
             if kind == 'w':
                 layer[l]['w'] = o4
