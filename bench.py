@@ -143,9 +143,18 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     # algorithmic FLOPs of one step: coarse SDF passes + [fwd, reverse sweep, tangent, reverse, 2 weight
     # contractions] of the SDF net + [fwd, reverse, weight contraction] of the colour net, per fine sample
     flop = 2.0 * B * (S_c * m_sdf + S_f * (6 * m_sdf + 3 * m_col))
+    # per kernel group: algorithmic FLOPs of what it computes (per fine sample: prog_fwd = SDF forward + reverse sweep + colour forward,
+    # prog_sbwd = tangent pass + second reverse sweep, prog_cbwd = colour reverse sweep, wgrad = 2 SDF + 1 colour contraction; the coarse
+    # passes are SDF forwards) over its HIP-event time, against the f32-input MFMA peak ("f32-equivalent" for the bf16x3 contraction)
+    kflop = {'vqn_neus_sdf_points': 2.0 * B * S_c * m_sdf, 'vqn_tile_program:prog_fwd': 2.0 * B * S_f * (2 * m_sdf + m_col),
+             'vqn_tile_program:prog_sbwd': 2.0 * B * S_f * 2 * m_sdf, 'vqn_tile_program:prog_cbwd': 2.0 * B * S_f * m_col,
+             'vqn_wgrad_partials': 2.0 * B * S_f * (2 * m_sdf + m_col), 'vqn_wgrad_partials_x3': 2.0 * B * S_f * (2 * m_sdf + m_col)}
+    kfrac = {k: {'ms': clk[k][1] / 6, 'tflops': kflop[k] / (clk[k][1] / 6 * 1e-3) / 1e12,
+                 'frac_of_f32_mfma_peak': kflop[k] / (clk[k][1] / 6 * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS} for k in kflop if k in clk}
     out['geo_train'] = {'rays_per_s': B / dt, 'ms_per_step': dt * 1e3, 'batch_rays': B,
                         'achieved_tflops': flop / dt / 1e12, 'frac_of_f32_mfma_peak': flop / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
-                        'kernel_ms_per_step': {k: v[1] / 6 for k, v in sorted(clk.items())},
+                        'kernel_ms_per_step': {k: v[1] / 6 for k, v in sorted(clk.items())}, 'kernel_roofline': kfrac,
+                        'device_ms_outside_listed_kernels': dt * 1e3 - sum(v[1] / 6 for v in clk.values()),
                         'note': 'all HIP: up-sampling kernels, forward / backward tile programs (second-order eikonal term via '
                                 'a tangent pass), weight-gradient contraction, compositing fwd/bwd; torch only for Adam, the '
                                 'weight-norm chain rule and small reductions'}
@@ -170,7 +179,7 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     except Exception as e:                                      # noqa: BLE001
         out['geo_train_wgrad_f32'] = {'error': repr(e)[:300]}
     finally:
-        _tp.wgrad_mode('f32')
+        _tp.wgrad_mode(os.environ.get('VQN_WGRAD', 'bf16x3'))
 
     # ---- the headline render on the split-precision kernels (renderer.matrix_mode = 'f16s'), opt-in mode ----
     Bq = 80000
@@ -179,30 +188,43 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     nq, fq = torch.full((Bq, 1), 2.0, device=dev), torch.full((Bq, 1), 6.0, device=dev)
     bgq = torch.ones(1, 3, device=dev)
     rend = lambda: ren.render(oq, dq, nq, fq, 2.0, perturb_overwrite=0, background_rgb=bgq, cos_anneal_ratio=1.0)
+    flop_fine = 2.0 * (2 * m_sdf + m_col) * Bq * 128
     with torch.no_grad():
         ref_img = rend()['color_fine']
-        ren.matrix_mode = 'f16s'
-        try:
-            got_img = rend()['color_fine']
-            _C.KernelClock.reset(True)
-            dt16 = _time_gpu(rend, 3, warm=0)
-            clk16 = _C.KernelClock.summary()
-        finally:
-            ren.matrix_mode = 'f32'
-            _C.KernelClock.reset(False)
-    t_fine16 = clk16['vqn_neus_fine_points_f16s'][1] / clk16['vqn_neus_fine_points_f16s'][0] * 1e-3
-    flop_fine = 2.0 * (2 * m_sdf + m_col) * Bq * 128
-    mse16 = float(((got_img - ref_img) ** 2).mean())
-    out['geo_render_f16s'] = {
-        'rays_per_s': Bq / dt16, 'ms_per_step': dt16 * 1e3, 'rays': Bq,
-        'psnr_vs_f32_render_db': -10.0 * math.log10(mse16 + 1e-30), 'max_abs_diff_vs_f32': float((got_img - ref_img).abs().max()),
-        'fine_kernel': {'ms': t_fine16 * 1e3, 'achieved': flop_fine / t_fine16 / 1e12, 'unit': 'TFLOP/s (algorithmic f32 FLOPs)',
-                        'issued_f16_tflops': 3.0 * flop_fine / t_fine16 / 1e12, 'peak': 2516.6,
-                        'frac': 3.0 * flop_fine / t_fine16 / 1e12 / 2516.6,
-                        'frac_note': 'issued f16 MFMA FLOPs (3 per algorithmic FLOP) over the dense f16 peak'},
-        'kernel_ms_per_step': {k: v[1] / 3 for k, v in sorted(clk16.items())},
-        'note': 'opt-in precision mode (renderer.matrix_mode = "f16s": f16 hi/lo operands, 3 f16 MFMAs per product, f32 accumulate); '
-                '`value` is the f32 path'}
+
+    def alt_mode_leg(mode, entry, issued_per_flop, peak, what):
+        with torch.no_grad():
+            ren.matrix_mode = mode
+            try:
+                got_img = rend()['color_fine']
+                _C.KernelClock.reset(True)
+                dtm = _time_gpu(rend, 3, warm=0)
+                clkm = _C.KernelClock.summary()
+            finally:
+                ren.matrix_mode = 'f32'
+                _C.KernelClock.reset(False)
+        t_f = clkm[entry][1] / clkm[entry][0] * 1e-3
+        mse = float(((got_img - ref_img) ** 2).mean())
+        return {'rays_per_s': Bq / dtm, 'ms_per_step': dtm * 1e3, 'rays': Bq,
+                'psnr_vs_f32_render_db': -10.0 * math.log10(mse + 1e-30), 'max_abs_diff_vs_f32': float((got_img - ref_img).abs().max()),
+                'fine_kernel': {'ms': t_f * 1e3, 'achieved': flop_fine / t_f / 1e12, 'unit': 'TFLOP/s (algorithmic f32 FLOPs)',
+                                'frac_of_f32_mfma_peak_equiv': flop_fine / t_f / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                                'issued_tflops': issued_per_flop * flop_fine / t_f / 1e12, 'peak': peak,
+                                'frac': issued_per_flop * flop_fine / t_f / 1e12 / peak,
+                                'frac_note': f'issued 16-bit MFMA FLOPs ({issued_per_flop:g} per algorithmic FLOP) over the dense 16-bit peak'},
+                'kernel_ms_per_step': {k: v[1] / 3 for k, v in sorted(clkm.items())}, 'note': what}
+
+    out['geo_render_f16s'] = alt_mode_leg('f16s', 'vqn_neus_fine_points_f16s', 3.0, 2516.6,
+                                          'opt-in precision mode (renderer.matrix_mode = "f16s": f16 hi/lo operands, 3 f16 MFMAs per product, '
+                                          'f32 accumulate; ~2^-21 per product, |w| < 6e4); `value` is the f32 path')
+    # round 3: the exact-split engine (every f32 operand as three bf16 pieces, six bf16 MFMAs per product down to 2^-24, f32
+    # accumulate): f32-level results with no operand-range caveat, held to the f32 kernels' tolerances against the reference goldens
+    try:
+        out['geo_render_x3'] = alt_mode_leg('x3', 'vqn_neus_fine_points_x3', 6.0, 2516.6,
+                                            'exact-split mode (renderer.matrix_mode = "x3"): bf16x3 operands, 6 bf16 MFMAs per product, f32 '
+                                            'accumulate; passes every reference-golden test at the f32 tolerances; `value` is the f32-input-MFMA path')
+    except Exception as e:                                      # noqa: BLE001
+        out['geo_render_x3'] = {'error': repr(e)[:300]}
 
     # ---- the literal "x64 samples" headline of the metric string: n_samples = 64, n_importance = 0 -- no
     # coarse pass at all (renderer.py:335), 169.0 MFLOP/ray -- one whole 800x800 view per step ----
@@ -256,7 +278,12 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     finally:
         ren.matrix_mode = 'f32'
     n_sec = int((torch.einsum('ijk,ik->ij', torch.nn.functional.normalize(ex.lxyz.to(dev) - surf[:, None, :], dim=-1), nrm) > 0).sum())
+    # per secondary ray: 64 coarse + 48 up-sampling SDF forwards, then 128 fine samples of SDF forward + reverse sweep (colour skipped)
+    vis_flop = 2.0 * n_sec * (112 * m_sdf + 128 * 2 * m_sdf)
     out['compute_vis'] = {'secondary_rays_per_s': n_sec / dtv, 'surface_points': npts, 'secondary_rays': n_sec, 'ms': dtv * 1e3,
+                          'roofline': {'bound': 'mfma', 'achieved': vis_flop / dtv / 1e12, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                       'frac': vis_flop / dtv / 1e12 / F32_MFMA_PEAK_TFLOPS, 'mflop_per_secondary_ray': vis_flop / n_sec / 1e6,
+                                       'note': 'whole call (wall clock incl. the host-side chunk loop), not one kernel'},
                           'secondary_rays_per_s_f16s': n_sec / dtv16, 'max_abs_diff_f16s_vs_f32': float((lv16 - lv).abs().max()),
                           'note': 'all front-lit (point, light) pairs of a chunk in one batch; colour network skipped (weights_only); '
                                   'the reference walks 512 lights one by one with a host sync each (gen_geo.py:202-242)'}
@@ -366,20 +393,23 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     opt2 = torch.optim.Adam(model.trainable_variables, lr=5e-4, eps=1e-7, amsgrad=True)
     tr = train_nfr.Trainer(model, opt2)
     dt = _time_gpu(lambda: tr.train_iter(small, global_bs=1024), 5, warm=2)
-    out['decomp_train'] = {'points_per_s': 2048 / dt, 'ms_per_step': dt * 1e3, 'batch_points': 2048,
+    TRAIN_FLOP_PER_POINT = 3 * 2.0 * (enc_macs + head_macs)      # forward + reverse sweep + weight-gradient contraction of every Dense layer
+    tfrac = lambda n, t: {'achieved_tflops': TRAIN_FLOP_PER_POINT * n / t / 1e12, 'flop_per_point': TRAIN_FLOP_PER_POINT,
+                          'frac_of_f32_mfma_peak': TRAIN_FLOP_PER_POINT * n / t / 1e12 / F32_MFMA_PEAK_TFLOPS}
+    out['decomp_train'] = {'points_per_s': 2048 / dt, 'ms_per_step': dt * 1e3, 'batch_points': 2048, 'roofline': tfrac(2048, dt),
                            'note': 'all HIP: encoder / heads forward + backward tile programs, weight-gradient contraction, fused '
                                    'shading forward + backward, VQ assign / EMA statistics; torch for the loss, Adam and glue '
                                    '(launch-latency-bound at the reference batch of 2048 points)'}
     big_tr = points(262144)
     dt = _time_gpu(lambda: tr.train_iter(big_tr, global_bs=262144), 3, warm=1)
-    out['decomp_train_256k'] = {'points_per_s': 262144 / dt, 'ms_per_step': dt * 1e3, 'batch_points': 262144,
+    out['decomp_train_256k'] = {'points_per_s': 262144 / dt, 'ms_per_step': dt * 1e3, 'batch_points': 262144, 'roofline': tfrac(262144, dt),
                                 'note': 'same step on a 128x larger batch (what a data-parallel / large-batch run would use)'}
     # the same reference-size step captured once into a HIP graph and replayed (Trainer(graph=True)); last, as it switches
     # the model to its all-foreground statement
     opt3, _, clip3 = train_nfr.make_optimizer(config_from_dict(DECOMP_INI), model.trainable_variables, capturable=True)
     tr_g = train_nfr.Trainer(model, opt3, clip=clip3, graph=True)
     dt = _time_gpu(lambda: tr_g.train_iter(small, global_bs=1024), 20, warm=train_nfr.Trainer.GRAPH_WARMUP + 2)
-    out['decomp_train_graph'] = {'points_per_s': 2048 / dt, 'ms_per_step': dt * 1e3, 'batch_points': 2048,
+    out['decomp_train_graph'] = {'points_per_s': 2048 / dt, 'ms_per_step': dt * 1e3, 'batch_points': 2048, 'roofline': tfrac(2048, dt),
                                  'captured': tr_g._captured is not None,
                                  'note': 'decomp_train with the whole step (forward, loss, backward, EMA codebook move, Adam) '
                                          'replayed from one captured HIP graph'}
@@ -397,6 +427,57 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
                         'frac': by_a / t_a / 1e9 / 8000.0, 'ms': t_a * 1e3, 'rows_per_s': Nv / t_a}
     out['vq_ema_stats'] = {'rows': Nv, 'bound': 'hbm', 'achieved': by_s / t_s / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                            'frac': by_s / t_s / 1e9 / 8000.0, 'ms': t_s * 1e3}
+
+    # ---- BASELINE.json configs[2]: the full decomposition with a 64-entry codebook (VERDICT r02 missing #2) ----
+    K64 = 64
+    cb64 = rng.uniform(0, 1, (K64, 256)).astype(np.float32)
+    C64 = torch.tensor((cb64 / np.linalg.norm(cb64, axis=1, keepdims=True)).T.copy(), device=dev)
+    t_a64 = _time_gpu(lambda: _C.vq_assign(x, C64, want_quant=False), 10)
+    by_a64 = Nv * (4 * D + 8) + 4 * D * K64
+    out['vq_assign_k64'] = {'rows': Nv, 'D': D, 'K': K64, 'bound': 'hbm', 'achieved': by_a64 / t_a64 / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                            'frac': by_a64 / t_a64 / 1e9 / 8000.0, 'ms': t_a64 * 1e3, 'rows_per_s': Nv / t_a64,
+                            'kernel': 'vq_assign_split_kernel (f16-pair prefilter, exact re-evaluation of the candidates: bit-identical indices)'}
+    xr = torch.rand(Nv, D, device=dev)                       # un-normalised rows: the fused quantiser normalises them itself
+    from vqnerf_release_amd.decomp.nerfactor.networks.vq_layers import VectorQuantizerEMA
+    vql = VectorQuantizerEMA(embedding_dim=D, num_embeddings=K64, commitment_cost=0.1, seed=0).to(dev)
+    with torch.no_grad():
+        vql.infer_from_raw(xr, C64)['quantize']
+        t_q64 = _time_gpu(lambda: vql.infer_from_raw(xr, C64)['quantize'], 10)
+    by_q64 = Nv * (8 * D + 8) + 4 * D * K64                  # rows in, straight-through rows out, index out
+    out['vq_quantize_rows_k64'] = {'rows': Nv, 'D': D, 'K': K64, 'bound': 'hbm', 'achieved': by_q64 / t_q64 / 1e9, 'peak': 8000.0,
+                                   'unit': 'GB/s', 'frac': by_q64 / t_q64 / 1e9 / 8000.0, 'ms': t_q64 * 1e3,
+                                   'what': 'l2-normalise + nearest code + straight-through rows + commitment term + usage, one pass'}
+    del x, xr
+    ini64 = dict(DECOMP_INI)
+    ini64['num_embed'] = K64
+    model64 = get_model_class('vq_nfr')(config_from_dict(ini64))
+    model64.build_nets(device=dev, seed=0).to(dev)
+    model64.set_codebook(cb64 / np.linalg.norm(cb64, axis=1, keepdims=True))
+    model64.set_light(rng.uniform(0, 1, (16, 32, 3)).astype(np.float32))
+    view = list(points(N))
+    alpha80 = (torch.rand(N, 1, device=dev) < 0.8).float()                    # 80 % foreground, like a test.py view (20-70 % background)
+    n_fg = int(alpha80.sum())
+
+    def call64():
+        # a FRESH alpha tensor per call: the foreground-row cache (keyed on the tensor) misses, the `nonzero` + gather / scatter are paid
+        view[5] = alpha80.clone()
+        return model64.call(tuple(view), mode='test')
+    with torch.no_grad():
+        call64()
+        _C.KernelClock.reset(True)
+        dt64 = _time_gpu(call64, 3, warm=0)
+    clk64 = _C.KernelClock.summary()
+    _C.KernelClock.reset(False)
+    t_front = sum(v[1] for k, v in clk64.items() if k in ('vqn_mlp_chain_fwd', 'vqn_mlp_chain_vq_fwd')) / 3 * 1e-3
+    out['decomp_render_k64'] = {
+        'rays': N, 'foreground_points': n_fg, 'ms_per_view': dt64 * 1e3, 'foreground_points_per_s': n_fg / dt64, 'K': K64,
+        'mlp_chain': {'bound': 'mfma', 'achieved': 2.0 * (enc_macs + head_macs) * n_fg / t_front / 1e12, 'peak': F32_MFMA_PEAK_TFLOPS,
+                      'unit': 'TFLOP/s', 'frac': 2.0 * (enc_macs + head_macs) * n_fg / t_front / 1e12 / F32_MFMA_PEAK_TFLOPS, 'ms': t_front * 1e3},
+        'kernel_ms_per_view': {k: v[1] / 3 for k, v in sorted(clk64.items())},
+        'kernel_launches_per_call': {k: v[0] // 3 for k, v in clk64.items()},
+        'note': 'vq_nfr.call(mode="test") on an 800x800 view with 80 % foreground rays and a 64-entry codebook; every call gets a fresh '
+                'alpha tensor, so the foreground `nonzero`, the row gathers and the scatters back to ray slots are inside the time'}
+    del model64
     return out
 
 
@@ -742,6 +823,9 @@ def main():
         try:
             step()
             got16 = out_box[0]['color_fine'][sel_t].cpu()
+            ren.matrix_mode = 'x3'                                # the exact-split mode on the same rays
+            step()
+            got_x3 = out_box[0]['color_fine'][sel_t].cpu()
         finally:
             ren.matrix_mode = 'f32'
     del out
@@ -797,6 +881,7 @@ def main():
         # the same check for the opt-in split-precision mode (reported under extra.geo_render_f16s)
         mse16 = float(((got16 - ref['color_fine'].detach()) ** 2).mean())
         result['psnr_f16s_vs_oracle_db'] = -10.0 * math.log10(mse16 + 1e-20)
+        result['psnr_x3_vs_oracle_db'] = -10.0 * math.log10(float(((got_x3 - ref['color_fine'].detach()) ** 2).mean()) + 1e-20)
         if not args.no_extras:
             result['cpu_baseline_decomp'] = decomp_cpu_leg(dev, cores)
     if extra:
