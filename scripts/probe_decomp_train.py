@@ -20,8 +20,13 @@ one = torch.ones(n, 1, device=dev)
 batch = (['v'], torch.zeros(n, 2, device=dev), torch.tensor([[0, 0, 4.0]], device=dev).repeat(n, 1), torch.zeros(n, 3, device=dev),
          torch.rand(n, 3, device=dev), one, one.clone(), xyz, nrm, (torch.rand(n, 512, device=dev) < 0.7).float())
 model.get_codebook(); _ = model.light
-opt = torch.optim.Adam(model.trainable_variables, lr=5e-4, eps=1e-7, amsgrad=True)
-tr = train_nfr.Trainer(model, opt)
+graph = len(sys.argv) > 3 and sys.argv[3] == 'graph'        # the captured step replayed (kernel trace of what one replay launches)
+if graph:
+    opt, _, clip = train_nfr.make_optimizer(config_from_dict(bench.DECOMP_INI), model.trainable_variables, capturable=True)
+    tr = train_nfr.Trainer(model, opt, clip=clip, graph=True)
+else:
+    opt = torch.optim.Adam(model.trainable_variables, lr=5e-4, eps=1e-7, amsgrad=True)
+    tr = train_nfr.Trainer(model, opt)
 for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4):
     tr.train_iter(batch, global_bs=n)
 torch.cuda.synchronize()

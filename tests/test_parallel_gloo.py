@@ -63,6 +63,30 @@ def _worker(rank, world, port, q):
             assert float(extra[1]) == x.shape[0]
             opt.step()
             parallel.assert_replicas_identical(list(net.parameters()))
+        # the same three steps with the gradient all-reduce cut into slices that leave as soon as their last gradient is in (overlap
+        # with the backward tail): bit-identical parameters, extras intact, unused parameters handled
+        net2 = _net()
+        dead = torch.nn.Parameter(torch.ones(3))                       # never used: its slice must still go out (as zeros)
+        opt2 = torch.optim.Adam(list(net2.parameters()) + [dead], lr=1e-2)
+        bucket2 = parallel.FlatBucket(list(net2.parameters()) + [dead], n_extra=2).enable_overlap(n_buckets=3)
+        assert len(bucket2._slices) >= 2 and bucket2._slices[-1]['hi'] == bucket2.n_grad
+        for step in range(3):
+            opt2.zero_grad(set_to_none=True)
+            if step == 1:
+                bucket2.attach()                                       # both styles: grads as views of the bucket, or fresh tensors
+            loss2 = ((net2(x[lo:hi]) - y[lo:hi]) ** 2).mean(-1).sum() / x.shape[0]
+            loss2.backward()
+            assert len(bucket2._pending) >= 1                          # slices really left during backward
+            with torch.no_grad():
+                bucket2.extra[0] = loss2
+                bucket2.extra[1] = float(hi - lo)
+            extra2 = bucket2.all_reduce()
+            assert float(extra2[1]) == x.shape[0] and not bucket2._pending
+            assert float(bucket2.views[-1].abs().sum()) == 0.0             # (no gradient: zeros went out, Adam skips it)
+            opt2.step()
+        for a, b in zip(net.parameters(), net2.parameters()):
+            assert torch.equal(a, b)
+        assert float(extra2[0]) == float(extra[0])
         # VQ statistics: local one-hot stats of this rank's rows, reduced
         g = np.random.default_rng(2)
         z = torch.tensor(g.uniform(0, 1, (40, 8)), dtype=torch.float32)

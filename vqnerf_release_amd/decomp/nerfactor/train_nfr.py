@@ -118,6 +118,10 @@ class Trainer:
         model = self.model
         if self.bucket is None:
             self.bucket = parallel.FlatBucket(model.trainable_variables, n_extra=1)
+            if parallel.is_dist() and not self.graph:
+                # eager data parallelism: the heads' gradients are final while the encoder's backward programs still run -- their
+                # slice of the bucket is reduced beside them (the captured step is cut at its collectives instead)
+                self.bucket.enable_overlap(n_buckets=2)
         if fresh_leaves:
             # (capture only) run the step on fresh leaf aliases of the parameters.  A parameter's AccumulateGrad node is bound to the
             # stream the parameter was first used on and lives as long as ANY tensor derived from it (a caller holding `model.light`,

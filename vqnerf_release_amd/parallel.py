@@ -159,14 +159,91 @@ class FlatBucket:
                 v.copy_(p.grad)
                 p.grad = v
 
+    # ---- overlap with the backward tail (trainvali.py:469-477 lets MirroredStrategy overlap its all-reduces the same way) ----
+    def enable_overlap(self, n_buckets=2, group=None):
+        """Cut the gradient part of the buffer into `n_buckets` contiguous slices (by bytes, along the parameter order) and send
+        each slice off (asynchronous all-reduce: RCCL runs it on its own stream, ordered after the kernels already queued on the
+        launch stream) as soon as the LAST gradient of the slice has been accumulated, while the backward pass goes on producing the
+        others.  The backward pass reaches the parameters roughly in reverse order, so the slices complete back to front; the
+        extras (loss terms, written after backward) travel with whatever is reduced at `all_reduce()`, which also reduces every
+        slice whose hooks did not all fire (an unused parameter).  Sums are slice-local, element-wise: the result is bit-identical
+        to the single all-reduce.  Not used while a SegmentedCapture records (a collective cuts the graph there)."""
+        if getattr(self, '_slices', None) is not None:
+            return self
+        target = max(1, -(-self.n_grad // max(1, n_buckets)))
+        self._slices, lo, acc, first = [], 0, 0, 0
+        self._slice_of = {}
+        for i, n in enumerate(self.sizes):
+            acc += n
+            self._slice_of[id(self.params[i])] = len(self._slices)
+            if acc >= target or i == len(self.sizes) - 1:
+                self._slices.append({'lo': lo, 'hi': lo + acc, 'n_params': i + 1 - first})
+                lo, acc, first = lo + acc, 0, i + 1
+        self._group = group
+        self._pending, self._left = {}, [sl['n_params'] for sl in self._slices]
+
+        def make_hook(i, k):
+            def hook(p):
+                if not is_dist() or _capture is not None:
+                    return
+                v = self.views[i]
+                if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+                    p.grad = v
+                self._left[k] -= 1
+                if self._left[k] == 0:
+                    sl = self._slices[k]
+                    with _clock('all_reduce:grad_bucket[%d]' % k):
+                        self._pending[k] = dist.all_reduce(self.flat[sl['lo']:sl['hi']], op=dist.ReduceOp.SUM, group=group, async_op=True)
+            return hook
+        for i, p in enumerate(self.params):
+            p.register_post_accumulate_grad_hook(make_hook(i, self._slice_of[id(p)]))
+        return self
+
     def all_reduce(self, average_grads=False, group=None):
-        """One collective for the whole step.  Gradients are summed (the trainers normalise their loss by the GLOBAL
-        batch, as train_nfr.py:571-572 does with `global_batch_size`), or averaged on request."""
-        self.gather_grads()
-        if is_dist():
-            all_reduce_sum(self.flat, group, 'all_reduce:grad_bucket')
-            if average_grads:
-                self.flat[:self.n_grad].div_(dist.get_world_size(group))
+        """One collective for the whole step (or, after `enable_overlap`, the wait for the slices already in flight + one collective
+        for the rest).  Gradients are summed (the trainers normalise their loss by the GLOBAL batch, as train_nfr.py:571-572 does
+        with `global_batch_size`), or averaged on request."""
+        slices = getattr(self, '_slices', None)
+        if slices is None or not is_dist() or _capture is not None:
+            self.gather_grads()
+            if is_dist():
+                all_reduce_sum(self.flat, group, 'all_reduce:grad_bucket')
+                if average_grads:
+                    self.flat[:self.n_grad].div_(dist.get_world_size(group))
+            return self.extra
+        # parameters that saw no gradient this step: their views must hold zeros before the slice goes out
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
+            k = self._slice_of[id(p)]
+            if k in self._pending:
+                continue
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+                p.grad = v
+        # slices not yet sent (+ the extras) go out as one contiguous run where possible: the unsent slices are a prefix in the
+        # usual back-to-front completion order
+        todo = [k for k in range(len(slices)) if k not in self._pending]
+        runs, k = [], 0
+        while k < len(todo):
+            j = k
+            while j + 1 < len(todo) and todo[j + 1] == todo[j] + 1:
+                j += 1
+            runs.append((slices[todo[k]]['lo'], slices[todo[j]]['hi']))
+            k = j + 1
+        tail = (self.n_grad, self.n_grad + self.n_extra)
+        if runs and runs[-1][1] == self.n_grad:
+            runs[-1] = (runs[-1][0], tail[1])
+        elif self.n_extra:
+            runs.append(tail)
+        for lo, hi in runs:
+            all_reduce_sum(self.flat[lo:hi], group, 'all_reduce:grad_bucket')
+        for w in self._pending.values():
+            w.wait()                                   # the launch stream waits for the collectives that ran beside the backward tail
+        self._pending, self._left = {}, [sl['n_params'] for sl in slices]
+        if average_grads:
+            self.flat[:self.n_grad].div_(dist.get_world_size(group))
         return self.extra
 
 
