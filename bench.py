@@ -181,6 +181,21 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     finally:
         _tp.wgrad_mode(os.environ.get('VQN_WGRAD', 'bf16x3'))
 
+    # ---- the same training step through the Runner, captured once into a HIP graph and replayed (Runner(graph=True)) ----
+    try:
+        g_runner, g_step = geo_train_setup(dev, 0, B, graph=True)
+        for _ in range(g_runner.GRAPH_WARMUP + 2):
+            g_step()
+        dtg = _time_gpu(g_step, 10, warm=0)
+        out['geo_train_graph'] = {'rays_per_s': B / dtg, 'ms_per_step': dtg * 1e3, 'batch_rays': B, 'captured': g_runner._cap is not None,
+                                  'achieved_tflops': flop / dtg / 1e12, 'frac_of_f32_mfma_peak': flop / dtg / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                                  'note': 'geo_train with the whole optimisation step (up-sampling passes, forward / backward tile programs, '
+                                          'compositing, weight-gradient contractions, weight-norm chain rule, capturable Adam) replayed from one '
+                                          'captured HIP graph; bit-identical to the eager step (tests/test_gpu_train.py)'}
+        del g_runner, g_step
+    except Exception as e:                                      # noqa: BLE001
+        out['geo_train_graph'] = {'error': repr(e)[:300]}
+
     # ---- the headline render on the split-precision kernels (renderer.matrix_mode = 'f16s'), opt-in mode ----
     Bq = 80000
     o_np, d_np = image_rays(np.arange(0, 800, 8))             # 100 rows spread over the view: hits and misses
@@ -545,14 +560,14 @@ def _collective_report(clock, steps):
     return rep
 
 
-def geo_train_setup(dev, rank, batch_rays=2560):
+def geo_train_setup(dev, rank, batch_rays=2560, graph=False):
     """The geo trainer (geo/nerf_runner.py `Runner`: nerf.conf batch of 2560 rays per rank, L1 colour + 0.1 eikonal + 0.1 mask
     BCE, Adam, cosine schedule; forward / backward on the HIP tile programs; under N ranks one flat-bucket all-reduce of the
     gradients + one 2-float all-reduce of the loss normalisers per step).  Every rank draws its own pixels."""
     from vqnerf_release_amd.geo.nerf_runner import Runner, SyntheticDataset
     torch.manual_seed(0)                                        # identical initial weights on every rank
     runner = Runner(conf_text=full_conf_text(batch_rays), case='bench', dataset=SyntheticDataset(device=dev, n_images=8, seed=rank),
-                    device=dev)
+                    device=dev, graph=graph)
     runner.update_learning_rate()
     it = [0]
 

@@ -42,6 +42,55 @@ def test_geo_runner_trains(tmp_path):
     assert all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(r.bucket.params, r.bucket.views))
 
 
+def test_geo_runner_graph_replays_the_eager_step(tmp_path):
+    """Runner(graph=True): the captured optimisation step (up-sampling passes, forward / backward tile programs, compositing,
+    weight-gradient contractions, weight-norm chain rule, Adam) replayed on new batches is the eager step bit for bit -- both
+    sides run the same capturable Adam; `perturb = 0` so that no random draw enters (with draws the replays take theirs from the
+    device generator: checked for finiteness and learning below)."""
+    from vqnerf_release_amd.geo.nerf_runner import Runner, SyntheticDataset
+    from tests.gpu_util import launches
+    text = open(os.path.join(HERE, 'golden', 'neus_like.conf')).read().replace('./exp/', str(tmp_path) + '/exp/')
+    text = text.replace('warm_up_end = 5000', 'warm_up_end = 0').replace('batch_size = 64', 'batch_size = 256')
+    assert 'perturb = 1.0' in text and 'anneal_end' in text
+    det = text.replace('perturb = 1.0', 'perturb = 0.0')
+    import re
+    det = re.sub(r'anneal_end = [0-9.]+', 'anneal_end = 0', det)
+    runs = {}
+    for graph in (False, True):
+        torch.manual_seed(0)
+        r = Runner(conf_text=det, case='lego', dataset=SyntheticDataset(n_images=4, H=64, W=64), graph=True)
+        r.graph = graph                                           # same (capturable, fused) Adam on both sides; eager when False
+        r.update_learning_rate()
+        torch.manual_seed(1)
+        batches = [r.dataset.gen_random_rays_at(it % 4, r.batch_size) for it in range(8)]
+        losses = []
+        with launches() as rec:
+            for b in batches:
+                losses.append(r.train_step(b)['loss'].clone())
+        assert (r._cap is not None) == graph and r.iter_step == 8
+        assert rec.ran('vqn_tile_program:prog_sbwd') and rec.ran('vqn_wgrad_partials')
+        runs[graph] = ([float(x) for x in losses], [p.detach().clone() for p in r.bucket.params],
+                       float(r.optimizer.param_groups[0]['lr']))
+    (l0, w0, lr0), (l1, w1, lr1) = runs[False], runs[True]
+    assert l0 == l1, (l0, l1)
+    assert all(torch.equal(a, b) for a, b in zip(w0, w1)) and lr0 == lr1
+    assert l1[-1] != l1[-2]                                       # the replays consumed different batches
+    # inference after replays sees the moved weights (pack caches key on the weights epoch)
+    probe = torch.tensor(np.random.default_rng(0).uniform(-0.8, 0.8, (64, 3)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        np.testing.assert_allclose(r.sdf_network.sdf(probe).cpu().numpy(), r.sdf_network.forward(probe)[:, :1].cpu().numpy(), rtol=0, atol=2e-5)
+    with pytest.raises(ValueError):
+        r.train_step(batches[0][:100])
+    # with the random perturbation of the shipped conf: draws come from the device generator inside the graph
+    torch.manual_seed(0)
+    r2 = Runner(conf_text=text, case='lego', dataset=SyntheticDataset(n_images=4, H=64, W=64), graph=True)
+    r2.update_learning_rate()
+    ls = [float(r2.train_step(r2.dataset.gen_random_rays_at(it % 4, r2.batch_size))['loss']) for it in range(14)]
+    assert all(np.isfinite(ls)) and (r2._cap is not None or r2.get_cos_anneal_ratio() < 1.0)
+    if r2._cap is not None:
+        assert np.mean(ls[-4:]) < np.mean(ls[:4]) and len(set(ls[4:])) > 5          # it learns, and the draws differ per replay
+
+
 def test_geo_runner_trains_from_a_blender_image_set(tmp_path):
     """conf `dataset.data_dir` -> models/nerfset.Dataset (images resident on the device) -> Runner.train_step."""
     from tests.test_datasets import _write_blender_set

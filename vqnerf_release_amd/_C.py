@@ -83,12 +83,16 @@ class _clock:
         self.name = name
 
     def __enter__(self):
-        if KernelClock.enabled:
+        # (not while a HIP graph records: an event recorded into a capture has no time stamp; the launch is still counted)
+        self.on = KernelClock.enabled and not torch.cuda.is_current_stream_capturing()
+        if KernelClock.enabled and not self.on:
+            KernelClock.pairs.setdefault(self.name + ' [captured]', [])
+        if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
 
     def __exit__(self, *exc):
-        if KernelClock.enabled:
+        if self.on:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             KernelClock.pairs.setdefault(self.name, []).append((self.e0, e1))

@@ -66,9 +66,18 @@ class SyntheticDataset:
 
 
 class Runner:
+    GRAPH_WARMUP = 2
+
     def __init__(self, conf_path=None, mode='train', case='CASE_NAME', is_continue=False, conf_text=None, dataset=None,
-                 device='cuda'):
+                 device='cuda', graph=False):
+        """`graph=True`: the optimisation step -- up-sampling passes, forward / backward tile programs, compositing, weight-gradient
+        contractions, weight-norm chain rule, Adam -- is captured once into a HIP graph (after GRAPH_WARMUP eager steps) and
+        replayed on static buffers: ~150 of its ~260 launches are a few microseconds long and the host cannot issue them as fast as
+        the device retires them.  Conditions (checked): fixed batch size, constant cos_anneal_ratio (annealing finished or off),
+        `perturb` draws from the device generator (they do).  The learning rate is a device scalar refreshed before every replay."""
         self.device = torch.device(device)
+        self.graph = bool(graph)
+        self._cap = None
         if conf_text is None:
             with open(conf_path) as f:
                 conf_text = f.read()
@@ -110,7 +119,11 @@ class Runner:
         self.color_network = RenderingNetwork(**m['rendering_network']).to(self.device)
         params = (list(self.nerf_outside.parameters()) + list(self.sdf_network.parameters())
                   + list(self.deviation_network.parameters()) + list(self.color_network.parameters()))
-        self.optimizer = torch.optim.Adam(params, lr=self.learning_rate)
+        if self.graph:
+            self.optimizer = torch.optim.Adam(params, lr=torch.tensor(float(self.learning_rate), device=self.device), capturable=True,
+                                              fused=True)
+        else:
+            self.optimizer = torch.optim.Adam(params, lr=self.learning_rate)
         self.renderer = NeuSRenderer(self.nerf_outside, self.sdf_network, self.deviation_network, self.color_network,
                                      **m['neus_renderer'])
         # data parallel: one flat bucket [grads of the nets that are evaluated || loss terms] -> one all-reduce / step
@@ -135,7 +148,10 @@ class Runner:
             progress = (self.iter_step - self.warm_up_end) / (end - self.warm_up_end)
             factor = (np.cos(np.pi * progress) + 1.0) * 0.5 * (1 - self.learning_rate_alpha) + self.learning_rate_alpha
         for g in self.optimizer.param_groups:
-            g['lr'] = float(self.learning_rate * factor)
+            if torch.is_tensor(g['lr']):
+                g['lr'].fill_(float(self.learning_rate * factor))         # (graph mode: a device scalar the captured Adam reads)
+            else:
+                g['lr'] = float(self.learning_rate * factor)
 
     def get_image_perm(self):
         return torch.randperm(self.dataset.n_images)
@@ -144,38 +160,88 @@ class Runner:
     def train_step(self, data, t_rand=None):
         """data [B,10] = o, d, rgb, mask: this rank's rays.  Under data parallelism the loss is normalised by the GLOBAL
         mask sum / ray count, gradients are summed over ranks in one bucket, and every rank takes the same step."""
+        if self.graph and t_rand is None and self.get_cos_anneal_ratio() == 1.0 and self.iter_step >= self.GRAPH_WARMUP:
+            return self._train_step_replay(data)
+        stats = self._train_step_body(data, t_rand)
+        self._finish_step(stats)
+        return self.last_stats
+
+    def _finish_step(self, extra):
+        self.iter_step += 1
+        self.update_learning_rate()
+        self.last_stats = {'loss': extra[0], 'color_loss': extra[1], 'eikonal_loss': extra[2], 'mask_loss': extra[3]}
+
+    def _train_step_replay(self, data):
+        if self._cap is None:
+            self._static_data = data.clone()
+            cap = parallel.SegmentedCapture()
+            with cap:
+                self._static_extra = self._train_step_body(self._static_data, None, fresh_leaves=True)
+            self._cap = cap
+        if data.shape != self._static_data.shape:
+            raise ValueError(f'the captured step takes batches of shape {tuple(self._static_data.shape)}, got {tuple(data.shape)}')
+        self._static_data.copy_(data)
+        self._cap.replay()
+        import vqnerf_release_amd
+        vqnerf_release_amd.weights_changed()              # a replay moves the weights without bumping any tensor `_version`
+        self._finish_step(self._static_extra)
+        return self.last_stats
+
+    def _train_step_body(self, data, t_rand=None, fresh_leaves=False):
         rays_o, rays_d, true_rgb, mask = data[:, :3], data[:, 3:6], data[:, 6:9], data[:, 9:10]
         near, far = self.dataset.near_far_from_sphere(rays_o, rays_d)
         bg = torch.ones([1, 3], device=data.device) if self.use_white_bkgd else None
         mask = (mask > 0.5).float() if self.mask_weight > 0.0 else torch.ones_like(mask)
         world = parallel.world_size()
-        sums = torch.stack([mask.sum(), torch.tensor(float(mask.numel()), device=data.device)])
+        sums = torch.stack([mask.sum(), torch.full((), float(mask.numel()), device=data.device)])
         if world > 1:
             parallel.all_reduce_sum(sums, what='all_reduce:loss_normalisers')
         mask_sum, n_rays = sums[0] + 1e-5, sums[1]
         if self.bucket is None:
             self.bucket = parallel.FlatBucket(self._dp_params, n_extra=4)
         self.optimizer.zero_grad(set_to_none=True)
-        self.bucket.attach()
-        out = self.renderer.render(rays_o, rays_d, near, far, self.dataset.max_radius, background_rgb=bg,
-                                   cos_anneal_ratio=self.get_cos_anneal_ratio(), t_rand=t_rand)
-        color_error = (out['color_fine'] - true_rgb) * mask
-        color_loss = color_error.abs().sum() / mask_sum
-        # eikonal: the renderer returns the mean over this rank's samples; weight by the rank's share of rays
-        share = mask.numel() / n_rays
-        eik = out['gradient_error'] * share
-        mask_loss = F.binary_cross_entropy(out['weight_sum'].clip(1e-3, 1.0 - 1e-3), mask, reduction='sum') / n_rays
-        loss = color_loss + eik * self.igr_weight + mask_loss * self.mask_weight
-        loss.backward()
+
+        def loss_terms():
+            out = self.renderer.render(rays_o, rays_d, near, far, self.dataset.max_radius, background_rgb=bg,
+                                       cos_anneal_ratio=self.get_cos_anneal_ratio(), t_rand=t_rand)
+            color_error = (out['color_fine'] - true_rgb) * mask
+            color_loss = color_error.abs().sum() / mask_sum
+            # eikonal: the renderer returns the mean over this rank's samples; weight by the rank's share of rays
+            share = mask.numel() / n_rays
+            eik = out['gradient_error'] * share
+            mask_loss = F.binary_cross_entropy(out['weight_sum'].clip(1e-3, 1.0 - 1e-3), mask, reduction='sum') / n_rays
+            return color_loss + eik * self.igr_weight + mask_loss * self.mask_weight, color_loss, eik, mask_loss
+
+        if fresh_leaves:
+            # (capture only) the step runs on fresh leaf aliases of the parameters: a parameter's AccumulateGrad node is bound to the
+            # stream it was first used on, and the autograd engine would pull that (default) stream into the capture -- see
+            # decomp/nerfactor/train_nfr.py, Trainer._step
+            from contextlib import ExitStack
+            from torch.nn.utils.stateless import _reparametrize_module
+            leaves = [p.detach().requires_grad_(True) for p in self.bucket.params]
+            by_id = {id(p): q for p, q in zip(self.bucket.params, leaves)}
+            with ExitStack() as st:
+                for net in (self.sdf_network, self.deviation_network, self.color_network):
+                    st.enter_context(_reparametrize_module(net, {n: by_id[id(p)] for n, p in net.named_parameters() if id(p) in by_id}))
+                loss, color_loss, eik, mask_loss = loss_terms()
+                grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+            with torch.no_grad():
+                for p, v, g in zip(self.bucket.params, self.bucket.views, grads):
+                    if g is None:
+                        v.zero_()
+                    else:
+                        v.copy_(g)
+                    p.grad = v
+        else:
+            self.bucket.attach()
+            loss, color_loss, eik, mask_loss = loss_terms()
+            loss.backward()
         with torch.no_grad():
             ex = self.bucket.extra
-            ex[0], ex[1], ex[2], ex[3] = loss, color_loss, eik, mask_loss
+            ex[0], ex[1], ex[2], ex[3] = loss.detach(), color_loss.detach(), eik.detach(), mask_loss.detach()
         extra = self.bucket.all_reduce()
         self.optimizer.step()
-        self.iter_step += 1
-        self.update_learning_rate()
-        self.last_stats = {'loss': extra[0], 'color_loss': extra[1], 'eikonal_loss': extra[2], 'mask_loss': extra[3]}
-        return self.last_stats
+        return extra
 
     def train(self, n_iters=None, log=None):
         self.update_learning_rate()
