@@ -200,7 +200,8 @@ int vqn_neus_fine_points_x3(const int32_t* sdf_desc, const float* wbuf_sdf, cons
  *   sdf_dims [sdf_n_lin + 1] = [3 + 6 multires, hidden..., d_out] (fields.py:24); sdf_skip: the layer whose input is
  *   [h, embedding] / sqrt(2) (fields.py:81-82; -1 none; one skip, not the last layer); col_mode 0 idr, 1 no_view_dir, 2 no_normal
  *   (fields.py:147-158); col_n_layers hidden layers of col_d_hidden (0: no colour network, SDF-only packs); the colour net's
- *   d_feature is d_out - 1.  f16s != 0: packs for the split-precision entry points (*_f16s). */
+ *   d_feature is d_out - 1.  `f16s` selects the engine the packs are for: 0 = the f32 entry points, 1 = the split-precision
+ *   (*_f16s) ones, 2 = the exact-split (*_x3) ones. */
 typedef struct vqn_neus_pack vqn_neus_pack;
 int vqn_neus_pack_create(const int32_t* sdf_dims, int sdf_n_lin, int sdf_skip, int multires, float scale, int col_mode,
                          int col_d_hidden, int col_n_layers, int multires_view, int squeeze_out, int f16s, vqn_neus_pack** out);

@@ -9,7 +9,7 @@ sequence a non-Python host would make (include/vqnerf_hip.h):
 
 The result is compared with tests/golden/geo_full.npz -- outputs of the REAL reference's NeuSRenderer.render on the same
 seeded weights and rays (oracle/gen_golden_geo.py).  Run by tests/test_gpu_cabi.py in a child process; exits non-zero on
-any mismatch.  `--f16s` uses the split-precision packs / entry points."""
+any mismatch.  `--f16s` uses the split-precision packs / entry points, `--x3` the exact-split (bf16x3) ones."""
 import ctypes
 import math
 import os
@@ -23,6 +23,8 @@ sys.path.insert(0, ROOT)
 from oracle import geo as og          # seeded weights / rays only (numpy)  # noqa: E402
 
 F16S = '--f16s' in sys.argv
+X3 = '--x3' in sys.argv
+ENGINE = 2 if X3 else int(F16S)
 lib = ctypes.CDLL(os.path.join(ROOT, 'vqnerf_release_amd', 'lib', 'libvqnerf_hip.so'))
 lib.vqn_last_error.restype = ctypes.c_char_p
 for f in ('vqn_neus_pack_sdf_desc', 'vqn_neus_pack_col_desc', 'vqn_neus_pack_sdf_wbuf', 'vqn_neus_pack_col_wbuf'):
@@ -60,12 +62,12 @@ ok(lib.vqn_weight_norm_fwd(nl, arr(v), arr(g), arr(w), rows, cols, STREAM), 'vqn
 pack = ctypes.c_void_p()
 c = cfg['color']
 ok(lib.vqn_neus_pack_create((ctypes.c_int32 * len(sdf_dims))(*sdf_dims), n_s, cfg['sdf']['skip_in'][0], cfg['sdf']['multires'],
-                            ctypes.c_float(cfg['sdf']['scale']), 0, c['d_hidden'], c['n_layers'], c['multires_view'], 1, int(F16S),
+                            ctypes.c_float(cfg['sdf']['scale']), 0, c['d_hidden'], c['n_layers'], c['multires_view'], 1, ENGINE,
                             ctypes.byref(pack)), 'vqn_neus_pack_create')
 ok(lib.vqn_neus_pack_update(pack, arr(w[:n_s]), arr(bias[:n_s]), arr(w[n_s:]), arr(bias[n_s:]), STREAM), 'vqn_neus_pack_update')
 d_s, d_c = ctypes.c_void_p(lib.vqn_neus_pack_sdf_desc(pack)), ctypes.c_void_p(lib.vqn_neus_pack_col_desc(pack))
 wb_s, wb_c = ctypes.c_void_p(lib.vqn_neus_pack_sdf_wbuf(pack)), ctypes.c_void_p(lib.vqn_neus_pack_col_wbuf(pack))
-sfx = '_f16s' if F16S else ''
+sfx = '_x3' if X3 else ('_f16s' if F16S else '')
 sdf_points, fine_points = getattr(lib, 'vqn_neus_sdf_points' + sfx), getattr(lib, 'vqn_neus_fine_points' + sfx)
 
 # ---- the render (renderer.py:299-401, perturb 0, white background, cos_anneal_ratio 1) ----
@@ -123,4 +125,4 @@ psnr = -10 * np.log10(np.mean((out['color'].cpu().numpy() - gold['render_white_1
 assert psnr > 70, psnr
 mods = [m for m in sys.modules if m.startswith('vqnerf_release_amd')]
 assert not mods, mods                                   # the Python package was never imported
-print(f'C-ABI-only render ({"split-precision" if F16S else "f32"}): PSNR vs the reference = {psnr:.1f} dB; imported package modules: {mods}')
+print(f'C-ABI-only render ({"exact-split bf16x3" if X3 else ("split-precision" if F16S else "f32")}): PSNR vs the reference = {psnr:.1f} dB; imported package modules: {mods}')

@@ -29,7 +29,7 @@ static int fail(const char* what) {
 int main() {
   int checked = 0;
   const int hidden[] = {33, 48, 64, 100, 160, 256};
-  for (int f16s = 0; f16s < 2; ++f16s)
+  for (int f16s = 0; f16s < 3; ++f16s)
     for (int h : hidden)
       for (int n_hidden = 1; n_hidden <= 8; n_hidden += 3)
         for (int multires = 2; multires <= 10; multires += 4) {
@@ -56,7 +56,7 @@ int main() {
               if (l >= n_lin) return fail("source layer out of range");
               const int out = (l + 1 == skip) ? dims[l + 1] - dims[0] : dims[l + 1];
               const int64_t lim = (id & 1) ? out : (int64_t)out * dims[l];
-              if (i0 >= lim || (kind != 0 && i1 >= lim) || kind < 0 || kind > 2 || (kind != 0) != (f16s && kind != 0))
+              if (i0 >= lim || (kind != 0 && i1 >= lim) || kind < 0 || kind > 5 || (kind != 0 && !f16s) || (f16s == 1 && kind > 2) || (f16s == 2 && kind != 0 && kind < 3))
                 return fail("gather index outside its source matrix");
             }
             for (int l = 0; l < n_lin; ++l)
@@ -66,7 +66,7 @@ int main() {
           }
         }
   const int modes[] = {0, 1, 2};
-  for (int f16s = 0; f16s < 2; ++f16s)
+  for (int f16s = 0; f16s < 3; ++f16s)
     for (int mode : modes)
       for (int d_feature : {32, 64, 100, 256})
         for (int h : {48, 64, 256})

@@ -73,6 +73,18 @@ def _apply_words(words, arrays):
             halves.append(hi if hl == 1 else ((v - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16))
         pair = np.stack(halves, -1).copy()                               # low half first
         out[m] = pair.view(np.float32)[:, 0]
+    for piece in (0, 1, 2):                                              # kind 3 / 4 / 5: exact bf16x3 split by truncation
+        m = kind == 3 + piece
+        if not m.any():
+            continue
+        halves = []
+        for idx in (i0[m], i1[m]):
+            r = get(src[m], idx)
+            for _ in range(piece + 1):
+                p = (r.view(np.uint32) & np.uint32(0xffff0000)).view(np.float32)
+                r = r - p
+            halves.append((p.view(np.uint32) >> np.uint32(16)).astype(np.uint16))
+        out[m] = np.stack(halves, -1).copy().view(np.float32)[:, 0]
     return out
 
 
@@ -85,13 +97,13 @@ SDF_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize('f16s', [0, 1])
+@pytest.mark.parametrize('f16s', [0, 1, 2])              # engine mode of the packs: 0 f32, 1 f16 pair, 2 bf16x3 (exact split)
 @pytest.mark.parametrize('dims,skip_in,multires', SDF_SHAPES)
 def test_c_sdf_pack_equals_python_pack(dims, skip_in, multires, f16s):
     from vqnerf_release_amd.geo import packing
     lib = _C.lib()
     lib.vqn_neus_sdf_pack_plan.restype = ctypes.c_int64
-    mode = 'f16s' if f16s else 'f32'
+    mode = ('f32', 'f16s', 'x3')[f16s]
     plan = packing.SdfPackPlan(dims, skip_in, multires, 1.5, max_tiles=8, mode=mode)
     n_lin = len(dims) - 1
     rng = np.random.default_rng(len(dims) + multires)
@@ -117,16 +129,22 @@ def test_c_sdf_pack_equals_python_pack(dims, skip_in, multires, f16s):
     np.testing.assert_array_equal(got[~scaled].view(np.int32), want[~scaled].view(np.int32))     # bit for bit
     if scaled.any():
         # x * (1 / sqrt 2) (device arithmetic of the Python pack, and of the C kernel) vs x / sqrt 2 (torch on the CPU): one ulp
-        if f16s:
+        if f16s == 1:
             g16, w16 = got[scaled].view(np.float16).astype(np.float32), want[scaled].view(np.float16).astype(np.float32)
             hi = (words[scaled, 3] == 1).repeat(2)
             np.testing.assert_allclose(g16[hi], w16[hi], rtol=2e-3, atol=0)
+        elif f16s == 2:
+            # leading pieces (8 significant bits of a value that differs by one f32 ulp): equal or one bf16 ulp apart
+            gb = (got[scaled].view(np.uint16).astype(np.uint32) << 16).view(np.float32)
+            wb = (want[scaled].view(np.uint16).astype(np.uint32) << 16).view(np.float32)
+            p0 = (words[scaled, 3] == 3).repeat(2)
+            np.testing.assert_allclose(gb[p0], wb[p0], rtol=2 ** -7, atol=0)
         else:
             np.testing.assert_allclose(got[scaled], want[scaled], rtol=2.5e-7, atol=0)
         assert skip > 0
 
 
-@pytest.mark.parametrize('f16s', [0, 1])
+@pytest.mark.parametrize('f16s', [0, 1, 2])
 @pytest.mark.parametrize('d_feature,mode,d_hidden,n_layers,mv', [(256, 'idr', 256, 4, 4), (64, 'idr', 64, 2, 4), (32, 'no_view_dir', 100, 3, 0),
                                                                   (96, 'no_normal', 48, 2, 2)])
 def test_c_colour_pack_equals_python_pack(d_feature, mode, d_hidden, n_layers, mv, f16s):
@@ -134,7 +152,7 @@ def test_c_colour_pack_equals_python_pack(d_feature, mode, d_hidden, n_layers, m
     lib = _C.lib()
     lib.vqn_neus_col_pack_plan.restype = ctypes.c_int64
     ft = (d_feature + 31) // 32
-    plan = packing.ColPackPlan(d_feature, mode, d_hidden, n_layers, 3, mv, True, ft, matrix_mode='f16s' if f16s else 'f32')
+    plan = packing.ColPackPlan(d_feature, mode, d_hidden, n_layers, 3, mv, True, ft, matrix_mode=('f32', 'f16s', 'x3')[f16s])
     rng = np.random.default_rng(d_feature + n_layers)
     W = [torch.tensor(rng.normal(size=(plan.dims[l + 1], plan.dims[l])).astype(np.float32)) for l in range(plan.n_lin)]
     b = [torch.tensor(rng.normal(size=(plan.dims[l + 1],)).astype(np.float32)) for l in range(plan.n_lin)]

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('flag', ['', '--f16s'])
+@pytest.mark.parametrize('flag', ['', '--f16s', '--x3'])
 def test_render_through_the_c_abi_alone(flag):
     """tests/cabi_render.py in a child process: ctypes + torch-as-allocator only, no module of the package imported."""
     cmd = [sys.executable, os.path.join(ROOT, 'tests', 'cabi_render.py')] + ([flag] if flag else [])
@@ -32,7 +32,7 @@ def test_reflectance_call_through_the_c_abi_alone():
     print(r.stdout.strip())
 
 
-@pytest.mark.parametrize('mode', ['f32', 'f16s'])
+@pytest.mark.parametrize('mode', ['f32', 'f16s', 'x3'])
 @pytest.mark.parametrize('name', ['full', 'small'])
 def test_c_packs_equal_python_packs_on_the_device(name, mode):
     from tests.test_gpu_neus_render import _build
@@ -55,7 +55,7 @@ def test_c_packs_equal_python_packs_on_the_device(name, mode):
     skip = [l for l in sdf.skip_in if 0 < l < len(dims) - 1]
     rc = lib.vqn_neus_pack_create((ctypes.c_int32 * len(dims))(*dims), len(dims) - 1, skip[0] if skip else -1, sdf.multires,
                                   ctypes.c_float(sdf.scale), 0, col.dims[1], col.num_layers - 2, col.multires_view, int(col.squeeze_out),
-                                  int(mode == 'f16s'), ctypes.byref(pack))
+                                  {'f32': 0, 'f16s': 1, 'x3': 2}[mode], ctypes.byref(pack))
     assert rc == 0, lib.vqn_last_error()
     try:
         ns = len(s_lins)

@@ -416,13 +416,21 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
   const int emb_tiles = (sd.emb_feats + 31) >> 5;
   const long n_tiles = (P + 31) >> 5, n_pairs = (n_tiles + 1) >> 1;
   const size_t per_img = (size_t)(n_lin - 1) * 4 * MT * 64;
+#ifdef VQN_DIAG_STASH_ROT     // timing only (make diag FLAG=VQN_DIAG_STASH_ROT=4): every workgroup walks ROT stash regions in turn, so ROT x 128 MB of
+                              // stash are in flight instead of 128 MB -- is the stash fast because it sits in the 256 MiB Infinity Cache?
+  f32x4* save0 = nullptr;
+#else
   f32x4* save0 = FINE ? scratch + (size_t)blockIdx.x * 2 * per_img : nullptr;
+#endif
   const int feat_slot = (n_lin - 2) * 4 * MT;
   f32x4 pre[4];
   f32x4 nopre[4];
 
   FS_DECL
   for (long pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+#ifdef VQN_DIAG_STASH_ROT
+    if (FINE) save0 = scratch + ((size_t)((pair / gridDim.x) % VQN_DIAG_STASH_ROT) * gridDim.x + blockIdx.x) * 2 * per_img;
+#endif
     FS(12)
     // ---------------- points of both tiles ----------------
     if (tid < 64) {
@@ -727,7 +735,11 @@ extern "C" int64_t vqn_neus_fine_scratch_bytes(const int32_t* sdf_desc) {
   const int emb_rows = sd.emb_rows;
   if (emb_rows >= 1 && emb_rows <= 12) sd.emb_rows = 1;
   if (check_sdf_desc(sd) != 0) return -2;
+#ifdef VQN_DIAG_STASH_ROT
+  return (int64_t)VQN_DIAG_STASH_ROT * vqn_num_cus() * 2 * (int64_t)(sd.n_lin - 1) * 4 * sd.max_tiles * 1024;
+#else
   return (int64_t)vqn_num_cus() * 2 * (int64_t)(sd.n_lin - 1) * 4 * sd.max_tiles * 1024;
+#endif
 }
 
 extern "C" int vqn_neus_fine_points(const int32_t* sdf_desc, const float* wbuf_sdf, const int32_t* col_desc,
@@ -761,7 +773,11 @@ extern "C" int vqn_neus_fine_points(const int32_t* sdf_desc, const float* wbuf_s
     VQN_HIP(hipFuncSetAttribute((const void*)neus_points2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     long grid = (long)vqn_num_cus();
     if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;
+#ifdef VQN_DIAG_STASH_ROT
+    VQN_CHECK_ARG((int64_t)VQN_DIAG_STASH_ROT * grid * 2 * per_wg <= scratch_bytes, "diag build: scratch must hold ROT regions per workgroup");
+#else
     if ((int64_t)grid * 2 * per_wg > scratch_bytes) grid = (long)(scratch_bytes / (2 * per_wg));
+#endif
     VQN_CHECK_ARG(grid >= 1, "scratch too small (see vqn_neus_fine_scratch_bytes)");
     hipLaunchKernelGGL(neus_points2_kernel<true>, dim3((unsigned)grid), dim3(512), lds2, (hipStream_t)stream, sd, cd,
                        reinterpret_cast<const f32x4*>(wbuf_sdf), reinterpret_cast<const f32x4*>(wbuf_col), rays_o, rays_d,

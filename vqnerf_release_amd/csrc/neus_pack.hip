@@ -25,7 +25,7 @@
 using namespace vqn_pack;
 
 struct vqn_neus_pack {
-  bool f16s;
+  int f16s;                  // engine mode: 0 f32, 1 f16 pair, 2 bf16x3
   SdfShape sdf;
   ColShape col;
   bool has_col;
@@ -44,8 +44,9 @@ int vqn_neus_pack_create(const int32_t* sdf_dims, int sdf_n_lin, int sdf_skip, i
                          int col_n_layers, int multires_view, int squeeze_out, int f16s, vqn_neus_pack** out) {
   VQN_CHECK_ARG(out != nullptr, "out == NULL");
   *out = nullptr;
+  VQN_CHECK_ARG(f16s >= 0 && f16s <= 2, "engine mode: 0 f32, 1 f16 pair (*_f16s entry points), 2 bf16x3 (*_x3 entry points)");
   vqn_neus_pack* p = new vqn_neus_pack();
-  p->f16s = f16s != 0;
+  p->f16s = f16s;
   p->has_col = col_n_layers > 0;
   int max_tiles = 1;
   std::vector<Word> ws, wc;

@@ -24,7 +24,9 @@ namespace vqn_pack {
 
 
 // one f32 word of the pack: kind 0 = copy src[i0] (src < 0: zero); kind 1 / 2 = the f16 hi / lo halves of the split-precision
-// engine for the element pair (i0, i1): hi = f16(w), lo = f16((w - hi) * 2^11), packed low half first
+// engine for the element pair (i0, i1): hi = f16(w), lo = f16((w - hi) * 2^11), packed low half first; kind 3 / 4 / 5 = the
+// bf16 pieces p0 / p1 / p2 of the exact-split engine for the pair (truncation: w = p0 + p1 + p2 exactly), low half first
+// Engine modes of the planners (the `f16s` argument of the C ABI, kept under that name): 0 = f32, 1 = f16 pair, 2 = bf16x3.
 struct Word {
   int32_t src;      // -1: zero;  2 l: W_l;  2 l + 1: bias_l;  bit 30: the matrix is divided by sqrt(2) (the skip layer, fields.py:82)
   int32_t i0, i1;
@@ -38,6 +40,9 @@ inline int phi(int i) { return 2 * (i & 3) + 8 * (i >> 3) + ((i >> 2) & 1); }
 inline int tiles_of(int n) { return (n + 31) / 32; }
 inline int emb_rows_f32(int n) { return (((n + 1) / 2) + 3) / 4; }
 inline int emb_rows_f16s(int n) { return 2 * ((n + 15) / 16); }
+inline int emb_rows_x3(int n) { return 3 * ((n + 15) / 16); }
+inline int emb_rows_mode(int n, int mode) { return mode == 0 ? emb_rows_f32(n) : (mode == 1 ? emb_rows_f16s(n) : emb_rows_x3(n)); }
+inline int rows_per_tile(int mode) { return mode == 2 ? 6 : 4; }
 
 // element (row, col) of the gathered matrix M -> flat index into the source array (or -1)
 struct View {
@@ -93,6 +98,31 @@ inline void gemm_words_f16s(std::vector<Word>& out, const View& M, const std::ve
           }
 }
 
+// geo/packing.py: gemm_index_x3 + split_pack_x3 -- [n_out_tiles][steps, padded to whole 2-step blocks][p0 | p1 | p2][64 lanes][8 bf16]
+inline void gemm_words_x3(std::vector<Word>& out, const View& M, const std::vector<Seg>& segs) {
+  const int nt = tiles_of(M.rows);
+  std::vector<std::pair<const Seg*, int>> steps;
+  for (const Seg& s : segs)
+    for (int sl = 0; sl < s.rows / 3; ++sl) steps.push_back({&s, sl});
+  while (steps.size() % 2) steps.push_back({nullptr, 0});
+  for (int ot = 0; ot < nt; ++ot)
+    for (auto& st : steps)
+      for (int piece = 0; piece < 3; ++piece)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int jw = 0; jw < 4; ++jw) {
+            int32_t idx[2];
+            for (int e = 0; e < 2; ++e) {
+              const int jj = 2 * jw + e;
+              idx[e] = -1;
+              if (st.first) {
+                const int f = 16 * st.second + 8 * (jj >> 2) + 4 * (lane >> 5) + (jj & 3);
+                idx[e] = M.at(32 * ot + (lane & 31), seg_col(*st.first, f));
+              }
+            }
+            out.push_back({(idx[0] < 0 && idx[1] < 0) ? -1 : M.src, idx[0], idx[1], 3 + piece});
+          }
+}
+
 // geo/packing.py: bias_index / bias_index_f16s -- [n_tiles][2][16]
 inline void bias_words(std::vector<Word>& out, int32_t src, int n_out, int first, bool f16s) {
   for (int ot = 0; ot < tiles_of(n_out); ++ot)
@@ -104,9 +134,9 @@ inline void bias_words(std::vector<Word>& out, int32_t src, int n_out, int first
 }
 
 // geo/packing.py: rowdot_index / rowdot_index_f16s -- f32 images of whole rows in activation-image order
-inline void rowdot_words(std::vector<Word>& out, const View& M, int n_rows, bool f16s) {
+inline void rowdot_words(std::vector<Word>& out, const View& M, int n_rows, int mode) {
   for (int o = 0; o < M.rows; ++o) {
-    if (!f16s) {
+    if (mode == 0) {
       for (int r = 0; r < n_rows; ++r)
         for (int h = 0; h < 2; ++h)
           for (int j = 0; j < 4; ++j) {
@@ -114,7 +144,7 @@ inline void rowdot_words(std::vector<Word>& out, const View& M, int n_rows, bool
             out.push_back({i < 0 ? -1 : M.src, i, 0, 0});
           }
     } else {
-      for (int sl = 0; sl < n_rows / 2; ++sl)
+      for (int sl = 0; sl < n_rows / (mode == 2 ? 3 : 2); ++sl)
         for (int h = 0; h < 2; ++h)
           for (int jj = 0; jj < 8; ++jj) {
             const int32_t i = M.at(o, 16 * sl + 8 * (jj >> 2) + 4 * h + (jj & 3));
@@ -131,13 +161,14 @@ struct SdfShape {
 };
 
 // geo/packing.py: SdfPackPlan.__init__ -- dims = [d0, hidden..., d_out] as in fields.py:24
-inline int sdf_shape(SdfShape& s, const int32_t* dims, int n_lin, int skip, int multires, float scale, int max_tiles, bool f16s) {
+inline int sdf_shape(SdfShape& s, const int32_t* dims, int n_lin, int skip, int multires, float scale, int max_tiles, int mode) {
+  VQN_PLAN_CHECK(mode >= 0 && mode <= 2, -1, "engine mode: 0 f32, 1 f16 pair, 2 bf16x3");
   VQN_PLAN_CHECK(dims != nullptr, -1, "dims == NULL");
   VQN_PLAN_CHECK(n_lin >= 2 && n_lin <= VQN_MAX_SDF_LAYERS, -2, "2 <= n_lin <= 12");
   VQN_PLAN_CHECK(skip == -1 || (skip > 0 && skip < n_lin - 1), -2, "skip layer must be an interior layer (or -1)");
   VQN_PLAN_CHECK(dims[0] == 3 + 6 * multires && dims[0] <= 64 && multires > 0, -2, "dims[0] must be 3 + 6 multires <= 64");
   s.n_lin = n_lin; s.skip = skip; s.multires = multires; s.E = dims[0]; s.scale = scale;
-  s.emb_rows = f16s ? emb_rows_f16s(s.E) : emb_rows_f32(s.E);
+  s.emb_rows = emb_rows_mode(s.E, mode);
   int mt = max_tiles > 0 ? max_tiles : 1;
   for (int l = 0; l < n_lin; ++l) {
     s.in_dims[l] = dims[l];
@@ -153,8 +184,12 @@ inline int sdf_shape(SdfShape& s, const int32_t* dims, int n_lin, int skip, int 
 }
 
 // geo/packing.py: SdfPackPlan._build + pack
-inline void sdf_plan(const SdfShape& s, bool with_reverse, bool f16s, std::vector<Word>& words, int32_t* desc) {
-  auto gemm = [&](const View& M, const std::vector<Seg>& segs) { f16s ? gemm_words_f16s(words, M, segs) : gemm_words(words, M, segs); };
+inline void sdf_plan(const SdfShape& s, bool with_reverse, int mode, std::vector<Word>& words, int32_t* desc) {
+  const bool f16s = mode != 0;               // (accumulator-order bias images: shared by the two 16-bit engines)
+  const int rpt = rows_per_tile(mode);
+  auto gemm = [&](const View& M, const std::vector<Seg>& segs) {
+    mode == 0 ? gemm_words(words, M, segs) : (mode == 1 ? gemm_words_f16s(words, M, segs) : gemm_words_x3(words, M, segs));
+  };
   memset(desc, 0, sizeof(int32_t) * (12 + 8 * VQN_MAX_SDF_LAYERS));
   int32_t lay[VQN_MAX_SDF_LAYERS][8];
   for (int l = 0; l < s.n_lin; ++l) {
@@ -164,7 +199,7 @@ inline void sdf_plan(const SdfShape& s, bool with_reverse, bool f16s, std::vecto
   int32_t last_w_off = -1;
   for (int l = 0; l < s.n_lin; ++l) {
     const int in = s.in_dims[l], out = s.out_dims[l];
-    const int rows_prev = l > 0 ? 4 * s.tiles[l - 1] : 0;
+    const int rows_prev = l > 0 ? rpt * s.tiles[l - 1] : 0;
     const int prev = l > 0 ? s.out_dims[l - 1] : 0;
     const int32_t srcW = 2 * l | (l == s.skip ? SKIP_SCALE : 0);
     std::vector<Seg> segs;
@@ -184,10 +219,10 @@ inline void sdf_plan(const SdfShape& s, bool with_reverse, bool f16s, std::vecto
         bias_words(words, 2 * l + 1, s.feat_out, 1, f16s);
       }
       last_w_off = (int32_t)(words.size() / 4);
-      rowdot_words(words, {srcW, 1, in, in, 0, 0, false}, rows_prev, f16s);
+      rowdot_words(words, {srcW, 1, in, in, 0, 0, false}, rows_prev, mode);
     }
     if (with_reverse && l < s.n_lin - 1) {
-      const std::vector<Seg> ksegs = {{4 * s.tiles[l], out, 0}};
+      const std::vector<Seg> ksegs = {{rpt * s.tiles[l], out, 0}};
       if (l >= 1) {                                            // rows = features of the previous activation
         lay[l][5] = (int32_t)(words.size() / 4);
         gemm({srcW, prev, out, in, 0, 0, true}, ksegs);
@@ -213,12 +248,13 @@ struct ColShape { int n_lin, n_view, has_normal, extra, extra_rows, d_feature, s
 
 // geo/packing.py: ColPackPlan -- input order [pts, view_embed, normals, feat] (fields.py:147-172); mode: 0 idr, 1 no_view_dir, 2 no_normal
 inline int col_shape(ColShape& c, int d_feature, int mode, int d_hidden, int n_layers, int d_out, int multires_view, int squeeze_out, int feat_tiles,
-              bool f16s) {
+              int engine) {
+  VQN_PLAN_CHECK(engine >= 0 && engine <= 2, -1, "engine mode: 0 f32, 1 f16 pair, 2 bf16x3");
   VQN_PLAN_CHECK(mode >= 0 && mode <= 2, -2, "mode: 0 idr, 1 no_view_dir, 2 no_normal");
   c.n_view = (mode == 0 || mode == 2) ? 3 + 6 * multires_view : 0;
   c.has_normal = (mode == 0 || mode == 1) ? 1 : 0;
   c.extra = 3 + c.n_view + 3 * c.has_normal;
-  c.extra_rows = f16s ? emb_rows_f16s(c.extra) : emb_rows_f32(c.extra);
+  c.extra_rows = emb_rows_mode(c.extra, engine);
   c.d_feature = d_feature; c.squeeze = squeeze_out ? 1 : 0; c.feat_tiles = feat_tiles;
   c.n_lin = n_layers + 1;
   VQN_PLAN_CHECK(c.n_lin >= 2 && c.n_lin <= VQN_MAX_COL_LAYERS && d_out == 3, -2, "2 <= colour layers <= 8, d_out == 3");
@@ -230,7 +266,9 @@ inline int col_shape(ColShape& c, int d_feature, int mode, int d_hidden, int n_l
   return 0;
 }
 
-inline void col_plan(const ColShape& c, bool f16s, std::vector<Word>& words, int32_t* desc) {
+inline void col_plan(const ColShape& c, int engine, std::vector<Word>& words, int32_t* desc) {
+  const bool f16s = engine != 0;
+  const int rpt = rows_per_tile(engine);
   memset(desc, 0, sizeof(int32_t) * (16 + 8 * VQN_MAX_COL_LAYERS));
   int32_t lay[VQN_MAX_COL_LAYERS][8];
   for (int l = 0; l < c.n_lin; ++l) {
@@ -239,17 +277,17 @@ inline void col_plan(const ColShape& c, bool f16s, std::vector<Word>& words, int
   }
   for (int l = 0; l < c.n_lin - 1; ++l) {
     std::vector<Seg> segs;
-    if (l == 0) segs = {{4 * c.feat_tiles, c.d_feature, c.extra}, {c.extra_rows, c.extra, 0}};
-    else segs = {{4 * c.tiles[l - 1], c.dims[l], 0}};
+    if (l == 0) segs = {{rpt * c.feat_tiles, c.d_feature, c.extra}, {c.extra_rows, c.extra, 0}};
+    else segs = {{rpt * c.tiles[l - 1], c.dims[l], 0}};
     const View M{2 * l, c.dims[l + 1], c.dims[l], c.dims[l], 0, 0, false};
     lay[l][3] = (int32_t)(words.size() / 4);
-    f16s ? gemm_words_f16s(words, M, segs) : gemm_words(words, M, segs);
+    engine == 0 ? gemm_words(words, M, segs) : (engine == 1 ? gemm_words_f16s(words, M, segs) : gemm_words_x3(words, M, segs));
     lay[l][4] = (int32_t)(words.size() / 4);
     bias_words(words, 2 * l + 1, c.dims[l + 1], 0, f16s);
   }
   const int L = c.n_lin - 1;
   const int32_t last_w_off = (int32_t)(words.size() / 4);
-  rowdot_words(words, {2 * L, c.dims[L + 1], c.dims[L], c.dims[L], 0, 0, false}, 4 * c.tiles[L - 1], f16s);
+  rowdot_words(words, {2 * L, c.dims[L + 1], c.dims[L], c.dims[L], 0, 0, false}, rpt * c.tiles[L - 1], engine);
   const int32_t last_b_off = (int32_t)(words.size() / 4);
   for (int i = 0; i < 3; ++i) words.push_back({2 * L + 1, i, 0, 0});
   words.push_back({-1, 0, 0, 0});

@@ -26,6 +26,20 @@ __global__ void pack_gather_kernel(const Word* __restrict__ words, int64_t n, Pt
     return div ? v * (1.0f / 1.41421356237309504880f) : v;
   };
   if (w.kind == 0) { out[i] = get(w.i0); return; }
+  if (w.kind >= 3) {                                        // exact bf16x3 split by truncation (geo/packing.py: split3_exact)
+    uint32_t b3 = 0;
+    for (int e = 0; e < 2; ++e) {
+      float r = get(e ? w.i1 : w.i0);
+      uint32_t piece = 0;
+      for (int k = 0; k <= w.kind - 3; ++k) {
+        piece = __float_as_uint(r) & 0xffff0000u;
+        r = r - __uint_as_float(piece);
+      }
+      b3 |= (piece >> 16) << (16 * e);
+    }
+    out[i] = __uint_as_float(b3);
+    return;
+  }
   uint32_t bits = 0;
   for (int e = 0; e < 2; ++e) {
     const float v = get(e ? w.i1 : w.i0);
