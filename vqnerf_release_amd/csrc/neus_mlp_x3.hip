@@ -17,6 +17,10 @@
 
 using namespace eng;
 
+// the reverse sweep's stashed act' rows are requested right after a tile's drain so that they land under the K loop; fetching them in
+// the epilogue instead frees 32 registers on paper, but the fine kernel then spills MORE (50 vs 39 registers: -Rpass-analysis)
+#define VQN_X3_HV_EARLY 1
+
 namespace {
 
 constexpr int E0 = 0;         // LDS rows [0, 12): embedding / colour-net extras / d sdf / d embedding (up to 4 steps = 64 features)
@@ -263,8 +267,9 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
             for (int i = 0; i < 16; ++i) v[i] = acc[i];
             store_tile_x3(lds + (size_t)im * IS, E0 + ot * 6, lane, v);
           });
-      f32x4 hv[2][4];                                // stashed act' of this tile: requested right after the drain, lands under the K loop
       const int tiles = sd.layers[l - 1].n_out_tiles;
+#ifdef VQN_X3_HV_EARLY       // stashed act' of the tile requested right after the drain (lands under the K loop) at the price of 32 registers
+      f32x4 hv[2][4];
       G(wsdf + L.wT_off, ks, tiles,
         [&](int ot, int im, f32x16& acc) {
           const f32x4* sv = save0 + (size_t)im * per_img + (size_t)(l - 1) * 4 * MT * 64;
@@ -278,6 +283,20 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
           for (int i = 0; i < 16; ++i) v[i] = acc[i] * hv[im][i >> 2][i & 3];
           split_tile_x3(v, o[im]);
         });
+#else                        // ... or in the epilogue itself: the kernel sits at the 256-register limit, and the other wave of the SIMD covers the wait
+      G(wsdf + L.wT_off, ks, tiles,
+        [&](int, int, f32x16& acc) { init_zero(acc); },
+        [&](int ot, int im, const f32x16& acc) {
+          const f32x4* sv = save0 + (size_t)im * per_img + (size_t)(l - 1) * 4 * MT * 64;
+          f32x4 hv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) hv[q] = ld_stream(sv + (ot * 4 + q) * 64 + lane);
+          float v[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] = acc[i] * hv[i >> 2][i & 3];
+          split_tile_x3(v, o[im]);
+        });
+#endif
       commit(tiles, X0);
     }
     {
