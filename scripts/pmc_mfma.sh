@@ -9,19 +9,19 @@ export TMPDIR=/tmp PROBE_B=20480
 i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INST_CYCLES_VMEM_RD"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -o c -- python3 scripts/probe_neus_f16s.py f32 f16s > $OUT/p$i.log 2>&1 || { tail -5 $OUT/p$i.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -o c -- python3 scripts/probe_neus_f16s.py f32 f16s x3 > $OUT/p$i.log 2>&1 || { tail -5 $OUT/p$i.log; exit 1; }
 done
 python3 - <<PY
 import csv, glob, json, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"neus_points\\w*<\\w+>", r["Kernel_Name"])
+        m = re.search(r"neus_points\\w*<[\\w, ]+>", r["Kernel_Name"])
         if not m:
             continue
         name = m.group(0)
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {"source": "rocprofv3 --kernel-trace --pmc <set> (4 separate passes) -- python3 scripts/probe_neus_f16s.py f32 f16s, PROBE_B=20480 rays "
+out = {"source": "rocprofv3 --kernel-trace --pmc <set> (4 separate passes) -- python3 scripts/probe_neus_f16s.py f32 f16s x3, PROBE_B=20480 rays "
                  "(SDF-only kernels at 64 samples/ray, fine kernels at 128), MI355X", "kernels": {}}
 for name, cs in sorted(agg.items()):
     m = {c: sum(v) / len(v) for c, v in cs.items()}
