@@ -708,6 +708,50 @@ def decomp_cpu_leg(dev, cores, N=16384):
             'near_tie_fraction': 1.0 - float(clear.float().mean())}
 
 
+def live_traffic(rays, timeout_s=170):
+    """Fabric-side bytes of ONE fine-kernel launch of the headline step, measured now: two child runs of this script (one 640,000-ray
+    render each, no extras) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` -- separate passes, kernel trace
+    only, the program itself after `--` -- exactly scripts/pmc_traffic.sh.  Called BEFORE this process touches the GPU (the children
+    are ordinary child processes).  Corrections of MI355X_MICROARCH.md (HBM section): counter values are KB; FETCH_SIZE reports half
+    the bytes of 16-B-per-lane coalesced reads on gfx950 (x2), WRITE_SIZE is exact; both count fabric requests, Infinity-Cache hits
+    included.  Returns (bytes per launch, note) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which('rocprofv3') is None:
+        return None, 'rocprofv3 not on PATH'
+    vals = {}
+    for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='vqn_pmc_', dir='/tmp')
+        cmd = ['rocprofv3', '--kernel-trace', '--pmc', c, '--output-format', 'csv', '-d', d, '-o', 'c', '--', sys.executable,
+               os.path.abspath(__file__), '--no-cpu-baseline', '--no-extras', '--no-traffic', '--steps', '1', '--warmup', '0', '--rays', str(rays)]
+        try:
+            subprocess.run(cmd, timeout=timeout_s, env={**os.environ, 'TMPDIR': '/tmp'}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           check=True, cwd='/tmp')
+            got = []
+            for fn in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                with open(fn) as fh:
+                    for r in csv.DictReader(fh):
+                        if 'neus_points2_kernel<true>' in r['Kernel_Name'].replace(' ', '') and r['Counter_Name'] == c:
+                            got.append(float(r['Counter_Value']))
+            if not got:
+                return None, f'no {c} rows for the fine kernel in the rocprofv3 output'
+            vals[c] = sum(got) / len(got)
+        except Exception as e:                                  # noqa: BLE001
+            return None, f'rocprofv3 --pmc {c} pass failed: {repr(e)[:160]}'
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0, (
+        'measured by THIS run: two child passes of this command under rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE '
+        f'(mean over the fine-kernel launches of one {rays}-ray render each): 2*FETCH_SIZE + WRITE_SIZE (KB, gfx950 corrections of '
+        'MI355X_MICROARCH.md); counts fabric requests incl. Infinity-Cache hits: the per-workgroup activation stash of the reverse sweep '
+        '(8 x 32 KB per tile, written once and read once with streaming accesses) is ~all of it; algorithmic bytes are 32 B in + 28 B out '
+        'per sample.  A 4x / 8x larger stash footprint (beyond the 256 MiB Infinity Cache) leaves the kernel time unchanged '
+        '(DESIGN.md, round 3): the stream is not what bounds the kernel')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -720,12 +764,17 @@ def main():
     ap.add_argument('--cpu-reps', type=int, default=3, help='timed CPU calls after one warm-up call (median is reported)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary workloads (train steps, decomp, VQ)')
+    ap.add_argument('--no-traffic', action='store_true', help='do not measure roofline.traffic with child rocprofv3 --pmc passes')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    # HBM-side traffic of the dominant kernel, measured live by child profiler passes -- before this process initialises the GPU
+    measured_traffic = (None, 'not measured (--no-traffic, --mode train or a multi-rank run)')
+    if world == 1 and not args.no_traffic and args.mode == 'render' and os.environ.get('VQN_BENCH_NO_TRAFFIC', '0') in ('', '0'):
+        measured_traffic = live_traffic(args.rays)
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback)'
     local_rank %= torch.cuda.device_count()        # (rehearsals put several ranks on one card; the driver gives one GPU per rank)
     torch.cuda.set_device(local_rank)
@@ -798,13 +847,13 @@ def main():
     # fabric-side bytes per launch of the dominant kernel: NOT measured by this run (PMC counters need rocprofv3 around the
     # process) -- the builder's committed passes of this same command (scripts/pmc_traffic.sh: separate `rocprofv3 --pmc
     # FETCH_SIZE` / `--pmc WRITE_SIZE` runs), per ray, scaled to this launch; null if the file is absent
-    traffic, traffic_note = None, None
-    for name in ('r02_pmc_render.json', 'r01_pmc_render.json'):
+    traffic, traffic_note = measured_traffic
+    for name in (() if traffic is not None else ('r02_pmc_render.json', 'r01_pmc_render.json')):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 pmc = json.load(f)
             traffic = pmc['dominant_kernel_traffic_bytes_per_launch'] * args.rays / pmc['rays_per_launch']
-            traffic_note = (f'from profiles/{name} (builder-run rocprofv3 PMC passes of this command, not re-measured here): '
+            traffic_note = (f'live measurement unavailable ({measured_traffic[1]}); from profiles/{name} (builder-run rocprofv3 PMC passes of this command): '
                             '2*FETCH_SIZE + WRITE_SIZE per launch; counts fabric requests incl. Infinity-Cache hits: the '
                             'per-workgroup activation stash of the reverse sweep (8 x 32 KB per tile, 134 MB in flight, '
                             'Infinity-Cache resident) is written once and read once per tile with streaming (nt) accesses; '
