@@ -356,9 +356,10 @@ extern "C" int vqn_wgrad_partials_x3(const float* A, int a_tiles, int a_t0, int 
   VQN_CHECK_SHAPE(a_nt >= 1 && a_nt <= 8 && b_nt >= 1 && b_nt <= 8, "1..8 feature tiles per operand and call");
   VQN_CHECK_SHAPE(a_t0 >= 0 && a_t0 + a_nt <= a_tiles && b_t0 >= 0 && b_t0 + b_nt <= b_tiles, "feature-tile range outside the tensor");
   VQN_CHECK_SHAPE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "operands must be 16-byte aligned");
-  // small blocks (<= 128 output features) at the reference batch are latency-, not matrix-bound: the f32 kernels with their deeper
-  // rings.  VQN_WGRAD_X3_SMALL_TILES=<n>: from n point tiles on they take the x3 kernel too (A/B knob for large batches).
-  static const long small_from = [] { const char* e = getenv("VQN_WGRAD_X3_SMALL_TILES"); return e ? atol(e) : (1L << 62); }();
+  // small blocks (<= 128 output features) at the reference batch (64 point tiles) are latency-, not matrix-bound: the f32 kernels with
+  // their deeper rings -- no difference measured there (6.50 vs 6.52 ms per 2048-point step).  From 1024 point tiles on they take the
+  // x3 kernel too: 262,144-point reflectance step 22.9 -> 22.0 ms (A / B / A on one box).  VQN_WGRAD_X3_SMALL_TILES=<n> moves the switch.
+  static const long small_from = [] { const char* e = getenv("VQN_WGRAD_X3_SMALL_TILES"); return (e && e[0]) ? atol(e) : 1024L; }();
   if (a_nt <= 4 && n_point_tiles < small_from)
     return vqn_wgrad_partials_f32_internal(A, a_tiles, a_t0, a_nt, B, b_tiles, b_t0, b_nt, n_point_tiles, n_split, ws, rowsum_ws, stream);
   long grid = n_split;
