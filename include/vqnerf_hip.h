@@ -61,6 +61,25 @@ int64_t vqn_vq_ema_stats_ws_bytes(int64_t N, int D, int K);
 int vqn_vq_ste_loss(const float* x, const float* quant, int64_t numel, float scale, float* ste, float* loss, float* ws,
                     void* stream);
 
+/* Per-example loss terms of the VQ reflectance stage in TRAIN mode and their gradients, one launch each (round 3).  Replaces the
+ * framework-op chains of vq_nfr.Model.compute_loss (decomp/nerfvq_nfr3/nerfactor/models/vq_nfr.py:876-986, train branch) and their
+ * autograd for the terms that are per surface point; N points, rows 2j / 2j+1 are a pixel pair (train_nfr.py:447-448):
+ *   terms[i] = { w_rgb mean_c (lin_gt - rgb_pred)^2,  mean_c (lin_gt - vq_rgb)^2,  w_chr mean_c (chr(lin_gt) - chr(vq_rgb))^2,
+ *                w_smooth exp(-chr_alpha e_j) (1 - <z_2j, z_2j+1>),  w_lambert max_c spec r' }
+ * with lin_gt = srgb2linear(rgb_gt) if nerf != 0 else rgb_gt (util/img.py:166-186), chr(v) = v / |v| (0 at |v| = 0, :869-874),
+ * e_j = |chr(rgb_gt_2j) - chr(rgb_gt_2j+1)| where that exceeds chr_thres else 0 (:927-953), r' = 0 for rough < 0.5 else 2 rough - 1
+ * (:970-981).  z [N,D] / spec [N,3] / rough [N,1] may be NULL (their terms are 0).  The scalar terms of the loss (commitment loss,
+ * code-separation term) stay with the caller.  _bwd: g_terms [N,5] = upstream gradient of every term -> d/d rgb_pred, d/d vq_rgb
+ * [N,3], d/d z [N,D] (g_z may be NULL), d/d spec [N,3] (may be NULL); gradients are 0 (as TensorFlow's divide_no_nan / SqrtGrad
+ * give) where |vq_rgb| = 0. */
+int vqn_decomp_loss_fwd(const float* rgb_pred, const float* vq_rgb, const float* rgb_gt, const float* z, const float* spec,
+                        const float* rough, int64_t N, int D, int nerf, float w_rgb, float w_chr, float w_smooth, float chr_alpha,
+                        float chr_thres, float w_lambert, float* terms, void* stream);
+int vqn_decomp_loss_bwd(const float* rgb_pred, const float* vq_rgb, const float* rgb_gt, const float* z, const float* spec,
+                        const float* rough, int64_t N, int D, int nerf, float w_rgb, float w_chr, float w_smooth, float chr_alpha,
+                        float chr_thres, float w_lambert, const float* g_terms, float* g_rgb_pred, float* g_vq_rgb, float* g_z,
+                        float* g_spec, void* stream);
+
 /* Replaces `mathutil.safe_l2_normalize(z, axis=1)` (util/math.py:63-64 = tf.linalg.l2_normalize: x * rsqrt(max(sum x^2, eps))) as
  * called at vq_nfr.py:575: y [N,D] = x / sqrt(max(sum_d x^2, eps)) row by row, the sum in the defined order of vqn_vq_assign's
  * |x|^2 and a correctly rounded sqrt / division (oracle/vq_strict.c states it in C).  D % 4 == 0. */

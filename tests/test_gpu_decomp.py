@@ -570,3 +570,59 @@ def test_fused_srgb_transfer_matches_the_torch_statement():
     assert torch.isnan(got_b[0]) and torch.isnan(got_b[4]) and torch.equal(torch.isnan(got_b), torch.isnan(want_b))
     ok = ~torch.isnan(want_b)
     np.testing.assert_allclose(got_b[ok].cpu().numpy(), want_b[ok].cpu().numpy(), rtol=0, atol=2e-7)
+
+
+@pytest.mark.parametrize('data_type', ['nerf', 'hw'])
+@pytest.mark.parametrize('N', [2, 258, 4096])
+def test_fused_train_loss_matches_the_torch_statement(data_type, N):
+    """`FusedTrainLoss` (vqn_decomp_loss_fwd / _bwd: the per-point terms of compute_loss's train branch, vq_nfr.py:906-981, two
+    launches) against the torch statement of the same branch (`fuse_train_loss = False`), values and gradients -- incl. rows with
+    vq_rgb = 0 (TensorFlow's divide_no_nan / SqrtGrad give a zero gradient there; the torch statement gives NaN, so those rows are
+    compared with 0), chromaticity differences on both sides of `chr_thres`, rough on both sides of 0.5, ties in max(spec)."""
+    from tests.decomp_util import make_config
+    from tests.gpu_util import launches
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    model = get_model_class('vq_nfr')(make_config(data_type=data_type, num_embed=8))
+    model.build_nets(device='cuda', seed=0).to('cuda')
+    rng = np.random.default_rng(N)
+    model.set_codebook(rng.uniform(0, 1, (8, 256)).astype(np.float32))
+    T = lambda a: torch.tensor(a.astype(np.float32), device='cuda')
+    gt = rng.uniform(0.02, 1, (N, 3))
+    gt[1::2] = np.where(rng.uniform(size=(N // 2, 1)) < 0.5, gt[::2] + rng.normal(0, 0.01, (N // 2, 3)), gt[1::2]).clip(0.02, 1)   # pairs under the threshold
+    vals = dict(rgb=T(rng.uniform(0, 1, (N, 3))), vqrgb=T(rng.uniform(0, 1, (N, 3))), z=T(rng.normal(size=(N, 256)) / 16),
+                spec=T(rng.uniform(0, 0.3, (N, 3))), rough=T(rng.uniform(0, 1, (N, 1))))
+    zero_rows = np.zeros(N, bool)
+    if N > 2:
+        zero_rows[[3, 10]] = True
+        vals['vqrgb'][zero_rows] = 0.0
+        vals['spec'][5] = 0.2                                              # a three-way tie in max(spec)
+    rgb_gt = T(gt)
+    out = {}
+    for fused in (False, True):
+        model.fuse_train_loss = fused
+        leaves = {k: v.clone().requires_grad_(True) for k, v in vals.items()}
+        kw = dict(mode='train', gtc=rgb_gt, rgb=leaves['rgb'], vqrgb=leaves['vqrgb'], vqloss=torch.tensor(0.37, device='cuda'), z=leaves['z'],
+                  spec=leaves['spec'], rough=leaves['rough'], embed=model._codebook)
+        with launches() as rec:
+            loss, ld = model.compute_loss({}, {}, **kw)
+            wts = T(rng.uniform(0.5, 1.5, (N,))) if fused is None else torch.linspace(0.5, 1.5, N, device='cuda')
+            (loss * wts).sum().backward()
+        assert rec.ran('vqn_decomp_loss_fwd') == fused and rec.ran('vqn_decomp_loss_bwd') == fused
+        out[fused] = (loss.detach(), {k: v.detach() for k, v in ld.items()}, {k: v.grad for k, v in leaves.items()})
+    (l0, d0, g0), (l1, d1, g1) = out[False], out[True]
+    assert set(d0) == set(d1) == {'rgb', 'vqrgb', 'vqloss', 'chromaticity', 'chr_smooth', 'sim_smooth', 'lambert', 'loss'}
+    np.testing.assert_allclose(l1.cpu().numpy(), l0.cpu().numpy(), rtol=2e-5, atol=1e-7)
+    for k in d0:
+        np.testing.assert_allclose(d1[k].cpu().numpy(), d0[k].cpu().numpy(), rtol=2e-5, atol=1e-7, err_msg=k)
+    ok = ~torch.tensor(zero_rows).cuda()
+    for k in ('rgb', 'vqrgb', 'z', 'spec'):
+        a, b = g1[k], g0[k]
+        assert torch.isfinite(a).all(), k
+        scale = float(b[ok].abs().max())
+        np.testing.assert_allclose(a[ok].cpu().numpy(), b[ok].cpu().numpy(), rtol=1e-4, atol=1e-6 * max(scale, 1e-3), err_msg=k)
+    assert g1['rough'] is None or float(g1['rough'].abs().max()) == 0.0      # rough is detached in the lambert term (vq_nfr.py:973)
+    if zero_rows.any():
+        # chromaticity has no gradient where |vq_rgb| = 0 (the mse term's is still there)
+        lin = (torch.where(rgb_gt <= 0.04045, rgb_gt / 12.92, ((rgb_gt + 0.055) / 1.055) ** 2.4) if data_type == 'nerf' else rgb_gt)
+        want = (2.0 / 3.0) * (vals['vqrgb'] - lin) * torch.linspace(0.5, 1.5, N, device='cuda')[:, None]
+        np.testing.assert_allclose(g1['vqrgb'][~ok].cpu().numpy(), want[~ok].cpu().numpy(), rtol=1e-5, atol=1e-7)

@@ -177,6 +177,39 @@ def vq_ste_loss(x, quant, want_ste=True):
     _check(rc, 'vqn_vq_ste_loss')
     return ste, loss
 
+def _loss_args(rgb_pred, vq_rgb, rgb_gt, z, spec, rough, nerf, w):
+    for t, n in ((rgb_pred, 'rgb_pred'), (vq_rgb, 'vq_rgb'), (rgb_gt, 'rgb_gt')):
+        _f32c(t, n)
+    for t, n in ((z, 'z'), (spec, 'spec'), (rough, 'rough')):
+        if t is not None:
+            _f32c(t, n)
+    N = rgb_pred.shape[0]
+    D = 0 if z is None else z.shape[1]
+    return (_ptr(rgb_pred), _ptr(vq_rgb), _ptr(rgb_gt), _ptr(z), _ptr(spec), _ptr(rough), ctypes.c_int64(N), ctypes.c_int(D),
+            ctypes.c_int(1 if nerf else 0)) + tuple(ctypes.c_float(float(w[k])) for k in ('rgb', 'chr', 'smooth', 'alpha', 'thres', 'lambert'))
+
+
+def decomp_loss_fwd(rgb_pred, vq_rgb, rgb_gt, z, spec, rough, nerf, w):
+    """-> terms [N,5] (rgb, vqrgb, chromaticity, chr_smooth, lambert); w: dict of the six scalars (see include/vqnerf_hip.h)."""
+    terms = torch.empty((rgb_pred.shape[0], 5), dtype=torch.float32, device=rgb_pred.device)
+    with _clock('vqn_decomp_loss_fwd'):
+        rc = lib().vqn_decomp_loss_fwd(*_loss_args(rgb_pred, vq_rgb, rgb_gt, z, spec, rough, nerf, w), _ptr(terms), _stream())
+    _check(rc, 'vqn_decomp_loss_fwd')
+    return terms
+
+
+def decomp_loss_bwd(rgb_pred, vq_rgb, rgb_gt, z, spec, rough, nerf, w, g_terms):
+    _f32c(g_terms, 'g_terms')
+    g_pred, g_vq = torch.empty_like(rgb_pred), torch.empty_like(vq_rgb)
+    g_z = None if z is None else torch.empty_like(z)
+    g_spec = None if spec is None else torch.empty_like(spec)
+    with _clock('vqn_decomp_loss_bwd'):
+        rc = lib().vqn_decomp_loss_bwd(*_loss_args(rgb_pred, vq_rgb, rgb_gt, z, spec, rough, nerf, w), _ptr(g_terms), _ptr(g_pred), _ptr(g_vq),
+                                       _ptr(g_z), _ptr(g_spec), _stream())
+    _check(rc, 'vqn_decomp_loss_bwd')
+    return g_pred, g_vq, g_z, g_spec
+
+
 def l2_normalize_rows(x, eps=1e-6):
     """x [N,D] -> x / sqrt(max(sum_d x^2, eps)) row by row, in the defined summation order of vqn_vq_assign's |x|^2."""
     _f32c(x, 'x')

@@ -1,0 +1,186 @@
+// Per-example loss terms of the VQ reflectance stage in TRAIN mode, forward and backward, one launch each.
+// Replaces the ~90 framework launches (and ~120 more in their autograd) of vq_nfr.Model.compute_loss
+// (decomp/nerfvq_nfr3/nerfactor/models/vq_nfr.py:876-986, train branch) for the terms that are per surface point:
+//     rgb          = combine_weight * mean_c (linear_gt - rgb_pred)^2                          (:906-908)
+//     vqrgb        = mean_c (linear_gt - vq_rgb)^2                                               (:909-911)
+//     chromaticity = w_chr * mean_c (chr(linear_gt) - chr(vq_rgb))^2,  chr(v) = v / |v| (0 where |v| = 0)   (:917-925, :869-874)
+//     chr_smooth   = w_s * exp(-alpha e) (1 - <z_2j, z_2j+1>) for both rows of pair j,
+//                    e = |chr(gt_2j) - chr(gt_2j+1)| if that exceeds chr_thres else 0  (sRGB targets)   (:927-953)
+//     lambert      = w_l * max_c spec * r',  r' = 0 for rough < 0.5 else 2 rough - 1 (rough detached)      (:970-981)
+// with linear_gt = srgb2linear(rgb_gt) for data_type 'nerf' (:896-901, util/img.py:166-186) else rgb_gt.  The scalar terms (vq
+// commitment loss, code-separation term) stay with the caller.  Gradients follow TensorFlow's conventions where they differ from
+// a naive chain rule: divide_no_nan and SqrtGrad give 0 (not NaN) at |v| = 0.
+// One wave per PAIR of points: lanes 0 / 1 do the per-point scalar arithmetic, all 64 lanes the D-long dot product of the pair.
+#include "common.h"
+
+namespace {
+
+struct LossArgs {
+  const float* rgb_pred; const float* vq_rgb; const float* rgb_gt; const float* z; const float* spec; const float* rough;
+  long N; int D; int nerf;
+  float w_rgb, w_chr, w_smooth, chr_alpha, chr_thres, w_lambert;
+};
+
+__device__ __forceinline__ float srgb2linear(float x) {
+  return x <= 0.04045f ? x / 12.92f : powf((x + 0.055f) / 1.055f, 2.4f);
+}
+
+__device__ __forceinline__ void chroma(const float v[3], float c[3], float& norm) {
+  norm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  const float inv = norm == 0.f ? 0.f : 1.f / norm;
+  c[0] = v[0] * inv; c[1] = v[1] * inv; c[2] = v[2] * inv;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// the pair's smoothness weight w_s * exp(-alpha e) (sRGB targets) and dot product <z_a, z_b>; every lane returns both
+__device__ __forceinline__ void pair_terms(const LossArgs& a, long i0, bool has_b, int lane, float& wexp, float& dot) {
+  wexp = 0.f; dot = 0.f;
+  if (a.w_smooth <= 0.f || a.z == nullptr || !has_b) return;
+  float ga[3], gb[3], ca[3], cb[3], na, nb;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { ga[c] = a.rgb_gt[i0 * 3 + c]; gb[c] = a.rgb_gt[(i0 + 1) * 3 + c]; }
+  chroma(ga, ca, na); chroma(gb, cb, nb);
+  float e = sqrtf((ca[0] - cb[0]) * (ca[0] - cb[0]) + (ca[1] - cb[1]) * (ca[1] - cb[1]) + (ca[2] - cb[2]) * (ca[2] - cb[2]));
+  e = e > a.chr_thres ? e : 0.f;
+  wexp = a.w_smooth * expf(-a.chr_alpha * e);
+  float s = 0.f;
+  for (int d = lane; d < a.D; d += 64) s = fmaf(a.z[i0 * a.D + d], a.z[(i0 + 1) * a.D + d], s);
+  dot = wave_sum(s);
+}
+
+__global__ __launch_bounds__(256) void decomp_loss_fwd_kernel(const LossArgs a, float* __restrict__ terms /* [N,5] */) {
+  const int lane = threadIdx.x & 63;
+  const long n_pairs = (a.N + 1) >> 1;
+  for (long pair = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pair < n_pairs; pair += (long)gridDim.x * 4) {
+    const long i0 = 2 * pair;
+    const bool has_b = i0 + 1 < a.N;
+    float wexp, dot;
+    pair_terms(a, i0, has_b, lane, wexp, dot);
+    if (lane < 2 && i0 + lane < a.N) {
+      const long i = i0 + lane;
+      float gt[3], lin[3], p[3], v[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        gt[c] = a.rgb_gt[i * 3 + c]; p[c] = a.rgb_pred[i * 3 + c]; v[c] = a.vq_rgb[i * 3 + c];
+        lin[c] = a.nerf ? srgb2linear(gt[c]) : gt[c];
+      }
+      float t_rgb = 0.f, t_vq = 0.f, t_chr = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { t_rgb += (lin[c] - p[c]) * (lin[c] - p[c]); t_vq += (lin[c] - v[c]) * (lin[c] - v[c]); }
+      float cl[3], cv[3], nl, nv;
+      chroma(lin, cl, nl); chroma(v, cv, nv);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) t_chr += (cl[c] - cv[c]) * (cl[c] - cv[c]);
+      float t_l = 0.f;
+      if (a.w_lambert > 0.f && a.spec != nullptr) {
+        const float r = a.rough[i], rp = r < 0.5f ? 0.f : 2.f * r - 1.f;
+        t_l = a.w_lambert * fmaxf(a.spec[i * 3], fmaxf(a.spec[i * 3 + 1], a.spec[i * 3 + 2])) * rp;
+      }
+      float* o = terms + i * 5;
+      o[0] = a.w_rgb * t_rgb * (1.f / 3.f);
+      o[1] = t_vq * (1.f / 3.f);
+      o[2] = a.w_chr * t_chr * (1.f / 3.f);
+      o[3] = has_b ? wexp * (1.f - dot) : 0.f;
+      o[4] = t_l;
+    }
+  }
+}
+
+// go [N,5]: upstream gradient of every term.  Writes d/d rgb_pred, d/d vq_rgb [N,3], d/d z [N,D] (if z), d/d spec [N,3] (if spec).
+__global__ __launch_bounds__(256) void decomp_loss_bwd_kernel(const LossArgs a, const float* __restrict__ go, float* __restrict__ g_pred,
+                                                              float* __restrict__ g_vq, float* __restrict__ g_z, float* __restrict__ g_spec) {
+  const int lane = threadIdx.x & 63;
+  const long n_pairs = (a.N + 1) >> 1;
+  for (long pair = (long)blockIdx.x * 4 + (threadIdx.x >> 6); pair < n_pairs; pair += (long)gridDim.x * 4) {
+    const long i0 = 2 * pair;
+    const bool has_b = i0 + 1 < a.N;
+    float wexp, dot;
+    pair_terms(a, i0, has_b, lane, wexp, dot);
+    if (g_z != nullptr) {
+      // d (wexp (1 - <za, zb>)) / d za = -wexp zb, and the term sits in BOTH rows of the pair
+      const float coef = has_b ? -wexp * (go[i0 * 5 + 3] + go[(i0 + 1) * 5 + 3]) : 0.f;
+      for (int d = lane; d < a.D; d += 64) {
+        const float za = a.z[i0 * a.D + d], zb = has_b ? a.z[(i0 + 1) * a.D + d] : 0.f;
+        g_z[i0 * a.D + d] = coef * zb;
+        if (has_b) g_z[(i0 + 1) * a.D + d] = coef * za;
+      }
+    }
+    if (lane < 2 && i0 + lane < a.N) {
+      const long i = i0 + lane;
+      const float* g = go + i * 5;
+      float lin[3], p[3], v[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float gt = a.rgb_gt[i * 3 + c];
+        p[c] = a.rgb_pred[i * 3 + c]; v[c] = a.vq_rgb[i * 3 + c];
+        lin[c] = a.nerf ? srgb2linear(gt) : gt;
+      }
+      float cl[3], cv[3], nl, nv;
+      chroma(lin, cl, nl); chroma(v, cv, nv);
+      // chromaticity: t = w/3 sum (cv - cl)^2, cv = v / |v|: d t / d v = (I - cv cv^T) (2 w / 3)(cv - cl) / |v|   (0 at |v| = 0)
+      float du[3], proj = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { du[c] = a.w_chr * (2.f / 3.f) * (cv[c] - cl[c]); proj += du[c] * cv[c]; }
+      const float inv = nv == 0.f ? 0.f : 1.f / nv;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        g_pred[i * 3 + c] = g[0] * a.w_rgb * (2.f / 3.f) * (p[c] - lin[c]);
+        g_vq[i * 3 + c] = g[1] * (2.f / 3.f) * (v[c] - lin[c]) + g[2] * (du[c] - proj * cv[c]) * inv;
+      }
+      if (g_spec != nullptr) {
+        const float r = a.rough[i], rp = r < 0.5f ? 0.f : 2.f * r - 1.f;
+        const float s0 = a.spec[i * 3], s1 = a.spec[i * 3 + 1], s2 = a.spec[i * 3 + 2];
+        const int am = (s0 >= s1 && s0 >= s2) ? 0 : (s1 >= s2 ? 1 : 2);          // first maximum, as torch.max(dim) reports it
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g_spec[i * 3 + c] = (c == am) ? g[4] * a.w_lambert * rp : 0.f;
+      }
+    }
+  }
+}
+
+int check(const LossArgs& a) {
+  if (a.N < 0 || a.D < 0) return 1;
+  if (a.N > 0 && (!a.rgb_pred || !a.vq_rgb || !a.rgb_gt)) return 2;
+  if (a.w_lambert > 0.f && a.spec != nullptr && a.rough == nullptr) return 3;
+  return 0;
+}
+
+unsigned grid_for(long N) {
+  long blocks = ((N + 1) / 2 + 3) / 4;
+  const long cap = (long)vqn_num_cus() * 16;
+  if (blocks > cap) blocks = cap;
+  return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
+}  // namespace
+
+extern "C" int vqn_decomp_loss_fwd(const float* rgb_pred, const float* vq_rgb, const float* rgb_gt, const float* z, const float* spec,
+                                   const float* rough, int64_t N, int D, int nerf, float w_rgb, float w_chr, float w_smooth,
+                                   float chr_alpha, float chr_thres, float w_lambert, float* terms, void* stream) {
+  const LossArgs a{rgb_pred, vq_rgb, rgb_gt, z, spec, rough, (long)N, D, nerf, w_rgb, w_chr, w_smooth, chr_alpha, chr_thres, w_lambert};
+  VQN_CHECK_ARG(check(a) == 0 && (N == 0 || terms != nullptr), "null pointer or negative size");
+  if (N == 0) return VQN_OK;
+  hipLaunchKernelGGL(decomp_loss_fwd_kernel, dim3(grid_for(N)), dim3(256), 0, (hipStream_t)stream, a, terms);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
+
+extern "C" int vqn_decomp_loss_bwd(const float* rgb_pred, const float* vq_rgb, const float* rgb_gt, const float* z, const float* spec,
+                                   const float* rough, int64_t N, int D, int nerf, float w_rgb, float w_chr, float w_smooth,
+                                   float chr_alpha, float chr_thres, float w_lambert, const float* g_terms, float* g_rgb_pred,
+                                   float* g_vq_rgb, float* g_z, float* g_spec, void* stream) {
+  const LossArgs a{rgb_pred, vq_rgb, rgb_gt, z, spec, rough, (long)N, D, nerf, w_rgb, w_chr, w_smooth, chr_alpha, chr_thres, w_lambert};
+  VQN_CHECK_ARG(check(a) == 0 && (N == 0 || (g_terms && g_rgb_pred && g_vq_rgb)), "null pointer or negative size");
+  VQN_CHECK_ARG(g_z == nullptr || z != nullptr, "g_z without z");
+  VQN_CHECK_ARG(g_spec == nullptr || spec != nullptr, "g_spec without spec");
+  if (N == 0) return VQN_OK;
+  hipLaunchKernelGGL(decomp_loss_bwd_kernel, dim3(grid_for(N)), dim3(256), 0, (hipStream_t)stream, a, g_terms, g_rgb_pred, g_vq_rgb, g_z,
+                     g_spec);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}

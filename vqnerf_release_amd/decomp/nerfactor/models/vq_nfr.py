@@ -21,6 +21,24 @@ from vqnerf_release_amd.decomp.nerfactor.networks.vq_layers import LazyKwargs, L
 from vqnerf_release_amd.decomp.nerfactor.util import img as imgutil, math as mathutil
 
 
+class FusedTrainLoss(torch.autograd.Function):
+    """The per-point terms of `compute_loss` in train mode (vq_nfr.py:906-981) as one launch forward (`vqn_decomp_loss_fwd`) and one
+    backward (`vqn_decomp_loss_bwd`) instead of ~90 + ~120 framework launches.  -> terms [N,5] = rgb, vqrgb, chromaticity,
+    chr_smooth, lambert."""
+
+    @staticmethod
+    def forward(ctx, rgb_pred, vq_rgb, rgb_gt, z_vq, spec, rough, nerf, w):
+        c = lambda t: None if t is None else t.detach().float().contiguous()
+        args = (c(rgb_pred), c(vq_rgb), c(rgb_gt), c(z_vq), c(spec), c(rough))
+        ctx.args, ctx.nerf, ctx.w = args, nerf, w
+        return _C.decomp_loss_fwd(*args, nerf, w)
+
+    @staticmethod
+    def backward(ctx, g_terms):
+        g_pred, g_vq, g_z, g_spec = _C.decomp_loss_bwd(*ctx.args, ctx.nerf, ctx.w, g_terms.float().contiguous())
+        return g_pred, g_vq, None, g_z, g_spec, None, None, None
+
+
 class Model(BrdfModel):
     def __init__(self, config, debug=False):
         self.no_brdf_chunk = config.getboolean('DEFAULT', 'no_brdf_chunk', fallback=True)
@@ -249,7 +267,10 @@ class Model(BrdfModel):
             del loss_kwargs['z']
             loss_kwargs = LazyKwargs(loss_kwargs, {'z': lambda: redo()[1]})
         srgb = (lambda t: imgutil.linear2srgb(t)) if self.data_type == 'nerf' else (lambda t: t)
-        pred = {'rgb': scatter_rows(mask, srgb(rgb_pred), n), 'normal': scatter_rows(mask, normal_pred, n),
+        # (train mode: the displayed colour is for visualisation only -- the loss reads loss_kwargs['rgb'], vq_nfr.py:876-905 -- so it
+        # is taken from the detached render: one fused launch instead of the torch statement + its never-used autograd records)
+        rgb_disp = srgb(rgb_pred.detach() if mode == 'train' else rgb_pred)
+        pred = {'rgb': scatter_rows(mask, rgb_disp, n), 'normal': scatter_rows(mask, normal_pred, n),
                 'albedo': scatter_rows(mask, albedo, n), 'alpha': pred_alpha, 'spec': scatter_rows(mask, spec, n),
                 'rough': scatter_rows(mask, rough, n), 'ks': scatter_rows(mask, ks, n)}
         if mode != 'train':
@@ -356,6 +377,44 @@ class Model(BrdfModel):
         den = torch.sqrt((rgb * rgb).sum(-1, keepdim=True))
         return mathutil.divide_no_nan(rgb, den * torch.ones_like(rgb))
 
+    fuse_train_loss = True     # train mode on the device: the per-point loss terms and their gradients as two launches (FusedTrainLoss)
+
+    def _sim_smooth(self, cfg):
+        """Code-separation term (vq_nfr.py:955-968) -- a scalar over the K x K code distances, torch statement."""
+        cb = self.get_codebook().t()
+        K = cb.shape[0]
+        eye = torch.eye(K, dtype=cb.dtype, device=cb.device)
+        # the diagonal is exactly 0 and masked below; "+ eye" only keeps d sqrt / dx finite there (TF's SqrtGrad
+        # yields 0 for a 0 incoming gradient, torch would give 0 * inf)
+        dist = torch.sqrt(((cb[:, None, :] - cb[None, :, :]) ** 2).sum(-1) + eye) * (1 - eye)
+        masked = dist * (1 - eye) + eye * dist.max()
+        return cfg('sim_loss_weight') * (-torch.log(masked.min()))
+
+    def _compute_loss_train_fused(self, rgb_gt, rgb_pred, vq_rgb, kwargs, cfg):
+        """The train branch of compute_loss (vq_nfr.py:906-986) with the per-point terms on `FusedTrainLoss`; same dict keys, same
+        values (tests/test_gpu_decomp.py: against the torch statement and, through it, the oracle)."""
+        w = {'rgb': cfg('combine_weight'), 'chr': max(cfg('chromaticity_loss_weight'), 0.0), 'smooth': max(cfg('mat_sloss_weight'), 0.0),
+             'alpha': cfg('chr_alpha'), 'thres': cfg('chr_thres'), 'lambert': max(cfg('lambert_weight'), 0.0)}
+        z_vq = kwargs.pop('z') if w['smooth'] > 0 else None
+        spec, rough = (kwargs.pop('spec'), kwargs.pop('rough')) if w['lambert'] > 0 else (None, None)
+        terms = FusedTrainLoss.apply(rgb_pred, vq_rgb, rgb_gt, z_vq, spec, rough, self.data_type == 'nerf', w)
+        ld = {'rgb': terms[:, 0], 'vqrgb': terms[:, 1], 'vqloss': cfg('vq_loss_weight') * kwargs.pop('vqloss')}
+        loss = terms[:, :2].sum(-1) + ld['vqloss']
+        if w['chr'] > 0:
+            ld['chromaticity'] = terms[:, 2]
+            loss = loss + ld['chromaticity']
+        if w['smooth'] > 0:
+            ld['chr_smooth'] = terms[:, 3]
+            loss = loss + ld['chr_smooth']
+        if cfg('sim_loss_weight') > 0:
+            ld['sim_smooth'] = self._sim_smooth(cfg)
+            loss = loss + ld['sim_smooth']
+        if w['lambert'] > 0:
+            ld['lambert'] = terms[:, 4]
+            loss = loss + ld['lambert']
+        ld['loss'] = loss
+        return self._numerics(loss, 'Loss'), ld
+
     def compute_loss(self, pred, gt, **kwargs):
         cfg = lambda k: self.config.getfloat('DEFAULT', k)
         mse = lambda a, b: ((a - b) ** 2).mean(-1)
@@ -372,6 +431,8 @@ class Model(BrdfModel):
             ld['vqrgb'] = mse(rgb_gt, imgutil.linear2srgb(vq_rgb))
             ld['chromaticity'] = mse(self._rgb2chromaticity(linear_gt), self._rgb2chromaticity(vq_rgb))
             return ld['rgb'] + ld['vqrgb'] + ld['chromaticity'], ld
+        if self.fuse_train_loss and self.train_backend == 'hip' and rgb_pred.is_cuda:
+            return self._compute_loss_train_fused(rgb_gt, rgb_pred, vq_rgb, kwargs, cfg)
         ld['rgb'] = cfg('combine_weight') * mse(linear_gt, rgb_pred)
         ld['vqrgb'] = mse(linear_gt, vq_rgb)
         ld['vqloss'] = cfg('vq_loss_weight') * kwargs.pop('vqloss')
