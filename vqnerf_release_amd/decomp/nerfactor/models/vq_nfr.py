@@ -420,6 +420,8 @@ class Model(BrdfModel):
         mse = lambda a, b: ((a - b) ** 2).mean(-1)
         mode = kwargs.pop('mode')
         rgb_gt, rgb_pred = kwargs.pop('gtc'), kwargs.pop('rgb')
+        if mode == 'train' and self.fuse_train_loss and self.train_backend == 'hip' and rgb_pred.is_cuda:
+            return self._compute_loss_train_fused(rgb_gt, rgb_pred, kwargs.pop('vqrgb'), kwargs, cfg)
         if self.data_type == 'nerf':
             linear_gt, srgb_pred = imgutil.srgb2linear(rgb_gt), imgutil.linear2srgb(rgb_pred)
         else:
@@ -431,8 +433,6 @@ class Model(BrdfModel):
             ld['vqrgb'] = mse(rgb_gt, imgutil.linear2srgb(vq_rgb))
             ld['chromaticity'] = mse(self._rgb2chromaticity(linear_gt), self._rgb2chromaticity(vq_rgb))
             return ld['rgb'] + ld['vqrgb'] + ld['chromaticity'], ld
-        if self.fuse_train_loss and self.train_backend == 'hip' and rgb_pred.is_cuda:
-            return self._compute_loss_train_fused(rgb_gt, rgb_pred, vq_rgb, kwargs, cfg)
         ld['rgb'] = cfg('combine_weight') * mse(linear_gt, rgb_pred)
         ld['vqrgb'] = mse(linear_gt, vq_rgb)
         ld['vqloss'] = cfg('vq_loss_weight') * kwargs.pop('vqloss')

@@ -9,7 +9,8 @@ def safe_l2_normalize(x, axis=None, eps=1e-6):
 
 
 def clip_preserve_gradient(x, lo, hi):
-    """tfp.math.clip_by_value_preserve_gradient: clipped value, identity gradient."""
+    """tfp.math.clip_by_value_preserve_gradient: clipped value, identity gradient -- in the reference's own arithmetic,
+    `x + stop_gradient(clip(x) - x)` (which is not always bitwise `clip(x)`)."""
     return x + (x.clamp(lo, hi) - x).detach()
 
 
