@@ -57,17 +57,6 @@ __device__ __forceinline__ void join3x8(const f32x4 q0, const f32x4 q1, const f3
   }
 }
 
-// nn.Softplus(beta = 100, threshold = 20) (fields.py:70) with the constants folded: exp2(x * 100 log2 e), log2(1 + e) * (ln 2 / 100) --
-// two multiplies per value instead of the four of act_fwd<ACT_SOFTPLUS100> (the epilogue VALU work is what the matrix pipe waits
-// for on this engine: all eight waves of the workgroup reach it together).  Same function to ~1e-8 absolute.
-__device__ __forceinline__ float softplus100_x3(float x) {
-  const float e = __builtin_amdgcn_exp2f(x * 144.26950408889634f);
-  const float y = __builtin_amdgcn_logf(1.f + e) * 0.006931471805599453f;
-  return x > 0.2f ? x : y;
-}
-// act'(x) = sigmoid(100 x) from the softplus OUTPUT h: 1 - exp(-100 h) = 1 - exp2(-h * 100 log2 e)
-__device__ __forceinline__ float softplus100_bwd_from_out_x3(float h) { return 1.f - __builtin_amdgcn_exp2f(h * -144.26950408889634f); }
-
 // rows of a region holding `feats` features
 __host__ __device__ __forceinline__ constexpr int x3_rows(int feats) { return 3 * ((feats + 15) / 16); }
 

@@ -179,14 +179,14 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
         [&](int ot, int im, const f32x16& acc) {
           float v[16];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) v[i] = softplus100_x3(acc[i]);
+          for (int i = 0; i < 16; ++i) v[i] = act_fwd<ACT_SOFTPLUS100>(acc[i]);
           split_tile_x3(v, o[im]);
           if (do_save) {                            // what the reverse sweep needs of this layer: act'(x) = 1 - exp(-100 h)
             f32x4* sv = save0 + (size_t)im * per_img + (size_t)l * 4 * MT * 64;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              st_stream(sv + (ot * 4 + q) * 64 + lane, (f32x4){softplus100_bwd_from_out_x3(v[4 * q]), softplus100_bwd_from_out_x3(v[4 * q + 1]),
-                                                               softplus100_bwd_from_out_x3(v[4 * q + 2]), softplus100_bwd_from_out_x3(v[4 * q + 3])});
+              st_stream(sv + (ot * 4 + q) * 64 + lane, (f32x4){act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q]), act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q + 1]),
+                                                               act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q + 2]), act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q + 3])});
           }
         });
       commit(L.n_out_tiles, X0);
@@ -242,8 +242,8 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
             join3x8(b0[c], b1[c], b2[c], x);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              x[i] = w0[c][i] * softplus100_bwd_from_out_x3(x[i]);
-              x[4 + i] = w1[c][i] * softplus100_bwd_from_out_x3(x[4 + i]);
+              x[i] = w0[c][i] * act_bwd_from_out<ACT_SOFTPLUS100>(x[i]);
+              x[4 + i] = w1[c][i] * act_bwd_from_out<ACT_SOFTPLUS100>(x[4 + i]);
             }
             f32x4 q0_, q1_, q2_;
             split3x8(x, q0_, q1_, q2_);
