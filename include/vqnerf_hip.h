@@ -61,6 +61,16 @@ int64_t vqn_vq_ema_stats_ws_bytes(int64_t N, int D, int K);
 int vqn_vq_ste_loss(const float* x, const float* quant, int64_t numel, float scale, float* ste, float* loss, float* ws,
                     void* stream);
 
+/* The EMA codebook move of VectorQuantizerEMA in training (vq_layers.py:304-325 with Sonnet's ExponentialMovingAverage for the
+ * cluster sizes and for dw, third party: hidden -= (hidden - v)(1 - decay); counter += 1; average = hidden / (1 - decay^counter)) as ONE
+ * launch (round 3): updates both averages' state in place (hidden / average / int64 counter each), then
+ *   n = sum_k cs_k;  cs'_k = (cs_k + eps) / (n + K eps) n;  update[d,k] = counts[k] > 0 ? average_dw[d,k] / cs'_k : codebook[d,k].
+ * counts [K] and dw [D,K] are the (already all-reduced) statistics of vqn_vq_ema_stats; codebook [D,K] the clipped, normalised one the
+ * assignment used.  The debias factor is taken in float64.  K <= 1024. */
+int vqn_vq_ema_update(const float* counts, const float* dw, const float* codebook, int D, int K, float decay, float eps,
+                      float* hidden_cs, float* average_cs, int64_t* counter_cs, float* hidden_dw, float* average_dw,
+                      int64_t* counter_dw, float* update, void* stream);
+
 /* Per-example loss terms of the VQ reflectance stage in TRAIN mode and their gradients, one launch each (round 3).  Replaces the
  * framework-op chains of vq_nfr.Model.compute_loss (decomp/nerfvq_nfr3/nerfactor/models/vq_nfr.py:876-986, train branch) and their
  * autograd for the terms that are per surface point; N points, rows 2j / 2j+1 are a pixel pair (train_nfr.py:447-448):

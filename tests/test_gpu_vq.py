@@ -361,3 +361,42 @@ def test_model_call_is_bit_identical_with_and_without_the_fused_quantiser(K):
     assert torch.equal(ta['vqrgb'], tb['vqrgb']) and torch.equal(ta['usage'], tb['usage'])
     np.testing.assert_allclose(float(la['vqloss']), float(lb['vqloss']), rtol=2e-6)
     assert int(pa['embed'].max()) <= K - 2                                   # the two dropped codes are never chosen
+
+
+@pytest.mark.parametrize('K', [8, 15, 64])
+def test_fused_ema_update_matches_the_torch_statement(K):
+    """`vqn_vq_ema_update` (both Sonnet moving averages, the Laplace-smoothed cluster sizes and the codebook move, vq_layers.py:304-325,
+    one launch) against the torch statement of the same lines over five training calls: state and `update` to 1e-6 relative (the
+    K-long sum and the f64 debias are the only places where the two can round differently), counters exact, unused codes keep their
+    codebook column."""
+    from vqnerf_release_amd.decomp.nerfactor.networks.vq_layers import VectorQuantizerEMA
+    D = 256
+    rng = np.random.default_rng(K)
+    layers = {}
+    for fused in (False, True):
+        vq = VectorQuantizerEMA(embedding_dim=D, num_embeddings=K, commitment_cost=0.1, seed=0).cuda()
+        vq.fuse_ema_update = fused
+        layers[fused] = vq
+    cb = torch.tensor(rng.uniform(0, 1, (D, K)).astype(np.float32)).cuda()
+    cb = cb / cb.norm(dim=0, keepdim=True)
+    for step in range(5):
+        x = torch.tensor(rng.uniform(0, 1, (500, D)).astype(np.float32)).cuda()
+        x = x / x.norm(dim=1, keepdim=True)
+        if step == 2:
+            x = cb.t()[torch.randint(0, max(K // 2, 1), (500,)).cuda()] * 0.999 + 1e-4      # leaves the upper half of the codes unused
+            x = (x / x.norm(dim=1, keepdim=True)).contiguous()
+        outs = {f: layers[f](x, cb, is_training=True) for f in (False, True)}
+        a, b = outs[False]['update'], outs[True]['update']
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-6, atol=1e-9)
+        assert torch.equal(outs[False]['encoding_indices'], outs[True]['encoding_indices'])
+        for name in ('ema_cluster_size', 'ema_dw'):
+            m0, m1 = getattr(layers[False], name), getattr(layers[True], name)
+            assert int(m0.counter) == int(m1.counter) == step + 1
+            np.testing.assert_allclose(m1.hidden.cpu().numpy(), m0.hidden.cpu().numpy(), rtol=1e-6, atol=1e-12)
+            np.testing.assert_allclose(m1.average.cpu().numpy(), m0.average.cpu().numpy(), rtol=1e-6, atol=1e-12)
+        if step == 2 and K > 2:
+            unused = torch.bincount(outs[True]['encoding_indices'], minlength=K) == 0
+            assert unused.any() and torch.equal(b[:, unused], cb[:, unused])
+        # the lazily computed entries are still there for whoever asks
+        assert outs[True]['encodings'].shape == (500, K) and float(outs[True]['perplexity']) > 0
+        cb = b.clone() / b.norm(dim=0, keepdim=True)

@@ -177,6 +177,22 @@ def vq_ste_loss(x, quant, want_ste=True):
     _check(rc, 'vqn_vq_ste_loss')
     return ste, loss
 
+def vq_ema_update(counts, dw, codebook, decay, eps, ema_cs, ema_dw):
+    """One launch for the EMA codebook move (both averages' state updated in place) -> update [D,K]."""
+    _f32c(counts, 'counts'); _f32c(dw, 'dw'); _f32c(codebook, 'codebook')
+    D, K = codebook.shape
+    for m in (ema_cs, ema_dw):
+        _f32c(m.hidden, 'hidden'); _f32c(m.average, 'average')
+        assert m.counter.dtype == torch.int64 and m.counter.is_cuda
+    update = torch.empty_like(codebook)
+    with _clock('vqn_vq_ema_update'):
+        rc = lib().vqn_vq_ema_update(_ptr(counts), _ptr(dw), _ptr(codebook), ctypes.c_int(D), ctypes.c_int(K), ctypes.c_float(decay),
+                                     ctypes.c_float(eps), _ptr(ema_cs.hidden), _ptr(ema_cs.average), _ptr(ema_cs.counter),
+                                     _ptr(ema_dw.hidden), _ptr(ema_dw.average), _ptr(ema_dw.counter), _ptr(update), _stream())
+    _check(rc, 'vqn_vq_ema_update')
+    return update
+
+
 def _loss_args(rgb_pred, vq_rgb, rgb_gt, z, spec, rough, nerf, w):
     for t, n in ((rgb_pred, 'rgb_pred'), (vq_rgb, 'vq_rgb'), (rgb_gt, 'rgb_gt')):
         _f32c(t, n)

@@ -184,3 +184,67 @@ extern "C" int vqn_decomp_loss_bwd(const float* rgb_pred, const float* vq_rgb, c
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }
+
+// ---- the EMA codebook move of VectorQuantizerEMA in training (vq_layers.py:304-325 + Sonnet's ExponentialMovingAverage, twice) as ONE
+// launch instead of ~35 framework launches on [K] / [D, K] tensors:
+//     for both averages:  counter += 1;  hidden -= (hidden - value) (1 - decay);  average = hidden / (1 - decay^counter)   (f64 debias)
+//     n = sum_k cs_k;  cs'_k = (cs_k + eps) / (n + K eps) n;  w = dw_avg / cs';  update = used ? w : codebook   (used: counts_k > 0)
+// One workgroup; the K-long sum in index order (bit-reproducible).
+namespace {
+__global__ __launch_bounds__(256) void vq_ema_update_kernel(const float* __restrict__ counts, const float* __restrict__ dw,
+                                                            const float* __restrict__ cb, const int D, const int K, const float decay,
+                                                            const float eps, float* __restrict__ hid_cs, float* __restrict__ avg_cs,
+                                                            long long* __restrict__ cnt_cs, float* __restrict__ hid_dw,
+                                                            float* __restrict__ avg_dw, long long* __restrict__ cnt_dw,
+                                                            float* __restrict__ update) {
+  __shared__ float cs_adj[1024];
+  __shared__ double deb[2];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    const long long c0 = cnt_cs[0] + 1, c1 = cnt_dw[0] + 1;
+    cnt_cs[0] = c0; cnt_dw[0] = c1;
+    deb[0] = 1.0 - pow((double)decay, (double)c0);
+    deb[1] = 1.0 - pow((double)decay, (double)c1);
+  }
+  __syncthreads();
+  const float om = 1.0f - decay;
+  for (int k = tid; k < K; k += 256) {
+    const float hdn = hid_cs[k] - (hid_cs[k] - counts[k]) * om;
+    hid_cs[k] = hdn;
+    const float a = (float)((double)hdn / deb[0]);
+    avg_cs[k] = a;
+    cs_adj[k] = a;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float n = 0.f;
+    for (int k = 0; k < K; ++k) n += cs_adj[k];
+    deb[0] = (double)n;                          // (reuse: the total)
+  }
+  __syncthreads();
+  const float n = (float)deb[0];
+  for (int k = tid; k < K; k += 256) cs_adj[k] = (cs_adj[k] + eps) / (n + (float)K * eps) * n;
+  __syncthreads();
+  const double d1 = deb[1];
+  for (int i = tid; i < D * K; i += 256) {
+    const int k = i % K;
+    const float hdn = hid_dw[i] - (hid_dw[i] - dw[i]) * om;
+    hid_dw[i] = hdn;
+    const float a = (float)((double)hdn / d1);
+    avg_dw[i] = a;
+    update[i] = counts[k] > 0.f ? a / cs_adj[k] : cb[i];
+  }
+}
+}  // namespace
+
+extern "C" int vqn_vq_ema_update(const float* counts, const float* dw, const float* codebook, int D, int K, float decay, float eps,
+                                 float* hidden_cs, float* average_cs, int64_t* counter_cs, float* hidden_dw, float* average_dw,
+                                 int64_t* counter_dw, float* update, void* stream) {
+  VQN_CHECK_ARG(counts && dw && codebook && hidden_cs && average_cs && counter_cs && hidden_dw && average_dw && counter_dw && update,
+                "null pointer");
+  VQN_CHECK_SHAPE(D >= 1 && K >= 1 && K <= 1024, "1 <= K <= 1024");
+  hipLaunchKernelGGL(vq_ema_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, counts, dw, codebook, D, K, decay, eps, hidden_cs,
+                     average_cs, (long long*)counter_cs, hidden_dw, average_dw, (long long*)counter_dw, update);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}

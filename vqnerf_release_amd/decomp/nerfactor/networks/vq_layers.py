@@ -148,6 +148,7 @@ class VectorQuantizerEMA(torch.nn.Module):
         # hook for data-parallel training: called with the flat [K + D*K] statistics buffer
         # (sum over ranks) before the EMAs are updated -- see parallel.py
         self.stats_all_reduce = None
+        self.fuse_ema_update = True      # training on the device: the EMA codebook move as one launch (False: the torch statement)
 
     def draw_roll(self, individual=True, device=None):
         """The code-dropout draw tf.random.uniform((1, K)) (vq_layers.py:287).  Normally from the layer's seeded host generator;
@@ -172,7 +173,6 @@ class VectorQuantizerEMA(torch.nn.Module):
             thres_t = torch.as_tensor(thres, dtype=torch.float32, device=x.device)
             sel = (roll.to(x.device) >= thres_t).to(torch.float32).expand(1, K).reshape(K).contiguous()
         idx, quant, dist = _C.vq_assign(x, cb, sel_mask=sel, want_quant=True, want_dist=return_distances)
-        encodings = torch.nn.functional.one_hot(idx, K).to(flat.dtype)
         encoding_indices = idx.reshape(inputs.shape[:-1])
         quantized, e_latent_loss = _SteAndCommitment.apply(inputs, quant)        # straight-through estimator + mean((sg(q) - x)^2)
         ret = {}
@@ -182,22 +182,29 @@ class VectorQuantizerEMA(torch.nn.Module):
             local_counts = counts
             if self.stats_all_reduce is not None:
                 counts, dw = self.stats_all_reduce(counts, dw)
-            cs = self.ema_cluster_size(counts)
-            ema_dw = self.ema_dw(dw)
-            n = cs.sum()
-            cs = (cs + self.epsilon) / (n + K * self.epsilon) * n
-            w = ema_dw / cs.reshape(1, -1)
-            used = (counts > 0).to(w.dtype)
-            ret['update'] = w * used[None, :] + cb * (1.0 - used[None, :])
+            if self.fuse_ema_update and cb.dtype == torch.float32 and self.ema_dw.hidden.is_cuda:
+                # both moving averages, the Laplace-smoothed cluster sizes and the codebook move in ONE launch (vqn_vq_ema_update)
+                ret['update'] = _C.vq_ema_update(counts.contiguous(), dw.contiguous(), cb, self.decay, self.epsilon,
+                                                 self.ema_cluster_size, self.ema_dw)
+            else:
+                cs = self.ema_cluster_size(counts)
+                ema_dw = self.ema_dw(dw)
+                n = cs.sum()
+                cs = (cs + self.epsilon) / (n + K * self.epsilon) * n
+                w = ema_dw / cs.reshape(1, -1)
+                used = (counts > 0).to(w.dtype)
+                ret['update'] = w * used[None, :] + cb * (1.0 - used[None, :])
             counts = local_counts
         else:
             counts = _C.vq_counts(idx, K)
         loss = self.commitment_cost * e_latent_loss
-        avg_probs = counts / max(idx.numel(), 1)                  # = mean(encodings, 0) of this replica's rows
-        perplexity = torch.exp(-torch.sum(avg_probs * torch.log(avg_probs + 1e-10)))
-        ret.update({'quantize': quantized, 'loss': loss, 'perplexity': perplexity, 'encodings': encodings,
-                    'encoding_indices': encoding_indices, 'distances': dist})
-        return ret
+
+        def perplexity():
+            avg_probs = counts / max(idx.numel(), 1)              # = mean(encodings, 0) of this replica's rows
+            return torch.exp(-torch.sum(avg_probs * torch.log(avg_probs + 1e-10)))
+        ret.update({'quantize': quantized, 'loss': loss, 'encoding_indices': encoding_indices, 'distances': dist})
+        # `encodings` (an [N, K] one-hot) and `perplexity` are computed when somebody reads them (nobody does in a training step)
+        return LazyResult(ret, {'perplexity': perplexity, 'encodings': lambda: torch.nn.functional.one_hot(idx, K).to(flat.dtype)})
 
     @torch.no_grad()
     def infer_from_raw(self, z_raw, codebook, thres=None, individual=True, roll=None, eps=1e-6):

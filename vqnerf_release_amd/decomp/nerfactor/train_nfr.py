@@ -152,11 +152,13 @@ class Trainer:
         else:
             grads = torch.autograd.grad(weighted, leaves, allow_unused=True)
             with torch.no_grad():
+                # one multi-tensor copy for all gradients (a launch per parameter is ~40 of the captured step's launches)
+                have = [(v, g) for v, g in zip(self.bucket.views, grads) if g is not None]
                 for v, g in zip(self.bucket.views, grads):
                     if g is None:
                         v.zero_()
-                    else:
-                        v.copy_(g)
+                if have:
+                    torch._foreach_copy_([v for v, _ in have], [g.reshape(v.shape) for v, g in have])
         with torch.no_grad():
             self.bucket.extra[0] = weighted
         extra = self.bucket.all_reduce()

@@ -226,12 +226,13 @@ class Runner:
                 loss, color_loss, eik, mask_loss = loss_terms()
                 grads = torch.autograd.grad(loss, leaves, allow_unused=True)
             with torch.no_grad():
+                have = [(v, g) for v, g in zip(self.bucket.views, grads) if g is not None]
                 for p, v, g in zip(self.bucket.params, self.bucket.views, grads):
                     if g is None:
                         v.zero_()
-                    else:
-                        v.copy_(g)
                     p.grad = v
+                if have:
+                    torch._foreach_copy_([v for v, _ in have], [g.reshape(v.shape) for v, g in have])      # one launch, not one per parameter
         else:
             self.bucket.attach()
             loss, color_loss, eik, mask_loss = loss_terms()
