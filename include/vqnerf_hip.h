@@ -67,7 +67,7 @@ int vqn_vq_ste_loss(const float* x, const float* quant, int64_t numel, float sca
  *   n = sum_k cs_k;  cs'_k = (cs_k + eps) / (n + K eps) n;  update[d,k] = counts[k] > 0 ? average_dw[d,k] / cs'_k : codebook[d,k].
  * counts [K] and dw [D,K] are the (already all-reduced) statistics of vqn_vq_ema_stats; codebook [D,K] the clipped, normalised one the
  * assignment used.  The debias factor is taken in float64.  K <= 1024. */
-int vqn_vq_ema_update(const float* counts, const float* dw, const float* codebook, int D, int K, float decay, float eps,
+int vqn_vq_ema_update(const float* counts, const float* dw, const float* codebook, int D, int K, double decay, float eps,
                       float* hidden_cs, float* average_cs, int64_t* counter_cs, float* hidden_dw, float* average_dw,
                       int64_t* counter_dw, float* update, void* stream);
 

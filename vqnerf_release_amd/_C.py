@@ -186,7 +186,7 @@ def vq_ema_update(counts, dw, codebook, decay, eps, ema_cs, ema_dw):
         assert m.counter.dtype == torch.int64 and m.counter.is_cuda
     update = torch.empty_like(codebook)
     with _clock('vqn_vq_ema_update'):
-        rc = lib().vqn_vq_ema_update(_ptr(counts), _ptr(dw), _ptr(codebook), ctypes.c_int(D), ctypes.c_int(K), ctypes.c_float(decay),
+        rc = lib().vqn_vq_ema_update(_ptr(counts), _ptr(dw), _ptr(codebook), ctypes.c_int(D), ctypes.c_int(K), ctypes.c_double(decay),
                                      ctypes.c_float(eps), _ptr(ema_cs.hidden), _ptr(ema_cs.average), _ptr(ema_cs.counter),
                                      _ptr(ema_dw.hidden), _ptr(ema_dw.average), _ptr(ema_dw.counter), _ptr(update), _stream())
     _check(rc, 'vqn_vq_ema_update')

@@ -192,7 +192,7 @@ extern "C" int vqn_decomp_loss_bwd(const float* rgb_pred, const float* vq_rgb, c
 // One workgroup; the K-long sum in index order (bit-reproducible).
 namespace {
 __global__ __launch_bounds__(256) void vq_ema_update_kernel(const float* __restrict__ counts, const float* __restrict__ dw,
-                                                            const float* __restrict__ cb, const int D, const int K, const float decay,
+                                                            const float* __restrict__ cb, const int D, const int K, const double decay,
                                                             const float eps, float* __restrict__ hid_cs, float* __restrict__ avg_cs,
                                                             long long* __restrict__ cnt_cs, float* __restrict__ hid_dw,
                                                             float* __restrict__ avg_dw, long long* __restrict__ cnt_dw,
@@ -203,11 +203,11 @@ __global__ __launch_bounds__(256) void vq_ema_update_kernel(const float* __restr
   if (tid == 0) {
     const long long c0 = cnt_cs[0] + 1, c1 = cnt_dw[0] + 1;
     cnt_cs[0] = c0; cnt_dw[0] = c1;
-    deb[0] = 1.0 - pow((double)decay, (double)c0);
-    deb[1] = 1.0 - pow((double)decay, (double)c1);
+    deb[0] = 1.0 - pow(decay, (double)c0);
+    deb[1] = 1.0 - pow(decay, (double)c1);
   }
   __syncthreads();
-  const float om = 1.0f - decay;
+  const float om = (float)(1.0 - decay);        // (1 - decay) taken in double, then rounded: what the framework statement multiplies by
   for (int k = tid; k < K; k += 256) {
     const float hdn = hid_cs[k] - (hid_cs[k] - counts[k]) * om;
     hid_cs[k] = hdn;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void vq_ema_update_kernel(const float* __restr
 }
 }  // namespace
 
-extern "C" int vqn_vq_ema_update(const float* counts, const float* dw, const float* codebook, int D, int K, float decay, float eps,
+extern "C" int vqn_vq_ema_update(const float* counts, const float* dw, const float* codebook, int D, int K, double decay, float eps,
                                  float* hidden_cs, float* average_cs, int64_t* counter_cs, float* hidden_dw, float* average_dw,
                                  int64_t* counter_dw, float* update, void* stream) {
   VQN_CHECK_ARG(counts && dw && codebook && hidden_cs && average_cs && counter_cs && hidden_dw && average_dw && counter_dw && update,
