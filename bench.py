@@ -722,6 +722,8 @@ def live_traffic(rays, timeout_s=170):
     import tempfile
     if shutil.which('rocprofv3') is None:
         return None, 'rocprofv3 not on PATH'
+    if any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', ''):
+        return None, 'this run is itself under a profiler: no nested rocprofv3 passes'
     vals = {}
     for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         d = tempfile.mkdtemp(prefix='vqn_pmc_', dir='/tmp')
