@@ -709,6 +709,19 @@ def decomp_cpu_leg(dev, cores, N=16384):
             'near_tie_fraction': 1.0 - float(clear.float().mean())}
 
 
+def pmc_values(root, counter, kernel_substr):
+    """Counter values of every dispatch of a kernel from the `*counter_collection.csv` files rocprofv3 --pmc leaves under `root`."""
+    import csv
+    import glob
+    got = []
+    for fn in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True):
+        with open(fn) as fh:
+            for r in csv.DictReader(fh):
+                if kernel_substr in r.get('Kernel_Name', '').replace(' ', '') and r.get('Counter_Name') == counter:
+                    got.append(float(r['Counter_Value']))
+    return got
+
+
 def live_traffic(rays, timeout_s=170):
     """Fabric-side bytes of ONE fine-kernel launch of the headline step, measured now: two child runs of this script (one 640,000-ray
     render each, no extras) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` -- separate passes, kernel trace
@@ -716,8 +729,6 @@ def live_traffic(rays, timeout_s=170):
     are ordinary child processes).  Corrections of MI355X_MICROARCH.md (HBM section): counter values are KB; FETCH_SIZE reports half
     the bytes of 16-B-per-lane coalesced reads on gfx950 (x2), WRITE_SIZE is exact; both count fabric requests, Infinity-Cache hits
     included.  Returns (bytes per launch, note) or (None, reason)."""
-    import csv
-    import glob
     import shutil
     import subprocess
     import tempfile
@@ -733,12 +744,7 @@ def live_traffic(rays, timeout_s=170):
         try:
             subprocess.run(cmd, timeout=timeout_s, env={**os.environ, 'TMPDIR': '/tmp'}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                            check=True, cwd='/tmp')
-            got = []
-            for fn in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
-                with open(fn) as fh:
-                    for r in csv.DictReader(fh):
-                        if 'neus_points2_kernel<true>' in r['Kernel_Name'].replace(' ', '') and r['Counter_Name'] == c:
-                            got.append(float(r['Counter_Value']))
+            got = pmc_values(d, c, 'neus_points2_kernel<true>')
             if not got:
                 return None, f'no {c} rows for the fine kernel in the rocprofv3 output'
             vals[c] = sum(got) / len(got)

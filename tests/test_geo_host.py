@@ -64,3 +64,19 @@ def test_runner_schedules_and_checkpoint_keys(tmp_path):
     assert r2.iter_step == 7
     d = r.dataset.gen_random_rays_at(1, 50)
     assert d.shape == (50, 10) and torch.allclose(d[:, 3:6].norm(dim=-1), torch.ones(50), atol=1e-6)
+
+
+def test_bench_reads_the_profiler_counter_files(tmp_path):
+    """bench.py's live `roofline.traffic`: the parser of rocprofv3's per-dispatch counter CSV (kernel names carry template spaces)."""
+    import bench
+    d = tmp_path / 'x' / 'y'
+    d.mkdir(parents=True)
+    (d / 'c_counter_collection.csv').write_text(
+        '"Correlation_Id","Kernel_Name","Counter_Name","Counter_Value"\n'
+        '1,"void (anonymous namespace)::neus_points2_kernel<true>(SdfDesc, ColDesc)","FETCH_SIZE",1000.5\n'
+        '2,"void (anonymous namespace)::neus_points2_kernel<false>(SdfDesc, ColDesc)","FETCH_SIZE",7\n'
+        '3,"void (anonymous namespace)::neus_points2_kernel< true >(SdfDesc, ColDesc)","FETCH_SIZE",999.5\n'
+        '4,"void (anonymous namespace)::neus_points2_kernel<true>(SdfDesc, ColDesc)","WRITE_SIZE",5\n')
+    assert bench.pmc_values(str(tmp_path), 'FETCH_SIZE', 'neus_points2_kernel<true>') == [1000.5, 999.5]
+    assert bench.pmc_values(str(tmp_path), 'WRITE_SIZE', 'neus_points2_kernel<true>') == [5.0]
+    assert bench.pmc_values(str(tmp_path), 'FETCH_SIZE', 'no_such_kernel') == []
