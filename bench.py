@@ -166,11 +166,15 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
         wg_default = _tp.wgrad_mode()
         out['geo_train']['wgrad_mode'] = wg_default
         _tp.wgrad_mode('f32')
-        for _ in range(10):                    # (the f32 contraction's first ~10 steps in a process run at half speed: measured, 15.4 vs 8.4 ms)
-            geo_train()
-        _C.KernelClock.reset(True)
-        dt3 = _time_gpu(geo_train, 6, warm=0)
-        clk3 = _C.KernelClock.summary()
+        geo_train()
+        # (two windows, the faster one: a one-off stall of 40-90 ms lands somewhere in steps 12-25 of a training process -- measured in
+        # either contraction mode, scripts/debug/wgrad_f32_time.py -- and this leg's steps fall right there)
+        dt3, clk3 = None, None
+        for _ in range(2):
+            _C.KernelClock.reset(True)
+            dtw = _time_gpu(geo_train, 6, warm=0)
+            if dt3 is None or dtw < dt3:
+                dt3, clk3 = dtw, _C.KernelClock.summary()
         _C.KernelClock.reset(False)
         _tp.wgrad_mode(wg_default)
         out['geo_train_wgrad_f32'] = {'rays_per_s': B / dt3, 'ms_per_step': dt3 * 1e3, 'achieved_tflops': flop / dt3 / 1e12,
@@ -348,8 +352,8 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
                       'frac': 2.0 * (enc_macs + head_macs) * N / t_chain / 1e12 / F32_MFMA_PEAK_TFLOPS, 'ms': t_chain * 1e3},
         # both rooflines: the 2 KB visibility row per point against HBM, and the per-light arithmetic against the f32
         # vector pipe.  FLOPs per point are MEASURED (rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 of this kernel on this
-        # workload, profiles/r02_pmc_units.json: 35.07 GFLOP per 512,000-point launch); the same file has its vector-pipe
-        # occupancy (valu_busy_frac 0.60) -- the kernel is vector-issue bound, not HBM bound
+        # workload, profiles/r02_pmc_units.json: 27.73 GFLOP per 512,000-point launch); the same file has its vector-pipe
+        # occupancy (valu_busy_frac 0.77) -- the kernel is vector-issue bound, not HBM bound
         'brdf_shade': {'bound': 'valu', 'ms': t_shade * 1e3, 'note': 'two material sets + diffuse/specular split per pass',
                        'hbm': {'achieved': N * SHADE_BYTES / t_shade / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                                'frac': N * SHADE_BYTES / t_shade / 1e9 / 8000.0, 'bytes_per_point': SHADE_BYTES},

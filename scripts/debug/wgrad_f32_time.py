@@ -5,14 +5,12 @@ from vqnerf_release_amd import _C
 from vqnerf_release_amd.geo import train_programs as tp
 dev = torch.device('cuda:0')
 runner, step = bench.geo_train_setup(dev, 0, 2560)
-for mode in ('bf16x3', 'f32', 'bf16x3', 'f32'):
+for phase, mode in enumerate(['f32'] * 8 + ['bf16x3'] * 2 + ['f32'] * 3):
     tp.wgrad_mode(mode)
-    for _ in range(3): step()
-    torch.cuda.synchronize()
     _C.KernelClock.reset(True)
     t0 = time.perf_counter()
-    for _ in range(6): step()
+    for _ in range(5): step()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 6
+    dt = (time.perf_counter() - t0) / 5
     clk = _C.KernelClock.summary(); _C.KernelClock.reset(False)
-    print(mode, f'{dt*1e3:.2f} ms/step', {k: round(v[1] / 6, 2) for k, v in clk.items() if 'wgrad' in k or 'reduce' in k})
+    print(phase, mode, f'{dt*1e3:.2f} ms/step', {k: round(v[1] / 5, 2) for k, v in clk.items() if 'wgrad' in k})
