@@ -93,6 +93,69 @@ def test_geo_trainer_dp2_equals_single_process(tmp_path):
     assert err <= 2e-4, err
 
 
+def _graph_worker(rank, world, port, tmp, q):
+    """Runner(graph=True) under data parallelism: the captured step is cut at its collectives (loss normalisers, gradient bucket)
+    into graph segments (parallel.SegmentedCapture); replayed steps must equal the eager DP steps of a twin runner bit for bit."""
+    import torch.distributed as dist
+    from vqnerf_release_amd import parallel
+    from vqnerf_release_amd.geo.nerf_runner import Runner, SyntheticDataset
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        text = open(os.path.join(HERE, 'golden', 'neus_like.conf')).read().replace('./exp/', tmp + '/exp/')
+        text = text.replace('warm_up_end = 5000', 'warm_up_end = 0')
+        out = {}
+        for graph in (False, True):
+            torch.manual_seed(0)
+            r = Runner(conf_text=text, case='dpg', dataset=SyntheticDataset(n_images=2, H=32, W=32, seed=3), graph=True)
+            r.graph = graph                                  # same capturable Adam on both sides
+            r.renderer.perturb = 0.0
+            r.update_learning_rate()
+            r.dataset.gen.manual_seed(11)
+            losses = []
+            for it in range(6):
+                data = r.dataset.gen_random_rays_at(it % 2, 192)
+                lo, hi = parallel.shard_range(data.shape[0])
+                losses.append(float(r.train_step(data[lo:hi].contiguous())['loss']))
+            parallel.assert_replicas_identical(list(r.sdf_network.parameters()) + list(r.color_network.parameters()))
+            out[graph] = (losses, [p.detach().clone() for p in r.bucket.params], None if r._cap is None else len(r._cap.graphs))
+        (l0, w0, _), (l1, w1, n_seg) = out[False], out[True]
+        assert n_seg == 3, n_seg                             # forward up to the normalisers | rest of the step up to the bucket | Adam
+        assert l0 == l1, (l0, l1)
+        assert all(torch.equal(a, b) for a, b in zip(w0, w1))
+        if rank == 0:
+            q.put(dict(ok=True, losses=l1, segments=n_seg))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_geo_runner_graph_replays_the_data_parallel_step(tmp_path):
+    import time
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graph_worker, args=(rk, 2, port, str(tmp_path), q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        t0 = time.time()
+        while q.empty():
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), 'a rank died'
+            assert time.time() - t0 < 240, 'ranks did not finish'
+            time.sleep(0.2)
+        got = q.get()
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    assert got['ok'] and got['segments'] == 3 and len(set(got['losses'])) > 1
+
+
 def _decomp_model():
     from oracle import decomp as od
     from tests.decomp_util import make_config, load_oracle_params
