@@ -659,6 +659,20 @@ def dp_train_leg(dev, rank, world, backend, steps=10, warmup=3):
                                'all_reduce': _collective_report(clk, steps)}
     except Exception as e:                                      # noqa: BLE001
         out['decomp_graph'] = {'error': repr(e)[:300]}
+    try:
+        del model, tr, gstep2
+    except Exception:                                           # noqa: BLE001
+        pass
+    # the geo step the same way (Runner(graph=True): under N ranks three graph segments around the loss-normaliser and gradient-bucket
+    # all-reduces; tests/test_gpu_parallel.py: bit-identical to the eager DP step on two gloo ranks)
+    try:
+        runner, gstep3 = geo_train_setup(dev, rank, graph=True)
+        dt, clk = _timed_steps(gstep3, steps, runner.GRAPH_WARMUP + 2, dev, world, backend)
+        out['geo_graph'] = {'rays_per_s': 2560 * world * steps / dt, 'ms_per_step': dt / steps * 1e3,
+                            'graph_segments': len(runner._cap.graphs) if runner._cap is not None else 0,
+                            'all_reduce': _collective_report(clk, steps)}
+    except Exception as e:                                      # noqa: BLE001
+        out['geo_graph'] = {'error': repr(e)[:300]}
     return out
 
 
