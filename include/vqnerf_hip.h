@@ -192,6 +192,18 @@ int vqn_neus_fine_points(const int32_t* sdf_desc, const float* wbuf_sdf, const i
                          const float* pts, const float* dirs, int64_t P, int S, void* scratch,
                          int64_t scratch_bytes, float* out_sdf, float* out_grad, float* out_rgb, void* stream);
 
+/* Training forward of the same path: vqn_neus_fine_points at explicit (pts, dirs) that also leaves, in the tile format of
+ * vqn_tile_program ([point tile][feature tile][32 features][32 points] f32), what the backward of
+ * geo/NeuS-ours2/models/renderer.py:216-227 under exp_runner.py:153-168 (loss.backward()) needs saved: tensors[] =
+ * [E, OUTF, EXTR, U_1..U_nL, GH_0..GH_{nL-1}, C_1..C_nC] (embedding; [sdf ; features]; colour-net extras; SDF hidden
+ * activations; the adjoints of the d sdf / d x sweep; colour hidden activations) with nL / nC the hidden layer counts of the
+ * descriptors, n_tensors = 3 + 2 nL + nC, and e_tiles / outf_tiles / extr_tiles the feature tiles of the first three.
+ * Networks of 5..8 feature tiles (the two-image kernel).  out_sdf [P], out_n [P,3], out_rgb [P,3]. */
+int vqn_neus_train_fwd(const int32_t* sdf_desc, const float* wbuf_sdf, const int32_t* col_desc, const float* wbuf_col,
+                       const float* pts, const float* dirs, int64_t P, void* scratch, int64_t scratch_bytes,
+                       float* const* tensors, int n_tensors, int e_tiles, int outf_tiles, int extr_tiles, float* out_sdf,
+                       float* out_n, float* out_rgb, void* stream);
+
 /* Split-precision twins of vqn_neus_sdf_points / vqn_neus_fine_points ("fp16 MFMA path"): same arguments, same outputs,
  * every product taken as hi*hi + 2^-11 (hi*lo + lo*hi) over f16 hi/lo operand pairs on v_mfma_f32_32x32x16_f16 with f32
  * accumulation.  Descriptors and packs must be built for it (SdfPackPlan(mode='f16s'), ColPackPlan(matrix_mode='f16s'):

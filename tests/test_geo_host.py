@@ -80,3 +80,43 @@ def test_bench_reads_the_profiler_counter_files(tmp_path):
     assert bench.pmc_values(str(tmp_path), 'FETCH_SIZE', 'neus_points2_kernel<true>') == [1000.5, 999.5]
     assert bench.pmc_values(str(tmp_path), 'WRITE_SIZE', 'neus_points2_kernel<true>') == [5.0]
     assert bench.pmc_values(str(tmp_path), 'FETCH_SIZE', 'no_such_kernel') == []
+
+
+def test_fused_forward_pack_indices_reproduce_the_render_packs():
+    """The training forward on the render kernel (vqn_neus_train_fwd) takes its two weight packs as ONE gather each from the
+    flat source vector of NeusTrainEngine.pack(); those gather indices must give exactly SdfPackPlan / ColPackPlan.pack() of the
+    same effective weights (skip layer's 1/sqrt2 included) and the same descriptors."""
+    import math
+    from vqnerf_release_amd.geo import packing
+    from vqnerf_release_amd.geo.models.fields import SDFNetwork, RenderingNetwork
+    from vqnerf_release_amd.geo.train_programs import NeusTrainEngine
+    sdf = SDFNetwork(d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=(4,), multires=6, bias=0.5, scale=1.5, geometric_init=True,
+                     weight_norm=True)
+    col = RenderingNetwork(d_feature=256, mode='idr', d_in=9, d_out=3, d_hidden=256, n_layers=4, weight_norm=True, multires_view=4,
+                           squeeze_out=True)
+    e = NeusTrainEngine(sdf, col)
+    assert e.fused_forward()
+    gi_s, d_s, gi_c, d_c = e._fused_static(torch.device('cpu'))
+    g = torch.Generator().manual_seed(0)
+    W = [torch.randn(e.out[l], e.inn[l], generator=g) for l in range(e.nL + 1)]
+    b = [torch.randn(e.out[l], generator=g) for l in range(e.nL + 1)]
+    Wc = [torch.randn(e.cout[l], e.cin[l], generator=g) for l in range(e.nC + 1)]
+    bc = [torch.randn(e.cout[l], generator=g) for l in range(e.nC + 1)]
+    src = {}
+    for l in range(e.nL + 1):
+        src['W%d' % l], src['b%d' % l] = (W[l] / math.sqrt(2.0) if l == e.skip else W[l]), b[l]
+    for l in range(e.nC + 1):
+        src['Wc%d' % l], src['bc%d' % l] = Wc[l], bc[l]
+    flat = e._layout().flatten(src)
+    plan = sdf.plan(max_tiles=col.max_tiles())
+    wb, d = plan.pack(W, b)
+    assert torch.equal(wb, flat[gi_s]) and (d == d_s).all()
+    cp = packing.ColPackPlan(col.d_feature, col.mode, col.dims[1], col.num_layers - 2, col.dims[-1], col.multires_view, col.squeeze_out,
+                             plan.tiles[-1])
+    wbc, dc = cp.pack(Wc, bc)
+    assert torch.equal(wbc, flat[gi_c]) and (dc == d_c).all()
+    # narrow networks (fewer than five feature tiles) keep the interpreted forward
+    small = NeusTrainEngine(SDFNetwork(d_in=3, d_out=65, d_hidden=64, n_layers=4, skip_in=(2,), multires=6, weight_norm=True),
+                            RenderingNetwork(d_feature=64, mode='idr', d_in=9, d_out=3, d_hidden=64, n_layers=2, weight_norm=True,
+                                             multires_view=4, squeeze_out=True))
+    assert not small.fused_forward()

@@ -165,7 +165,7 @@ def test_training_path_grads_vs_reference(case, wgrad):
         tgt = torch.tensor(np.random.default_rng(4).uniform(0, 1, (B, 3)).astype(np.float32)).cuda()
         loss = (rr['color_fine'] - tgt).abs().sum() / B + 0.1 * rr['gradient_error']
         loss.backward()
-    assert ren.last_train_backend == 'hip' and rec.ran('vqn_tile_program:prog_fwd') and rec.ran('vqn_wgrad_partials')
+    assert ren.last_train_backend == 'hip' and (rec.ran('vqn_tile_program:prog_fwd') or rec.ran('vqn_neus_train_fwd')) and rec.ran('vqn_wgrad_partials')
     assert rec.ran('vqn_wgrad_partials_x3') == (wgrad == 'bf16x3')
     np.testing.assert_allclose(loss.item(), float(g['bwd_loss']), rtol=2e-4)
     for name, m in (('sdf', case['sdf']), ('col', case['col']), ('var', case['var'])):

@@ -391,7 +391,7 @@ def test_hip_training_programs_match_torch_autograd(name, B):
         # 'hip' must be the tile-program engine, not a silent fall-back to the autograd statement it is compared with
         assert ren.last_train_backend == backend
         hip = backend == 'hip'
-        assert rec.ran('vqn_tile_program:prog_fwd') == hip and rec.ran('vqn_tile_program:prog_sbwd') == hip
+        assert (rec.ran('vqn_tile_program:prog_fwd') or rec.ran('vqn_neus_train_fwd')) == hip and rec.ran('vqn_tile_program:prog_sbwd') == hip
         assert rec.ran('vqn_wgrad_partials') == hip and rec.ran('vqn_neus_composite_bwd') == hip
         res[backend] = (loss.item(), {f'{nm}.{k}': p.grad.detach().clone() for nm, m in (('sdf', sdf), ('col', col), ('var', var))
                                       for k, p in m.named_parameters()},
@@ -410,6 +410,76 @@ def test_hip_training_programs_match_torch_autograd(name, B):
         worst = max(worst, err)
         assert err <= 5e-3, (k, err, scale)
     print(f'{name}: loss {lh:.6f} vs {lt:.6f}; worst relative gradient error {worst:.2e}')
+
+
+@pytest.mark.parametrize('P', [1, 33, 4096 + 17, 40000])
+def test_training_forward_on_the_render_kernel_matches_the_interpreted_program(P):
+    """vqn_neus_train_fwd (the two-image render kernel leaving the backward's saved tensors) against the interpreted prog_fwd of
+    the same engine on the full-size networks: sdf / normals / colours and every saved tensor (valid features of valid points) to
+    f32 summation-order differences; odd tile counts leave the second image of the last pair a phantom."""
+    from tests.test_gpu_neus_render import _build
+    cfg, sdf, col, var, ren = _build('full')
+    eng = ren._train_engine(sdf, col)
+    assert eng is not None and eng.fused_forward()
+    dev = torch.device('cuda')
+    g = torch.Generator(device='cuda').manual_seed(P)
+    x = torch.rand(P, 3, device=dev, generator=g) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(P, 3, device=dev, generator=g), dim=-1)
+    sl = [getattr(sdf, 'lin%d' % l) for l in range(sdf.num_layers - 1)]
+    cl = [getattr(col, 'lin%d' % l) for l in range(col.num_layers - 1)]
+    with torch.no_grad():
+        wbuf, descs, flat = eng.pack([m.effective_weight().float() for m in sl], [m.bias.float() for m in sl],
+                                     [m.effective_weight().float() for m in cl], [m.bias.float() for m in cl], want_flat=True)
+        Ta, Tb = eng.alloc_tensors(P, dev), eng.alloc_tensors(P, dev)
+        for T in (Ta, Tb):
+            T['X'].copy_(x)
+            T['DIRS'].copy_(d)
+            for k in T:
+                if k not in ('X', 'DIRS', 'ONES'):
+                    T[k].fill_(float('nan'))
+        with launches() as rec:
+            eng.run('prog_fwd', descs, wbuf, Ta, P)
+            eng.run_fused_forward(flat, Tb, P)
+        assert rec.ran('vqn_tile_program:prog_fwd') and rec.ran('vqn_neus_train_fwd')
+    width = {'E': eng.E, 'OUTF': eng.F, 'EXTR': eng.X, 'SDF': 1, 'N': 3, 'RGB': 3}
+    for l in range(eng.nL):
+        width['U%d' % (l + 1)] = width['GH%d' % l] = eng.out[l]
+    for l in range(eng.nC):
+        width['C%d' % (l + 1)] = eng.cout[l]
+    for n, w in width.items():
+        a, c = Ta[n], Tb[n]
+        if a.dim() == 4:
+            a = a.permute(0, 3, 1, 2).reshape(a.shape[0] * 32, -1)[:P, :w]
+            c = c.permute(0, 3, 1, 2).reshape(c.shape[0] * 32, -1)[:P, :w]
+        assert not torch.isnan(c).any(), n
+        scale = max(float(a.abs().max()), 1e-6)
+        assert float((a - c).abs().max()) <= 5e-6 * scale, (n, float((a - c).abs().max()), scale)
+    # the padded feature rows the weight-gradient contraction reads along with the valid ones hold finite numbers
+    for n in ('E', 'OUTF', 'EXTR', 'U%d' % eng.skip if eng.skip > 0 else 'U1'):
+        nt = (P + 31) // 32
+        assert torch.isfinite(Tb[n][:nt - 1]).all(), n
+
+
+@pytest.mark.parametrize('mode', ['prog', 'fused'])
+def test_training_forward_switch(mode, monkeypatch):
+    """VQN_TRAIN_FWD selects the forward of the training engine; both reach the same gradients (to f32 rounding)."""
+    from oracle import geo as og
+    from tests.test_gpu_neus_render import _build
+    monkeypatch.setenv('VQN_TRAIN_FWD', mode)
+    cfg, sdf, col, var, ren = _build('full')
+    B = 24
+    o, d, near, far = [torch.tensor(a).cuda() for a in og.make_rays(B, 5)]
+    with launches() as rec:
+        rr = ren.render(o, d, near, far, 2.0, perturb_overwrite=0, background_rgb=torch.ones(1, 3).cuda(), cos_anneal_ratio=1.0)
+        (rr['color_fine'].sum() + rr['gradient_error']).backward()
+    assert rec.ran('vqn_neus_train_fwd') == (mode == 'fused') and rec.ran('vqn_tile_program:prog_fwd') == (mode == 'prog')
+    grads = torch.cat([p.grad.reshape(-1) for m in (sdf, col) for p in m.parameters()])
+    assert torch.isfinite(grads).all()
+    test_training_forward_switch.seen = getattr(test_training_forward_switch, 'seen', {})
+    test_training_forward_switch.seen[mode] = grads
+    if len(test_training_forward_switch.seen) == 2:
+        a, b = test_training_forward_switch.seen['prog'], test_training_forward_switch.seen['fused']
+        assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max())
 
 
 def test_empty_and_degenerate_inputs():

@@ -328,6 +328,33 @@ def neus_fine_points(sdf_desc, wbuf_sdf, col_desc, wbuf_col, rays_o=None, rays_d
     return sdf, grad, rgb
 
 
+def neus_train_fwd(sdf_desc, wbuf_sdf, col_desc, wbuf_col, pts, dirs, saved, e_tiles, outf_tiles, extr_tiles, out_sdf, out_n, out_rgb):
+    """Training forward of the NeuS core at explicit (pts, dirs): the two-image fine kernel, which also leaves the tensors the backward
+    tile programs read (`saved`: [E, OUTF, EXTR, U_1.., GH_0.., C_1..], tile format).  Fills out_sdf [P,1], out_n [P,3], out_rgb [P,3]."""
+    _f32c(wbuf_sdf, 'wbuf_sdf'); _f32c(wbuf_col, 'wbuf_col'); _f32c(pts, 'pts'); _f32c(dirs, 'dirs')
+    for t in saved + [out_sdf, out_n, out_rgb]:
+        _f32c(t, 'saved tensor')
+    sd, sdp = _i32(sdf_desc)
+    cd, cdp = _i32(col_desc)
+    P, dev = pts.shape[0], pts.device
+    L = lib()
+    L.vqn_neus_fine_scratch_bytes.restype = ctypes.c_int64
+    need = int(L.vqn_neus_fine_scratch_bytes(sdp))
+    if need <= 0:
+        raise VqnError('vqn_neus_fine_scratch_bytes: invalid SDF descriptor')
+    key = (str(dev), torch.cuda.current_stream().cuda_stream)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty((need,), dtype=torch.uint8, device=dev)
+        _scratch[key] = buf
+    ptrs = (ctypes.c_void_p * len(saved))(*[t.data_ptr() for t in saved])
+    with _clock('vqn_neus_train_fwd'):
+        rc = L.vqn_neus_train_fwd(sdp, _ptr(wbuf_sdf), cdp, _ptr(wbuf_col), _ptr(pts), _ptr(dirs), ctypes.c_int64(P), _ptr(buf),
+                                  ctypes.c_int64(buf.numel()), ptrs, ctypes.c_int(len(saved)), ctypes.c_int(e_tiles),
+                                  ctypes.c_int(outf_tiles), ctypes.c_int(extr_tiles), _ptr(out_sdf), _ptr(out_n), _ptr(out_rgb), _stream())
+    _check(rc, 'vqn_neus_train_fwd')
+
+
 # --------------------------------------------------------------------------------------
 # per-ray NeuS kernels (csrc/neus_rays.hip)
 def neus_upsample(rays_o, rays_d, z, sdf, r_limit, inv_s, u):

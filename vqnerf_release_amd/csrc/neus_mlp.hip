@@ -396,13 +396,31 @@ __device__ __forceinline__ void wte_split_k(f32x4* __restrict__ lds, const int I
   __syncthreads();
 }
 
-template <bool FINE>
+// ---- training forward (TRAIN): the two-image fine kernel also leaves what the backward tile programs and the weight-gradient
+// contraction read (geo/train_programs.py, prog_fwd's stores) in the tile format of csrc/tile_vm.hip, [point tile][feature tile][32
+// features][32 points] f32: E (embedding), U_1..U_nL (hidden activations), OUTF ([sdf ; features], 257 rows), GH_0..GH_{nL-1} (adjoints of
+// the reverse sweep), EXTR (colour-net extras), C_1..C_nC (colour activations).  A row quad of the activation image -- lane (p, h), component
+// j = feature 2 (4 rq + j) + h of the tile -- goes out as four 256-byte stores (feature rows 8 rq + 2 j and 8 rq + 2 j + 1 are adjacent).
+struct TrainOut {
+  float* E; float* OUTF; float* EXTR;
+  float* U[VQN_MAX_SDF_LAYERS]; float* GH[VQN_MAX_SDF_LAYERS]; float* C[VQN_MAX_COL_LAYERS];
+  int e_tiles, outf_tiles, extr_tiles;
+};
+
+__device__ __forceinline__ void tfmt_store_quad(float* __restrict__ T, const long ptile, const int n_ft, const int ft, const int rq,
+                                                const int lane, const f32x4 v) {
+  float* base = T + ((ptile * n_ft + ft) * 32 + 8 * rq) * 32 + lane;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(v[j], base + 64 * j);     // written once, read by later launches: past the L2-resident packs
+}
+
+template <bool FINE, bool TRAIN = false>
 __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
     const SdfDesc sd, const ColDesc cd, const f32x4* __restrict__ wsdf, const f32x4* __restrict__ wcol,
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ zv,
     const float* __restrict__ pts_direct, const float* __restrict__ dirs_direct, const long P, const int S,
     f32x4* __restrict__ scratch, float* __restrict__ out_sdf, float* __restrict__ out_grad,
-    float* __restrict__ out_rgb) {
+    float* __restrict__ out_rgb, const TrainOut to) {
   extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
   const int MT = sd.max_tiles;
   const int IMG = E_ROWS + 8 * MT, IS = IMG * 64;
@@ -454,14 +472,16 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
     }
     __syncthreads();
     const float xs = sm->pts[img][p * 3 + 0] * sd.scale, ys = sm->pts[img][p * 3 + 1] * sd.scale, zs = sm->pts[img][p * 3 + 2] * sd.scale;
-    for (int r = w4; r < sd.emb_rows; r += 4) {
+    const long ptile_w = 2 * pair + img;                   // (TRAIN) the point tile of this wave's image; stores are skipped for a phantom tile
+    for (int r = w4; r < (TRAIN ? 4 * to.e_tiles : sd.emb_rows); r += 4) {
       f32x4 v;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int f = row_feat(r, h, j);
-        v[j] = f < sd.emb_feats ? posenc_feat(f, xs, ys, zs) : 0.f;
+        v[j] = (r < sd.emb_rows && f < sd.emb_feats) ? posenc_feat(f, xs, ys, zs) : 0.f;
       }
-      ldsi[(E0 + r) * 64 + lane] = v;
+      if (r < sd.emb_rows) ldsi[(E0 + r) * 64 + lane] = v;
+      if (TRAIN && ptile_w < n_tiles) tfmt_store_quad(to.E, ptile_w, to.e_tiles, r >> 2, r & 3, lane, v);
     }
     __syncthreads();
 
@@ -483,6 +503,7 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
       const int dst = (l == 0) ? X0 : oth;
       const bool do_save = FINE && (l < n_lin - 2);
       const f32x4* bp = wsdf + L.b_off;
+      float* const t_u = TRAIN ? to.U[l + 1] : nullptr;          // (one scalar load per layer: no dynamic index inside the epilogue)
       auto bias_init = [&](int ot, int im, f32x16& acc) { if (im == 0) { FS(2) } init_bias(bp, ot, lane, acc); };
       auto epi_rq = [&](int ot, int im, int rq, const f32x16& acc) {
         if (im == 0 && rq == 0) { FS(1) }
@@ -493,6 +514,7 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
         for (int j = 0; j < 4; ++j) v[j] = act_fwd<ACT_SOFTPLUS100>(v[j]);
         li[(dst + ot * 4 + rq) * 64 + lane] = v;
         if (do_save) st_stream(sv + (ot * 4 + rq) * 64 + lane, v);
+        if (TRAIN && 2 * pair + im < n_tiles) tfmt_store_quad(t_u, 2 * pair + im, L.n_out_tiles, ot, rq, lane, v);
       };
       gemm_tiles2<8>(lds, IS, ks, wsdf + L.w_off, L.n_out_tiles, wave, lane, pre, true, next_wp, bias_init, epi_rq);
       FS(2)
@@ -511,7 +533,16 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
                      [&](int ot, int, f32x16& acc) { init_bias(bp, ot, lane, acc); },
                      [&](int ot, int im, int rq, const f32x16& acc) {
                        f32x4* sv = save0 + (size_t)im * per_img + (size_t)feat_slot * 64;
-                       st_stream(sv + (ot * 4 + rq) * 64 + lane, (f32x4){acc[4 * rq], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]});
+                       const f32x4 v = {acc[4 * rq], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]};
+                       st_stream(sv + (ot * 4 + rq) * 64 + lane, v);
+                       if (TRAIN && 2 * pair + im < n_tiles) {              // OUTF = [sdf ; features]: feature f of this GEMM is row f + 1
+                         float* base = to.OUTF + (2 * pair + im) * (long)to.outf_tiles * 1024;
+#pragma unroll
+                         for (int j = 0; j < 4; ++j) {
+                           const int f = 32 * ot + 2 * (4 * rq + j) + h + 1;
+                           if (f < 32 * to.outf_tiles) __builtin_nontemporal_store(v[j], base + f * 32 + p);
+                         }
+                       }
                      });
     }
     __syncthreads();
@@ -523,11 +554,18 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
         const float s = ((pr[t] + pr[32 + t]) + (pr[64 + t] + pr[96 + t])) + (sd.last_b_off > 0 ? wsdf[sd.last_b_off][0] : sd.last_bias);
         out_sdf[pt] = s / sd.scale;
       }
+      if (TRAIN && 2 * pair + im < n_tiles) {                        // row 0 of OUTF (the raw sdf output) and the zero tail beyond row F - 1
+        float* base = to.OUTF + (2 * pair + im) * (long)to.outf_tiles * 1024;
+        const float* pr = sm->part[im];
+        base[t] = ((pr[t] + pr[32 + t]) + (pr[64 + t] + pr[96 + t])) + (sd.last_b_off > 0 ? wsdf[sd.last_b_off][0] : sd.last_bias);
+        for (int f = 32 * sd.layers[n_lin - 1].n_out_tiles + 1; f < 32 * to.outf_tiles; ++f) base[f * 32 + t] = 0.f;
+      }
     }
     if (!FINE) { __syncthreads(); FS(4) continue; }
     FS(4)
 
     // ---------------- reverse sweep: d sdf / d x ----------------
+    float* const t_gh_top = TRAIN ? to.GH[n_lin - 2] : nullptr;
     for (int r0 = w4; r0 < hid_rows; r0 += 32) {
       f32x4 v[8], wv[8];
 #pragma unroll
@@ -542,6 +580,8 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[c][j] = wv[c][j] * act_bwd_from_out<ACT_SOFTPLUS100>(v[c][j]);
           ldsi[(cur + r0 + 4 * c) * 64 + lane] = v[c];
+          if (TRAIN && ptile_w < n_tiles)
+            tfmt_store_quad(t_gh_top, ptile_w, sd.layers[n_lin - 2].n_out_tiles, (r0 + 4 * c) >> 2, (r0 + 4 * c) & 3, lane, v[c]);
         }
     }
     __syncthreads();
@@ -553,6 +593,8 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
       if (l == sd.skip)                                 // embedding part of the skip layer first: `oth` is still free for the partials
         wte_split_k(lds, IS, cur, 4 * L.n_out_tiles, wsdf + L.wTE_off, emb_tiles, oth, 4 * MT, E0, false, wave, lane);
       f32x4 hv[2][4];
+      float* const t_gh = TRAIN ? to.GH[l - 1] : nullptr;
+      const int gh_tiles = sd.layers[l - 1].n_out_tiles;
       gemm_tiles2<8>(lds, IS, ks, wsdf + L.wT_off, sd.layers[l - 1].n_out_tiles, wave, lane, nopre, false, nullptr,
                      [&](int ot, int im, f32x16& acc) {
                        if (im == 0) { FS(7) }
@@ -568,6 +610,7 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
 #pragma unroll
                        for (int j = 0; j < 4; ++j) v[j] *= act_bwd_from_out<ACT_SOFTPLUS100>(hv[im][rq][j]);
                        li[(dst + ot * 4 + rq) * 64 + lane] = v;
+                       if (TRAIN && 2 * pair + im < n_tiles) tfmt_store_quad(t_gh, 2 * pair + im, gh_tiles, ot, rq, lane, v);
                      });
       FS(7)
       __syncthreads();
@@ -603,18 +646,20 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
     {
       const float px = sm->pts[img][p * 3 + 0], py = sm->pts[img][p * 3 + 1], pz = sm->pts[img][p * 3 + 2];
       const float dx = sm->dirs[img][p * 3 + 0], dy = sm->dirs[img][p * 3 + 1], dz = sm->dirs[img][p * 3 + 2];
-      for (int r = w4; r < cd.extra_rows; r += 4) {
+      for (int r = w4; r < (TRAIN ? 4 * to.extr_tiles : cd.extra_rows); r += 4) {
         f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int f = row_feat(r, h, j);
           float val = 0.f;
-          if (f < 3) val = f == 0 ? px : (f == 1 ? py : pz);
+          if (r >= cd.extra_rows) val = 0.f;
+          else if (f < 3) val = f == 0 ? px : (f == 1 ? py : pz);
           else if (f < 3 + cd.n_view_feats) val = posenc_feat(f - 3, dx, dy, dz);
           else if (f < cd.extra_feats) val = sm->grad[img][p * 3 + (f - 3 - cd.n_view_feats)];
           v[j] = val;
         }
-        ldsi[(E0 + r) * 64 + lane] = v;
+        if (r < cd.extra_rows) ldsi[(E0 + r) * 64 + lane] = v;
+        if (TRAIN && ptile_w < n_tiles) tfmt_store_quad(to.EXTR, ptile_w, to.extr_tiles, r >> 2, r & 3, lane, v);
       }
       const f32x4* sv = save0 + (size_t)img * per_img + (size_t)feat_slot * 64;
       const int feat_rows = 4 * sd.layers[n_lin - 1].n_out_tiles;
@@ -635,6 +680,7 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
         const KSegs ks{cur, in_rows, E0, l == 0 ? cd.extra_rows : 0};
         const f32x4* bp = wcol + L.b_off;
         const int dst = oth;
+        float* const t_c = TRAIN ? to.C[l + 1] : nullptr;
         gemm_tiles2<8>(lds, IS, ks, wcol + L.w_off, L.n_out_tiles, wave, lane, nopre, false, nullptr,
                        [&](int ot, int, f32x16& acc) { init_bias(bp, ot, lane, acc); },
                        [&](int ot, int im, int rq, const f32x16& acc) {
@@ -643,6 +689,7 @@ __global__ __launch_bounds__(512, 1) void neus_points2_kernel(
 #pragma unroll
                          for (int j = 0; j < 4; ++j) v[j] = act_fwd<ACT_RELU>(v[j]);
                          li[(dst + ot * 4 + rq) * 64 + lane] = v;
+                         if (TRAIN && 2 * pair + im < n_tiles) tfmt_store_quad(t_c, 2 * pair + im, L.n_out_tiles, ot, rq, lane, v);
                        });
         __syncthreads();
         const int t = cur; cur = oth; oth = t;
@@ -710,7 +757,7 @@ extern "C" int vqn_neus_sdf_points(const int32_t* sdf_desc, const float* wbuf_sd
     if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;
     hipLaunchKernelGGL(neus_points2_kernel<false>, dim3((unsigned)grid), dim3(512), lds2, (hipStream_t)stream, sd, cd,
                        reinterpret_cast<const f32x4*>(wbuf_sdf), (const f32x4*)nullptr, rays_o, rays_d, z, pts,
-                       (const float*)nullptr, (long)P, S, (f32x4*)nullptr, out_sdf, (float*)nullptr, (float*)nullptr);
+                       (const float*)nullptr, (long)P, S, (f32x4*)nullptr, out_sdf, (float*)nullptr, (float*)nullptr, TrainOut{});
     VQN_LAUNCH_CHECK();
     return VQN_OK;
   }
@@ -723,6 +770,51 @@ extern "C" int vqn_neus_sdf_points(const int32_t* sdf_desc, const float* wbuf_sd
   hipLaunchKernelGGL(neus_points_kernel<false>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, sd, cd,
                      reinterpret_cast<const f32x4*>(wbuf_sdf), (const f32x4*)nullptr, rays_o, rays_d, z, pts,
                      (const float*)nullptr, (long)P, S, (f32x4*)nullptr, out_sdf, (float*)nullptr, (float*)nullptr);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
+
+// Training forward: vqn_neus_fine_points at explicit (pts, dirs) that ALSO writes the saved tensors of the training engine (see
+// TrainOut above).  tensors: device pointers in the order [E, OUTF, EXTR, U_1..U_nL, GH_0..GH_{nL-1}, C_1..C_nC] with nL = n_lin - 1
+// SDF hidden layers and nC = col n_lin - 1 colour hidden layers; each [ceil(P/32)][tiles][32][32] f32 with tiles = ceil(width / 32)
+// (e_tiles / outf_tiles / extr_tiles given, the others from the descriptors).  Needs the two-image form (networks of >= 5 tiles that fit).
+extern "C" int vqn_neus_train_fwd(const int32_t* sdf_desc, const float* wbuf_sdf, const int32_t* col_desc, const float* wbuf_col,
+                                  const float* pts, const float* dirs, int64_t P, void* scratch, int64_t scratch_bytes,
+                                  float* const* tensors, int n_tensors, int e_tiles, int outf_tiles, int extr_tiles, float* out_sdf,
+                                  float* out_n, float* out_rgb, void* stream) {
+  VQN_CHECK_ARG(sdf_desc && wbuf_sdf && col_desc && wbuf_col && pts && dirs && scratch && tensors && out_sdf && out_n && out_rgb, "null pointer");
+  VQN_CHECK_ARG(P >= 1, "P >= 1");
+  SdfDesc sd;
+  ColDesc cd;
+  memcpy(&sd, sdf_desc, sizeof(SdfDesc));
+  memcpy(&cd, col_desc, sizeof(ColDesc));
+  VQN_CHECK_SHAPE(check_sdf_desc(sd) == 0, "invalid SDF network descriptor");
+  VQN_CHECK_SHAPE(cd.n_lin >= 2 && cd.n_lin <= VQN_MAX_COL_LAYERS && cd.d_out == 3 && sd.layers[sd.n_lin - 1].n_out_tiles >= 1, "colour net");
+  VQN_CHECK_SHAPE(use_two_images(sd.max_tiles), "the training forward kernel is the two-image form only");
+  const int nL = sd.n_lin - 1, nC = cd.n_lin - 1;
+  VQN_CHECK_ARG(n_tensors == 3 + 2 * nL + nC, "tensors: [E, OUTF, EXTR, U_1..U_nL, GH_0..GH_{nL-1}, C_1..C_nC]");
+  VQN_CHECK_SHAPE(e_tiles * 4 >= sd.emb_rows && e_tiles <= 2 && extr_tiles * 4 >= cd.extra_rows && extr_tiles <= 2 &&
+                  outf_tiles >= sd.layers[sd.n_lin - 1].n_out_tiles && 32 * outf_tiles >= 32 * sd.layers[sd.n_lin - 1].n_out_tiles + 1, "tile counts");
+  TrainOut to;
+  memset(&to, 0, sizeof(to));
+  for (int i = 0; i < n_tensors; ++i) VQN_CHECK_ARG(tensors[i] != nullptr, "null tensor pointer");
+  to.E = tensors[0]; to.OUTF = tensors[1]; to.EXTR = tensors[2];
+  for (int l = 1; l <= nL; ++l) to.U[l] = tensors[3 + (l - 1)];
+  for (int l = 0; l < nL; ++l) to.GH[l] = tensors[3 + nL + l];
+  for (int l = 1; l <= nC; ++l) to.C[l] = tensors[3 + 2 * nL + (l - 1)];
+  to.e_tiles = e_tiles; to.outf_tiles = outf_tiles; to.extr_tiles = extr_tiles;
+  const long n_tiles = (P + 31) / 32;
+  const int64_t per_wg = (int64_t)(sd.n_lin - 1) * 4 * sd.max_tiles * 1024;
+  const size_t lds2 = lds_bytes2(sd.max_tiles);
+  VQN_HIP(hipFuncSetAttribute((const void*)neus_points2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+  long grid = (long)vqn_num_cus();
+  if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;
+  if ((int64_t)grid * 2 * per_wg > scratch_bytes) grid = (long)(scratch_bytes / (2 * per_wg));
+  VQN_CHECK_ARG(grid >= 1, "scratch too small (see vqn_neus_fine_scratch_bytes)");
+  hipLaunchKernelGGL((neus_points2_kernel<true, true>), dim3((unsigned)grid), dim3(512), lds2, (hipStream_t)stream, sd, cd,
+                     reinterpret_cast<const f32x4*>(wbuf_sdf), reinterpret_cast<const f32x4*>(wbuf_col), (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, pts, dirs, (long)P, 1, reinterpret_cast<f32x4*>(scratch), out_sdf, out_n,
+                     out_rgb, to);
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }
@@ -781,7 +873,7 @@ extern "C" int vqn_neus_fine_points(const int32_t* sdf_desc, const float* wbuf_s
     VQN_CHECK_ARG(grid >= 1, "scratch too small (see vqn_neus_fine_scratch_bytes)");
     hipLaunchKernelGGL(neus_points2_kernel<true>, dim3((unsigned)grid), dim3(512), lds2, (hipStream_t)stream, sd, cd,
                        reinterpret_cast<const f32x4*>(wbuf_sdf), reinterpret_cast<const f32x4*>(wbuf_col), rays_o, rays_d,
-                       z, pts, dirs, (long)P, S, reinterpret_cast<f32x4*>(scratch), out_sdf, out_grad, out_rgb);
+                       z, pts, dirs, (long)P, S, reinterpret_cast<f32x4*>(scratch), out_sdf, out_grad, out_rgb, TrainOut{});
     VQN_LAUNCH_CHECK();
     return VQN_OK;
   }
