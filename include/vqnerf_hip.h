@@ -204,6 +204,18 @@ int vqn_neus_train_fwd(const int32_t* sdf_desc, const float* wbuf_sdf, const int
                        float* const* tensors, int n_tensors, int e_tiles, int outf_tiles, int extr_tiles, float* out_sdf,
                        float* out_n, float* out_rgb, void* stream);
 
+/* Backward of the same path in one launch (colour-network backward, tangent pass and reverse sweep of the SDF network with the
+ * second-order terms of the normals): what loss.backward() does to renderer.py:216-227 under exp_runner.py:153-168, down to the
+ * per-point adjoints the weight-gradient contraction (vqn_wgrad_partials*) sums over points.  desc: int32[76] (feature tiles and
+ * pack offsets, geo/train_programs.py NeusTrainEngine._bwd_static); wbuf: the transposed / forward matrices in A-fragment order.
+ * g_rgb [P,3], rgb [P,3] (the forward's colours when the colour net ends in a sigmoid, else NULL), g_n [P,3] or NULL, g_sdf [P]
+ * or NULL.  saved = [U_1..U_nL, GH_0..GH_{nL-1}, C_1..C_nC] as vqn_neus_train_fwd left them; outs = [DC_0..DC_nC, GOUTF, ED,
+ * UD_1..UD_nL, AB_0..AB_{nL-1}] in the same tile format.  Networks of 5..9 feature tiles. */
+int64_t vqn_neus_train_bwd_scratch_bytes(const int32_t* desc);
+int vqn_neus_train_bwd(const int32_t* desc, const float* wbuf, const float* pts, const float* g_rgb, const float* rgb,
+                       const float* g_n, const float* g_sdf, int64_t P, void* scratch, int64_t scratch_bytes,
+                       const float* const* saved, int n_saved, float* const* outs, int n_outs, void* stream);
+
 /* Split-precision twins of vqn_neus_sdf_points / vqn_neus_fine_points ("fp16 MFMA path"): same arguments, same outputs,
  * every product taken as hi*hi + 2^-11 (hi*lo + lo*hi) over f16 hi/lo operand pairs on v_mfma_f32_32x32x16_f16 with f32
  * accumulation.  Descriptors and packs must be built for it (SdfPackPlan(mode='f16s'), ColPackPlan(matrix_mode='f16s'):

@@ -283,6 +283,7 @@ class NeusTrainEngine:
         self.n_split = n_split
         self._rs_ws = None             # workspace of the fused bias-gradient partial sums
         self._fused_dev = {}           # per device: gather indices + descriptors of the fused forward's packs
+        self._bwd_dev = {}             # per device: gather index + descriptor of the fused backward's pack
         for name, build in (('prog_fwd', self._build_forward), ('prog_cbwd', self._build_colour_backward),
                             ('prog_sbwd', self._build_sdf_backward)):
             prog = build()
@@ -540,6 +541,84 @@ class NeusTrainEngine:
         _C.neus_train_fwd(d_s, flat[gi_s], d_c, flat[gi_c], T['X'], T['DIRS'], saved, self._tiles(self.E), self._tiles(self.F),
                           self._tiles(self.X), T['SDF'], T['N'], T['RGB'])
 
+    # the backward on the two-image engine ---------------------------------------------------------------
+    TB_MAX_L = 12
+
+    def fused_backward(self):
+        """Run colour backward + SDF backward as ONE launch of csrc/neus_train_bwd.hip (vqn_neus_train_bwd) instead of the
+        interpreted prog_cbwd / prog_sbwd (VQN_TRAIN_BWD=prog selects those).  Same tensors out, the kernel's summation order."""
+        if os.environ.get('VQN_TRAIN_BWD', 'fused') != 'fused' or os.environ.get('VQN_NEUS_TILE32') is not None:
+            return False
+        mt = max(self._tiles(w) for w in self.out[:self.nL] + self.cout[:self.nC] + [self.F - 1])
+        return 5 <= mt <= 9 and self.skip != 0 and self.nL >= 2 and self.nC >= 1 and max(self.nL, self.nC) < self.TB_MAX_L
+
+    def _bwd_static(self, device):
+        """Gather index (into the flat source vector of pack()) of the backward kernel's weight pack + its int32 descriptor
+        (csrc/neus_train_bwd.hip: TrainBwdDesc).  Matrices in A-fragment order (geo/packing.py: gemm_index), row-dot images for the
+        two thin ones."""
+        k = str(device)
+        if k in self._bwd_dev:
+            return self._bwd_dev[k]
+        L, nL, nC, M = self._layout(), self.nL, self.nC, self.TB_MAX_L
+        tl = self._tiles
+        emb_rows = packing.emb_rows_for(self.E)
+        chunks, off = [], [0]
+
+        def add(view, idx):
+            """view: int64 array of flat positions shaped like the matrix; idx: gather index into view.flatten() ++ [zero]"""
+            src = np.append(np.ascontiguousarray(view).reshape(-1), L.zero)
+            c = src[idx.reshape(-1)]
+            assert c.size % 4 == 0
+            o4 = off[0] // 4
+            chunks.append(c)
+            off[0] += c.size
+            return o4
+
+        offT, offB, offCB = [0] * M, [0] * M, [0] * M
+        for l in range(nL):                                   # W_l over K = [u_{l-1} (, e at the skip layer)] (the 1/sqrt2 is in the flat vector)
+            if l == 0:
+                segs = [(emb_rows, _ident(self.E))]
+            elif l == self.skip:
+                segs = [(4 * tl(self.out[l - 1]), _ident(self.out[l - 1])), (emb_rows, _ident(self.E, base=self.out[l - 1]))]
+            else:
+                segs = [(4 * tl(self.inn[l]), _ident(self.inn[l]))]
+            offT[l] = add(L['W%d' % l], gemm_index(self.out[l], self.inn[l], segs))
+        for l in range(1, nL):                                # W_l[:, :out_{l-1}]^T
+            view = L['W%d' % l][:, :self.out[l - 1]].T
+            offB[l] = add(view, gemm_index(self.out[l - 1], self.out[l], [(4 * tl(self.out[l]), _ident(self.out[l]))]))
+        nf = self.F - 1
+        offBtop = add(L['W%d' % nL][1:].T, gemm_index(self.inn[nL], nf, [(4 * tl(nf), _ident(nf))]))
+        offWrow = add(L['W%d' % nL][:1], packing.rowdot_index(1, 4 * tl(self.inn[nL]), self.inn[nL]))
+        for l in range(1, nC + 1):                            # Wc_l^T (l = nC: three columns in one K row)
+            rows = 1 if l == nC else 4 * tl(self.cout[l])
+            offCB[l] = add(L['Wc%d' % l].T, gemm_index(self.cin[l], self.cout[l], [(rows, _ident(self.cout[l]))]))
+        offCBfeat = add(L['Wc0'][:, self.X:].T, gemm_index(nf, self.cout[0], [(4 * tl(self.cout[0]), _ident(self.cout[0]))]))
+        offCBnrm = add(L['Wc0'][:, self.X - 3:self.X].T, packing.rowdot_index(3, 4 * tl(self.cout[0]), self.cout[0]))
+        mt = max(tl(w) for w in self.out[:nL] + self.cout[:nC] + [nf])
+        desc = np.zeros(16 + 5 * M, np.int32)
+        desc[0:14] = [nL, nC, self.skip, emb_rows, self.E, tl(self.E), mt, tl(nf), tl(self.F), int(self.squeeze), offBtop, offWrow, offCBfeat,
+                      offCBnrm]
+        desc[14] = np.float32(self.scale).view(np.int32)
+        desc[15] = np.float32(1.0 / self.scale).view(np.int32)
+        for l in range(nL):
+            desc[16 + l] = tl(self.out[l])
+        for l in range(nC):
+            desc[16 + M + l] = tl(self.cout[l])
+        desc[16 + 2 * M:16 + 3 * M] = offT
+        desc[16 + 3 * M:16 + 4 * M] = offB
+        desc[16 + 4 * M:16 + 5 * M] = offCB
+        self._bwd_dev[k] = (torch.from_numpy(np.concatenate(chunks)).to(device), desc)
+        return self._bwd_dev[k]
+
+    def run_fused_backward(self, flat, T, P, g_rgb, g_n, g_sdf):
+        """g_rgb [P,3] (adjoint of the colours AFTER the sigmoid when the colour net has one), g_n [P,3] | None, g_sdf [P] | None."""
+        gidx, desc = self._bwd_static(flat.device)
+        nL, nC = self.nL, self.nC
+        saved = [T['U%d' % (l + 1)] for l in range(nL)] + [T['GH%d' % l] for l in range(nL)] + [T['C%d' % (l + 1)] for l in range(nC)]
+        outs = [T['DC%d' % l] for l in range(nC + 1)] + [T['GOUTF'], T['ED']] + [T['UD%d' % (l + 1)] for l in range(nL)] + \
+            [T['AB%d' % l] for l in range(nL)]
+        _C.neus_train_bwd(desc, flat[gidx], T['X'], g_rgb, T['RGB'] if self.squeeze else None, g_n, g_sdf, saved, outs)
+
     def wgrad(self, A, B, a_rows, b_cols, ws, A2=None, B2=None, rowsum=False):
         """sum_p A[o][p] B[i][p] (+ sum_p A2[o][p] B2[i][p]) -> [a_rows, b_cols] (TFMT tensors [tiles, ft, 32, 32]); the partial
         blocks of the split over points are summed in a fixed order by vqn_reduce_partials (deterministic).
@@ -640,7 +719,7 @@ class NeusCoreFunction(torch.autograd.Function):
                 engine.run_fused_forward(flat, T, P)
             else:
                 engine.run('prog_fwd', descs, wbuf, T, P)
-        ctx.engine, ctx.T, ctx.descs, ctx.wbuf, ctx.P = engine, T, descs, wbuf, P
+        ctx.engine, ctx.T, ctx.descs, ctx.wbuf, ctx.P, ctx.flat = engine, T, descs, wbuf, P, flat
         return T['SDF'], T['N'], T['RGB']
 
     @staticmethod
@@ -649,12 +728,16 @@ class NeusCoreFunction(torch.autograd.Function):
         with torch.no_grad():
             rgb = T['RGB']
             g_rgb = torch.zeros_like(rgb) if g_rgb is None else g_rgb
-            T['DOUT'].copy_(g_rgb * rgb * (1.0 - rgb) if e.squeeze else g_rgb)
-            e.run('prog_cbwd', ctx.descs, ctx.wbuf, T, P)
-            T['V'].copy_(T['GNCOL'] if g_n is None else g_n + T['GNCOL'])
             gs = torch.zeros_like(T['SDF']) if g_sdf is None else g_sdf.reshape(-1, 1).contiguous()
-            T['GS'].copy_(gs)
-            e.run('prog_sbwd', ctx.descs, ctx.wbuf, T, P)
+            if e.fused_backward():
+                e.run_fused_backward(ctx.flat, T, P, g_rgb.contiguous().float(), None if g_n is None else g_n.contiguous().float(),
+                                     None if g_sdf is None else gs.float())
+            else:
+                T['DOUT'].copy_(g_rgb * rgb * (1.0 - rgb) if e.squeeze else g_rgb)
+                e.run('prog_cbwd', ctx.descs, ctx.wbuf, T, P)
+                T['V'].copy_(T['GNCOL'] if g_n is None else g_n + T['GNCOL'])
+                T['GS'].copy_(gs)
+                e.run('prog_sbwd', ctx.descs, ctx.wbuf, T, P)
             dW, db, dWc, dbc = e.weight_grads(T, gs)
-        ctx.T = None
+        ctx.T = ctx.flat = None
         return (None, None, None) + tuple(dW) + tuple(db) + tuple(dWc) + tuple(dbc)
