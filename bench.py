@@ -148,6 +148,8 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     # passes are SDF forwards) over its HIP-event time, against the f32-input MFMA peak ("f32-equivalent" for the bf16x3 contraction)
     kflop = {'vqn_neus_sdf_points': 2.0 * B * S_c * m_sdf, 'vqn_tile_program:prog_fwd': 2.0 * B * S_f * (2 * m_sdf + m_col),
              'vqn_tile_program:prog_sbwd': 2.0 * B * S_f * 2 * m_sdf, 'vqn_tile_program:prog_cbwd': 2.0 * B * S_f * m_col,
+             # (round 3: the full-size networks run the forward / backward on the two-image engine instead of the interpreted programs)
+             'vqn_neus_train_fwd': 2.0 * B * S_f * (2 * m_sdf + m_col), 'vqn_neus_train_bwd': 2.0 * B * S_f * (2 * m_sdf + m_col),
              'vqn_wgrad_partials': 2.0 * B * S_f * (2 * m_sdf + m_col), 'vqn_wgrad_partials_x3': 2.0 * B * S_f * (2 * m_sdf + m_col)}
     kfrac = {k: {'ms': clk[k][1] / 6, 'tflops': kflop[k] / (clk[k][1] / 6 * 1e-3) / 1e12,
                  'frac_of_f32_mfma_peak': kflop[k] / (clk[k][1] / 6 * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS} for k in kflop if k in clk}
@@ -155,9 +157,10 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
                         'achieved_tflops': flop / dt / 1e12, 'frac_of_f32_mfma_peak': flop / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
                         'kernel_ms_per_step': {k: v[1] / 6 for k, v in sorted(clk.items())}, 'kernel_roofline': kfrac,
                         'device_ms_outside_listed_kernels': dt * 1e3 - sum(v[1] / 6 for v in clk.values()),
-                        'note': 'all HIP: up-sampling kernels, forward / backward tile programs (second-order eikonal term via '
-                                'a tangent pass), weight-gradient contraction, compositing fwd/bwd; torch only for Adam, the '
-                                'weight-norm chain rule and small reductions'}
+                        'note': 'all HIP: up-sampling kernels, forward (vqn_neus_train_fwd) and backward (vqn_neus_train_bwd: colour '
+                                'backward + tangent pass + reverse sweep, second-order eikonal term included) on the two-image engine, '
+                                'weight-gradient contraction, compositing fwd/bwd; torch only for Adam, the weight-norm chain rule and '
+                                'small reductions'}
     # the same step with the weight-gradient contraction on the f32-input MFMA (round 2's default; VQN_WGRAD=f32).  The default since
     # round 3 is the exact three-way bf16 split (csrc/wgrad_x3.hip: six bf16 MFMAs per product down to 2^-24), which passes the
     # reference-gradient goldens at the same 5e-3 bound.

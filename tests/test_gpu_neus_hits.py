@@ -141,7 +141,7 @@ def test_hits_training_grads_vs_reference(hits, wgrad):
         tgt = torch.tensor(np.random.default_rng(4).uniform(0, 1, (64, 3)).astype(np.float32)).cuda()
         loss = (rr['color_fine'] - tgt).abs().sum() / 64 + 0.1 * rr['gradient_error']
         loss.backward()
-    assert ren.last_train_backend == 'hip' and rec.ran('vqn_tile_program:prog_sbwd') and rec.ran('vqn_wgrad_partials')
+    assert ren.last_train_backend == 'hip' and (rec.ran('vqn_tile_program:prog_sbwd') or rec.ran('vqn_neus_train_bwd')) and rec.ran('vqn_wgrad_partials')
     assert rec.ran('vqn_wgrad_partials_x3') == (wgrad == 'bf16x3')
     np.testing.assert_allclose(loss.item(), float(g['bwd_loss']), rtol=2e-4)
     worst = 0.0

@@ -68,7 +68,7 @@ def test_geo_runner_graph_replays_the_eager_step(tmp_path):
             for b in batches:
                 losses.append(r.train_step(b)['loss'].clone())
         assert (r._cap is not None) == graph and r.iter_step == 8
-        assert rec.ran('vqn_tile_program:prog_sbwd') and rec.ran('vqn_wgrad_partials')
+        assert (rec.ran('vqn_tile_program:prog_sbwd') or rec.ran('vqn_neus_train_bwd')) and rec.ran('vqn_wgrad_partials')
         runs[graph] = ([float(x) for x in losses], [p.detach().clone() for p in r.bucket.params],
                        float(r.optimizer.param_groups[0]['lr']))
     (l0, w0, lr0), (l1, w1, lr1) = runs[False], runs[True]
@@ -391,7 +391,7 @@ def test_hip_training_programs_match_torch_autograd(name, B):
         # 'hip' must be the tile-program engine, not a silent fall-back to the autograd statement it is compared with
         assert ren.last_train_backend == backend
         hip = backend == 'hip'
-        assert (rec.ran('vqn_tile_program:prog_fwd') or rec.ran('vqn_neus_train_fwd')) == hip and rec.ran('vqn_tile_program:prog_sbwd') == hip
+        assert (rec.ran('vqn_tile_program:prog_fwd') or rec.ran('vqn_neus_train_fwd')) == hip and (rec.ran('vqn_tile_program:prog_sbwd') or rec.ran('vqn_neus_train_bwd')) == hip
         assert rec.ran('vqn_wgrad_partials') == hip and rec.ran('vqn_neus_composite_bwd') == hip
         res[backend] = (loss.item(), {f'{nm}.{k}': p.grad.detach().clone() for nm, m in (('sdf', sdf), ('col', col), ('var', var))
                                       for k, p in m.named_parameters()},
@@ -460,12 +460,71 @@ def test_training_forward_on_the_render_kernel_matches_the_interpreted_program(P
         assert torch.isfinite(Tb[n][:nt - 1]).all(), n
 
 
+@pytest.mark.parametrize('P', [1, 33, 4096 + 17, 40000])
+def test_training_backward_on_the_two_image_engine_matches_the_interpreted_programs(P):
+    """vqn_neus_train_bwd (colour backward + tangent pass + reverse sweep in one launch) against the interpreted prog_cbwd +
+    prog_sbwd of the same engine, full-size networks, same saved tensors and incoming adjoints: every tensor the weight-gradient
+    contraction reads, padding rows and points past P included (zeros on both sides), to f32 summation-order differences."""
+    from tests.test_gpu_neus_render import _build
+    cfg, sdf, col, var, ren = _build('full')
+    eng = ren._train_engine(sdf, col)
+    assert eng is not None and eng.fused_backward()
+    dev = torch.device('cuda')
+    g = torch.Generator(device='cuda').manual_seed(P)
+    x = torch.rand(P, 3, device=dev, generator=g) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(P, 3, device=dev, generator=g), dim=-1)
+    g_rgb, g_n, g_sdf = (torch.randn(P, k, device=dev, generator=g) for k in (3, 3, 1))
+    sl = [getattr(sdf, 'lin%d' % l) for l in range(sdf.num_layers - 1)]
+    cl = [getattr(col, 'lin%d' % l) for l in range(col.num_layers - 1)]
+    outs = ['DC%d' % l for l in range(eng.nC + 1)] + ['GOUTF', 'ED'] + ['UD%d' % (l + 1) for l in range(eng.nL)] + \
+        ['AB%d' % l for l in range(eng.nL)]
+    with torch.no_grad():
+        wbuf, descs, flat = eng.pack([m.effective_weight().float() for m in sl], [m.bias.float() for m in sl],
+                                     [m.effective_weight().float() for m in cl], [m.bias.float() for m in cl], want_flat=True)
+        Ta, Tb = eng.alloc_tensors(P, dev), eng.alloc_tensors(P, dev)
+        for T in (Ta, Tb):
+            T['X'].copy_(x)
+            T['DIRS'].copy_(d)
+            eng.run_fused_forward(flat, T, P)
+            for n in outs:
+                T[n].fill_(float('nan'))
+        with launches() as rec:
+            Ta['DOUT'].copy_(g_rgb * Ta['RGB'] * (1.0 - Ta['RGB']))
+            eng.run('prog_cbwd', descs, wbuf, Ta, P)
+            Ta['V'].copy_(g_n + Ta['GNCOL'])
+            Ta['GS'].copy_(g_sdf)
+            eng.run('prog_sbwd', descs, wbuf, Ta, P)
+            eng.run_fused_backward(flat, Tb, P, g_rgb, g_n, g_sdf)
+        assert rec.ran('vqn_tile_program:prog_sbwd') and rec.ran('vqn_neus_train_bwd')
+    nt = (P + 31) // 32
+    for n in outs:
+        a, c = Ta[n][:nt], Tb[n][:nt]
+        assert torch.isfinite(c).all(), n
+        wrote = ~torch.isnan(a)                  # (the interpreter leaves the feature rows past a one-row-quad tensor's eight unwritten)
+        assert wrote.float().mean() > 0.2, n
+        a, c = a[wrote], c[wrote]
+        scale = max(float(a.abs().max()), 1e-6)
+        assert float((a - c).abs().max()) <= 5e-6 * scale, (n, float((a - c).abs().max()), scale)
+    # no incoming adjoint for the normals / the sdf (None in autograd): the same as zeros
+    with torch.no_grad():
+        Tc = eng.alloc_tensors(P, dev)
+        Tc['X'].copy_(x)
+        Tc['DIRS'].copy_(d)
+        eng.run_fused_forward(flat, Tc, P)
+        eng.run_fused_backward(flat, Tb, P, g_rgb, torch.zeros_like(g_n), torch.zeros_like(g_sdf))
+        eng.run_fused_backward(flat, Tc, P, g_rgb, None, None)
+    for n in outs:
+        assert torch.equal(Tb[n][:nt], Tc[n][:nt]), n
+
+
 @pytest.mark.parametrize('mode', ['prog', 'fused'])
 def test_training_forward_switch(mode, monkeypatch):
-    """VQN_TRAIN_FWD selects the forward of the training engine; both reach the same gradients (to f32 rounding)."""
+    """VQN_TRAIN_FWD / VQN_TRAIN_BWD select the forward / backward of the training engine (the two-image kernels or the interpreted
+    programs); both reach the same gradients (to f32 rounding)."""
     from oracle import geo as og
     from tests.test_gpu_neus_render import _build
     monkeypatch.setenv('VQN_TRAIN_FWD', mode)
+    monkeypatch.setenv('VQN_TRAIN_BWD', mode)
     cfg, sdf, col, var, ren = _build('full')
     B = 24
     o, d, near, far = [torch.tensor(a).cuda() for a in og.make_rays(B, 5)]
@@ -473,6 +532,7 @@ def test_training_forward_switch(mode, monkeypatch):
         rr = ren.render(o, d, near, far, 2.0, perturb_overwrite=0, background_rgb=torch.ones(1, 3).cuda(), cos_anneal_ratio=1.0)
         (rr['color_fine'].sum() + rr['gradient_error']).backward()
     assert rec.ran('vqn_neus_train_fwd') == (mode == 'fused') and rec.ran('vqn_tile_program:prog_fwd') == (mode == 'prog')
+    assert rec.ran('vqn_neus_train_bwd') == (mode == 'fused') and rec.ran('vqn_tile_program:prog_sbwd') == (mode == 'prog')
     grads = torch.cat([p.grad.reshape(-1) for m in (sdf, col) for p in m.parameters()])
     assert torch.isfinite(grads).all()
     test_training_forward_switch.seen = getattr(test_training_forward_switch, 'seen', {})

@@ -89,9 +89,32 @@ __global__ __launch_bounds__(512, 1) void neus_train_bwd2_kernel(const TrainBwdD
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 nopre[4];
 
+  // Epilogue operands (saved activations from HBM, second-order sources from the stash) of a wave's tile, both images.  Every GEMM
+  // here has at most eight output tiles: a wave owns tile `wave` or none.  A row quad of the NEXT GEMM's operands is requested into
+  // the same registers right after the current epilogue has used them, so the HBM round trip runs under the rest of the epilogue,
+  // the barrier and the weight prologue (vmcnt retires in order: a request made at a GEMM's own start would hold up its first
+  // weight wait for the whole HBM latency) at no cost in registers.
+  struct Aux { const float* a; const float* b; const f32x4* s; int tiles; };
+  f32x4 ca[2][4], cb[2][4];
+
   for (long pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
     const long ptile_w = 2 * pair + img;
     const bool live_w = ptile_w < n_tiles;
+    auto fetch_q = [&](const Aux& x, int im, int rq) {
+      if (wave >= x.tiles) return;
+      const bool live = 2 * pair + im < n_tiles;
+      ca[im][rq] = (x.a != nullptr && live) ? tf_load(x.a, 2 * pair + im, x.tiles, wave, rq, lane) : zero4;
+      if (x.b != nullptr) cb[im][rq] = live ? tf_load(x.b, 2 * pair + im, x.tiles, wave, rq, lane) : zero4;
+      else if (x.s != nullptr) cb[im][rq] = ld_stream(x.s + (size_t)im * per_img + (wave * 4 + rq) * 64 + lane);
+    };
+    auto fetch = [&](const Aux& x) {
+#pragma unroll
+      for (int im = 0; im < 2; ++im) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) fetch_q(x, im, rq);
+      }
+    };
+    fetch(Aux{tp.C[nC], nullptr, nullptr, bd.tc[nC - 1]});
     // ---------------- points and incoming adjoints of both tiles (zero for points past P: everything below is linear in them) -----------
     if (tid < 64) {
       const int im = tid >> 5, t = tid & 31;
@@ -130,24 +153,20 @@ __global__ __launch_bounds__(512, 1) void neus_train_bwd2_kernel(const TrainBwdD
       const KSegs ks = (l == nC) ? KSegs{E0, 1, 0, 0} : KSegs{cur, 4 * bd.tc[l], 0, 0};
       const int dst = (l == nC) ? X0 : oth;
       const int n_ot = bd.tc[l - 1];
-      const float* const t_c = tp.C[l];
       float* const t_dc = tp.DC[l - 1];
-      f32x4 hc[2][4];
+      const Aux nxt = (l > 1) ? Aux{tp.C[l - 1], nullptr, nullptr, bd.tc[l - 2]} : Aux{tp.U[1], tp.GH[0], nullptr, bd.ts[0]};
       gemm_tiles2<8>(lds, IS, ks, wb + bd.offCB[l], n_ot, wave, lane, nopre, false, nullptr,
-                     [&](int ot, int im, f32x16& acc) {
-                       const bool live = 2 * pair + im < n_tiles;
-#pragma unroll
-                       for (int rq = 0; rq < 4; ++rq) hc[im][rq] = live ? tf_load(t_c, 2 * pair + im, n_ot, ot, rq, lane) : zero4;
-                       init_zero(acc);
-                     },
+                     [&](int, int, f32x16& acc) { init_zero(acc); },
                      [&](int ot, int im, int rq, const f32x16& acc) {
                        f32x4* li = lds + (size_t)im * IS;
                        f32x4 v = {acc[4 * rq], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]};
 #pragma unroll
-                       for (int j = 0; j < 4; ++j) v[j] *= act_bwd_from_out<ACT_RELU>(hc[im][rq][j]);
+                       for (int j = 0; j < 4; ++j) v[j] *= act_bwd_from_out<ACT_RELU>(ca[im][rq][j]);
+                       fetch_q(nxt, im, rq);
                        li[(dst + ot * 4 + rq) * 64 + lane] = v;
                        if (2 * pair + im < n_tiles) tf_store(t_dc, 2 * pair + im, n_ot, ot, rq, lane, v);
                      });
+      if (wave >= n_ot) fetch(nxt);                        // (a wave without a tile in this GEMM may own one in the next)
       __syncthreads();
       if (l == nC) { cur = X0; oth = Y0; } else { const int t = cur; cur = oth; oth = t; }
     }
@@ -214,20 +233,13 @@ __global__ __launch_bounds__(512, 1) void neus_train_bwd2_kernel(const TrainBwdD
       const KSegs ks = (l == 0) ? KSegs{E0, bd.emb_rows, 0, 0} : KSegs{cur, 4 * bd.ts[l - 1], E0, (l == bd.skip) ? bd.emb_rows : 0};
       const int dst = (l == 0) ? X0 : oth;
       const int n_ot = bd.ts[l];
-      const float* const t_u = tp.U[l + 1];
-      const float* const t_gh = tp.GH[l];
       float* const t_ud = tp.UD[l + 1];
-      f32x4 hu[2][4], hg[2][4];
+      // next: the following tangent layer, or the top of the reverse sweep (u_L and S_{L-1}: this very GEMM's stash stores when
+      // l = nL - 1 -- same wave, same addresses, issued after them)
+      const Aux nxt = (l + 1 < nL) ? Aux{tp.U[l + 2], tp.GH[l + 1], nullptr, bd.ts[l + 1]}
+                                   : Aux{tp.U[nL], nullptr, save0 + (size_t)(nL - 1) * 4 * MT * 64, bd.ts[nL - 1]};
       gemm_tiles2<8>(lds, IS, ks, wb + bd.offT[l], n_ot, wave, lane, nopre, false, nullptr,
-                     [&](int ot, int im, f32x16& acc) {
-                       const bool live = 2 * pair + im < n_tiles;
-#pragma unroll
-                       for (int rq = 0; rq < 4; ++rq) {
-                         hu[im][rq] = live ? tf_load(t_u, 2 * pair + im, n_ot, ot, rq, lane) : zero4;
-                         hg[im][rq] = live ? tf_load(t_gh, 2 * pair + im, n_ot, ot, rq, lane) : zero4;
-                       }
-                       init_zero(acc);
-                     },
+                     [&](int, int, f32x16& acc) { init_zero(acc); },
                      [&](int ot, int im, int rq, const f32x16& acc) {
                        f32x4* li = lds + (size_t)im * IS;
                        f32x4* sv = save0 + (size_t)im * per_img + (size_t)l * 4 * MT * 64;
@@ -235,14 +247,16 @@ __global__ __launch_bounds__(512, 1) void neus_train_bwd2_kernel(const TrainBwdD
 #pragma unroll
                        for (int j = 0; j < 4; ++j) {
                          const float a = acc[4 * rq + j];
-                         const float e = fast_exp(-100.f * hu[im][rq][j]);           // softplus(beta = 100): s' = 1 - e, s''/s' = 100 e
+                         const float e = fast_exp(-100.f * ca[im][rq][j]);           // softplus(beta = 100): s' = 1 - e, s''/s' = 100 e
                          v[j] = a * (1.f - e);
-                         s[j] = hg[im][rq][j] * a * (100.f * e);
+                         s[j] = cb[im][rq][j] * a * (100.f * e);
                        }
                        li[(dst + ot * 4 + rq) * 64 + lane] = v;
                        st_stream(sv + (ot * 4 + rq) * 64 + lane, s);
+                       fetch_q(nxt, im, rq);                 // (l = nL - 1: reads back the stash quad stored just above -- same wave, in order)
                        if (2 * pair + im < n_tiles) tf_store(t_ud, 2 * pair + im, n_ot, ot, rq, lane, v);
                      });
+      if (wave >= n_ot) fetch(nxt);
       __syncthreads();
       if (l == 0) { cur = X0; oth = Y0; } else { const int t = cur; cur = oth; oth = t; }
     }
@@ -267,19 +281,11 @@ __global__ __launch_bounds__(512, 1) void neus_train_bwd2_kernel(const TrainBwdD
       const KSegs ks = top ? KSegs{oth, 4 * bd.feat_tiles, 0, 0} : KSegs{cur, 4 * bd.ts[l], 0, 0};
       const int dst = top ? cur : oth;
       const int n_ot = bd.ts[l - 1];
-      const float* const t_u = tp.U[l];
       float* const t_ab = tp.AB[l - 1];
       const f32x4* const wrow = wb + bd.offWrow;
-      f32x4 hu[2][4], hs[2][4];
+      const Aux nxt = (l > 1) ? Aux{tp.U[l - 1], nullptr, save0 + (size_t)(l - 2) * 4 * MT * 64, bd.ts[l - 2]} : Aux{nullptr, nullptr, nullptr, 0};
       gemm_tiles2<8>(lds, IS, ks, wb + (top ? bd.offBtop : bd.offB[l]), n_ot, wave, lane, nopre, false, nullptr,
                      [&](int ot, int im, f32x16& acc) {
-                       const bool live = 2 * pair + im < n_tiles;
-                       const f32x4* sv = save0 + (size_t)im * per_img + (size_t)(l - 1) * 4 * MT * 64;
-#pragma unroll
-                       for (int rq = 0; rq < 4; ++rq) {
-                         hu[im][rq] = live ? tf_load(t_u, 2 * pair + im, n_ot, ot, rq, lane) : zero4;
-                         hs[im][rq] = ld_stream(sv + (ot * 4 + rq) * 64 + lane);
-                       }
                        if (top) {
                          const float gs = sm->gs[im][p];
 #pragma unroll
@@ -295,10 +301,12 @@ __global__ __launch_bounds__(512, 1) void neus_train_bwd2_kernel(const TrainBwdD
                        f32x4 v;
 #pragma unroll
                        for (int j = 0; j < 4; ++j)
-                         v[j] = acc[4 * rq + j] * act_bwd_from_out<ACT_SOFTPLUS100>(hu[im][rq][j]) + hs[im][rq][j];
+                         v[j] = acc[4 * rq + j] * act_bwd_from_out<ACT_SOFTPLUS100>(ca[im][rq][j]) + cb[im][rq][j];
+                       fetch_q(nxt, im, rq);
                        li[(dst + ot * 4 + rq) * 64 + lane] = v;
                        if (2 * pair + im < n_tiles) tf_store(t_ab, 2 * pair + im, n_ot, ot, rq, lane, v);
                      });
+      if (wave >= n_ot) fetch(nxt);
       __syncthreads();
       if (!top) { const int t = cur; cur = oth; oth = t; }
     }
@@ -310,7 +318,7 @@ size_t lds_bytes_b(int MT) { return (size_t)2 * (E_ROWS + 8 * MT) * 1024 + sizeo
 int load_desc(const int32_t* desc, TrainBwdDesc& bd) {
   memcpy(&bd, desc, sizeof(TrainBwdDesc));
   if (bd.nL < 2 || bd.nL >= TB_MAX_L || bd.nC < 1 || bd.nC >= TB_MAX_L) return 1;
-  if (bd.max_tiles < 5 || lds_bytes_b(bd.max_tiles) > 160 * 1024) return 2;
+  if (bd.max_tiles < 5 || bd.max_tiles > 8 || lds_bytes_b(bd.max_tiles) > 160 * 1024) return 2;      // (<= 8: a wave owns at most one tile per GEMM)
   if (bd.emb_rows < 1 || bd.emb_rows > E_ROWS || bd.e_tiles * 4 < bd.emb_rows || bd.e_tiles > 2 || bd.emb_feats < 3 || bd.emb_feats > 8 * bd.emb_rows) return 3;
   if (bd.skip == 0 || bd.skip >= bd.nL) return 4;
   if (bd.feat_tiles < 1 || bd.feat_tiles > bd.max_tiles || 32 * bd.outf_tiles < 32 * bd.feat_tiles + 1) return 5;

@@ -550,7 +550,7 @@ class NeusTrainEngine:
         if os.environ.get('VQN_TRAIN_BWD', 'fused') != 'fused' or os.environ.get('VQN_NEUS_TILE32') is not None:
             return False
         mt = max(self._tiles(w) for w in self.out[:self.nL] + self.cout[:self.nC] + [self.F - 1])
-        return 5 <= mt <= 9 and self.skip != 0 and self.nL >= 2 and self.nC >= 1 and max(self.nL, self.nC) < self.TB_MAX_L
+        return 5 <= mt <= 8 and self.skip != 0 and self.nL >= 2 and self.nC >= 1 and max(self.nL, self.nC) < self.TB_MAX_L
 
     def _bwd_static(self, device):
         """Gather index (into the flat source vector of pack()) of the backward kernel's weight pack + its int32 descriptor
