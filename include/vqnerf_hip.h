@@ -431,6 +431,22 @@ int vqn_wgrad_partials_x3(const float* A, int a_tiles, int a_t0, int a_nt, const
  * written into a [rows, cols] window of a matrix with row stride out_ld.  cols, out_ld multiples of 4. */
 int vqn_reduce_partials(const float* ws, int n, int rows, int cols, float* out, int64_t out_ld, int accumulate, void* stream);
 
+/* The same ordered sums for MANY contractions in one launch, each result written where it belongs: entry i sums the n[i] partial
+ * blocks [src_rows[i], src_cols[i]] at ws[i] (and, if ws2[i] != NULL, the n2[i] blocks at ws2[i], added: the first- and second-order
+ * terms of an SDF layer, renderer.py:216-227 under autograd) in vqn_reduce_partials' order (bit-identical), multiplies by scale[i]
+ * and stores element (r < rows_valid[i], col_first[i] <= c < cols_valid[i]) at dst[i][r * dst_row_stride[i] + c * dst_col_stride[i]] -- a slice
+ * of a concatenated matrix, a transposed ([in, out], the layout of the reflectance nets' kernels) one, a bias row.  Replaces the
+ * per-weight reduce / transpose / cat / scale kernel sequences of the training steps (launch-count bound at the reference's
+ * 2048-point batches, trainvali.py:443-486). */
+int vqn_wgrad_finalize(int count, const float* const* ws, const int32_t* n, const float* const* ws2, const int32_t* n2,
+                       const int32_t* src_rows, const int32_t* src_cols, const int32_t* rows_valid, const int32_t* col_first,
+                       const int32_t* cols_valid, float* const* dst, const int64_t* dst_row_stride, const int64_t* dst_col_stride, const float* scale,
+                       void* stream);
+
+/* count contiguous f32 copies dst[i][0..n[i]) = src[i][0..n[i]) in one launch (the per-parameter gradients into the flat
+ * gradient bucket of the data-parallel step, trainvali.py:469-477). */
+int vqn_multi_copy(int count, const float* const* src, float* const* dst, const int64_t* n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -187,6 +187,64 @@ def test_decomp_trainer_trains():
     assert set(ld2) >= {'rgb', 'vqrgb', 'chromaticity'}
 
 
+def test_batched_weight_gradients_are_the_per_weight_sequence_bit_for_bit():
+    """vqn_wgrad_finalize (one launch per backward pass: ordered sums of every contraction's partial blocks, written transposed /
+    sliced / scaled where they belong) against the per-weight sequence it replaces (vqn_reduce_partials + torch transpose / cat /
+    scale): identical gradients, bit for bit, for the reflectance trainer and for the geometry networks."""
+    from oracle import decomp as od
+    from oracle import geo as og
+    from vqnerf_release_amd.geo import train_programs as tp
+    from vqnerf_release_amd.decomp.nerfactor import train_nfr
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    from tests.test_gpu_neus_render import _build
+    old = tp.BATCHED_WGRAD[0]
+    try:
+        res = {}
+        for batched in (False, True):
+            tp.BATCHED_WGRAD[0] = batched
+            p, specs = od.make_model_params(seed=0, K=15)
+            model = load_oracle_params(get_model_class('vq_nfr')(make_config(n_rays_per_step=256)), p, 'cuda')
+            batch = make_batch(od.make_points(300, seed=11), 'cuda')
+            model.get_codebook(); _ = model.light
+            opt = torch.optim.SGD(model.trainable_variables, lr=0.0)
+            tr = train_nfr.Trainer(model, opt)
+            with launches() as rec:
+                tr.train_iter(batch, global_bs=300)
+            assert rec.ran('vqn_wgrad_finalize') == batched and rec.ran('vqn_reduce_partials') == (not batched)
+            g_dec = [v.grad.detach().clone() for v in model.trainable_variables if v.grad is not None]
+            cfg, sdf, col, var, ren = _build('full')
+            o, d, near, far = [torch.tensor(a).cuda() for a in og.make_rays(24, 5)]
+            with launches() as rec:
+                rr = ren.render(o, d, near, far, 2.0, perturb_overwrite=0, background_rgb=torch.ones(1, 3).cuda(), cos_anneal_ratio=1.0)
+                (rr['color_fine'].sum() + rr['gradient_error']).backward()
+            assert rec.ran('vqn_wgrad_finalize') == batched and rec.ran('vqn_reduce_partials') == (not batched)
+            res[batched] = (g_dec, [q.grad.detach().clone() for m in (sdf, col) for q in m.parameters()])
+        for a, b in zip(res[False][0] + res[False][1], res[True][0] + res[True][1]):
+            assert a.shape == b.shape and torch.equal(a, b)
+        assert len(res[True][0]) > 20 and len(res[True][1]) > 20
+    finally:
+        tp.BATCHED_WGRAD[0] = old
+
+
+def test_multi_copy():
+    from vqnerf_release_amd import parallel
+    g = torch.Generator(device='cuda').manual_seed(0)
+    srcs = [torch.randn(n, device='cuda', generator=g) for n in (1, 1023, 1024, 1025, 70000, 3)] + [torch.randn(7, 33, device='cuda', generator=g)]
+    srcs += [torch.randn(5, device='cuda', generator=g) for _ in range(120)]                # more than one table
+    flat = torch.full((sum(s.numel() for s in srcs) + 4,), float('nan'), device='cuda')
+    dsts, o = [], 2
+    for s in srcs:
+        dsts.append(flat[o:o + s.numel()].view_as(s))
+        o += s.numel()
+    with launches() as rec:
+        parallel.multi_copy(dsts, srcs)
+    assert rec.ran('vqn_multi_copy') and rec.counts['vqn_multi_copy'] == 1
+    for d, s in zip(dsts, srcs):
+        assert torch.equal(d, s)
+    assert torch.isnan(flat[:2]).all() and torch.isnan(flat[-2:]).all()
+    parallel.multi_copy([], [])
+
+
 def test_decomp_trainer_graph_with_code_dropout():
     """Trainer(graph=True) with the code-dropout thresholds as a graph input: a code whose threshold is 1 is never assigned
     (its draw in [0, 1) never reaches it), one with threshold 0 always may be; new thresholds take effect at the next replay;

@@ -381,6 +381,24 @@ def neus_train_bwd(desc, wbuf, pts, g_rgb, rgb, g_n, g_sdf, saved, outs):
     _check(rc, 'vqn_neus_train_bwd')
 
 
+def multi_copy(dsts, srcs):
+    """dsts[i].copy_(srcs[i]) for contiguous f32 tensors of equal element counts, all in ONE launch (vqn_multi_copy)."""
+    k = len(dsts)
+    if k == 0:
+        return
+    import numpy as np
+    for d, s in zip(dsts, srcs):
+        _f32c(d, 'dst'); _f32c(s, 'src')
+        if d.numel() != s.numel():
+            raise VqnError('multi_copy: element counts differ')
+    sp = (ctypes.c_void_p * k)(*[t.data_ptr() for t in srcs])
+    dp = (ctypes.c_void_p * k)(*[t.data_ptr() for t in dsts])
+    n = np.array([t.numel() for t in dsts], np.int64)
+    with _clock('vqn_multi_copy'):
+        rc = lib().vqn_multi_copy(ctypes.c_int(k), sp, dp, n.ctypes.data_as(ctypes.c_void_p), _stream())
+    _check(rc, 'vqn_multi_copy')
+
+
 # --------------------------------------------------------------------------------------
 # per-ray NeuS kernels (csrc/neus_rays.hip)
 def neus_upsample(rays_o, rays_d, z, sdf, r_limit, inv_s, u):

@@ -158,7 +158,7 @@ class Trainer:
                     if g is None:
                         v.zero_()
                 if have:
-                    torch._foreach_copy_([v for v, _ in have], [g.reshape(v.shape) for v, g in have])
+                    parallel.multi_copy([v for v, _ in have], [g for _, g in have])
         with torch.no_grad():
             self.bucket.extra[0] = weighted
         extra = self.bucket.all_reduce()

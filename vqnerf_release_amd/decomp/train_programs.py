@@ -13,7 +13,8 @@ import torch
 
 from vqnerf_release_amd import _C
 from vqnerf_release_amd.geo.train_programs import (Program, _ident, _f2i, DESC_INTS, K_LD_POSENC, K_LD_T, EPI_ACT, EPI_MUL_DACT,
-                                                   ACT_NONE, ACT_RELU, ACT_SIGMOID, FlatLayout, build_static_packs, WGRAD_ENTRY, wgrad_mode)
+                                                   ACT_NONE, ACT_RELU, ACT_SIGMOID, FlatLayout, build_static_packs, WGRAD_ENTRY, wgrad_mode,
+                                                   WgradBatch, BATCHED_WGRAD)
 
 ACTS = {None: ACT_NONE, 'relu': ACT_RELU, 'sigmoid': ACT_SIGMOID}
 
@@ -215,16 +216,30 @@ class EncoderEngine(_Engine):
         to_tfmt(delta, self.specs['GZ'][1], out=T['GZ'])
         T['D%d' % top] = T['GZ']
         self.run('prog_bwd', descs, wbuf, T, self.specs, N)
-        ws = torch.empty(min(self.n_split, (N + 31) // 32) * 256 * 256, dtype=torch.float32, device=g_z.device)
-        dW, db = [], []
+        if not BATCHED_WGRAD[0]:
+            ws = torch.empty(min(self.n_split, (N + 31) // 32) * 256 * 256, dtype=torch.float32, device=g_z.device)
+        dW, db, dev = [], [], g_z.device
+        batch = WgradBatch(self.n_split)
         for k, L in enumerate(self.layers):
             D = T['D%d' % k]
             src = T['E'] if k == 0 else T['Y%d' % (k - 1)]
+            if BATCHED_WGRAD[0]:
+                # straight into the Keras layout [in, out] (element (o, i) at i * out + o), the skip input's rows after the y-part's
+                n_in, n_out = L['in_y'] + (self.E if L['skip'] else 0), L['out']
+                G = torch.empty((n_in, n_out), dtype=torch.float32, device=dev)
+                bsum = torch.empty((n_out,), dtype=torch.float32, device=dev)
+                batch.contract(D, src, n_out, L['in_y'], G, 1, n_out, bias_dst=bsum)
+                if L['skip']:
+                    batch.contract(D, T['E'], n_out, self.E, G[L['in_y']:], 1, n_out)
+                dW.append(G)
+                db.append(bsum)
+                continue
             g, bsum = self.wgrad(D, src, L['out'], L['in_y'], ws, rowsum=True)
             if L['skip']:
                 g = torch.cat([g, self.wgrad(D, T['E'], L['out'], self.E, ws)], 1)
             dW.append(g.t().contiguous())                              # Keras layout [in, out]
             db.append(bsum)
+        batch.flush()
         return dW, db
 
 
@@ -340,11 +355,23 @@ class HeadsEngine(_Engine):
             gg = torch.zeros_like(out) if g is None else g
             to_tfmt(gg * out * (1 - out), 1, out=T['D%d_2' % h])
         self.run('prog_bwd', descs, wbuf, T, self.specs, N)
-        ws = torch.empty(min(self.n_split, (N + 31) // 32) * 256 * 256, dtype=torch.float32, device=T['Z'].device)
-        dW, db = [], []
+        if not BATCHED_WGRAD[0]:
+            ws = torch.empty(min(self.n_split, (N + 31) // 32) * 256 * 256, dtype=torch.float32, device=T['Z'].device)
+        dW, db, dev = [], [], T['Z'].device
+        batch = WgradBatch(self.n_split)
         for h, net in enumerate(self.nets):
             w0, w1, c = net.widths
             D0, D1, D2 = T['D%d_0' % h], T['D%d_1' % h], T['D%d_2' % h]
+            if BATCHED_WGRAD[0]:
+                new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+                g0, g1, g2, b0, b1, b2 = new(self.Z, w0), new(w0, w1), new(w1 + self.Z, c), new(w0), new(w1), new(c)
+                batch.contract(D0, T['Z'], w0, self.Z, g0, 1, w0, bias_dst=b0)
+                batch.contract(D1, T['Y%d_0' % h], w1, w0, g1, 1, w1, bias_dst=b1)
+                batch.contract(D2, T['Y%d_1' % h], c, w1, g2, 1, c, bias_dst=b2)
+                batch.contract(D2, T['Z'], c, self.Z, g2[w1:], 1, c)
+                dW += [g0, g1, g2]
+                db += [b0, b1, b2]
+                continue
             g0, b0 = self.wgrad(D0, T['Z'], w0, self.Z, ws, rowsum=True)
             g1, b1 = self.wgrad(D1, T['Y%d_0' % h], w1, w0, ws, rowsum=True)
             g2a, b2 = self.wgrad(D2, T['Y%d_1' % h], c, w1, ws, rowsum=True)
@@ -352,6 +379,7 @@ class HeadsEngine(_Engine):
             g2 = torch.cat([g2a, self.wgrad(D2, T['Z'], c, self.Z, ws)], 1).t().contiguous()
             dW += [g0, g1, g2]
             db += [b0, b1, b2]
+        batch.flush()
         return from_tfmt(T['GZ'], N, self.Z), dW, db
 
 

@@ -232,7 +232,7 @@ class Runner:
                         v.zero_()
                     p.grad = v
                 if have:
-                    torch._foreach_copy_([v for v, _ in have], [g.reshape(v.shape) for v, g in have])      # one launch, not one per parameter
+                    parallel.multi_copy([v for v, _ in have], [g for _, g in have])      # one launch, not one per parameter
         else:
             self.bucket.attach()
             loss, color_loss, eik, mask_loss = loss_terms()

@@ -42,6 +42,80 @@ def wgrad_mode(new=None):
 from vqnerf_release_amd.geo import packing
 from vqnerf_release_amd.geo.packing import gemm_index, bias_index, _take
 
+# one finalize launch per backward pass (WgradBatch) instead of a reduce / transpose / cat / scale sequence per weight; VQN_WGRAD_BATCH=0
+# keeps the per-weight sequence (same sums, bit for bit)
+BATCHED_WGRAD = [os.environ.get('VQN_WGRAD_BATCH', '1') != '0']
+
+
+class WgradBatch:
+    """Deferred weight-gradient contractions of one backward pass.  contract() launches the split-over-points partial-block kernel
+    at once, into a workspace of its own; flush() sums every contraction's blocks (the fixed order of vqn_reduce_partials) and
+    writes each result where it belongs -- a slice of a concatenated matrix, transposed, scaled, two contractions added -- in ONE
+    launch (vqn_wgrad_finalize) instead of a reduce + transpose + cat + scale kernel sequence per weight."""
+
+    def __init__(self, n_split):
+        self.n_split = n_split
+        self.e, self.keep = [], []
+
+    def _partials(self, A, B, at, a0, an, bt, b0, bn, nt, want_rs):
+        dev = A.device
+        n_blocks = min(self.n_split, nt)
+        ws = torch.empty(n_blocks * an * 32 * bn * 32, dtype=torch.float32, device=dev)
+        rs = torch.empty(n_blocks * an * 32, dtype=torch.float32, device=dev) if want_rs else None
+        entry = WGRAD_ENTRY[wgrad_mode()]
+        with _C._clock(entry):
+            n = getattr(_C.lib(), entry)(_C._ptr(A), ctypes.c_int(at), ctypes.c_int(a0), ctypes.c_int(an), _C._ptr(B), ctypes.c_int(bt),
+                                         ctypes.c_int(b0), ctypes.c_int(bn), ctypes.c_int64(nt), ctypes.c_int(self.n_split), _C._ptr(ws),
+                                         _C._ptr(rs), _C._stream())
+        if n <= 0:
+            _C._check(n if n < 0 else -3, 'vqn_wgrad_partials')
+        assert n <= n_blocks
+        self.keep += [ws, rs]
+        return ws, rs, n
+
+    def contract(self, A, B, a_rows, b_cols, dst, sr, sc, bias_dst=None, A2=None, B2=None, scale=1.0, col_first=0):
+        """sum_p A[o][p] B[i][p] (+ sum_p A2[o][p] B2[i][p]), times scale -> element (o, i) at dst.flatten()[o * sr + i * sc] for
+        o < a_rows, col_first <= i < b_cols (dst: a tensor / view whose first element is where (0, 0) goes); bias_dst [a_rows]:
+        also sum_p A[o][p].  A, B: TFMT tensors [point tiles, feature tiles, 32, 32]."""
+        nt, at, bt = A.shape[0], A.shape[1], B.shape[1]
+        a_nt_all, b_nt_all = (a_rows + 31) // 32, (b_cols + 31) // 32
+        for a0 in range(0, a_nt_all, 8):
+            an = min(8, a_nt_all - a0)
+            for b0 in range(0, b_nt_all, 8):
+                bn = min(8, b_nt_all - b0)
+                if col_first >= min(bn * 32, b_cols - b0 * 32) + b0 * 32:
+                    continue
+                want_rs = bias_dst is not None and b0 == 0
+                ws, rs, n = self._partials(A, B, at, a0, an, bt, b0, bn, nt, want_rs)
+                ws2, n2 = None, 0
+                if A2 is not None:
+                    ws2, _, n2 = self._partials(A2, B2, A2.shape[1], a0, an, B2.shape[1], b0, bn, nt, False)
+                self.e.append(dict(ws=ws, n=n, ws2=ws2, n2=n2, src_rows=an * 32, src_cols=bn * 32, rows_valid=min(an * 32, a_rows - a0 * 32),
+                                   col_first=max(0, col_first - b0 * 32), cols_valid=min(bn * 32, b_cols - b0 * 32),
+                                   dst=dst.data_ptr() + 4 * (a0 * 32 * sr + b0 * 32 * sc), sr=sr, sc=sc, scale=scale))
+                if want_rs:
+                    self.e.append(dict(ws=rs, n=n, ws2=None, n2=0, src_rows=1, src_cols=an * 32, rows_valid=1, col_first=0,
+                                       cols_valid=min(an * 32, a_rows - a0 * 32), dst=bias_dst.data_ptr() + 4 * a0 * 32, sr=0, sc=1, scale=1.0))
+        self.keep.append(dst)
+        if bias_dst is not None:
+            self.keep.append(bias_dst)
+
+    def flush(self):
+        e, k = self.e, len(self.e)
+        if k:
+            vp = lambda key: (ctypes.c_void_p * k)(*[(x[key].data_ptr() if torch.is_tensor(x[key]) else (x[key] or 0)) for x in e])
+            i32 = lambda key: np.array([x[key] for x in e], np.int32)
+            i64 = lambda key: np.array([x[key] for x in e], np.int64)
+            arrs = [i32('n'), i32('n2'), i32('src_rows'), i32('src_cols'), i32('rows_valid'), i32('col_first'), i32('cols_valid'),
+                    i64('sr'), i64('sc'), np.array([x['scale'] for x in e], np.float32)]
+            p = [a.ctypes.data_as(ctypes.c_void_p) for a in arrs]
+            with _C._clock('vqn_wgrad_finalize'):
+                rc = _C.lib().vqn_wgrad_finalize(ctypes.c_int(k), vp('ws'), p[0], vp('ws2'), p[1], p[2], p[3], p[4], p[5], p[6], vp('dst'), p[7],
+                                                 p[8], p[9], _C._stream())
+            _C._check(rc, 'vqn_wgrad_finalize')
+        self.e, self.keep = [], []
+
+
 K_LD_POSENC, K_LD_POSENC_JVP, K_LD_T, K_LD_VEC, K_LD_EXTRAS, K_GEMM, K_ST_VEC, K_POSENC_VJP = 1, 2, 3, 4, 5, 6, 7, 8
 EPI_ACT, EPI_MUL_DACT, EPI_TANGENT, EPI_BWD2 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_SIGMOID = 0, 1, 2, 3
@@ -664,9 +738,43 @@ class NeusTrainEngine:
         """dict of gradients w.r.t. the EFFECTIVE weights / biases, from the saved tensors."""
         nL, nC, s2 = self.nL, self.nC, 1.0 / math.sqrt(2.0)
         dev = T['X'].device
-        ws = torch.empty(self.n_split * 256 * 256, dtype=torch.float32, device=dev)
         tsum = lambda t, n: t.sum((0, 3)).reshape(-1)[:n]        # sum over points of a TFMT tensor -> [features]
         dW, db, dWc, dbc = [None] * (nL + 1), [None] * (nL + 1), [None] * (nC + 1), [None] * (nC + 1)
+        uL, udL = T['U%d' % nL], T['UD%d' % nL]
+        nt = uL.shape[0]
+        gs = torch.zeros(nt * 32, dtype=torch.float32, device=dev)
+        gs[:g_sdf.numel()] = g_sdf.reshape(-1) / self.scale
+        if BATCHED_WGRAD[0]:
+            new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+            batch = WgradBatch(self.n_split)
+            for l in range(nL):
+                ab, gh = T['AB%d' % l], T['GH%d' % l]
+                dW[l], db[l] = new(self.out[l], self.inn[l]), new(self.out[l])
+                ld, sc = self.inn[l], (s2 if l == self.skip else 1.0)
+                if l == 0:
+                    batch.contract(ab, T['E'], self.out[0], self.E, dW[0], ld, 1, bias_dst=db[0], A2=gh, B2=T['ED'])
+                else:
+                    pu = self.out[l - 1]
+                    batch.contract(ab, T['U%d' % l], self.out[l], pu, dW[l], ld, 1, bias_dst=db[l], A2=gh, B2=T['UD%d' % l], scale=sc)
+                    if l == self.skip:
+                        batch.contract(ab, T['E'], self.out[l], self.E, dW[l][:, pu:], ld, 1, A2=gh, B2=T['ED'], scale=sc)
+            # final layer: rows 1.. from the feature adjoints (row 0 of the contraction is dropped: set below)
+            dW[nL], db[nL] = new(self.F, self.inn[nL]), new(self.F)
+            batch.contract(T['GOUTF'], uL, self.F, self.out[nL - 1], dW[nL], self.inn[nL], 1, bias_dst=db[nL])
+            # colour net: layer 0's input is [extras ; features], the features' columns come from OUTF = [sdf ; features] without its row 0
+            dWc[0], dbc[0] = new(self.cout[0], self.cin[0]), new(self.cout[0])
+            d0 = T['DC0']
+            batch.contract(d0, T['EXTR'], self.cout[0], self.X, dWc[0], self.cin[0], 1)
+            batch.contract(d0, T['OUTF'], self.cout[0], self.F, dWc[0][:, self.X - 1:], self.cin[0], 1, bias_dst=dbc[0], col_first=1)
+            for l in range(1, nC + 1):
+                dWc[l], dbc[l] = new(self.cout[l], self.cin[l]), new(self.cout[l])
+                batch.contract(T['DC%d' % l], T['C%d' % l], self.cout[l], self.cin[l], dWc[l], self.cin[l], 1, bias_dst=dbc[l])
+            batch.flush()
+            # row 0 of the final layer = (g_sdf/scale) (x) u_L + u'_L ; its bias = sum of g_sdf / scale
+            dW[nL][0] = (uL * gs.view(nt, 1, 1, 32)).sum((0, 3)).reshape(-1)[:self.out[nL - 1]] + tsum(udL, self.out[nL - 1])
+            db[nL][0] = gs.sum()
+            return dW, db, dWc, dbc
+        ws = torch.empty(self.n_split * 256 * 256, dtype=torch.float32, device=dev)
         for l in range(nL):
             ab, gh = T['AB%d' % l], T['GH%d' % l]
             if l == 0:
@@ -680,10 +788,6 @@ class NeusTrainEngine:
             dW[l], db[l] = g, bsum
         # final layer: rows 1.. from the feature adjoints, row 0 = (g_sdf/scale) (x) u_L + u'_L
         gl, bl = self.wgrad(T['GOUTF'], T['U%d' % nL], self.F, self.out[nL - 1], ws, rowsum=True)
-        uL, udL = T['U%d' % nL], T['UD%d' % nL]
-        nt = uL.shape[0]
-        gs = torch.zeros(nt * 32, dtype=torch.float32, device=dev)
-        gs[:g_sdf.numel()] = g_sdf.reshape(-1) / self.scale
         row0 = (uL * gs.view(nt, 1, 1, 32)).sum((0, 3)).reshape(-1)[:self.out[nL - 1]] + tsum(udL, self.out[nL - 1])
         gl = torch.cat([row0[None], gl[1:]], 0)
         bl = bl.clone()
