@@ -127,14 +127,17 @@ def rank():
 
 
 def multi_copy(dsts, srcs):
-    """dsts[i].copy_(srcs[i]): one HIP launch for all of them when they are contiguous f32 device tensors (vqn_multi_copy -- a
-    launch per parameter is ~60 of a captured 2048-point training step's ~420 launches), torch's foreach copy otherwise."""
-    if dsts and all(d.is_cuda and s.is_cuda and d.is_contiguous() and s.is_contiguous() and d.dtype == s.dtype == torch.float32
-                    for d, s in zip(dsts, srcs)):
+    """dsts[i].copy_(srcs[i]): ONE HIP launch for all pairs that are contiguous f32 device tensors (vqn_multi_copy -- a launch per
+    parameter is ~60 of a captured 2048-point training step's ~420 launches), torch's foreach copy for the others (an expanded or
+    transposed gradient)."""
+    fast = [d.is_cuda and s.is_cuda and d.is_contiguous() and s.is_contiguous() and d.dtype == s.dtype == torch.float32 and
+            d.numel() == s.numel() for d, s in zip(dsts, srcs)]
+    if any(fast):
         from vqnerf_release_amd import _C
-        _C.multi_copy(dsts, srcs)
-    elif dsts:
-        torch._foreach_copy_(dsts, [s.reshape(d.shape) for d, s in zip(dsts, srcs)])
+        _C.multi_copy([d for d, f in zip(dsts, fast) if f], [s for s, f in zip(srcs, fast) if f])
+    rest = [(d, s) for d, s, f in zip(dsts, srcs, fast) if not f]
+    if rest:
+        torch._foreach_copy_([d for d, _ in rest], [s.reshape(d.shape) for d, s in rest])
 
 
 class FlatBucket:
