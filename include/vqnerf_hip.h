@@ -427,6 +427,15 @@ int vqn_wgrad_partials(const float* A, int a_tiles, int a_t0, int a_nt, const fl
 int vqn_wgrad_partials_x3(const float* A, int a_tiles, int a_t0, int a_nt, const float* B, int b_tiles, int b_t0, int b_nt,
                           int64_t n_point_tiles, int n_split, float* ws, float* rowsum_ws, void* stream);
 
+/* The contractions of a whole backward pass in as few launches as they have kernel shapes: problem i is vqn_wgrad_partials
+ * (x3 == 0) / vqn_wgrad_partials_x3 (x3 != 0) of (A[i], a_tiles[i], a_t0[i], a_nt[i], B[i], ..., ws[i], rowsum_ws[i]) over the same
+ * n_point_tiles -- the same kernels, hence the same partial blocks bit for bit -- a launch per kernel variant and 24 problems
+ * (the reference's 2048-point steps are bound by their launch count, trainvali.py:443-486).  Returns the number of partial
+ * blocks per problem (>= 1) or a negative error code. */
+int vqn_wgrad_partials_batched(int count, const float* const* A, const int32_t* a_tiles, const int32_t* a_t0, const int32_t* a_nt,
+                               const float* const* B, const int32_t* b_tiles, const int32_t* b_t0, const int32_t* b_nt,
+                               int64_t n_point_tiles, int n_split, float* const* ws, float* const* rowsum_ws, int x3, void* stream);
+
 /* The ordered sum of those partial blocks: out[r][c] (+)= sum_s ws[s][r][c], s = 0 .. n-1 (fixed order: deterministic),
  * written into a [rows, cols] window of a matrix with row stride out_ld.  cols, out_ld multiples of 4. */
 int vqn_reduce_partials(const float* ws, int n, int rows, int cols, float* out, int64_t out_ld, int accumulate, void* stream);

@@ -10,6 +10,7 @@
 // over points does not care about.  Partial blocks go to a workspace [n_split][rows][cols]; the caller reduces them
 // in a fixed order (deterministic, no float atomics).
 #include "common.h"
+#include "wgrad_batch.h"
 
 namespace {
 
@@ -18,9 +19,9 @@ namespace {
 #define VQN_WGRAD_D 2          // operand ring depth of the 256 x 256 form (see the experiments table of DESIGN.md)
 #endif
 template <int NOT, int BT, int D>
-__global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__ A, int a_tiles, int a_t0, int a_nt,
-                                                       const float* __restrict__ B, int b_tiles, int b_t0, int b_nt,
-                                                       long n_ptiles, float* __restrict__ ws, float* __restrict__ rowsum_ws) {
+__device__ __forceinline__ void wgrad_body(const float* __restrict__ A, int a_tiles, int a_t0, int a_nt,
+                                           const float* __restrict__ B, int b_tiles, int b_t0, int b_nt,
+                                           long n_ptiles, float* __restrict__ ws, float* __restrict__ rowsum_ws) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: scalar guards around the MFMA groups
   const int fi = lane & 31, kk = lane >> 5;
@@ -99,6 +100,20 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
   }
 }
 
+template <int NOT, int BT, int D>
+__global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__ A, int a_tiles, int a_t0, int a_nt,
+                                                       const float* __restrict__ B, int b_tiles, int b_t0, int b_nt,
+                                                       long n_ptiles, float* __restrict__ ws, float* __restrict__ rowsum_ws) {
+  wgrad_body<NOT, BT, D>(A, a_tiles, a_t0, a_nt, B, b_tiles, b_t0, b_nt, n_ptiles, ws, rowsum_ws);
+}
+
+// many contractions over the same points in one launch (blockIdx.y: the problem): the reference's 2048-point steps are launch-bound
+template <int NOT, int BT, int D>
+__global__ __launch_bounds__(256, 1) void wgrad_batched_kernel(const WgTable tab, long n_ptiles) {
+  const WgProblem& P = tab.p[blockIdx.y];
+  wgrad_body<NOT, BT, D>(P.A, P.a_tiles, P.a_t0, P.a_nt, P.B, P.b_tiles, P.b_t0, P.b_nt, n_ptiles, P.ws, P.rs);
+}
+
 // out[r][c] (+)= sum_s ws[s][r][c] in a fixed order.  A block owns 16 consecutive float4 of the output; its 16 thread groups
 // each sum a contiguous share of the n partial blocks (all loads independent: bandwidth-, not latency-bound), then thread
 // group 0 adds the 16 group sums in group order (LDS): the same order for every launch, hence deterministic.
@@ -167,4 +182,20 @@ int vqn_wgrad_partials_f32_internal(const float* A, int a_tiles, int a_t0, int a
 #undef VQN_WGRAD
   VQN_LAUNCH_CHECK();
   return (int)grid;      // number of partial blocks written (>= 1)
+}
+
+int vqn_wgrad_f32_batched_internal(const WgProblem* probs, int count, int cls, long n_point_tiles, long grid, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  for (int c0 = 0; c0 < count; c0 += WG_MAX) {
+    WgTable tab;
+    memset(&tab, 0, sizeof(tab));
+    const int k = count - c0 < WG_MAX ? count - c0 : WG_MAX;
+    for (int i = 0; i < k; ++i) tab.p[i] = probs[c0 + i];
+    const dim3 g((unsigned)grid, (unsigned)k);
+    if (cls == 0) hipLaunchKernelGGL((wgrad_batched_kernel<1, 4, 6>), g, dim3(256), 0, s, tab, n_point_tiles);
+    else if (cls == 1) hipLaunchKernelGGL((wgrad_batched_kernel<1, 8, 4>), g, dim3(256), 0, s, tab, n_point_tiles);
+    else hipLaunchKernelGGL((wgrad_batched_kernel<2, 8, VQN_WGRAD_D>), g, dim3(256), 0, s, tab, n_point_tiles);
+    VQN_LAUNCH_CHECK();
+  }
+  return VQN_OK;
 }

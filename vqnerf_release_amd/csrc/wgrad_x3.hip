@@ -8,6 +8,7 @@
 // HBM rate of their operand stream instead of the f32 pipe's.  Same workspace / reduction contract as vqn_wgrad_partials
 // (deterministic: fixed order, no atomics).
 #include "common.h"
+#include "wgrad_batch.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -156,9 +157,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(const float* __restric
 // (24 ds_read_b128 per step and wave).  Without it each wave fetches all of B itself, half a 128-byte line per instruction, and the
 // L2 -> L1 traffic (B four times over) binds the launch at 2.5x its matrix time.  One barrier per step.
 template <bool FULL>          // FULL: a_nt == b_nt == 8 -- no guards in the instruction stream
-__global__ __launch_bounds__(256, 1) void wgrad_x3_lds_kernel(const float* __restrict__ A, int a_tiles, int a_t0, int a_nt,
-                                                              const float* __restrict__ B, int b_tiles, int b_t0, int b_nt, long n_ptiles,
-                                                              float* __restrict__ ws, float* __restrict__ rowsum_ws) {
+__device__ __forceinline__ void wgrad_x3_lds_body(const float* __restrict__ A, int a_tiles, int a_t0, int a_nt,
+                                                  const float* __restrict__ B, int b_tiles, int b_t0, int b_nt, long n_ptiles,
+                                                  float* __restrict__ ws, float* __restrict__ rowsum_ws) {
   const bool two = FULL || (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + 4 < a_nt);      // this wave owns a second output tile
   constexpr int NOT = 2, BT = 8;
   __shared__ u32x4 pieces[2][BT][3][64];                       // 48 KB
@@ -347,7 +348,75 @@ __global__ __launch_bounds__(256, 1) void wgrad_x3_lds_kernel(const float* __res
   }
 }
 
+template <bool FULL>
+__global__ __launch_bounds__(256, 1) void wgrad_x3_lds_kernel(const float* __restrict__ A, int a_tiles, int a_t0, int a_nt,
+                                                              const float* __restrict__ B, int b_tiles, int b_t0, int b_nt, long n_ptiles,
+                                                              float* __restrict__ ws, float* __restrict__ rowsum_ws) {
+  wgrad_x3_lds_body<FULL>(A, a_tiles, a_t0, a_nt, B, b_tiles, b_t0, b_nt, n_ptiles, ws, rowsum_ws);
+}
+
+// many contractions over the same points in one launch (blockIdx.y: the problem)
+template <bool FULL>
+__global__ __launch_bounds__(256, 1) void wgrad_x3_lds_batched_kernel(const WgTable tab, long n_ptiles) {
+  const WgProblem& P = tab.p[blockIdx.y];
+  wgrad_x3_lds_body<FULL>(P.A, P.a_tiles, P.a_t0, P.a_nt, P.B, P.b_tiles, P.b_t0, P.b_nt, n_ptiles, P.ws, P.rs);
+}
+
 }  // namespace
+
+extern "C" int vqn_wgrad_partials_x3(const float* A, int a_tiles, int a_t0, int a_nt, const float* B, int b_tiles, int b_t0,
+                                     int b_nt, int64_t n_point_tiles, int n_split, float* ws, float* rowsum_ws, void* stream);
+
+// The contractions of a whole backward pass (same points, hence the same split) in as few launches as they have kernel shapes:
+// problem i is vqn_wgrad_partials (x3 == 0) / vqn_wgrad_partials_x3 (x3 != 0) of (A[i], a_tiles[i], ..., ws[i], rowsum_ws[i]) -- the
+// same kernels, hence the same partial blocks bit for bit -- grouped by kernel variant, a launch per group of up to 24.
+extern "C" int vqn_wgrad_partials_batched(int count, const float* const* A, const int32_t* a_tiles, const int32_t* a_t0, const int32_t* a_nt,
+                                          const float* const* B, const int32_t* b_tiles, const int32_t* b_t0, const int32_t* b_nt,
+                                          int64_t n_point_tiles, int n_split, float* const* ws, float* const* rowsum_ws, int x3, void* stream) {
+  VQN_CHECK_ARG(count >= 0 && A && a_tiles && a_t0 && a_nt && B && b_tiles && b_t0 && b_nt && ws && rowsum_ws, "null pointer");
+  VQN_CHECK_ARG(n_point_tiles >= 1 && n_split >= 1, "n_point_tiles >= 1, n_split >= 1");
+  long grid = n_split;
+  if (grid > n_point_tiles) grid = n_point_tiles;
+  static const long small_from = [] { const char* e = getenv("VQN_WGRAD_X3_SMALL_TILES"); return (e && e[0]) ? atol(e) : 1024L; }();
+  static const int no_lds = [] { const char* e = getenv("VQN_WGRAD_X3_NO_LDS"); return (e != nullptr && atoi(e) != 0) ? 1 : 0; }();
+  // classes 0..2: the f32 kernels by shape; 3 / 4: the x3 LDS kernel, full / guarded
+  WgProblem cls[5][WG_MAX];
+  int n_cls[5] = {0, 0, 0, 0, 0};
+  auto flush = [&](int c) -> int {
+    if (n_cls[c] == 0) return VQN_OK;
+    int rc = VQN_OK;
+    if (c < 3) rc = vqn_wgrad_f32_batched_internal(cls[c], n_cls[c], c, (long)n_point_tiles, grid, stream);
+    else {
+      WgTable tab;
+      memset(&tab, 0, sizeof(tab));
+      for (int i = 0; i < n_cls[c]; ++i) tab.p[i] = cls[c][i];
+      const dim3 g((unsigned)grid, (unsigned)n_cls[c]);
+      if (c == 3) hipLaunchKernelGGL(wgrad_x3_lds_batched_kernel<true>, g, dim3(256), 0, (hipStream_t)stream, tab, (long)n_point_tiles);
+      else hipLaunchKernelGGL(wgrad_x3_lds_batched_kernel<false>, g, dim3(256), 0, (hipStream_t)stream, tab, (long)n_point_tiles);
+      VQN_LAUNCH_CHECK();
+    }
+    n_cls[c] = 0;
+    return rc;
+  };
+  for (int i = 0; i < count; ++i) {
+    VQN_CHECK_ARG(A[i] && B[i] && ws[i], "null pointer in problem");
+    VQN_CHECK_SHAPE(a_nt[i] >= 1 && a_nt[i] <= 8 && b_nt[i] >= 1 && b_nt[i] <= 8, "1..8 feature tiles per operand and problem");
+    VQN_CHECK_SHAPE(a_t0[i] >= 0 && a_t0[i] + a_nt[i] <= a_tiles[i] && b_t0[i] >= 0 && b_t0[i] + b_nt[i] <= b_tiles[i], "feature-tile range outside the tensor");
+    VQN_CHECK_SHAPE(((uintptr_t)A[i] & 15) == 0 && ((uintptr_t)B[i] & 15) == 0, "operands must be 16-byte aligned");
+    const bool f32 = !x3 || (a_nt[i] <= 4 && n_point_tiles < small_from);
+    if (!f32 && no_lds) {                                   // (diagnostic switch: the non-LDS x3 kernels have no batched form)
+      const int n = vqn_wgrad_partials_x3(A[i], a_tiles[i], a_t0[i], a_nt[i], B[i], b_tiles[i], b_t0[i], b_nt[i], n_point_tiles, n_split, ws[i],
+                                          rowsum_ws[i], stream);
+      if (n < 0) return n;
+      continue;
+    }
+    const int c = f32 ? ((a_nt[i] <= 4 && b_nt[i] <= 4) ? 0 : (a_nt[i] <= 4 ? 1 : 2)) : ((a_nt[i] == 8 && b_nt[i] == 8) ? 3 : 4);
+    cls[c][n_cls[c]++] = WgProblem{A[i], B[i], ws[i], rowsum_ws[i], a_tiles[i], a_t0[i], a_nt[i], b_tiles[i], b_t0[i], b_nt[i]};
+    if (n_cls[c] == WG_MAX) { const int rc = flush(c); if (rc != VQN_OK) return rc; }
+  }
+  for (int c = 0; c < 5; ++c) { const int rc = flush(c); if (rc != VQN_OK) return rc; }
+  return (int)grid;
+}
 
 extern "C" int vqn_wgrad_partials_x3(const float* A, int a_tiles, int a_t0, int a_nt, const float* B, int b_tiles, int b_t0,
                                      int b_nt, int64_t n_point_tiles, int n_split, float* ws, float* rowsum_ws, void* stream) {

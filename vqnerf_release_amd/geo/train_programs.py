@@ -55,23 +55,19 @@ class WgradBatch:
 
     def __init__(self, n_split):
         self.n_split = n_split
-        self.e, self.keep = [], []
+        self.e, self.keep, self.p, self.nt = [], [], [], None
 
     def _partials(self, A, B, at, a0, an, bt, b0, bn, nt, want_rs):
+        """queue one partial-block problem (launched with all the others of the pass at flush()); -> (ws, rowsum ws, n blocks)"""
         dev = A.device
+        if self.nt is None:
+            self.nt = nt
+        assert nt == self.nt, 'one WgradBatch = contractions over the same points'
         n_blocks = min(self.n_split, nt)
         ws = torch.empty(n_blocks * an * 32 * bn * 32, dtype=torch.float32, device=dev)
         rs = torch.empty(n_blocks * an * 32, dtype=torch.float32, device=dev) if want_rs else None
-        entry = WGRAD_ENTRY[wgrad_mode()]
-        with _C._clock(entry):
-            n = getattr(_C.lib(), entry)(_C._ptr(A), ctypes.c_int(at), ctypes.c_int(a0), ctypes.c_int(an), _C._ptr(B), ctypes.c_int(bt),
-                                         ctypes.c_int(b0), ctypes.c_int(bn), ctypes.c_int64(nt), ctypes.c_int(self.n_split), _C._ptr(ws),
-                                         _C._ptr(rs), _C._stream())
-        if n <= 0:
-            _C._check(n if n < 0 else -3, 'vqn_wgrad_partials')
-        assert n <= n_blocks
-        self.keep += [ws, rs]
-        return ws, rs, n
+        self.p.append((A, at, a0, an, B, bt, b0, bn, ws, rs))
+        return ws, rs, n_blocks
 
     def contract(self, A, B, a_rows, b_cols, dst, sr, sc, bias_dst=None, A2=None, B2=None, scale=1.0, col_first=0):
         """sum_p A[o][p] B[i][p] (+ sum_p A2[o][p] B2[i][p]), times scale -> element (o, i) at dst.flatten()[o * sr + i * sc] for
@@ -102,6 +98,20 @@ class WgradBatch:
 
     def flush(self):
         e, k = self.e, len(self.e)
+        if self.p:
+            q, m = self.p, len(self.p)
+            vp = lambda j: (ctypes.c_void_p * m)(*[(x[j].data_ptr() if x[j] is not None else 0) for x in q])
+            ia = [np.array([x[j] for x in q], np.int32) for j in (1, 2, 3, 5, 6, 7)]
+            ip = [a.ctypes.data_as(ctypes.c_void_p) for a in ia]
+            x3 = wgrad_mode() == 'bf16x3'
+            with _C._clock(WGRAD_ENTRY[wgrad_mode()]):
+                n = _C.lib().vqn_wgrad_partials_batched(ctypes.c_int(m), vp(0), ip[0], ip[1], ip[2], vp(4), ip[3], ip[4], ip[5],
+                                                        ctypes.c_int64(self.nt), ctypes.c_int(self.n_split), vp(8), vp(9), ctypes.c_int(int(x3)),
+                                                        _C._stream())
+            if n <= 0:
+                _C._check(n if n < 0 else -3, 'vqn_wgrad_partials_batched')
+            assert n == min(self.n_split, self.nt)
+            self.keep += [x[j] for x in q for j in (0, 4, 8, 9)]
         if k:
             vp = lambda key: (ctypes.c_void_p * k)(*[(x[key].data_ptr() if torch.is_tensor(x[key]) else (x[key] or 0)) for x in e])
             i32 = lambda key: np.array([x[key] for x in e], np.int32)
@@ -113,7 +123,7 @@ class WgradBatch:
                 rc = _C.lib().vqn_wgrad_finalize(ctypes.c_int(k), vp('ws'), p[0], vp('ws2'), p[1], p[2], p[3], p[4], p[5], p[6], vp('dst'), p[7],
                                                  p[8], p[9], _C._stream())
             _C._check(rc, 'vqn_wgrad_finalize')
-        self.e, self.keep = [], []
+        self.e, self.keep, self.p, self.nt = [], [], [], None
 
 
 K_LD_POSENC, K_LD_POSENC_JVP, K_LD_T, K_LD_VEC, K_LD_EXTRAS, K_GEMM, K_ST_VEC, K_POSENC_VJP = 1, 2, 3, 4, 5, 6, 7, 8
