@@ -22,3 +22,18 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(5): tr.train_iter(batch, global_bs=n)
 torch.cuda.synchronize()
 print(f'VQN_WGRAD_X3_SMALL_TILES={os.environ.get("VQN_WGRAD_X3_SMALL_TILES", "-")} n={n}: {(time.perf_counter()-t0)/5*1e3:.2f} ms/step')
+from vqnerf_release_amd import _C
+from vqnerf_release_amd.geo import train_programs as tp
+for batched in (False, True):
+    tp.BATCHED_WGRAD[0] = batched
+    for _ in range(2): tr.train_iter(batch, global_bs=n)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): tr.train_iter(batch, global_bs=n)
+    torch.cuda.synchronize()
+    print(f'batched wgrad {batched}: {(time.perf_counter()-t0)/5*1e3:.2f} ms/step')
+    _C.KernelClock.reset(True)
+    tr.train_iter(batch, global_bs=n); torch.cuda.synchronize()
+    summ = _C.KernelClock.summary(); _C.KernelClock.reset(False)
+    print('   clocked total', sum(v[1] for v in summ.values()))
+    for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])[:8]:
+        print('      ', k, v)

@@ -48,26 +48,28 @@ BATCHED_WGRAD = [os.environ.get('VQN_WGRAD_BATCH', '1') != '0']
 
 
 class WgradBatch:
-    """Deferred weight-gradient contractions of one backward pass.  contract() launches the split-over-points partial-block kernel
-    at once, into a workspace of its own; flush() sums every contraction's blocks (the fixed order of vqn_reduce_partials) and
-    writes each result where it belongs -- a slice of a concatenated matrix, transposed, scaled, two contractions added -- in ONE
-    launch (vqn_wgrad_finalize) instead of a reduce + transpose + cat + scale kernel sequence per weight."""
+    """Deferred weight-gradient contractions of one backward pass.  contract() queues a contraction; flush() launches the
+    split-over-points partial-block kernels of all of them (one launch per kernel variant, vqn_wgrad_partials_batched, each problem
+    into its own slice of ONE workspace), then sums every contraction's blocks in the fixed order of vqn_reduce_partials and writes
+    each result where it belongs -- a slice of a concatenated matrix, transposed, scaled, two contractions added -- in ONE launch
+    (vqn_wgrad_finalize) instead of a reduce + transpose + cat + scale kernel sequence per weight."""
 
     def __init__(self, n_split):
         self.n_split = n_split
-        self.e, self.keep, self.p, self.nt = [], [], [], None
+        self.e, self.keep, self.p, self.nt, self.ws_floats = [], [], [], None, 0
 
     def _partials(self, A, B, at, a0, an, bt, b0, bn, nt, want_rs):
-        """queue one partial-block problem (launched with all the others of the pass at flush()); -> (ws, rowsum ws, n blocks)"""
-        dev = A.device
+        """queue one partial-block problem; -> (workspace offset, row-sum workspace offset | None) in floats"""
         if self.nt is None:
             self.nt = nt
         assert nt == self.nt, 'one WgradBatch = contractions over the same points'
         n_blocks = min(self.n_split, nt)
-        ws = torch.empty(n_blocks * an * 32 * bn * 32, dtype=torch.float32, device=dev)
-        rs = torch.empty(n_blocks * an * 32, dtype=torch.float32, device=dev) if want_rs else None
+        ws, self.ws_floats = self.ws_floats, self.ws_floats + n_blocks * an * 32 * bn * 32
+        rs = None
+        if want_rs:
+            rs, self.ws_floats = self.ws_floats, self.ws_floats + n_blocks * an * 32
         self.p.append((A, at, a0, an, B, bt, b0, bn, ws, rs))
-        return ws, rs, n_blocks
+        return ws, rs
 
     def contract(self, A, B, a_rows, b_cols, dst, sr, sc, bias_dst=None, A2=None, B2=None, scale=1.0, col_first=0):
         """sum_p A[o][p] B[i][p] (+ sum_p A2[o][p] B2[i][p]), times scale -> element (o, i) at dst.flatten()[o * sr + i * sc] for
@@ -82,48 +84,50 @@ class WgradBatch:
                 if col_first >= min(bn * 32, b_cols - b0 * 32) + b0 * 32:
                     continue
                 want_rs = bias_dst is not None and b0 == 0
-                ws, rs, n = self._partials(A, B, at, a0, an, bt, b0, bn, nt, want_rs)
-                ws2, n2 = None, 0
+                ws, rs = self._partials(A, B, at, a0, an, bt, b0, bn, nt, want_rs)
+                ws2 = None
                 if A2 is not None:
-                    ws2, _, n2 = self._partials(A2, B2, A2.shape[1], a0, an, B2.shape[1], b0, bn, nt, False)
-                self.e.append(dict(ws=ws, n=n, ws2=ws2, n2=n2, src_rows=an * 32, src_cols=bn * 32, rows_valid=min(an * 32, a_rows - a0 * 32),
+                    ws2, _ = self._partials(A2, B2, A2.shape[1], a0, an, B2.shape[1], b0, bn, nt, False)
+                self.e.append(dict(ws=ws, ws2=ws2, src_rows=an * 32, src_cols=bn * 32, rows_valid=min(an * 32, a_rows - a0 * 32),
                                    col_first=max(0, col_first - b0 * 32), cols_valid=min(bn * 32, b_cols - b0 * 32),
                                    dst=dst.data_ptr() + 4 * (a0 * 32 * sr + b0 * 32 * sc), sr=sr, sc=sc, scale=scale))
                 if want_rs:
-                    self.e.append(dict(ws=rs, n=n, ws2=None, n2=0, src_rows=1, src_cols=an * 32, rows_valid=1, col_first=0,
+                    self.e.append(dict(ws=rs, ws2=None, src_rows=1, src_cols=an * 32, rows_valid=1, col_first=0,
                                        cols_valid=min(an * 32, a_rows - a0 * 32), dst=bias_dst.data_ptr() + 4 * a0 * 32, sr=0, sc=1, scale=1.0))
-        self.keep.append(dst)
-        if bias_dst is not None:
-            self.keep.append(bias_dst)
+        self.keep += [A, B, A2, B2, dst, bias_dst]
 
     def flush(self):
-        e, k = self.e, len(self.e)
-        if self.p:
-            q, m = self.p, len(self.p)
-            vp = lambda j: (ctypes.c_void_p * m)(*[(x[j].data_ptr() if x[j] is not None else 0) for x in q])
+        e, k, q, m = self.e, len(self.e), self.p, len(self.p)
+        if m:
+            buf = torch.empty(self.ws_floats, dtype=torch.float32, device=q[0][0].device)
+            base = buf.data_ptr()
+            assert base % 16 == 0
+            at = lambda off: 0 if off is None else base + 4 * off
+            tp = lambda j: (ctypes.c_void_p * m)(*[x[j].data_ptr() for x in q])
+            op = lambda j: (ctypes.c_void_p * m)(*[at(x[j]) for x in q])
             ia = [np.array([x[j] for x in q], np.int32) for j in (1, 2, 3, 5, 6, 7)]
             ip = [a.ctypes.data_as(ctypes.c_void_p) for a in ia]
             x3 = wgrad_mode() == 'bf16x3'
             with _C._clock(WGRAD_ENTRY[wgrad_mode()]):
-                n = _C.lib().vqn_wgrad_partials_batched(ctypes.c_int(m), vp(0), ip[0], ip[1], ip[2], vp(4), ip[3], ip[4], ip[5],
-                                                        ctypes.c_int64(self.nt), ctypes.c_int(self.n_split), vp(8), vp(9), ctypes.c_int(int(x3)),
+                n = _C.lib().vqn_wgrad_partials_batched(ctypes.c_int(m), tp(0), ip[0], ip[1], ip[2], tp(4), ip[3], ip[4], ip[5],
+                                                        ctypes.c_int64(self.nt), ctypes.c_int(self.n_split), op(8), op(9), ctypes.c_int(int(x3)),
                                                         _C._stream())
             if n <= 0:
                 _C._check(n if n < 0 else -3, 'vqn_wgrad_partials_batched')
             assert n == min(self.n_split, self.nt)
-            self.keep += [x[j] for x in q for j in (0, 4, 8, 9)]
-        if k:
-            vp = lambda key: (ctypes.c_void_p * k)(*[(x[key].data_ptr() if torch.is_tensor(x[key]) else (x[key] or 0)) for x in e])
+            vp = lambda key: (ctypes.c_void_p * k)(*[at(x[key]) for x in e])
+            dp = (ctypes.c_void_p * k)(*[x['dst'] for x in e])
             i32 = lambda key: np.array([x[key] for x in e], np.int32)
             i64 = lambda key: np.array([x[key] for x in e], np.int64)
-            arrs = [i32('n'), i32('n2'), i32('src_rows'), i32('src_cols'), i32('rows_valid'), i32('col_first'), i32('cols_valid'),
+            nn = np.full(k, n, np.int32)
+            arrs = [nn, nn, i32('src_rows'), i32('src_cols'), i32('rows_valid'), i32('col_first'), i32('cols_valid'),
                     i64('sr'), i64('sc'), np.array([x['scale'] for x in e], np.float32)]
             p = [a.ctypes.data_as(ctypes.c_void_p) for a in arrs]
             with _C._clock('vqn_wgrad_finalize'):
-                rc = _C.lib().vqn_wgrad_finalize(ctypes.c_int(k), vp('ws'), p[0], vp('ws2'), p[1], p[2], p[3], p[4], p[5], p[6], vp('dst'), p[7],
+                rc = _C.lib().vqn_wgrad_finalize(ctypes.c_int(k), vp('ws'), p[0], vp('ws2'), p[1], p[2], p[3], p[4], p[5], p[6], dp, p[7],
                                                  p[8], p[9], _C._stream())
             _C._check(rc, 'vqn_wgrad_finalize')
-        self.e, self.keep, self.p, self.nt = [], [], [], None
+        self.e, self.keep, self.p, self.nt, self.ws_floats = [], [], [], None, 0
 
 
 K_LD_POSENC, K_LD_POSENC_JVP, K_LD_T, K_LD_VEC, K_LD_EXTRAS, K_GEMM, K_ST_VEC, K_POSENC_VJP = 1, 2, 3, 4, 5, 6, 7, 8
