@@ -731,6 +731,10 @@ def decomp_cpu_leg(dev, cores, N=16384):
             'near_tie_fraction': 1.0 - float(clear.float().mean())}
 
 
+# the fine render kernel as rocprofv3 names it (spaces removed): template arguments <FINE, TRAIN>
+FINE_KERNEL = 'neus_points2_kernel<true,false>'
+
+
 def pmc_values(root, counter, kernel_substr):
     """Counter values of every dispatch of a kernel from the `*counter_collection.csv` files rocprofv3 --pmc leaves under `root`."""
     import csv
@@ -766,7 +770,7 @@ def live_traffic(rays, timeout_s=170):
         try:
             subprocess.run(cmd, timeout=timeout_s, env={**os.environ, 'TMPDIR': '/tmp'}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                            check=True, cwd='/tmp')
-            got = pmc_values(d, c, 'neus_points2_kernel<true>')
+            got = pmc_values(d, c, FINE_KERNEL)
             if not got:
                 return None, f'no {c} rows for the fine kernel in the rocprofv3 output'
             vals[c] = sum(got) / len(got)
@@ -902,7 +906,7 @@ def main():
                                'sdf 8x256 (skip 4, posenc 6), colour 4x256 (idr, posenc_view 4), random-init weights '
                                '(geometric-init sphere of radius 0.85: ~30 % of the rays hit)',
                    'rays_per_step_per_gpu': args.rays, 'parallelism': f'views x{world} (no data-path collective)'},
-        'roofline': {'bound': 'mfma', 'kernel': 'neus_points2_kernel<FINE> (vqn_neus_fine_points)', 'achieved': achieved,
+        'roofline': {'bound': 'mfma', 'kernel': 'neus_points2_kernel<FINE = true, TRAIN = false> (vqn_neus_fine_points)', 'achieved': achieved,
                      'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
                      'traffic': traffic, 'traffic_note': traffic_note, 'avg_launch_ms': avg_ms, 'flop_per_launch': flop_fine,
                      'macs_per_point': {'sdf': m_sdf, 'colour': m_col}},

@@ -78,6 +78,13 @@ def test_bench_reads_the_profiler_counter_files(tmp_path):
         '3,"void (anonymous namespace)::neus_points2_kernel< true >(SdfDesc, ColDesc)","FETCH_SIZE",999.5\n'
         '4,"void (anonymous namespace)::neus_points2_kernel<true>(SdfDesc, ColDesc)","WRITE_SIZE",5\n')
     assert bench.pmc_values(str(tmp_path), 'FETCH_SIZE', 'neus_points2_kernel<true>') == [1000.5, 999.5]
+    # the name bench looks for is the fine render kernel's, not the training instantiation's
+    (tmp_path / 'p').mkdir()
+    (tmp_path / 'p' / 'd_counter_collection.csv').write_text(
+        'Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n'
+        '1,"void (anonymous namespace)::neus_points2_kernel<true, false>(SdfDesc, ColDesc, TrainOut)","FETCH_SIZE",11\n'
+        '2,"void (anonymous namespace)::neus_points2_kernel<true, true>(SdfDesc, ColDesc, TrainOut)","FETCH_SIZE",13\n')
+    assert bench.pmc_values(str(tmp_path), 'FETCH_SIZE', bench.FINE_KERNEL) == [11.0]
     assert bench.pmc_values(str(tmp_path), 'WRITE_SIZE', 'neus_points2_kernel<true>') == [5.0]
     assert bench.pmc_values(str(tmp_path), 'FETCH_SIZE', 'no_such_kernel') == []
 
