@@ -95,6 +95,14 @@ int vqn_decomp_loss_bwd(const float* rgb_pred, const float* vq_rgb, const float*
  * |x|^2 and a correctly rounded sqrt / division (oracle/vq_strict.c states it in C).  D % 4 == 0. */
 int vqn_l2_normalize_rows(const float* x, int64_t N, int D, float eps, float* y, void* stream);
 
+/* Backward of vqn_l2_normalize_rows: gx = g s - [sum x^2 > eps] x s^3 (x . g), s = max(sum x^2, eps)^(-1/2) (the gradient of
+ * tf.linalg.l2_normalize, util/math.py:63-64, under the reference's autograd), one pass over [N, D].  D % 4 == 0, D <= 1024. */
+int vqn_l2_normalize_rows_bwd(const float* x, const float* g, int64_t N, int D, float eps, float* gx, void* stream);
+
+/* Backward of the straight-through estimator + commitment loss (networks/vq_layers.py:302, :327): gx = g_ste + (x - quant) *
+ * (g_loss[0] * 2 / numel); g_ste may be NULL, g_loss is a device scalar; each operation separately rounded. */
+int vqn_vq_ste_loss_bwd(const float* x, const float* quant, const float* g_ste, const float* g_loss, int64_t numel, float* gx, void* stream);
+
 /* The inference path of vq_nfr.Model.call / fast_embed / vq_test (vq_nfr.py:575-578 -> vq_layers.py:277-302, :327-330) in ONE pass
  * over the rows: z [N,D] un-normalised encoder output -> l2-normalise (as vqn_l2_normalize_rows) -> nearest code (as vqn_vq_assign,
  * incl. the code-dropout mask) -> idx [N], ste [N,D] = z^ + (q - z^) (or NULL), *loss = loss_scale * sum (q - z^)^2 (fixed order
@@ -411,6 +419,11 @@ int vqn_weight_norm_bwd(int n_layers, const float* const* v, const float* const*
  * (TFMT [ceil(N/32)][tiles_f][32 features][32 points], include/vqn_vm_desc.h), zero padded on pack.  In the reference these
  * hand-offs are implicit (autograd passes dense [N, F] tensors between the Keras layers, the VQ layer and the renderer). */
 int vqn_tfmt_pack(const float* x, int64_t N, int F, int64_t ldx, float* t, int tiles_f, void* stream);
+
+/* The top-layer delta of a backward program in one launch: t = g act'(y) with y the layer's saved TFMT output (act 0: t = g,
+ * 1 ReLU: g [y > 0], 3 sigmoid: (g y) (1 - y), each product separately rounded); g [N, F] rows with row stride ldg, or NULL for
+ * zeros (an unused head: autograd hands no gradient).  Same tile format and padding rule as vqn_tfmt_pack. */
+int vqn_tfmt_pack_delta(const float* g, int64_t N, int F, int64_t ldg, const float* y_tfmt, int act, float* t, int tiles_f, void* stream);
 int vqn_tfmt_unpack(const float* t, int tiles_f, int64_t N, int F, float* x, int64_t ldx, void* stream);
 
 /* Weight-gradient contraction over points (autograd's grad_weight GEMMs): partial blocks

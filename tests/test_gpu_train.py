@@ -693,3 +693,21 @@ def test_bf16x3_weight_gradient_contraction_matches_the_f32_one(a_nt, b_nt, n_ti
     assert ex3 <= max(2.0 * e32, 2e-7), (ex3, e32)
     assert torch.equal(outs['vqn_wgrad_partials'][1], outs['vqn_wgrad_partials_x3'][1]) or \
         float((outs['vqn_wgrad_partials'][1] - outs['vqn_wgrad_partials_x3'][1]).abs().max()) <= 1e-6 * float(Ad.abs().sum(1).max())
+
+
+@pytest.mark.parametrize('N,F,act', [(100, 3, 3), (33, 1, 3), (4097, 256, 1), (64, 70, 0), (5, 3, 3)])
+def test_pack_delta_is_unpack_times_activation_derivative_pack(N, F, act):
+    """vqn_tfmt_pack_delta (the top-layer delta of a backward program in one launch) against the sequence it replaces: unpack the
+    saved output, g * y * (1 - y) (sigmoid) / g * (y > 0) (ReLU) / g, pack -- bit for bit, zero padding included; g = None: zeros."""
+    from vqnerf_release_amd.decomp.train_programs import to_tfmt, from_tfmt, pack_delta
+    g = torch.Generator(device='cuda').manual_seed(N + F)
+    y_rows = torch.rand(N, F, device='cuda', generator=g) - (0.5 if act == 1 else 0.0)
+    gr = torch.randn(N, F, device='cuda', generator=g)
+    Y = to_tfmt(y_rows)
+    y = from_tfmt(Y, N, F)
+    ref = to_tfmt(gr * y * (1 - y) if act == 3 else (gr * (y > 0) if act == 1 else gr), Y.shape[1])
+    out = torch.full_like(Y, float('nan'))
+    pack_delta(gr, Y, act, N, F, out)
+    assert torch.equal(out, ref)
+    pack_delta(None, Y, act, N, F, out)
+    assert torch.equal(out, torch.zeros_like(out))

@@ -400,3 +400,32 @@ def test_fused_ema_update_matches_the_torch_statement(K):
         # the lazily computed entries are still there for whoever asks
         assert outs[True]['encodings'].shape == (500, K) and float(outs[True]['perplexity']) > 0
         cb = b.clone() / b.norm(dim=0, keepdim=True)
+
+
+@pytest.mark.parametrize('N,D', [(1, 256), (1000, 256), (37, 64), (5, 1024)])
+def test_l2_normalize_rows_backward_kernel_matches_autograd(N, D):
+    """vqn_l2_normalize_rows_bwd against autograd through the torch statement of tf.linalg.l2_normalize (util/math.py:63-64),
+    rows below the eps clamp included (gradient g s there)."""
+    from vqnerf_release_amd import _C
+    from vqnerf_release_amd.decomp.nerfactor.util.math import safe_l2_normalize
+    g = torch.Generator(device='cuda').manual_seed(N)
+    x = torch.randn(N, D, device='cuda', generator=g)
+    if N > 2:
+        x[1] *= 1e-5                                              # sum x^2 < eps = 1e-6: the clamp is active
+        x[2] = 0.0
+    gy = torch.randn(N, D, device='cuda', generator=g)
+    xr = x.clone().requires_grad_(True)
+    safe_l2_normalize(xr, axis=1).backward(gy)
+    got = _C.l2_normalize_rows_bwd(x, gy, 1e-6)
+    ref = xr.grad
+    assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+def test_ste_commitment_backward_kernel_is_the_framework_sequence_bit_for_bit():
+    from vqnerf_release_amd import _C
+    g = torch.Generator(device='cuda').manual_seed(0)
+    x, q, gs = (torch.randn(513, 256, device='cuda', generator=g) for _ in range(3))
+    gl = torch.tensor(0.37, device='cuda')
+    ref = gs + (x - q) * (gl * (2.0 / x.numel()))
+    assert torch.equal(_C.vq_ste_loss_bwd(x, q, gs, gl), ref)
+    assert torch.equal(_C.vq_ste_loss_bwd(x, q, None, gl), (x - q) * (gl * (2.0 / x.numel())))

@@ -226,6 +226,31 @@ def decomp_loss_bwd(rgb_pred, vq_rgb, rgb_gt, z, spec, rough, nerf, w, g_terms):
     return g_pred, g_vq, g_z, g_spec
 
 
+def l2_normalize_rows_bwd(x, g, eps=1e-6):
+    """Gradient of l2_normalize_rows at x [N, D] for the incoming g [N, D]: one pass (vqn_l2_normalize_rows_bwd)."""
+    _f32c(x, 'x'); _f32c(g, 'g')
+    if x.shape != g.shape or x.dim() != 2:
+        raise VqnError('l2_normalize_rows_bwd: x and g must be [N, D]')
+    gx = torch.empty_like(x)
+    with _clock('vqn_l2_normalize_rows_bwd'):
+        rc = lib().vqn_l2_normalize_rows_bwd(_ptr(x), _ptr(g), ctypes.c_int64(x.shape[0]), ctypes.c_int(x.shape[1]), ctypes.c_float(eps), _ptr(gx),
+                                             _stream())
+    _check(rc, 'vqn_l2_normalize_rows_bwd')
+    return gx
+
+
+def vq_ste_loss_bwd(x, quant, g_ste, g_loss):
+    """g_ste + (x - quant) * (g_loss * 2 / numel) in one pass (g_ste may be None; g_loss a 0-dim device tensor)."""
+    _f32c(x, 'x'); _f32c(quant, 'quant'); _f32c(g_loss, 'g_loss')
+    if g_ste is not None:
+        _f32c(g_ste, 'g_ste')
+    gx = torch.empty_like(x)
+    with _clock('vqn_vq_ste_loss_bwd'):
+        rc = lib().vqn_vq_ste_loss_bwd(_ptr(x), _ptr(quant), _ptr(g_ste), _ptr(g_loss), ctypes.c_int64(x.numel()), _ptr(gx), _stream())
+    _check(rc, 'vqn_vq_ste_loss_bwd')
+    return gx
+
+
 def l2_normalize_rows(x, eps=1e-6):
     """x [N,D] -> x / sqrt(max(sum_d x^2, eps)) row by row, in the defined summation order of vqn_vq_assign's |x|^2."""
     _f32c(x, 'x')

@@ -248,3 +248,90 @@ extern "C" int vqn_vq_ema_update(const float* counts, const float* dw, const flo
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }
+
+// ---- backward of the two row-wise steps around the quantiser (networks/vq_layers.py of the reference: the l2-normalised encoder output,
+// :302 / :327 the straight-through estimator + commitment loss), one pass over [N, D] each instead of 8 + 3 framework passes ----------
+namespace {
+
+// y = x s, s = max(sum x^2, eps)^(-1/2)  ->  gx = g s - [sum x^2 > eps] x s^3 (x . g).  One wave per row, D <= 1024, D % 4 == 0.
+__global__ __launch_bounds__(256) void l2_normalize_rows_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, long N, int D,
+                                                                    float eps, float* __restrict__ gx) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * D);
+  const f32x4* gr = reinterpret_cast<const f32x4*>(g + row * D);
+  f32x4* or_ = reinterpret_cast<f32x4*>(gx + row * D);
+  const int n4 = D >> 2;
+  f32x4 xv[4], gv[4];
+  float x2 = 0.f, xg = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = lane + 64 * k;
+    if (i < n4) {
+      xv[k] = xr[i]; gv[k] = gr[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { x2 = fmaf(xv[k][j], xv[k][j], x2); xg = fmaf(xv[k][j], gv[k][j], xg); }
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) { x2 += __shfl_xor(x2, m); xg += __shfl_xor(xg, m); }
+  const float s = 1.0f / sqrtf(fmaxf(x2, eps));
+  const float t = x2 > eps ? (s * s * s) * xg : 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = lane + 64 * k;
+    if (i < n4) {
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = gv[k][j] * s - xv[k][j] * t;
+      or_[i] = o;
+    }
+  }
+}
+
+// g = g_ste + (x - q) (g_loss 2 / numel)   (g_ste may be absent; g_loss a device scalar) -- separately rounded, as the framework ops were
+__global__ __launch_bounds__(256) void ste_commit_bwd_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ q, const f32x4* __restrict__ g_ste,
+                                                             const float* __restrict__ g_loss, float two_over_numel, long n4, f32x4* __restrict__ out) {
+  const float t = __fmul_rn(g_loss[0], two_over_numel);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 a = x[i], b = q[i];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = __fmul_rn(__fsub_rn(a[j], b[j]), t);
+    if (g_ste != nullptr) {
+      const f32x4 c = g_ste[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = __fadd_rn(c[j], o[j]);
+    }
+    out[i] = o;
+  }
+}
+
+}  // namespace
+
+extern "C" int vqn_l2_normalize_rows_bwd(const float* x, const float* g, int64_t N, int D, float eps, float* gx, void* stream) {
+  VQN_CHECK_ARG(N >= 0 && D > 0, "N >= 0, D > 0");
+  if (N == 0) return VQN_OK;
+  VQN_CHECK_ARG(x && g && gx, "null pointer");
+  VQN_CHECK_SHAPE(D % 4 == 0 && D <= 1024, "D a multiple of 4, at most 1024");
+  hipLaunchKernelGGL(l2_normalize_rows_bwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, g, (long)N, D, eps, gx);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
+
+extern "C" int vqn_vq_ste_loss_bwd(const float* x, const float* quant, const float* g_ste, const float* g_loss, int64_t numel, float* gx,
+                                   void* stream) {
+  VQN_CHECK_ARG(numel >= 0, "numel >= 0");
+  if (numel == 0) return VQN_OK;
+  VQN_CHECK_ARG(x && quant && g_loss && gx, "null pointer");
+  VQN_CHECK_SHAPE(numel % 4 == 0, "numel a multiple of 4");
+  const long n4 = numel / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 256L * 16) blocks = 256L * 16;
+  hipLaunchKernelGGL(ste_commit_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(x),
+                     reinterpret_cast<const f32x4*>(quant), reinterpret_cast<const f32x4*>(g_ste), g_loss, (float)(2.0 / (double)numel), n4,
+                     reinterpret_cast<f32x4*>(gx));
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}

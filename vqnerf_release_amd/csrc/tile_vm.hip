@@ -384,7 +384,47 @@ __global__ __launch_bounds__(256) void tfmt_convert_kernel(const float* __restri
   }
 }
 
+// [N, F] rows of incoming adjoints -> TFMT, multiplied on the way by the activation's derivative taken from the layer's SAVED TFMT
+// output: D = g act'(y) (sigmoid: (g y) (1 - y), ReLU: g [y > 0], none: g), g == nullptr: zeros.  The top-layer delta of a backward
+// program in one launch instead of unpack + three element-wise passes + pack.
+__global__ __launch_bounds__(256) void tfmt_pack_delta_kernel(const float* __restrict__ g, const float* __restrict__ Y, float* __restrict__ dst, long N,
+                                                              int F, long ld, int tiles_f, int act) {
+  __shared__ float sq[32][33];
+  const long tile = blockIdx.x;
+  const int ft = blockIdx.y, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long tbase = ((tile * tiles_f + ft) * 32) * 32;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {                       // r: point in tile, tx: feature in tile
+    const long pt = tile * 32 + r;
+    const int f = ft * 32 + tx;
+    sq[r][tx] = (g != nullptr && pt < N && f < F) ? g[pt * ld + f] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {                       // r: feature, tx: point
+    const float gv = sq[tx][r], y = Y[tbase + r * 32 + tx];
+    float v = gv;
+    if (act == ACT_SIGMOID) v = __fmul_rn(__fmul_rn(gv, y), __fsub_rn(1.0f, y));
+    else if (act == ACT_RELU) v = y > 0.f ? gv : 0.f;
+    dst[tbase + r * 32 + tx] = (ft * 32 + r < F && tile * 32 + tx < N) ? v : 0.f;
+  }
+}
+
 }  // namespace
+
+extern "C" int vqn_tfmt_pack_delta(const float* g, int64_t N, int F, int64_t ldg, const float* y_tfmt, int act, float* t, int tiles_f,
+                                   void* stream) {
+  VQN_CHECK_ARG(N >= 0 && F >= 1 && (g == nullptr || ldg >= F) && tiles_f * 32 >= F, "N >= 0, 1 <= F <= ldg, tiles_f * 32 >= F");
+  VQN_CHECK_ARG(act == ACT_NONE || act == ACT_RELU || act == ACT_SIGMOID, "act: 0 none, 1 relu, 3 sigmoid");
+  if (N == 0) return VQN_OK;
+  VQN_CHECK_ARG(y_tfmt && t, "null pointer");
+  const long n_tiles = (N + 31) / 32;
+  VQN_CHECK_SHAPE(tiles_f <= 65535, "at most 65535 feature tiles");
+  hipLaunchKernelGGL(tfmt_pack_delta_kernel, dim3((unsigned)n_tiles, (unsigned)tiles_f), dim3(256), 0, (hipStream_t)stream, g, y_tfmt, t, (long)N,
+                     F, (long)ldg, tiles_f, act);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
 
 extern "C" int vqn_tfmt_pack(const float* x, int64_t N, int F, int64_t ldx, float* t, int tiles_f, void* stream) {
   VQN_CHECK_ARG(N >= 0 && F >= 1 && ldx >= F && tiles_f * 32 >= F, "N >= 0, 1 <= F <= ldx, tiles_f * 32 >= F");

@@ -62,6 +62,9 @@ class _SteAndCommitment(torch.autograd.Function):
     def backward(ctx, g_ste, g_loss):
         x, q = ctx.saved_tensors
         g = g_ste
+        if g_loss is not None and x.is_cuda and x.numel() % 4 == 0 and g_loss.dim() == 0:
+            gs = None if g_ste is None else g_ste.reshape(x.shape).float().contiguous()
+            return _C.vq_ste_loss_bwd(x, q.reshape(x.shape).contiguous(), gs, g_loss.float().contiguous()), None
         if g_loss is not None:
             gl = (x - q.reshape(x.shape)) * (g_loss * (2.0 / x.numel()))
             g = gl if g is None else g + gl
@@ -83,6 +86,8 @@ class L2NormalizeRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
+        if x.is_cuda and x.shape[1] % 4 == 0 and x.shape[1] <= 1024:
+            return _C.l2_normalize_rows_bwd(x, g.float().contiguous(), ctx.eps), None
         x2 = (x * x).sum(1, keepdim=True)
         s = torch.rsqrt(torch.clamp(x2, min=ctx.eps))
         gx = g * s - torch.where(x2 > ctx.eps, x * (s * s * s) * (x * g).sum(1, keepdim=True), torch.zeros_like(x))

@@ -36,6 +36,22 @@ def to_tfmt(x, tiles=None, out=None):
     return out
 
 
+def pack_delta(g, y_tfmt, act, N, F, out):
+    """out (TFMT) = g act'(y): the adjoint rows g [N, F] (None: zeros) times the activation derivative taken from the layer's saved
+    TFMT output, in one launch (vqn_tfmt_pack_delta)."""
+    if g is not None:
+        g = g.detach()
+        if g.dtype != torch.float32 or g.stride(1) != 1:
+            g = g.float().contiguous()
+        _C.require_device(g, 'pack_delta')
+    assert out.is_contiguous() and y_tfmt.is_contiguous() and out.shape == y_tfmt.shape
+    with _C._clock('vqn_tfmt_pack_delta'):
+        rc = _C.lib().vqn_tfmt_pack_delta(_C._ptr(g), ctypes.c_int64(N), ctypes.c_int(F), ctypes.c_int64((g.stride(0) if N > 1 else F) if g is not None else F),
+                                          _C._ptr(y_tfmt), ctypes.c_int(act), _C._ptr(out), ctypes.c_int(out.shape[1]), _C._stream())
+    _C._check(rc, 'vqn_tfmt_pack_delta')
+    return out
+
+
 def from_tfmt(t, N, F):
     """TFMT -> contiguous [N, F] rows."""
     nt, ft = t.shape[0], t.shape[1]
@@ -210,10 +226,7 @@ class EncoderEngine(_Engine):
 
     def backward(self, T, wbuf, descs, g_z, N):
         top = self.nl - 1
-        z = from_tfmt(T['Y%d' % top], N, self.layers[top]['out'])
-        act = self.layers[top]['act']
-        delta = g_z * z * (1 - z) if act == ACT_SIGMOID else (g_z * (z > 0) if act == ACT_RELU else g_z)
-        to_tfmt(delta, self.specs['GZ'][1], out=T['GZ'])
+        pack_delta(g_z, T['Y%d' % top], self.layers[top]['act'], N, self.layers[top]['out'], T['GZ'])
         T['D%d' % top] = T['GZ']
         self.run('prog_bwd', descs, wbuf, T, self.specs, N)
         if not BATCHED_WGRAD[0]:
@@ -350,10 +363,7 @@ class HeadsEngine(_Engine):
 
     def backward(self, T, wbuf, descs, g_outs, N):
         for h, (net, g) in enumerate(zip(self.nets, g_outs)):
-            c = net.widths[2]
-            out = from_tfmt(T['Y%d_2' % h], N, c)
-            gg = torch.zeros_like(out) if g is None else g
-            to_tfmt(gg * out * (1 - out), 1, out=T['D%d_2' % h])
+            pack_delta(g, T['Y%d_2' % h], ACT_SIGMOID, N, net.widths[2], T['D%d_2' % h])
         self.run('prog_bwd', descs, wbuf, T, self.specs, N)
         if not BATCHED_WGRAD[0]:
             ws = torch.empty(min(self.n_split, (N + 31) // 32) * 256 * 256, dtype=torch.float32, device=T['Z'].device)
