@@ -32,6 +32,23 @@ def test_argument_errors_do_not_need_a_gpu():
     assert rc == -1 and b'bad argument' in lib.vqn_last_error()
     rc = lib.vqn_vq_assign(None, ctypes.c_int64(0), 256, None, 16, None, None, None, None, None, None)
     assert rc == 0          # empty input is a no-op
+    # round-3 entry points: the same contract (bad argument -> -1 with a message, empty work -> 0), before anything touches a device
+    assert lib.vqn_neus_train_fwd(None, None, None, None, None, None, ctypes.c_int64(8), None, ctypes.c_int64(0), None, 0, 2, 9, 2, None, None,
+                                  None, None) == -1 and b'null pointer' in lib.vqn_last_error()
+    assert lib.vqn_neus_train_bwd(None, None, None, None, None, None, None, ctypes.c_int64(8), None, ctypes.c_int64(0), None, 0, None, 0,
+                                  None) == -1
+    lib.vqn_neus_train_bwd_scratch_bytes.restype = ctypes.c_int64
+    assert lib.vqn_neus_train_bwd_scratch_bytes(None) == -1
+    bad = (ctypes.c_int32 * 76)()                                   # all zeros: no layers
+    assert lib.vqn_neus_train_bwd_scratch_bytes(bad) == -1
+    assert lib.vqn_wgrad_finalize(1, None, None, None, None, None, None, None, None, None, None, None, None, None, None) == -1
+    assert lib.vqn_multi_copy(1, None, None, None, None) == -1
+    assert lib.vqn_multi_copy(0, (ctypes.c_void_p * 1)(), (ctypes.c_void_p * 1)(), (ctypes.c_int64 * 1)(), None) == 0
+    assert lib.vqn_wgrad_partials_batched(1, None, None, None, None, None, None, None, None, ctypes.c_int64(4), 256, None, None, 1, None) == -1
+    assert lib.vqn_l2_normalize_rows_bwd(None, None, ctypes.c_int64(0), 256, ctypes.c_float(1e-6), None, None) == 0
+    assert lib.vqn_l2_normalize_rows_bwd(None, None, ctypes.c_int64(4), 255, ctypes.c_float(1e-6), None, None) == -1
+    assert lib.vqn_vq_ste_loss_bwd(None, None, None, None, ctypes.c_int64(8), None, None) == -1
+    assert lib.vqn_tfmt_pack_delta(None, ctypes.c_int64(4), 3, ctypes.c_int64(3), None, 2, None, 1, None) == -1      # softplus is not a head activation
 
 
 # ---- vqn_neus_*_pack_plan: the C pack builder against the Python one (host-only halves, no GPU needed) ------------------------
