@@ -252,6 +252,13 @@ int vqn_neus_fine_points_x3(const int32_t* sdf_desc, const float* wbuf_sdf, cons
                             const float* pts, const float* dirs, int64_t P, int S, void* scratch,
                             int64_t scratch_bytes, float* out_sdf, float* out_grad, float* out_rgb, void* stream);
 
+/* vqn_neus_train_fwd on the exact-split engine: x3 packs and descriptors (vqn_neus_pack_create(..., f16s = 2)), the same outputs
+ * and saved tensors (the f32 values the epilogues hold before the split into bf16 pieces).  Layers of at most 256 outputs. */
+int vqn_neus_train_fwd_x3(const int32_t* sdf_desc, const float* wbuf_sdf, const int32_t* col_desc, const float* wbuf_col,
+                          const float* pts, const float* dirs, int64_t P, void* scratch, int64_t scratch_bytes,
+                          float* const* tensors, int n_tensors, int e_tiles, int outf_tiles, int extr_tiles, float* out_sdf,
+                          float* out_n, float* out_rgb, void* stream);
+
 /* ---- weight packs of the fused NeuS kernels, built in C ------------------------------------------------ */
 
 /* A pack handle owns the device memory of the two weight buffers + their gather tables and the two host descriptors

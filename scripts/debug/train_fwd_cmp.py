@@ -43,7 +43,24 @@ with torch.no_grad():
         worst = max(worst, err / max(sc, 1e-12))
         print(f'{n:6s} max|prog| {sc:.4e}  max diff {err:.3e}  rel {err/max(sc,1e-12):.2e}  nan {nan}')
     print('worst rel', worst)
-for mode in ('prog', 'fused'):
+    Tc = eng.alloc_tensors(P, dev)
+    Tc['X'].copy_(x); Tc['DIRS'].copy_(d)
+    for k in Tc:
+        if k not in ('X', 'DIRS', 'ONES'): Tc[k].fill_(float('nan'))
+    eng.run_fused_forward_x3(W, b, Wc, bc, Tc, P)
+    torch.cuda.synchronize()
+    worst = 0
+    for n in names:
+        a, c = Ta[n], Tc[n]
+        if a.dim() == 4:
+            a = a.permute(0, 3, 1, 2).reshape(a.shape[0] * 32, -1)[:P, :width[n]]
+            c = c.permute(0, 3, 1, 2).reshape(c.shape[0] * 32, -1)[:P, :width[n]]
+        nan = int(torch.isnan(c).sum())
+        err = float((a - c).abs().max()); sc = float(a.abs().max())
+        worst = max(worst, err / max(sc, 1e-12))
+        print(f'x3 {n:6s} max|prog| {sc:.4e}  max diff {err:.3e}  rel {err/max(sc,1e-12):.2e}  nan {nan}')
+    print('x3 worst rel', worst)
+for mode in ('prog', 'fused', 'x3'):
     os.environ['VQN_TRAIN_FWD'] = mode
     for _ in range(5): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -516,6 +516,28 @@ def test_training_forward_on_the_render_kernel_matches_the_interpreted_program(P
     for n in ('E', 'OUTF', 'EXTR', 'U%d' % eng.skip if eng.skip > 0 else 'U1'):
         nt = (P + 31) // 32
         assert torch.isfinite(Tb[n][:nt - 1]).all(), n
+    # the same forward on the exact-split engine (vqn_neus_train_fwd_x3: bf16 piece triples, products to 2^-24): f32-level agreement
+    with torch.no_grad():
+        Tc = eng.alloc_tensors(P, dev)
+        Tc['X'].copy_(x)
+        Tc['DIRS'].copy_(d)
+        for k in Tc:
+            if k not in ('X', 'DIRS', 'ONES'):
+                Tc[k].fill_(float('nan'))
+        with launches() as rec:
+            eng.run_fused_forward_x3([m.effective_weight().float() for m in sl], [m.bias.float() for m in sl],
+                                     [m.effective_weight().float() for m in cl], [m.bias.float() for m in cl], Tc, P)
+        assert rec.ran('vqn_neus_train_fwd_x3') and rec.ran('vqn_neus_pack_update')
+    for n, w in width.items():
+        a, c = Ta[n], Tc[n]
+        if a.dim() == 4:
+            a = a.permute(0, 3, 1, 2).reshape(a.shape[0] * 32, -1)[:P, :w]
+            c = c.permute(0, 3, 1, 2).reshape(c.shape[0] * 32, -1)[:P, :w]
+        assert torch.isfinite(c).all(), n
+        scale = max(float(a.abs().max()), 1e-6)
+        assert float((a - c).abs().max()) <= 2e-5 * scale, (n, float((a - c).abs().max()), scale)
+    for n in ('E', 'OUTF', 'EXTR', 'U1'):
+        assert torch.isfinite(Tc[n][:(P + 31) // 32 - 1]).all(), n
 
 
 @pytest.mark.parametrize('P', [1, 33, 4096 + 17, 40000])
@@ -575,29 +597,31 @@ def test_training_backward_on_the_two_image_engine_matches_the_interpreted_progr
         assert torch.equal(Tb[n][:nt], Tc[n][:nt]), n
 
 
-@pytest.mark.parametrize('mode', ['prog', 'fused'])
+@pytest.mark.parametrize('mode', ['prog', 'fused', 'x3'])
 def test_training_forward_switch(mode, monkeypatch):
     """VQN_TRAIN_FWD / VQN_TRAIN_BWD select the forward / backward of the training engine (the two-image kernels or the interpreted
     programs); both reach the same gradients (to f32 rounding)."""
     from oracle import geo as og
     from tests.test_gpu_neus_render import _build
     monkeypatch.setenv('VQN_TRAIN_FWD', mode)
-    monkeypatch.setenv('VQN_TRAIN_BWD', mode)
+    monkeypatch.setenv('VQN_TRAIN_BWD', 'prog' if mode == 'prog' else 'fused')
     cfg, sdf, col, var, ren = _build('full')
     B = 24
     o, d, near, far = [torch.tensor(a).cuda() for a in og.make_rays(B, 5)]
     with launches() as rec:
         rr = ren.render(o, d, near, far, 2.0, perturb_overwrite=0, background_rgb=torch.ones(1, 3).cuda(), cos_anneal_ratio=1.0)
         (rr['color_fine'].sum() + rr['gradient_error']).backward()
-    assert rec.ran('vqn_neus_train_fwd') == (mode == 'fused') and rec.ran('vqn_tile_program:prog_fwd') == (mode == 'prog')
-    assert rec.ran('vqn_neus_train_bwd') == (mode == 'fused') and rec.ran('vqn_tile_program:prog_sbwd') == (mode == 'prog')
+    assert ('vqn_neus_train_fwd' in rec.names) == (mode == 'fused') and ('vqn_neus_train_fwd_x3' in rec.names) == (mode == 'x3')
+    assert rec.ran('vqn_tile_program:prog_fwd') == (mode == 'prog')
+    assert rec.ran('vqn_neus_train_bwd') == (mode != 'prog') and rec.ran('vqn_tile_program:prog_sbwd') == (mode == 'prog')
     grads = torch.cat([p.grad.reshape(-1) for m in (sdf, col) for p in m.parameters()])
     assert torch.isfinite(grads).all()
     test_training_forward_switch.seen = getattr(test_training_forward_switch, 'seen', {})
     test_training_forward_switch.seen[mode] = grads
-    if len(test_training_forward_switch.seen) == 2:
-        a, b = test_training_forward_switch.seen['prog'], test_training_forward_switch.seen['fused']
-        assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max())
+    seen = test_training_forward_switch.seen
+    for other in seen:
+        if other != mode:
+            assert float((seen[other] - grads).abs().max()) <= 2e-4 * float(grads.abs().max()), (other, mode)
 
 
 def test_empty_and_degenerate_inputs():

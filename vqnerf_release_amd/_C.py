@@ -353,14 +353,52 @@ def neus_fine_points(sdf_desc, wbuf_sdf, col_desc, wbuf_col, rays_o=None, rays_d
     return sdf, grad, rgb
 
 
-def neus_train_fwd(sdf_desc, wbuf_sdf, col_desc, wbuf_col, pts, dirs, saved, e_tiles, outf_tiles, extr_tiles, out_sdf, out_n, out_rgb):
+class NeusPackHandle:
+    """vqn_neus_pack_create / _update / _destroy: the packs of one (SDFNetwork, RenderingNetwork) shape built by the library from
+    tables of device pointers to the effective weights [out, in] and biases (one gather launch per network and update)."""
+
+    def __init__(self, sdf_dims, sdf_skip, multires, scale, col_mode, col_d_hidden, col_n_layers, multires_view, squeeze_out, engine):
+        L = lib()
+        for f in ('vqn_neus_pack_sdf_desc', 'vqn_neus_pack_col_desc', 'vqn_neus_pack_sdf_wbuf', 'vqn_neus_pack_col_wbuf'):
+            getattr(L, f).restype = ctypes.c_void_p
+        self.h = ctypes.c_void_p()
+        dims = (ctypes.c_int32 * len(sdf_dims))(*sdf_dims)
+        _check(L.vqn_neus_pack_create(dims, ctypes.c_int(len(sdf_dims) - 1), ctypes.c_int(sdf_skip), ctypes.c_int(multires), ctypes.c_float(scale),
+                                      ctypes.c_int(col_mode), ctypes.c_int(col_d_hidden), ctypes.c_int(col_n_layers), ctypes.c_int(multires_view),
+                                      ctypes.c_int(int(squeeze_out)), ctypes.c_int(engine), ctypes.byref(self.h)), 'vqn_neus_pack_create')
+        self.sdf_desc, self.col_desc = ctypes.c_void_p(L.vqn_neus_pack_sdf_desc(self.h)), ctypes.c_void_p(L.vqn_neus_pack_col_desc(self.h))
+        self.sdf_wbuf, self.col_wbuf = ctypes.c_void_p(L.vqn_neus_pack_sdf_wbuf(self.h)), ctypes.c_void_p(L.vqn_neus_pack_col_wbuf(self.h))
+
+    def update(self, W, b, Wc, bc):
+        for t in W + b + Wc + bc:
+            _f32c(t, 'weight / bias')
+        arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        with _clock('vqn_neus_pack_update'):
+            rc = lib().vqn_neus_pack_update(self.h, arr(W), arr(b), arr(Wc), arr(bc), _stream())
+        _check(rc, 'vqn_neus_pack_update')
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().vqn_neus_pack_destroy(self.h)
+        except Exception:      # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+def neus_train_fwd(sdf_desc, wbuf_sdf, col_desc, wbuf_col, pts, dirs, saved, e_tiles, outf_tiles, extr_tiles, out_sdf, out_n, out_rgb, pack=None):
     """Training forward of the NeuS core at explicit (pts, dirs): the two-image fine kernel, which also leaves the tensors the backward
-    tile programs read (`saved`: [E, OUTF, EXTR, U_1.., GH_0.., C_1..], tile format).  Fills out_sdf [P,1], out_n [P,3], out_rgb [P,3]."""
-    _f32c(wbuf_sdf, 'wbuf_sdf'); _f32c(wbuf_col, 'wbuf_col'); _f32c(pts, 'pts'); _f32c(dirs, 'dirs')
+    tile programs read (`saved`: [E, OUTF, EXTR, U_1.., GH_0.., C_1..], tile format).  Fills out_sdf [P,1], out_n [P,3], out_rgb [P,3].
+    pack: a NeusPackHandle of the exact-split engine -> vqn_neus_train_fwd_x3 on its packs (the descriptor / buffer arguments unused)."""
+    _f32c(pts, 'pts'); _f32c(dirs, 'dirs')
     for t in saved + [out_sdf, out_n, out_rgb]:
         _f32c(t, 'saved tensor')
-    sd, sdp = _i32(sdf_desc)
-    cd, cdp = _i32(col_desc)
+    if pack is not None:
+        sdp, cdp, wsp, wcp, entry = pack.sdf_desc, pack.col_desc, pack.sdf_wbuf, pack.col_wbuf, 'vqn_neus_train_fwd_x3'
+    else:
+        _f32c(wbuf_sdf, 'wbuf_sdf'); _f32c(wbuf_col, 'wbuf_col')
+        sd, sdp = _i32(sdf_desc)
+        cd, cdp = _i32(col_desc)
+        wsp, wcp, entry = _ptr(wbuf_sdf), _ptr(wbuf_col), 'vqn_neus_train_fwd'
     P, dev = pts.shape[0], pts.device
     L = lib()
     L.vqn_neus_fine_scratch_bytes.restype = ctypes.c_int64
@@ -373,11 +411,11 @@ def neus_train_fwd(sdf_desc, wbuf_sdf, col_desc, wbuf_col, pts, dirs, saved, e_t
         buf = torch.empty((need,), dtype=torch.uint8, device=dev)
         _scratch[key] = buf
     ptrs = (ctypes.c_void_p * len(saved))(*[t.data_ptr() for t in saved])
-    with _clock('vqn_neus_train_fwd'):
-        rc = L.vqn_neus_train_fwd(sdp, _ptr(wbuf_sdf), cdp, _ptr(wbuf_col), _ptr(pts), _ptr(dirs), ctypes.c_int64(P), _ptr(buf),
-                                  ctypes.c_int64(buf.numel()), ptrs, ctypes.c_int(len(saved)), ctypes.c_int(e_tiles),
-                                  ctypes.c_int(outf_tiles), ctypes.c_int(extr_tiles), _ptr(out_sdf), _ptr(out_n), _ptr(out_rgb), _stream())
-    _check(rc, 'vqn_neus_train_fwd')
+    with _clock(entry):
+        rc = getattr(L, entry)(sdp, wsp, cdp, wcp, _ptr(pts), _ptr(dirs), ctypes.c_int64(P), _ptr(buf),
+                               ctypes.c_int64(buf.numel()), ptrs, ctypes.c_int(len(saved)), ctypes.c_int(e_tiles),
+                               ctypes.c_int(outf_tiles), ctypes.c_int(extr_tiles), _ptr(out_sdf), _ptr(out_n), _ptr(out_rgb), _stream())
+    _check(rc, entry)
 
 
 def neus_train_bwd(desc, wbuf, pts, g_rgb, rgb, g_n, g_sdf, saved, outs):

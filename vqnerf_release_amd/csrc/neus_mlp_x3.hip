@@ -36,13 +36,34 @@ struct Smalls2 {
   int n_calls;
 };
 
-template <bool FINE, int NACC>
+// ---- training forward (TRAIN): as neus_points2_kernel<FINE, TRAIN> of csrc/neus_mlp.hip -- the fine kernel also leaves what the backward
+// (csrc/neus_train_bwd.hip) and the weight-gradient contraction read, in the tile format [point tile][feature tile][32 features][32 points]
+// f32.  The values stored are the f32 ones the epilogues hold BEFORE the split into bf16 pieces.
+struct TrainOut {
+  float* E; float* OUTF; float* EXTR;
+  float* U[VQN_MAX_SDF_LAYERS]; float* GH[VQN_MAX_SDF_LAYERS]; float* C[VQN_MAX_COL_LAYERS];
+  int e_tiles, outf_tiles, extr_tiles;
+};
+// an accumulator tile: register i of lane (p, h) is feature (i & 3) + 8 (i >> 2) + 4 h of the tile
+__device__ __forceinline__ void tfmt_store_acc(float* __restrict__ T, const long ptile, const int n_ft, const int ot, const int lane, const float (&v)[16]) {
+  float* base = T + ((ptile * n_ft + ot) * 32 + 4 * (lane >> 5)) * 32 + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) __builtin_nontemporal_store(v[i], base + ((i & 3) + 8 * (i >> 2)) * 32);
+}
+// a K step of an image: slot jj of lane (p, h) is feature 16 sl + 8 (jj >> 2) + 4 h + (jj & 3)
+__device__ __forceinline__ void tfmt_store_step(float* __restrict__ T, const long ptile, const int n_ft, const int sl, const int lane, const float (&x)[8]) {
+  float* base = T + ((ptile * n_ft + (sl >> 1)) * 32 + 16 * (sl & 1) + 4 * (lane >> 5)) * 32 + (lane & 31);
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) __builtin_nontemporal_store(x[jj], base + (8 * (jj >> 2) + (jj & 3)) * 32);
+}
+
+template <bool FINE, int NACC, bool TRAIN = false>
 __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
     const SdfDesc sd, const ColDesc cd, const f32x4* __restrict__ wsdf, const f32x4* __restrict__ wcol,
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ zv,
     const float* __restrict__ pts_direct, const float* __restrict__ dirs_direct, const long P, const int S,
     f32x4* __restrict__ scratch, float* __restrict__ out_sdf, float* __restrict__ out_grad,
-    float* __restrict__ out_rgb) {
+    float* __restrict__ out_rgb, const TrainOut to) {
   extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
   const int MT = sd.max_tiles;
   const int IMG = E_ROWS + 6 * MT, IS = IMG * 64;            // rows / float4 per image
@@ -152,18 +173,22 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
     __syncthreads();
     const float xs = sm->pts[img][p * 3 + 0] * sd.scale, ys = sm->pts[img][p * 3 + 1] * sd.scale, zs = sm->pts[img][p * 3 + 2] * sd.scale;
     // ---------------- positional encoding -> E rows (x3 image) ----------------
-    for (int sl = w4; sl < sd.emb_rows / 3; sl += 4) {
+    const long ptile_w = 2 * pair + img;                    // (TRAIN) this wave's image; stores are skipped for a phantom tile
+    for (int sl = w4; sl < (TRAIN ? 2 * to.e_tiles : sd.emb_rows / 3); sl += 4) {
       float x[8];
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) {
         const int f = step_feat(sl, h, jj);
-        x[jj] = f < sd.emb_feats ? posenc_feat(f, xs, ys, zs) : 0.f;
+        x[jj] = (sl < sd.emb_rows / 3 && f < sd.emb_feats) ? posenc_feat(f, xs, ys, zs) : 0.f;
       }
-      f32x4 q0, q1, q2;
-      split3x8(x, q0, q1, q2);
-      ldsi[(E0 + 3 * sl) * 64 + lane] = q0;
-      ldsi[(E0 + 3 * sl + 1) * 64 + lane] = q1;
-      ldsi[(E0 + 3 * sl + 2) * 64 + lane] = q2;
+      if (TRAIN && ptile_w < n_tiles) tfmt_store_step(to.E, ptile_w, to.e_tiles, sl, lane, x);
+      if (sl < sd.emb_rows / 3) {
+        f32x4 q0, q1, q2;
+        split3x8(x, q0, q1, q2);
+        ldsi[(E0 + 3 * sl) * 64 + lane] = q0;
+        ldsi[(E0 + 3 * sl + 1) * 64 + lane] = q1;
+        ldsi[(E0 + 3 * sl + 2) * 64 + lane] = q2;
+      }
     }
     __syncthreads();
 
@@ -174,12 +199,14 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
                                 : KSegs{X0, 6 * sd.layers[l - 1].n_out_tiles, E0, (l == sd.skip) ? sd.emb_rows : 0};
       const bool do_save = FINE && (l < n_lin - 2);
       const f32x4* bp = wsdf + L.b_off;
+      float* const t_u = TRAIN ? to.U[l + 1] : nullptr;
       G(wsdf + L.w_off, ks, L.n_out_tiles,
         [&](int ot, int, f32x16& acc) { init_bias_f16s(bp, ot, lane, acc); },
         [&](int ot, int im, const f32x16& acc) {
           float v[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) v[i] = act_fwd<ACT_SOFTPLUS100>(acc[i]);
+          if (TRAIN && 2 * pair + im < n_tiles) tfmt_store_acc(t_u, 2 * pair + im, L.n_out_tiles, ot, lane, v);
           split_tile_x3(v, o[im]);
           if (do_save) {                            // what the reverse sweep needs of this layer: act'(x) = 1 - exp(-100 h)
             f32x4* sv = save0 + (size_t)im * per_img + (size_t)l * 4 * MT * 64;
@@ -205,16 +232,27 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             st_stream(sv + (ot * 4 + q) * 64 + lane, (f32x4){acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
+          if (TRAIN && 2 * pair + im < n_tiles) {            // OUTF = [sdf ; features]: feature f of this GEMM is row f + 1
+            float* base = to.OUTF + (2 * pair + im) * (long)to.outf_tiles * 1024;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int f = 32 * ot + (i & 3) + 8 * (i >> 2) + 4 * h + 1;
+              if (f < 32 * to.outf_tiles) __builtin_nontemporal_store(acc[i], base + f * 32 + p);
+            }
+          }
         });
     }
     __syncthreads();
     if (tid < 64) {
       const int im = tid >> 5, t = tid & 31;
       const long pt = ((2 * pair + im) << 5) + t;
-      if (pt < P) {
-        const float* pr = sm->part[im];
-        const float s = ((pr[t] + pr[32 + t]) + (pr[64 + t] + pr[96 + t])) + (sd.last_b_off > 0 ? wsdf[sd.last_b_off][0] : sd.last_bias);
-        out_sdf[pt] = s / sd.scale;
+      const float* pr = sm->part[im];
+      const float s = ((pr[t] + pr[32 + t]) + (pr[64 + t] + pr[96 + t])) + (sd.last_b_off > 0 ? wsdf[sd.last_b_off][0] : sd.last_bias);
+      if (pt < P) out_sdf[pt] = s / sd.scale;
+      if (TRAIN && 2 * pair + im < n_tiles) {                 // row 0 of OUTF (the raw sdf output) and the zero tail beyond row F - 1
+        float* base = to.OUTF + (2 * pair + im) * (long)to.outf_tiles * 1024;
+        base[t] = s;
+        for (int f = 32 * sd.layers[n_lin - 1].n_out_tiles + 1; f < 32 * to.outf_tiles; ++f) base[f * 32 + t] = 0.f;
       }
     }
     if (!FINE) { __syncthreads(); continue; }
@@ -248,6 +286,7 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
             f32x4 q0_, q1_, q2_;
             split3x8(x, q0_, q1_, q2_);
             const int q = q0 + 4 * c;
+            if (TRAIN && ptile_w < n_tiles) tfmt_store_step(to.GH[n_lin - 2], ptile_w, sd.layers[n_lin - 2].n_out_tiles, q, lane, x);
             ldsi[(X0 + 3 * q) * 64 + lane] = q0_;
             ldsi[(X0 + 3 * q + 1) * 64 + lane] = q1_;
             ldsi[(X0 + 3 * q + 2) * 64 + lane] = q2_;
@@ -277,10 +316,11 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
           for (int q = 0; q < 4; ++q) hv[im][q] = ld_stream(sv + (ot * 4 + q) * 64 + lane);
           init_zero(acc);
         },
-        [&](int, int im, const f32x16& acc) {
+        [&](int ot, int im, const f32x16& acc) {
           float v[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) v[i] = acc[i] * hv[im][i >> 2][i & 3];
+          if (TRAIN && 2 * pair + im < n_tiles) tfmt_store_acc(to.GH[l - 1], 2 * pair + im, tiles, ot, lane, v);
           split_tile_x3(v, o[im]);
         });
 #else                        // ... or in the epilogue itself: the kernel sits at the 256-register limit, and the other wave of the SIMD covers the wait
@@ -294,6 +334,7 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
           float v[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) v[i] = acc[i] * hv[i >> 2][i & 3];
+          if (TRAIN && 2 * pair + im < n_tiles) tfmt_store_acc(to.GH[l - 1], 2 * pair + im, tiles, ot, lane, v);
           split_tile_x3(v, o[im]);
         });
 #endif
@@ -342,22 +383,26 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
     {
       const float px = sm->pts[img][p * 3 + 0], py = sm->pts[img][p * 3 + 1], pz = sm->pts[img][p * 3 + 2];
       const float dx = sm->dirs[img][p * 3 + 0], dy = sm->dirs[img][p * 3 + 1], dz = sm->dirs[img][p * 3 + 2];
-      for (int sl = w4; sl < cd.extra_rows / 3; sl += 4) {
+      for (int sl = w4; sl < (TRAIN ? 2 * to.extr_tiles : cd.extra_rows / 3); sl += 4) {
         float x[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
           const int f = step_feat(sl, h, jj);
           float val = 0.f;
-          if (f < 3) val = f == 0 ? px : (f == 1 ? py : pz);
+          if (sl >= cd.extra_rows / 3) val = 0.f;
+          else if (f < 3) val = f == 0 ? px : (f == 1 ? py : pz);
           else if (f < 3 + cd.n_view_feats) val = posenc_feat(f - 3, dx, dy, dz);
           else if (f < cd.extra_feats) val = sm->grad[img][p * 3 + (f - 3 - cd.n_view_feats)];
           x[jj] = val;
         }
-        f32x4 q0, q1, q2;
-        split3x8(x, q0, q1, q2);
-        ldsi[(E0 + 3 * sl) * 64 + lane] = q0;
-        ldsi[(E0 + 3 * sl + 1) * 64 + lane] = q1;
-        ldsi[(E0 + 3 * sl + 2) * 64 + lane] = q2;
+        if (TRAIN && ptile_w < n_tiles) tfmt_store_step(to.EXTR, ptile_w, to.extr_tiles, sl, lane, x);
+        if (sl < cd.extra_rows / 3) {
+          f32x4 q0, q1, q2;
+          split3x8(x, q0, q1, q2);
+          ldsi[(E0 + 3 * sl) * 64 + lane] = q0;
+          ldsi[(E0 + 3 * sl + 1) * 64 + lane] = q1;
+          ldsi[(E0 + 3 * sl + 2) * 64 + lane] = q2;
+        }
       }
       const f32x4* sv = save0 + (size_t)img * per_img + (size_t)feat_slot * 64;
       const int feat_tiles = sd.layers[n_lin - 1].n_out_tiles;
@@ -376,12 +421,14 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
         const LayerDesc L = cd.layers[l];
         const KSegs ks{X0, in_rows, E0, l == 0 ? cd.extra_rows : 0};
         const f32x4* bp = wcol + L.b_off;
+        float* const t_c = TRAIN ? to.C[l + 1] : nullptr;
         G(wcol + L.w_off, ks, L.n_out_tiles,
           [&](int ot, int, f32x16& acc) { init_bias_f16s(bp, ot, lane, acc); },
-          [&](int, int im, const f32x16& acc) {
+          [&](int ot, int im, const f32x16& acc) {
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = act_fwd<ACT_RELU>(acc[i]);
+            if (TRAIN && 2 * pair + im < n_tiles) tfmt_store_acc(t_c, 2 * pair + im, L.n_out_tiles, ot, lane, v);
             split_tile_x3(v, o[im]);
           });
         commit(L.n_out_tiles, X0);
@@ -448,7 +495,7 @@ extern "C" int vqn_neus_sdf_points_x3(const int32_t* sdf_desc, const float* wbuf
   if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds2, (hipStream_t)stream, sd, cd,
                      reinterpret_cast<const f32x4*>(wbuf_sdf), (const f32x4*)nullptr, rays_o, rays_d, z, pts,
-                     (const float*)nullptr, (long)P, S, (f32x4*)nullptr, out_sdf, (float*)nullptr, (float*)nullptr);
+                     (const float*)nullptr, (long)P, S, (f32x4*)nullptr, out_sdf, (float*)nullptr, (float*)nullptr, TrainOut{});
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }
@@ -489,7 +536,53 @@ extern "C" int vqn_neus_fine_points_x3(const int32_t* sdf_desc, const float* wbu
   VQN_CHECK_ARG(grid >= 1, "scratch too small (see vqn_neus_fine_scratch_bytes)");
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds2, (hipStream_t)stream, sd, cd,
                      reinterpret_cast<const f32x4*>(wbuf_sdf), reinterpret_cast<const f32x4*>(wbuf_col), rays_o, rays_d,
-                     z, pts, dirs, (long)P, S, reinterpret_cast<f32x4*>(scratch), out_sdf, out_grad, out_rgb);
+                     z, pts, dirs, (long)P, S, reinterpret_cast<f32x4*>(scratch), out_sdf, out_grad, out_rgb, TrainOut{});
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
+
+// Training forward on the exact-split engine: vqn_neus_train_fwd with x3 packs and descriptors (vqn_neus_pack_create(..., f16s = 2)).
+// Same outputs and saved tensors (f32 values, taken before the split into pieces); layers of at most 256 outputs.
+extern "C" int vqn_neus_train_fwd_x3(const int32_t* sdf_desc, const float* wbuf_sdf, const int32_t* col_desc, const float* wbuf_col,
+                                     const float* pts, const float* dirs, int64_t P, void* scratch, int64_t scratch_bytes,
+                                     float* const* tensors, int n_tensors, int e_tiles, int outf_tiles, int extr_tiles, float* out_sdf,
+                                     float* out_n, float* out_rgb, void* stream) {
+  VQN_CHECK_ARG(sdf_desc && wbuf_sdf && col_desc && wbuf_col && pts && dirs && scratch && tensors && out_sdf && out_n && out_rgb, "null pointer");
+  VQN_CHECK_ARG(P >= 1, "P >= 1");
+  SdfDesc sd;
+  ColDesc cd;
+  memcpy(&sd, sdf_desc, sizeof(SdfDesc));
+  memcpy(&cd, col_desc, sizeof(ColDesc));
+  VQN_CHECK_SHAPE(check_sdf_desc_x3(sd) == 0, "invalid SDF network descriptor for the x3 engine");
+  VQN_CHECK_SHAPE(cd.n_lin >= 2 && cd.n_lin <= VQN_MAX_COL_LAYERS && cd.d_out == 3 && sd.layers[sd.n_lin - 1].n_out_tiles >= 1, "colour net");
+  VQN_CHECK_SHAPE(cd.extra_feats >= 3 && cd.extra_feats <= 64 && cd.extra_rows == x3_rows(cd.extra_feats), "colour net extras");
+  for (int l = 0; l < cd.n_lin - 1; ++l)
+    VQN_CHECK_SHAPE(cd.layers[l].n_out_tiles >= 1 && cd.layers[l].n_out_tiles <= sd.max_tiles, "colour layer wider than max_tiles");
+  const int nL = sd.n_lin - 1, nC = cd.n_lin - 1;
+  VQN_CHECK_ARG(n_tensors == 3 + 2 * nL + nC, "tensors: [E, OUTF, EXTR, U_1..U_nL, GH_0..GH_{nL-1}, C_1..C_nC]");
+  VQN_CHECK_SHAPE(2 * e_tiles * 3 >= sd.emb_rows && e_tiles <= 2 && 2 * extr_tiles * 3 >= cd.extra_rows && extr_tiles <= 2 &&
+                  32 * outf_tiles >= 32 * sd.layers[sd.n_lin - 1].n_out_tiles + 1, "tile counts");
+  TrainOut to;
+  memset(&to, 0, sizeof(to));
+  for (int i = 0; i < n_tensors; ++i) VQN_CHECK_ARG(tensors[i] != nullptr, "null tensor pointer");
+  to.E = tensors[0]; to.OUTF = tensors[1]; to.EXTR = tensors[2];
+  for (int l = 1; l <= nL; ++l) to.U[l] = tensors[3 + (l - 1)];
+  for (int l = 0; l < nL; ++l) to.GH[l] = tensors[3 + nL + l];
+  for (int l = 1; l <= nC; ++l) to.C[l] = tensors[3 + 2 * nL + (l - 1)];
+  to.e_tiles = e_tiles; to.outf_tiles = outf_tiles; to.extr_tiles = extr_tiles;
+  const long n_tiles = (P + 31) / 32;
+  const int64_t per_wg = (int64_t)(sd.n_lin - 1) * 4 * sd.max_tiles * 1024;
+  const size_t lds2 = lds_bytes_x3(sd.max_tiles);
+  VQN_CHECK_SHAPE(lds2 <= 160 * 1024, "network too wide for LDS");
+  auto kern = x3_nacc() == 2 ? neus_points_x3_kernel<true, 2, true> : neus_points_x3_kernel<true, 1, true>;
+  VQN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+  long grid = (long)vqn_num_cus();
+  if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;
+  if ((int64_t)grid * 2 * per_wg > scratch_bytes) grid = (long)(scratch_bytes / (2 * per_wg));
+  VQN_CHECK_ARG(grid >= 1, "scratch too small (see vqn_neus_fine_scratch_bytes)");
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds2, (hipStream_t)stream, sd, cd, reinterpret_cast<const f32x4*>(wbuf_sdf),
+                     reinterpret_cast<const f32x4*>(wbuf_col), (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, pts, dirs,
+                     (long)P, 1, reinterpret_cast<f32x4*>(scratch), out_sdf, out_n, out_rgb, to);
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }
