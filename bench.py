@@ -152,6 +152,7 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
              # (round 3: the full-size networks run the forward / backward on the two-image engine instead of the interpreted programs)
              'vqn_neus_train_fwd': 2.0 * B * S_f * (2 * m_sdf + m_col), 'vqn_neus_train_bwd': 2.0 * B * S_f * (2 * m_sdf + m_col),
              'vqn_neus_train_fwd_x3': 2.0 * B * S_f * (2 * m_sdf + m_col),       # (exact-split engine: f32-equivalent FLOPs over the f32 peak)
+             'vqn_neus_train_bwd_x3': 2.0 * B * S_f * (2 * m_sdf + m_col),
              'vqn_wgrad_partials': 2.0 * B * S_f * (2 * m_sdf + m_col), 'vqn_wgrad_partials_x3': 2.0 * B * S_f * (2 * m_sdf + m_col)}
     kfrac = {k: {'ms': clk[k][1] / 6, 'tflops': kflop[k] / (clk[k][1] / 6 * 1e-3) / 1e12,
                  'frac_of_f32_mfma_peak': kflop[k] / (clk[k][1] / 6 * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS} for k in kflop if k in clk}

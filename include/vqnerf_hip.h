@@ -224,6 +224,21 @@ int vqn_neus_train_bwd(const int32_t* desc, const float* wbuf, const float* pts,
                        const float* g_n, const float* g_sdf, int64_t P, void* scratch, int64_t scratch_bytes,
                        const float* const* saved, int n_saved, float* const* outs, int n_outs, void* stream);
 
+/* vqn_neus_train_bwd on the exact-split engine (csrc/neus_train_bwd_x3.hip): the same pass, saved tensors, adjoints and outputs;
+ * every layer GEMM as six bf16 MFMAs per product over bf16 piece triples, the layers in place (networks of at most 256-wide
+ * layers).  desc as for vqn_neus_train_bwd with emb_rows in x3 rows (3 per 16 features); wbuf_pieces: the matrices as piece
+ * triples in the x3 A-fragment order (geo/packing.py gemm_index_x3 + split_pack_x3 -- vqn_pack_x3_gather builds it in one launch);
+ * wbuf_f32: the two thin f32 images (the last layer's sdf row in accumulator order, the normals' row dots). */
+int64_t vqn_neus_train_bwd_x3_scratch_bytes(const int32_t* desc);
+int vqn_neus_train_bwd_x3(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, const float* pts, const float* g_rgb,
+                          const float* rgb, const float* g_n, const float* g_sdf, int64_t P, void* scratch, int64_t scratch_bytes,
+                          const float* const* saved, int n_saved, float* const* outs, int n_outs, void* stream);
+
+/* out[t][q][lane][k] (bf16, q = 0..2) = piece q of flat[gidx[t][lane][k]] for t < n_steps (64 lanes x 8 slots per K step): a
+ * gather from a flat parameter vector fused with the exact three-way split x = p0 + p1 + p2 into bf16 pieces (truncation of the
+ * word, twice on the exact remainders) -- a whole x3 weight pack in one launch. */
+int vqn_pack_x3_gather(const float* flat, const int32_t* gidx, int64_t n_steps, void* out, void* stream);
+
 /* Split-precision twins of vqn_neus_sdf_points / vqn_neus_fine_points ("fp16 MFMA path"): same arguments, same outputs,
  * every product taken as hi*hi + 2^-11 (hi*lo + lo*hi) over f16 hi/lo operand pairs on v_mfma_f32_32x32x16_f16 with f32
  * accumulation.  Descriptors and packs must be built for it (SdfPackPlan(mode='f16s'), ColPackPlan(matrix_mode='f16s'):

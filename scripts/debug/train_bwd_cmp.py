@@ -54,7 +54,25 @@ for P in (4096 + 17, 64):
             pad = float((full_a - full_c).abs().max())
             print(f'{n:6s} max|prog| {sc:.4e}  max diff {err:.3e}  rel {err/max(sc,1e-12):.2e}  nan(all of the tiles) {nanfull}  diff incl. padding {pad:.3e}')
         print('P', P, 'worst rel', worst)
-for mode in ('prog', 'fused'):
+        Tc = eng.alloc_tensors(P, dev)
+        Tc['X'].copy_(x); Tc['DIRS'].copy_(d)
+        eng.run_fused_forward(flat, Tc, P)
+        for n in outs:
+            Tc[n].fill_(float('nan'))
+        eng.run_fused_backward_x3(flat, Tc, P, g_rgb, g_n, g_sdf)
+        torch.cuda.synchronize()
+        worst = 0
+        for n in outs:
+            a, c = Ta[n], Tc[n]
+            nt = (P + 31) // 32
+            nanfull = int(torch.isnan(c[:nt]).sum())
+            a = a.permute(0, 3, 1, 2).reshape(a.shape[0] * 32, -1)[:P, :width[n]]
+            c = c.permute(0, 3, 1, 2).reshape(c.shape[0] * 32, -1)[:P, :width[n]]
+            err = float((a - c).abs().max()); sc = float(a.abs().max())
+            worst = max(worst, err / max(sc, 1e-12))
+            print(f'x3 {n:6s} max|prog| {sc:.4e}  max diff {err:.3e}  rel {err/max(sc,1e-12):.2e}  nan {nanfull}')
+        print('x3 P', P, 'worst rel', worst)
+for mode in ('prog', 'fused', 'x3'):
     os.environ['VQN_TRAIN_BWD'] = mode
     for _ in range(5): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()

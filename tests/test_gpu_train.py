@@ -585,6 +585,24 @@ def test_training_backward_on_the_two_image_engine_matches_the_interpreted_progr
         a, c = a[wrote], c[wrote]
         scale = max(float(a.abs().max()), 1e-6)
         assert float((a - c).abs().max()) <= 5e-6 * scale, (n, float((a - c).abs().max()), scale)
+    # the same pass on the exact-split engine (vqn_neus_train_bwd_x3: packs by vqn_pack_x3_gather): f32-level agreement
+    with torch.no_grad():
+        Tx = eng.alloc_tensors(P, dev)
+        Tx['X'].copy_(x)
+        Tx['DIRS'].copy_(d)
+        eng.run_fused_forward(flat, Tx, P)
+        for n in outs:
+            Tx[n].fill_(float('nan'))
+        with launches() as rec:
+            eng.run_fused_backward_x3(flat, Tx, P, g_rgb, g_n, g_sdf)
+        assert rec.ran('vqn_neus_train_bwd_x3') and rec.ran('vqn_pack_x3_gather')
+    for n in outs:
+        a, c = Ta[n][:nt], Tx[n][:nt]
+        assert torch.isfinite(c).all(), n
+        wrote = ~torch.isnan(a)
+        a, c = a[wrote], c[wrote]
+        scale = max(float(a.abs().max()), 1e-6)
+        assert float((a - c).abs().max()) <= 2e-5 * scale, (n, float((a - c).abs().max()), scale)
     # no incoming adjoint for the normals / the sdf (None in autograd): the same as zeros
     with torch.no_grad():
         Tc = eng.alloc_tensors(P, dev)
@@ -604,7 +622,7 @@ def test_training_forward_switch(mode, monkeypatch):
     from oracle import geo as og
     from tests.test_gpu_neus_render import _build
     monkeypatch.setenv('VQN_TRAIN_FWD', mode)
-    monkeypatch.setenv('VQN_TRAIN_BWD', 'prog' if mode == 'prog' else 'fused')
+    monkeypatch.setenv('VQN_TRAIN_BWD', mode)
     cfg, sdf, col, var, ren = _build('full')
     B = 24
     o, d, near, far = [torch.tensor(a).cuda() for a in og.make_rays(B, 5)]
@@ -613,7 +631,8 @@ def test_training_forward_switch(mode, monkeypatch):
         (rr['color_fine'].sum() + rr['gradient_error']).backward()
     assert ('vqn_neus_train_fwd' in rec.names) == (mode == 'fused') and ('vqn_neus_train_fwd_x3' in rec.names) == (mode == 'x3')
     assert rec.ran('vqn_tile_program:prog_fwd') == (mode == 'prog')
-    assert rec.ran('vqn_neus_train_bwd') == (mode != 'prog') and rec.ran('vqn_tile_program:prog_sbwd') == (mode == 'prog')
+    assert ('vqn_neus_train_bwd' in rec.names) == (mode == 'fused') and ('vqn_neus_train_bwd_x3' in rec.names) == (mode == 'x3')
+    assert rec.ran('vqn_tile_program:prog_sbwd') == (mode == 'prog')
     grads = torch.cat([p.grad.reshape(-1) for m in (sdf, col) for p in m.parameters()])
     assert torch.isfinite(grads).all()
     test_training_forward_switch.seen = getattr(test_training_forward_switch, 'seen', {})

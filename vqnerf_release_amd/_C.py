@@ -418,6 +418,44 @@ def neus_train_fwd(sdf_desc, wbuf_sdf, col_desc, wbuf_col, pts, dirs, saved, e_t
     _check(rc, entry)
 
 
+def pack_x3_gather(flat, gidx, n_steps):
+    """bf16 piece triples [n_steps, 3, 64, 8] (as an int16 tensor) of flat[gidx] -- gather + exact split in one launch."""
+    _f32c(flat, 'flat')
+    if gidx.dtype != torch.int32 or not gidx.is_contiguous() or gidx.numel() != n_steps * 512:
+        raise VqnError('pack_x3_gather: gidx must be a contiguous int32 tensor of n_steps * 512 entries')
+    out = torch.empty((n_steps, 3, 64, 8), dtype=torch.int16, device=flat.device)
+    with _clock('vqn_pack_x3_gather'):
+        rc = lib().vqn_pack_x3_gather(_ptr(flat), _ptr(gidx), ctypes.c_int64(n_steps), _ptr(out), _stream())
+    _check(rc, 'vqn_pack_x3_gather')
+    return out
+
+
+def neus_train_bwd_x3(desc, wbuf_pieces, wbuf_f32, pts, g_rgb, rgb, g_n, g_sdf, saved, outs):
+    """neus_train_bwd on the exact-split engine (csrc/neus_train_bwd_x3.hip)."""
+    _f32c(wbuf_f32, 'wbuf_f32'); _f32c(pts, 'pts'); _f32c(g_rgb, 'g_rgb')
+    for t in saved + outs + [t for t in (rgb, g_n, g_sdf) if t is not None]:
+        _f32c(t, 'tensor')
+    d, dp = _i32(desc)
+    P, dev = pts.shape[0], pts.device
+    L = lib()
+    L.vqn_neus_train_bwd_x3_scratch_bytes.restype = ctypes.c_int64
+    need = int(L.vqn_neus_train_bwd_x3_scratch_bytes(dp))
+    if need <= 0:
+        raise VqnError('vqn_neus_train_bwd_x3_scratch_bytes: invalid descriptor')
+    key = (str(dev), torch.cuda.current_stream().cuda_stream, 'bwd')
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty((need,), dtype=torch.uint8, device=dev)
+        _scratch[key] = buf
+    sp = (ctypes.c_void_p * len(saved))(*[t.data_ptr() for t in saved])
+    op = (ctypes.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
+    with _clock('vqn_neus_train_bwd_x3'):
+        rc = L.vqn_neus_train_bwd_x3(dp, _ptr(wbuf_pieces), _ptr(wbuf_f32), _ptr(pts), _ptr(g_rgb), _ptr(rgb), _ptr(g_n), _ptr(g_sdf),
+                                     ctypes.c_int64(P), _ptr(buf), ctypes.c_int64(buf.numel()), sp, ctypes.c_int(len(saved)), op,
+                                     ctypes.c_int(len(outs)), _stream())
+    _check(rc, 'vqn_neus_train_bwd_x3')
+
+
 def neus_train_bwd(desc, wbuf, pts, g_rgb, rgb, g_n, g_sdf, saved, outs):
     """Backward of the NeuS core in one launch (csrc/neus_train_bwd.hip): fills `outs` ([DC_0.., GOUTF, ED, UD_1.., AB_0..]) from the
     incoming adjoints and the forward's `saved` tensors ([U_1.., GH_0.., C_1..]); rgb / g_n / g_sdf may be None."""

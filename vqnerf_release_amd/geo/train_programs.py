@@ -47,6 +47,7 @@ from vqnerf_release_amd.geo.packing import gemm_index, bias_index, _take
 # VQN_TRAIN_FWD overrides.  x3 is the default since every training test -- the reference's gradient goldens at the unchanged 5e-3 bound,
 # the torch-autograd comparisons, the graph replays -- passes under it (the gate VERDICT r02 set for the bf16x3 contraction).
 TRAIN_FWD_DEFAULT = 'x3'
+TRAIN_BWD_DEFAULT = 'x3'          # the backward likewise: 'x3' 6.8 ms, 'fused' (f32-input MFMA) 8.6 ms, 'prog' 9.8 ms; same gate, same result
 
 # one finalize launch per backward pass (WgradBatch) instead of a reduce / transpose / cat / scale sequence per weight; VQN_WGRAD_BATCH=0
 # keeps the per-weight sequence (same sums, bit for bit)
@@ -393,6 +394,7 @@ class NeusTrainEngine:
         self._fused_dev = {}           # per device: gather indices + descriptors of the fused forward's packs
         self._bwd_dev = {}             # per device: gather index + descriptor of the fused backward's pack
         self._x3_pack = None           # library-built packs of the exact-split forward (vqn_neus_pack_create, engine 2)
+        self._bwd_x3_dev = {}          # per device: gather indices + descriptor of the exact-split backward's packs
         for name, build in (('prog_fwd', self._build_forward), ('prog_cbwd', self._build_colour_backward),
                             ('prog_sbwd', self._build_sdf_backward)):
             prog = build()
@@ -674,10 +676,97 @@ class NeusTrainEngine:
     # the backward on the two-image engine ---------------------------------------------------------------
     TB_MAX_L = 12
 
+    def backward_mode(self):
+        """'x3' (vqn_neus_train_bwd_x3, layers of at most 256 outputs) | 'f32' (vqn_neus_train_bwd) | None (the interpreted programs).
+        VQN_TRAIN_BWD = x3 | fused | prog."""
+        want = os.environ.get('VQN_TRAIN_BWD', TRAIN_BWD_DEFAULT)
+        if want not in ('fused', 'x3') or not self._fused_backward_shape():
+            return None
+        return 'x3' if want == 'x3' else 'f32'
+
     def fused_backward(self):
+        return self.backward_mode() is not None
+
+    def _bwd_static_x3(self, device):
+        """the x3 backward kernel's packs: int32 gather index [steps, 64, 8] of the piece pack (vqn_pack_x3_gather splits what it gathers),
+        int64 gather index of the two thin f32 images, int32 descriptor"""
+        k = str(device)
+        if k in self._bwd_x3_dev:
+            return self._bwd_x3_dev[k]
+        L, nL, nC, M = self._layout(), self.nL, self.nC, self.TB_MAX_L
+        tl = self._tiles
+        emb_rows = packing.emb_rows_for_x3(self.E)
+        chunks, off, fch, foff = [], [0], [], [0]
+
+        def add(view, idx):                                   # idx [T, S, 64, 8] into view.flatten() ++ [zero]; offsets in float4 of the PIECE pack
+            src = np.append(np.ascontiguousarray(view).reshape(-1), L.zero)
+            c = src[idx.reshape(-1)]
+            o4 = off[0]
+            chunks.append(c)
+            off[0] += (c.size // 512) * 192                   # a K step of one tile: 3 pieces x 64 lanes x 16 B = 192 float4
+            return o4
+
+        def addf(view, idx):
+            src = np.append(np.ascontiguousarray(view).reshape(-1), L.zero)
+            c = src[idx.reshape(-1)]
+            assert c.size % 4 == 0
+            o4 = foff[0] // 4
+            fch.append(c)
+            foff[0] += c.size
+            return o4
+
+        gx = packing.gemm_index_x3
+        offT, offB, offCB = [0] * M, [0] * M, [0] * M
+        for l in range(nL):
+            if l == 0:
+                segs = [(emb_rows, _ident(self.E))]
+            elif l == self.skip:
+                segs = [(6 * tl(self.out[l - 1]), _ident(self.out[l - 1])), (emb_rows, _ident(self.E, base=self.out[l - 1]))]
+            else:
+                segs = [(6 * tl(self.inn[l]), _ident(self.inn[l]))]
+            offT[l] = add(L['W%d' % l], gx(self.out[l], self.inn[l], segs))
+        for l in range(1, nL):
+            offB[l] = add(L['W%d' % l][:, :self.out[l - 1]].T, gx(self.out[l - 1], self.out[l], [(6 * tl(self.out[l]), _ident(self.out[l]))]))
+        nf = self.F - 1
+        offBtop = add(L['W%d' % nL][1:].T, gx(self.inn[nL], nf, [(6 * tl(nf), _ident(nf))]))
+        offWrow = addf(L['W%d' % nL][0], packing.bias_index_f16s(self.inn[nL]))
+        for l in range(1, nC + 1):
+            rows = 3 if l == nC else 6 * tl(self.cout[l])
+            offCB[l] = add(L['Wc%d' % l].T, gx(self.cin[l], self.cout[l], [(rows, _ident(self.cout[l]))]))
+        offCBfeat = add(L['Wc0'][:, self.X:].T, gx(nf, self.cout[0], [(6 * tl(self.cout[0]), _ident(self.cout[0]))]))
+        offCBnrm = addf(L['Wc0'][:, self.X - 3:self.X].T, packing.rowdot_index_x3(3, 6 * tl(self.cout[0]), self.cout[0]))
+        mt = max(tl(w) for w in self.out[:nL] + self.cout[:nC] + [nf])
+        desc = np.zeros(16 + 5 * M, np.int32)
+        desc[0:14] = [nL, nC, self.skip, emb_rows, self.E, tl(self.E), mt, tl(nf), tl(self.F), int(self.squeeze), offBtop, offWrow, offCBfeat,
+                      offCBnrm]
+        desc[14] = np.float32(self.scale).view(np.int32)
+        desc[15] = np.float32(1.0 / self.scale).view(np.int32)
+        for l in range(nL):
+            desc[16 + l] = tl(self.out[l])
+        for l in range(nC):
+            desc[16 + M + l] = tl(self.cout[l])
+        desc[16 + 2 * M:16 + 3 * M] = offT
+        desc[16 + 3 * M:16 + 4 * M] = offB
+        desc[16 + 4 * M:16 + 5 * M] = offCB
+        gidx = np.concatenate(chunks)
+        assert gidx.size % 512 == 0 and gidx.max() < 2 ** 31
+        self._bwd_x3_dev[k] = (torch.from_numpy(gidx.astype(np.int32)).to(device), gidx.size // 512,
+                               torch.from_numpy(np.concatenate(fch)).to(device), desc)
+        return self._bwd_x3_dev[k]
+
+    def run_fused_backward_x3(self, flat, T, P, g_rgb, g_n, g_sdf):
+        gidx, n_steps, fidx, desc = self._bwd_static_x3(flat.device)
+        nL, nC = self.nL, self.nC
+        saved = [T['U%d' % (l + 1)] for l in range(nL)] + [T['GH%d' % l] for l in range(nL)] + [T['C%d' % (l + 1)] for l in range(nC)]
+        outs = [T['DC%d' % l] for l in range(nC + 1)] + [T['GOUTF'], T['ED']] + [T['UD%d' % (l + 1)] for l in range(nL)] + \
+            [T['AB%d' % l] for l in range(nL)]
+        _C.neus_train_bwd_x3(desc, _C.pack_x3_gather(flat, gidx, n_steps), flat[fidx], T['X'], g_rgb, T['RGB'] if self.squeeze else None, g_n,
+                             g_sdf, saved, outs)
+
+    def _fused_backward_shape(self):
         """Run colour backward + SDF backward as ONE launch of csrc/neus_train_bwd.hip (vqn_neus_train_bwd) instead of the
         interpreted prog_cbwd / prog_sbwd (VQN_TRAIN_BWD=prog selects those).  Same tensors out, the kernel's summation order."""
-        if os.environ.get('VQN_TRAIN_BWD', 'fused') != 'fused' or os.environ.get('VQN_NEUS_TILE32') is not None:
+        if os.environ.get('VQN_NEUS_TILE32') is not None:
             return False
         mt = max(self._tiles(w) for w in self.out[:self.nL] + self.cout[:self.nC] + [self.F - 1])
         return 5 <= mt <= 8 and self.skip != 0 and self.nL >= 2 and self.nC >= 1 and max(self.nL, self.nC) < self.TB_MAX_L
@@ -893,9 +982,11 @@ class NeusCoreFunction(torch.autograd.Function):
             rgb = T['RGB']
             g_rgb = torch.zeros_like(rgb) if g_rgb is None else g_rgb
             gs = torch.zeros_like(T['SDF']) if g_sdf is None else g_sdf.reshape(-1, 1).contiguous()
-            if e.fused_backward():
-                e.run_fused_backward(ctx.flat, T, P, g_rgb.contiguous().float(), None if g_n is None else g_n.contiguous().float(),
-                                     None if g_sdf is None else gs.float())
+            bmode = e.backward_mode()
+            if bmode is not None:
+                run = e.run_fused_backward_x3 if bmode == 'x3' else e.run_fused_backward
+                run(ctx.flat, T, P, g_rgb.contiguous().float(), None if g_n is None else g_n.contiguous().float(),
+                    None if g_sdf is None else gs.float())
             else:
                 T['DOUT'].copy_(g_rgb * rgb * (1.0 - rgb) if e.squeeze else g_rgb)
                 e.run('prog_cbwd', ctx.descs, ctx.wbuf, T, P)
