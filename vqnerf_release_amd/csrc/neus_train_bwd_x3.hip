@@ -129,7 +129,10 @@ __global__ __launch_bounds__(512, 1) void neus_train_bwd_x3_kernel(const TrainBw
     }
     __syncthreads();
   };
-  float au[2][16], ab[2][16];          // epilogue operands of this wave's tile, both images (requested before the K loop)
+  // epilogue operands of this wave's tile, both images, requested right before the K loop.  (The f32 kernel's refinement -- the NEXT GEMM's
+  // operands requested in place from inside the current epilogue -- measured slower here: 6.80 -> 7.19 ms, 39 -> 99 spilled VGPRs: the
+  // operands would live across commit() and the ring refills, and this engine has no registers to spare.)
+  float au[2][16], ab[2][16];
 
   for (long pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
     call = 0;
