@@ -423,13 +423,17 @@ def test_outer_sample_pairs_are_neighbours():
 
 
 @pytest.mark.parametrize('name,B', [('small', 96), ('full', 48), ('small', 7), ('full', 2), ('full', 700)])
-def test_hip_training_programs_match_torch_autograd(name, B):
+def test_hip_training_programs_match_torch_autograd(name, B, monkeypatch):
     """The explicit forward / backward tile programs (+ compositing backward kernel + weight-gradient contraction)
     against torch autograd over the torch statements of the same modules: loss, every parameter gradient.  B = 700 rays of
     the full networks = 89,600 fine samples = 2,800 point tiles: more than one pass of the persistent workgroups and of the
     split-K weight-gradient partials."""
     from oracle import geo as og
     from tests.test_gpu_neus_render import _build
+    # both sides on the SAME sample positions: the no-grad up-sampling passes of the HIP side on the f32-input SDF kernel, as the
+    # torch side's (on the step's x3 packs -- the default -- a few samples in 10^5 land in another section of the inverse CDF and their
+    # normals differ by more than this test's 5e-4; the default is held to the reference's goldens by test_training_path_grads_vs_reference)
+    monkeypatch.setenv('VQN_TRAIN_COARSE', 'f32')
     cfg, sdf, col, var, ren = _build(name)
     if cfg['renderer']['n_importance'] == 0:
         ren.n_importance, ren.up_sample_steps = 16, 4            # exercise the up-sampled path for the small nets too
@@ -633,14 +637,17 @@ def test_training_forward_switch(mode, monkeypatch):
     assert rec.ran('vqn_tile_program:prog_fwd') == (mode == 'prog')
     assert ('vqn_neus_train_bwd' in rec.names) == (mode == 'fused') and ('vqn_neus_train_bwd_x3' in rec.names) == (mode == 'x3')
     assert rec.ran('vqn_tile_program:prog_sbwd') == (mode == 'prog')
+    # the up-sampling passes of a training render read the step's x3 packs when the forward runs on the exact-split engine
+    assert ('vqn_neus_sdf_points_x3' in rec.names) == (mode == 'x3') and ('vqn_neus_sdf_points' in rec.names) == (mode != 'x3')
     grads = torch.cat([p.grad.reshape(-1) for m in (sdf, col) for p in m.parameters()])
     assert torch.isfinite(grads).all()
     test_training_forward_switch.seen = getattr(test_training_forward_switch, 'seen', {})
     test_training_forward_switch.seen[mode] = grads
     seen = test_training_forward_switch.seen
     for other in seen:
-        if other != mode:
-            assert float((seen[other] - grads).abs().max()) <= 2e-4 * float(grads.abs().max()), (other, mode)
+        if other != mode:                      # (x3: its own up-sampling arithmetic moves a few sample positions -- looser bound)
+            tol = 2e-3 if 'x3' in (other, mode) else 2e-4
+            assert float((seen[other] - grads).abs().max()) <= tol * float(grads.abs().max()), (other, mode)
 
 
 def test_empty_and_degenerate_inputs():

@@ -297,10 +297,15 @@ def _i32(desc):
     return d, d.ctypes.data_as(ctypes.c_void_p)
 
 
-def neus_sdf_points(sdf_desc, wbuf_sdf, rays_o=None, rays_d=None, z=None, pts=None, mode='f32'):
-    """SDF value at ray samples (rays_o/rays_d [B,3], z [B,S]) or at explicit pts [P,3] -> [P]."""
-    _f32c(wbuf_sdf, 'wbuf_sdf')
-    d, dp = _i32(sdf_desc)
+def neus_sdf_points(sdf_desc, wbuf_sdf, rays_o=None, rays_d=None, z=None, pts=None, mode='f32', pack=None):
+    """SDF value at ray samples (rays_o/rays_d [B,3], z [B,S]) or at explicit pts [P,3] -> [P].  pack: a NeusPackHandle (its
+    descriptor and SDF buffer are used, `mode` names the engine it was created for)."""
+    if pack is not None:
+        dp, wp = pack.sdf_desc, pack.sdf_wbuf
+    else:
+        _f32c(wbuf_sdf, 'wbuf_sdf')
+        d, dp = _i32(sdf_desc)
+        wp = _ptr(wbuf_sdf)
     if pts is not None:
         _f32c(pts, 'pts'); P, S = pts.shape[0], 1
         dev = pts.device
@@ -312,7 +317,7 @@ def neus_sdf_points(sdf_desc, wbuf_sdf, rays_o=None, rays_d=None, z=None, pts=No
     out = torch.empty((P,), dtype=torch.float32, device=dev)
     entry = {'f32': 'vqn_neus_sdf_points', 'f16s': 'vqn_neus_sdf_points_f16s', 'x3': 'vqn_neus_sdf_points_x3'}[mode]
     with _clock(entry):
-        rc = getattr(lib(), entry)(dp, _ptr(wbuf_sdf), _ptr(rays_o), _ptr(rays_d), _ptr(z), _ptr(pts),
+        rc = getattr(lib(), entry)(dp, wp, _ptr(rays_o), _ptr(rays_d), _ptr(z), _ptr(pts),
                                    ctypes.c_int64(P), ctypes.c_int(S), _ptr(out), _stream())
     _check(rc, entry)
     return out

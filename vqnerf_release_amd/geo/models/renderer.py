@@ -120,6 +120,7 @@ class NeuSRenderer:
         self.perturb = perturb
         self._u = {}
         self._engines = {}
+        self._step_pack = None            # x3 packs of the training render in flight (NeusTrainEngine.prepare_step)
         self.weights_only = False         # True: no-graph renders skip the colour net (weights / weight_sum / surf stay exact)
         self.matrix_mode = 'f32'          # 'f16s': no-graph renders on the split-precision kernels (f16 hi/lo MFMA; ~1e-6 relative, opt-in)
         self.train_backend = 'hip'        # 'hip': tile programs of geo/train_programs.py; 'torch': autograd over torch ops
@@ -149,19 +150,24 @@ class NeuSRenderer:
         if last:
             z, _ = _C.neus_merge(z_vals.contiguous(), None, new_z_vals.contiguous(), None)
             return z, sdf
-        wb_s, d_s = self._sdf_pack()
-        new_sdf = _C.neus_sdf_points(d_s, wb_s, rays_o=rays_o.contiguous(), rays_d=rays_d.contiguous(),
-                                     z=new_z_vals.contiguous(), mode=self.matrix_mode).reshape(new_z_vals.shape)
+        new_sdf = self._sdf_at(rays_o.contiguous(), rays_d.contiguous(), new_z_vals.contiguous()).reshape(new_z_vals.shape)
         return _C.neus_merge(z_vals.contiguous(), sdf.reshape(z_vals.shape).contiguous(), new_z_vals.contiguous(), new_sdf)
 
     def _sdf_pack(self):
         return self.sdf_network.packs(max_tiles=self.color_network.max_tiles(), mode=self.matrix_mode)
 
+    def _sdf_at(self, rays_o, rays_d, z):
+        """SDF at the ray samples: on the step's library-built x3 packs inside a training render that prepared them
+        (NeusTrainEngine.prepare_step), else on the network's own cached packs."""
+        if self._step_pack is not None:
+            return _C.neus_sdf_points(None, None, rays_o=rays_o, rays_d=rays_d, z=z, mode='x3', pack=self._step_pack)
+        wb_s, d_s = self._sdf_pack()
+        return _C.neus_sdf_points(d_s, wb_s, rays_o=rays_o, rays_d=rays_d, z=z, mode=self.matrix_mode)
+
     @torch.no_grad()
     def _importance_z(self, rays_o, rays_d, z_vals, radius):
-        wb_s, d_s = self._sdf_pack()
         B = rays_o.shape[0]
-        sdf = _C.neus_sdf_points(d_s, wb_s, rays_o=rays_o, rays_d=rays_d, z=z_vals, mode=self.matrix_mode).reshape(B, self.n_samples)
+        sdf = self._sdf_at(rays_o, rays_d, z_vals).reshape(B, self.n_samples)
         m = self.n_importance // self.up_sample_steps
         for i in range(self.up_sample_steps):
             new_z = self.up_sample(rays_o, rays_d, z_vals, sdf, radius, m, 64 * 2 ** i)
@@ -229,6 +235,20 @@ class NeuSRenderer:
             'surf': o['surf'], 'depth': o['depth'], 'weight_sum': o['weight_sum'], 'weight_max': o['weight_max'],
             'sampled_color': rgb.reshape(B, n, 3),
         }
+
+    def _prepare_train_step(self, rays_o):
+        """the step's x3 packs when this render is going to take the HIP training path with the exact-split forward (see
+        NeusTrainEngine.prepare_step); None otherwise"""
+        if self.n_outside > 0 or self.train_backend != 'hip' or not rays_o.is_cuda or not torch.is_grad_enabled():
+            return None
+        sn, cn, dn = self.sdf_network, self.color_network, self.deviation_network
+        if not (_needs_graph(sn, rays_o) or any(p.requires_grad for m in (dn, cn) for p in m.parameters())):
+            return None
+        engine = self._train_engine(sn, cn)
+        if engine is None:
+            return None
+        return engine.prepare_step([getattr(sn, 'lin%d' % l) for l in range(sn.num_layers - 1)],
+                                   [getattr(cn, 'lin%d' % l) for l in range(cn.num_layers - 1)])
 
     # ---- training: explicit forward / backward tile programs (geo/train_programs.py) ----------------
     def _train_engine(self, sdf_network, color_network):
@@ -346,7 +366,11 @@ class NeuSRenderer:
             z_vals_outside = far / torch.flip(zo, dims=[-1]) + 1.0 / self.n_samples
         n = self.n_samples
         if self.n_importance > 0:
-            z_vals = self._importance_z(rays_o, rays_d, z_vals, radius)
+            self._step_pack = self._prepare_train_step(rays_o)
+            try:
+                z_vals = self._importance_z(rays_o, rays_d, z_vals, radius)
+            finally:
+                self._step_pack = None
             n = self.n_samples + self.n_importance
         bg_alpha = bg_color = None
         if self.n_outside > 0:
