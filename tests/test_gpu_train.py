@@ -761,3 +761,26 @@ def test_pack_delta_is_unpack_times_activation_derivative_pack(N, F, act):
     assert torch.equal(out, ref)
     pack_delta(None, Y, act, N, F, out)
     assert torch.equal(out, torch.zeros_like(out))
+
+
+def test_prepared_step_packs_are_not_reused_after_the_weights_moved():
+    """NeusTrainEngine.prepare_step packs the step's weights for the up-sampling passes and the forward; a forward that runs later on
+    OTHER weights (an in-place edit, an optimiser step in between) must re-pack: keyed on the weights epoch + parameter versions."""
+    from oracle import geo as og
+    from tests.test_gpu_neus_render import _build
+    cfg, sdf, col, var, ren = _build('full')
+    o, d, near, far = [torch.tensor(a).cuda() for a in og.make_rays(8, 3)]
+    eng = ren._train_engine(sdf, col)
+    assert eng.forward_mode() == 'x3'
+    s_l = [getattr(sdf, 'lin%d' % l) for l in range(sdf.num_layers - 1)]
+    c_l = [getattr(col, 'lin%d' % l) for l in range(col.num_layers - 1)]
+    assert eng.prepare_step(s_l, c_l) is not None and eng._x3_prepared is not None
+    with torch.no_grad():
+        sdf.lin8.bias.add_(0.05)                                  # the packs made above are stale now
+    z = torch.linspace(0.0, 1.0, 16, device='cuda')[None, :] * (far - near) + near
+    with launches() as rec:
+        rc = ren.render_core(o, d, z.contiguous(), 2.0 / 16, 2.0, sdf, var, col, background_rgb=torch.ones(1, 3).cuda(), cos_anneal_ratio=1.0)
+    assert ren.last_train_backend == 'hip' and rec.counts.get('vqn_neus_pack_update', 0) == 1      # re-packed, not reused
+    with torch.no_grad():
+        ref = sdf.sdf(((o[:, None, :] + d[:, None, :] * rc['mid_z_vals'][..., None]).reshape(-1, 3)).contiguous())
+    assert float((rc['sdf'].detach().reshape(-1) - ref.reshape(-1)).abs().max()) < 2e-5

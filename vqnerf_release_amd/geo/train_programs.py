@@ -396,7 +396,7 @@ class NeusTrainEngine:
         self._bwd_dev = {}             # per device: gather index + descriptor of the fused backward's pack
         self._x3_pack = None           # library-built packs of the exact-split forward (vqn_neus_pack_create, engine 2)
         self._bwd_x3_dev = {}          # per device: gather indices + descriptor of the exact-split backward's packs
-        self._x3_prepared = False      # prepare_step() packed this step's weights already
+        self._x3_prepared = None       # prepare_step() packed these weights already (their key)
         for name, build in (('prog_fwd', self._build_forward), ('prog_cbwd', self._build_colour_backward),
                             ('prog_sbwd', self._build_sdf_backward)):
             prog = build()
@@ -650,14 +650,20 @@ class NeusTrainEngine:
             n = len(s_lins)
             h = self._x3_handle()
             h.update(ws[:n], [m.bias.detach().float().contiguous() for m in s_lins], ws[n:], [m.bias.detach().float().contiguous() for m in c_lins])
-        self._x3_prepared = True
+        self._x3_prepared = self._weights_key()
         return h
+
+    def _weights_key(self):
+        """what the x3 packs were built from: the process-wide weights epoch (optimiser steps, graph replays) + every parameter's version"""
+        import vqnerf_release_amd
+        return (vqnerf_release_amd.weights_epoch(),) + tuple((id(p), p._version) for m in (self.sdf_net, self.col_net) for p in m.parameters())
 
     def run_fused_forward_x3(self, W, b, Wc, bc, T, P):
         """the forward on the exact-split engine: packs by the library's own builder (one gather + split launch per network)"""
-        if self._x3_prepared:                                  # packed at the start of this render (prepare_step): same weights
-            self._x3_prepared = False
+        if self._x3_prepared is not None and self._x3_prepared == self._weights_key():      # packed at the start of this render: same weights
+            self._x3_prepared = None
         else:
+            self._x3_prepared = None
             cont = lambda ts: [t if t.is_contiguous() else t.contiguous() for t in ts]
             self._x3_handle().update(cont(W), cont(b), cont(Wc), cont(bc))
         saved = [T['E'], T['OUTF'], T['EXTR']] + [T['U%d' % (l + 1)] for l in range(self.nL)] + [T['GH%d' % l] for l in range(self.nL)] \
