@@ -784,3 +784,38 @@ def test_prepared_step_packs_are_not_reused_after_the_weights_moved():
     with torch.no_grad():
         ref = sdf.sdf(((o[:, None, :] + d[:, None, :] * rc['mid_z_vals'][..., None]).reshape(-1, 3)).contiguous())
     assert float((rc['sdf'].detach().reshape(-1) - ref.reshape(-1)).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize('amsgrad,tensor_lr,wd', [(True, True, 0.0), (False, True, 0.0), (True, False, 0.01), (False, False, 0.0)])
+def test_hip_adam_is_torch_adam(amsgrad, tensor_lr, wd):
+    """optim.HipAdam (vqn_adam_step, one launch) against torch.optim.Adam(capturable=True, fused=True): parameters and the whole
+    optimiser state after 6 steps on the same gradients, state_dict interchangeable."""
+    from vqnerf_release_amd.optim import HipAdam
+    g = torch.Generator(device='cuda').manual_seed(0)
+    shapes = [(7,), (1,), (), (300, 257), (1025,), (64, 64)] + [(33,)] * 60          # more tensors than one kernel table holds
+    mk = lambda: [torch.nn.Parameter(t.clone()) for t in init]
+    init = [torch.randn(s, device='cuda', generator=g) for s in shapes]
+    pa, pb = mk(), mk()
+    lr = lambda: torch.tensor(3e-3, device='cuda') if tensor_lr else 3e-3
+    oa = torch.optim.Adam(pa, lr=lr(), eps=1e-7, amsgrad=amsgrad, weight_decay=wd, capturable=True, fused=True)
+    ob = HipAdam(pb, lr=lr(), eps=1e-7, amsgrad=amsgrad, weight_decay=wd)
+    for it in range(6):
+        grads = [torch.randn(s, device='cuda', generator=g) for s in shapes]
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        if it == 3:
+            pa[0].grad = pb[0].grad = None                    # a parameter without a gradient is skipped (its step count too)
+        with launches() as rec:
+            oa.step()
+            ob.step()
+        assert rec.counts['vqn_adam_step'] == 1
+    for p, q in zip(pa, pb):
+        assert float((p - q).detach().abs().max()) <= 2e-6 * max(1.0, float(p.detach().abs().max()))
+    sa, sb = oa.state_dict()['state'], ob.state_dict()['state']
+    assert sa.keys() == sb.keys()
+    for k in sa:
+        assert sa[k].keys() == sb[k].keys()
+        for name in sa[k]:
+            a, b = sa[k][name].float(), sb[k][name].float()
+            assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max())), (k, name)
+    ob.load_state_dict(oa.state_dict())                          # interchangeable checkpoints

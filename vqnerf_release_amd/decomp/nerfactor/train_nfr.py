@@ -15,13 +15,17 @@ from vqnerf_release_amd import parallel
 def make_optimizer(config, params, capturable=False):
     """Keras Adam(lr, amsgrad=True) (train_nfr.py:121-139): epsilon 1e-7 (Keras default, torch's is 1e-8), optional
     ExponentialDecay(lr_decay_steps, lr_decay_rate) -> returned as a LambdaLR, clipnorm / clipvalue as a closure.
-    `capturable`: step counters and lr live on the device, as `Trainer(graph=True)` needs (and the update is torch's fused
-    multi-tensor kernel: one launch instead of a dozen foreach passes)."""
+    `capturable`: step counters and lr live on the device, as `Trainer(graph=True)` needs, and the update is one launch
+    (optim.HipAdam on a GPU: torch's fused multi-tensor kernel takes 2 x 85 us for these ~1 M parameters, 16 workgroups each)."""
     lr = config.getfloat('DEFAULT', 'lr')
     params = list(params)
     if capturable:
         lr = torch.tensor(lr, dtype=torch.float32, device=params[0].device)
-    opt = torch.optim.Adam(params, lr=lr, eps=1e-7, amsgrad=True, capturable=capturable, fused=bool(capturable))
+    if capturable and params[0].is_cuda:
+        from vqnerf_release_amd.optim import HipAdam
+        opt = HipAdam(params, lr=lr, eps=1e-7, amsgrad=True)           # the same update as ONE launch (csrc/adam.hip)
+    else:
+        opt = torch.optim.Adam(params, lr=lr, eps=1e-7, amsgrad=True, capturable=capturable, fused=bool(capturable))
     decay_steps = config.getint('DEFAULT', 'lr_decay_steps', fallback=-1)
     sched = None
     if decay_steps > 0:

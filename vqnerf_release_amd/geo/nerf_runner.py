@@ -120,8 +120,13 @@ class Runner:
         params = (list(self.nerf_outside.parameters()) + list(self.sdf_network.parameters())
                   + list(self.deviation_network.parameters()) + list(self.color_network.parameters()))
         if self.graph:
-            self.optimizer = torch.optim.Adam(params, lr=torch.tensor(float(self.learning_rate), device=self.device), capturable=True,
-                                              fused=True)
+            # step counters and lr on the device (the update lives inside the captured step): one HIP launch on a GPU (optim.HipAdam)
+            lr_t = torch.tensor(float(self.learning_rate), device=self.device)
+            if torch.device(self.device).type == 'cuda':
+                from vqnerf_release_amd.optim import HipAdam
+                self.optimizer = HipAdam(params, lr=lr_t)
+            else:
+                self.optimizer = torch.optim.Adam(params, lr=lr_t, capturable=True, fused=True)
         else:
             self.optimizer = torch.optim.Adam(params, lr=self.learning_rate)
         self.renderer = NeuSRenderer(self.nerf_outside, self.sdf_network, self.deviation_network, self.color_network,
