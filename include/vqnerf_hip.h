@@ -103,6 +103,17 @@ int vqn_l2_normalize_rows_bwd(const float* x, const float* g, int64_t N, int D, 
  * (g_loss[0] * 2 / numel); g_ste may be NULL, g_loss is a device scalar; each operation separately rounded. */
 int vqn_vq_ste_loss_bwd(const float* x, const float* quant, const float* g_ste, const float* g_loss, int64_t numel, float* gx, void* stream);
 
+/* The codebook as the model uses it (vq_nfr.py: tfp clip_by_value_preserve_gradient to [0, 1], then l2-normalise every code = a
+ * column of the [D, K] variable): out = c s, c = x + (clip(x) - x), s_k = max(sum_d c^2, eps)^(-1/2).  g == NULL: forward;
+ * g != NULL: out = the gradient wrt the raw variable for the incoming g [D, K] (identity through the clip). */
+int vqn_codebook_prep(const float* raw, const float* g, int D, int K, float eps, float* out, void* stream);
+
+/* The code-separation term (vq_nfr.py:955-968): out4[0] = -weight log(min_{i != j} |c_i - c_j|) over the columns of codebook [D, K]
+ * (out4[1..3]: the minimum and its pair, for the backward); _bwd: g_codebook = g_loss[0] times its gradient (two non-zero columns). */
+int vqn_sim_smooth_fwd(const float* codebook, int D, int K, float weight, float* out4, void* stream);
+int vqn_sim_smooth_bwd(const float* codebook, const float* fwd4, const float* g_loss, int D, int K, float weight, float* g_codebook,
+                       void* stream);
+
 /* The inference path of vq_nfr.Model.call / fast_embed / vq_test (vq_nfr.py:575-578 -> vq_layers.py:277-302, :327-330) in ONE pass
  * over the rows: z [N,D] un-normalised encoder output -> l2-normalise (as vqn_l2_normalize_rows) -> nearest code (as vqn_vq_assign,
  * incl. the code-dropout mask) -> idx [N], ste [N,D] = z^ + (q - z^) (or NULL), *loss = loss_scale * sum (q - z^)^2 (fixed order

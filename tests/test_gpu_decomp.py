@@ -626,3 +626,36 @@ def test_fused_train_loss_matches_the_torch_statement(data_type, N):
         lin = (torch.where(rgb_gt <= 0.04045, rgb_gt / 12.92, ((rgb_gt + 0.055) / 1.055) ** 2.4) if data_type == 'nerf' else rgb_gt)
         want = (2.0 / 3.0) * (vals['vqrgb'] - lin) * torch.linspace(0.5, 1.5, N, device='cuda')[:, None]
         np.testing.assert_allclose(g1['vqrgb'][~ok].cpu().numpy(), want[~ok].cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_codebook_prep_and_code_separation_kernels_match_the_torch_statements():
+    """vqn_codebook_prep / vqn_sim_smooth_* (one launch each way) against autograd over the torch statements of get_codebook()
+    (clip with identity gradient + l2-normalise per code) and of the code-separation term (vq_nfr.py:955-968): values and the
+    gradient wrt the raw codebook variable, entries outside [0, 1] and a code below the eps clamp included."""
+    from vqnerf_release_amd.decomp.nerfactor.models import vq_nfr
+    from vqnerf_release_amd.decomp.nerfactor.util import math as mathutil
+    for D, K in ((256, 15), (256, 64), (32, 2)):
+        g = torch.Generator(device='cuda').manual_seed(K)
+        raw = torch.rand(D, K, device='cuda', generator=g) * 1.4 - 0.2            # some entries outside [0, 1]
+        raw[:, 0] *= 1e-5                                                          # sum c^2 < eps: the clamp of the normalisation is active
+        gy = torch.randn(D, K, device='cuda', generator=g)
+        w = 0.3
+
+        def torch_statement(x):
+            cb = mathutil.safe_l2_normalize(mathutil.clip_preserve_gradient(x, 0.0, 1.0), axis=0)
+            c = cb.t()
+            eye = torch.eye(K, device='cuda')
+            dist = torch.sqrt(((c[:, None, :] - c[None, :, :]) ** 2).sum(-1) + eye) * (1 - eye)
+            masked = dist * (1 - eye) + eye * dist.max()
+            return cb, w * (-torch.log(masked.min()))
+
+        xr = raw.clone().requires_grad_(True)
+        cb_ref, sim_ref = torch_statement(xr)
+        ((cb_ref * gy).sum() + 2.0 * sim_ref).backward()
+        xh = raw.clone().requires_grad_(True)
+        cb = vq_nfr._CodebookPrep.apply(xh)
+        sim = vq_nfr._SimSmooth.apply(cb, w)
+        ((cb * gy).sum() + 2.0 * sim).backward()
+        # (the term is -w log(d) with d near 1 for two codes: its error is absolute, ~ w ulp(d))
+        assert float((cb - cb_ref).detach().abs().max()) <= 2e-7 and abs(float(sim.detach()) - float(sim_ref.detach())) <= 2e-6 * max(abs(float(sim_ref.detach())), w)
+        assert float((xh.grad - xr.grad).abs().max()) <= 2e-5 * float(xr.grad.abs().max())

@@ -226,6 +226,37 @@ def decomp_loss_bwd(rgb_pred, vq_rgb, rgb_gt, z, spec, rough, nerf, w, g_terms):
     return g_pred, g_vq, g_z, g_spec
 
 
+def codebook_prep(raw, g=None, eps=1e-6):
+    """clip-with-identity-gradient to [0, 1] + l2-normalise every column of raw [D, K] (g None), or the gradient wrt raw for g [D, K]."""
+    _f32c(raw, 'raw')
+    if g is not None:
+        _f32c(g, 'g')
+    out = torch.empty_like(raw)
+    with _clock('vqn_codebook_prep'):
+        rc = lib().vqn_codebook_prep(_ptr(raw), _ptr(g), ctypes.c_int(raw.shape[0]), ctypes.c_int(raw.shape[1]), ctypes.c_float(eps), _ptr(out), _stream())
+    _check(rc, 'vqn_codebook_prep')
+    return out
+
+
+def sim_smooth_fwd(cb, weight):
+    _f32c(cb, 'codebook')
+    out = torch.empty(4, dtype=torch.float32, device=cb.device)
+    with _clock('vqn_sim_smooth_fwd'):
+        rc = lib().vqn_sim_smooth_fwd(_ptr(cb), ctypes.c_int(cb.shape[0]), ctypes.c_int(cb.shape[1]), ctypes.c_float(weight), _ptr(out), _stream())
+    _check(rc, 'vqn_sim_smooth_fwd')
+    return out
+
+
+def sim_smooth_bwd(cb, fwd4, g_loss, weight):
+    _f32c(cb, 'codebook'); _f32c(fwd4, 'fwd4'); _f32c(g_loss, 'g_loss')
+    g = torch.empty_like(cb)
+    with _clock('vqn_sim_smooth_bwd'):
+        rc = lib().vqn_sim_smooth_bwd(_ptr(cb), _ptr(fwd4), _ptr(g_loss), ctypes.c_int(cb.shape[0]), ctypes.c_int(cb.shape[1]), ctypes.c_float(weight),
+                                      _ptr(g), _stream())
+    _check(rc, 'vqn_sim_smooth_bwd')
+    return g
+
+
 def l2_normalize_rows_bwd(x, g, eps=1e-6):
     """Gradient of l2_normalize_rows at x [N, D] for the incoming g [N, D]: one pass (vqn_l2_normalize_rows_bwd)."""
     _f32c(x, 'x'); _f32c(g, 'g')

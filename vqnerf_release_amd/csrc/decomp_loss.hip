@@ -335,3 +335,111 @@ extern "C" int vqn_vq_ste_loss_bwd(const float* x, const float* quant, const flo
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }
+
+// ---- the codebook as the model uses it (vq_nfr.py: clip with identity gradient to [0, 1], l2-normalise every code) and the
+// code-separation term (vq_nfr.py:955-968), each one launch forward and one backward instead of ~8 + ~15 framework kernels and their
+// autograd: [D, K] with K <= 64 codes is a few KB ----------------------------------------------------------------------------------
+namespace {
+
+// y[:, k] = c s_k, c = x + (clamp(x, 0, 1) - x), s_k = max(sum_d c^2, eps)^(-1/2); one workgroup per code.  BWD: g -> gx.
+template <bool BWD>
+__global__ __launch_bounds__(256) void codebook_prep_kernel(const float* __restrict__ x, const float* __restrict__ gy, int D, int K, float eps,
+                                                            float* __restrict__ out) {
+  __shared__ float red[2][256];
+  const int k = blockIdx.x, t = threadIdx.x;
+  float s2 = 0.f, cg = 0.f;
+  for (int d = t; d < D; d += 256) {
+    const float v = x[(size_t)d * K + k];
+    const float c = __fadd_rn(v, __fsub_rn(fminf(fmaxf(v, 0.f), 1.f), v));
+    s2 = fmaf(c, c, s2);
+    if (BWD) cg = fmaf(c, gy[(size_t)d * K + k], cg);
+  }
+  red[0][t] = s2; red[1][t] = cg;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) { red[0][t] += red[0][t + w]; red[1][t] += red[1][t + w]; }
+    __syncthreads();
+  }
+  s2 = red[0][0]; cg = red[1][0];
+  const float s = 1.0f / sqrtf(fmaxf(s2, eps));
+  const float tt = s2 > eps ? (s * s * s) * cg : 0.f;
+  for (int d = t; d < D; d += 256) {
+    const float v = x[(size_t)d * K + k];
+    const float c = __fadd_rn(v, __fsub_rn(fminf(fmaxf(v, 0.f), 1.f), v));
+    out[(size_t)d * K + k] = BWD ? gy[(size_t)d * K + k] * s - c * tt : c * s;
+  }
+}
+
+// out[0] = -w log(min_{i != j} |c_i - c_j|), out[1] = the min, out[2..3] = its pair (i < j) as floats.  One workgroup; cb [D, K] (codes = columns).
+__global__ __launch_bounds__(256) void sim_smooth_fwd_kernel(const float* __restrict__ cb, int D, int K, float w, float* __restrict__ out) {
+  __shared__ float best[256];
+  __shared__ int bi[256];
+  const int t = threadIdx.x;
+  float bd = INFINITY;
+  int bp = 0;
+  for (int pr = t; pr < K * K; pr += 256) {
+    const int i = pr / K, j = pr - i * K;
+    if (i >= j) continue;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) { const float dl = cb[(size_t)d * K + i] - cb[(size_t)d * K + j]; s = fmaf(dl, dl, s); }
+    const float dist = sqrtf(s);
+    if (dist < bd || !(dist == dist)) { bd = dist; bp = pr; }
+  }
+  best[t] = bd; bi[t] = bp;
+  __syncthreads();
+  if (t == 0) {
+    for (int k = 1; k < 256; ++k)
+      if (best[k] < bd || (best[k] == bd && bi[k] < bp) || !(best[k] == best[k])) { bd = best[k]; bp = bi[k]; }
+    out[0] = w * (-logf(bd));
+    out[1] = bd;
+    out[2] = (float)(bp / K);
+    out[3] = (float)(bp % K);
+  }
+}
+
+// g_cb = g_loss * d(-w log dmin)/d cb: -w (c_i - c_j) / dmin^2 into column i, the negative into column j, zeros elsewhere
+__global__ __launch_bounds__(256) void sim_smooth_bwd_kernel(const float* __restrict__ cb, const float* __restrict__ fwd, const float* __restrict__ g_loss,
+                                                             int D, int K, float w, float* __restrict__ g_cb) {
+  const float dmin = fwd[1];
+  const int i = (int)fwd[2], j = (int)fwd[3];
+  const float f = -w * g_loss[0] / (dmin * dmin);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)D * K; e += (long)gridDim.x * 256) {
+    const int d = (int)(e / K), k = (int)(e - (long)d * K);
+    float v = 0.f;
+    if (k == i || k == j) {
+      const float dl = cb[(size_t)d * K + i] - cb[(size_t)d * K + j];
+      v = k == i ? f * dl : -f * dl;
+    }
+    g_cb[e] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int vqn_codebook_prep(const float* raw, const float* g, int D, int K, float eps, float* out, void* stream) {
+  VQN_CHECK_ARG(raw && out, "null pointer");
+  VQN_CHECK_SHAPE(D >= 1 && K >= 1 && K <= 65535, "D >= 1, 1 <= K");
+  if (g == nullptr) hipLaunchKernelGGL(codebook_prep_kernel<false>, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, raw, g, D, K, eps, out);
+  else hipLaunchKernelGGL(codebook_prep_kernel<true>, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, raw, g, D, K, eps, out);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
+
+extern "C" int vqn_sim_smooth_fwd(const float* codebook, int D, int K, float weight, float* out4, void* stream) {
+  VQN_CHECK_ARG(codebook && out4, "null pointer");
+  VQN_CHECK_SHAPE(D >= 1 && K >= 2 && K <= 256, "D >= 1, 2 <= K <= 256");
+  hipLaunchKernelGGL(sim_smooth_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, codebook, D, K, weight, out4);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
+
+extern "C" int vqn_sim_smooth_bwd(const float* codebook, const float* fwd4, const float* g_loss, int D, int K, float weight, float* g_codebook,
+                                  void* stream) {
+  VQN_CHECK_ARG(codebook && fwd4 && g_loss && g_codebook, "null pointer");
+  VQN_CHECK_SHAPE(D >= 1 && K >= 2 && K <= 256, "D >= 1, 2 <= K <= 256");
+  long blocks = ((long)D * K + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(sim_smooth_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, codebook, fwd4, g_loss, D, K, weight, g_codebook);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
