@@ -16,7 +16,8 @@
 //   reverse sweep     ab_{L-1} = (W_L[1:]^T g_feat + W_L[0]^T d sdf / scale) s'(u_L) + S_{L-1};
 //                     ab_{l-1} = (W_l[:, u]^T ab_l) s'(u_l) + S_{l-1}                                                    -> AB_l
 // (the same statement as the interpreted programs prog_cbwd / prog_sbwd of geo/train_programs.py, which remain the path of
-// networks this kernel does not take: fewer than five or more than nine feature tiles.)
+// networks this kernel does not take: fewer than five or more than eight feature tiles.  csrc/neus_train_bwd_x3.hip is the same pass on the
+// exact-split engine, the trainers' default.)
 #include "mlp_prims.h"
 #include "vqnerf_hip.h"
 #include <stdlib.h>
