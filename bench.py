@@ -34,6 +34,8 @@ import numpy as np
 import torch
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA (= f32 vector peak)
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # same guide: dense bf16 MFMA.  The exact-split (x3) kernels spend SIX bf16 MFMAs per f32 product, so a kernel
+                                 # doing A algorithmic TFLOP/s keeps the bf16 pipe 6 A / 2500 busy; both fractions are reported for them
 
 # `bias` is the radius of the geometric-init sphere (fields.py:45-63; nerf.conf ships 0.5): 0.85 makes its silhouette cover
 # ~29 % of the 800x800 view from (0, 0, 4), the "~30 % of rays hit" of SURVEY 8(d), so hit and miss compositing both count
@@ -161,14 +163,22 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
              'vqn_wgrad_partials': 2.0 * B * S_f * (2 * m_sdf + m_col), 'vqn_wgrad_partials_x3': 2.0 * B * S_f * (2 * m_sdf + m_col)}
     kfrac = {k: {'ms': clk[k][1] / 6, 'tflops': kflop[k] / (clk[k][1] / 6 * 1e-3) / 1e12,
                  'frac_of_f32_mfma_peak': kflop[k] / (clk[k][1] / 6 * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS} for k in kflop if k in clk}
+    for k, v in kfrac.items():               # exact-split kernels: the pipe they run on is the bf16 one, six MFMAs per product
+        if k.endswith('_x3'):
+            v['frac_of_bf16_mfma_peak_at_6_mfma_per_product'] = 6.0 * v['tflops'] / BF16_MFMA_PEAK_TFLOPS
     out['geo_train'] = {'rays_per_s': B / dt, 'ms_per_step': dt * 1e3, 'batch_rays': B,
                         'achieved_tflops': flop / dt / 1e12, 'frac_of_f32_mfma_peak': flop / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
                         'kernel_ms_per_step': {k: v[1] / 6 for k, v in sorted(clk.items())}, 'kernel_roofline': kfrac,
                         'device_ms_outside_listed_kernels': dt * 1e3 - sum(v[1] / 6 for v in clk.values()),
-                        'note': 'all HIP: up-sampling kernels, forward (vqn_neus_train_fwd) and backward (vqn_neus_train_bwd: colour '
+                        'arithmetic': 'layer products of the up-sampling passes, the forward and the backward as exact bf16 piece triples (six bf16 '
+                                      'MFMAs per f32 product, f32 accumulation: the *_x3 kernels, default since they pass the reference gradient '
+                                      'goldens), the weight-gradient contraction likewise; frac_of_f32_mfma_peak = f32-equivalent FLOPs over the '
+                                      'f32-input MFMA peak, as rounds 1-2 priced the f32 kernels; VQN_TRAIN_FWD/BWD=fused, VQN_TRAIN_COARSE=f32, '
+                                      'VQN_WGRAD=f32 select the f32-input MFMA kernels',
+                        'note': 'all HIP: up-sampling kernels, forward (vqn_neus_train_fwd_x3) and backward (vqn_neus_train_bwd_x3: colour '
                                 'backward + tangent pass + reverse sweep, second-order eikonal term included) on the two-image engine, '
-                                'weight-gradient contraction, compositing fwd/bwd; torch only for Adam, the weight-norm chain rule and '
-                                'small reductions'}
+                                'weight-gradient contraction, compositing fwd/bwd; torch only for Adam (one launch under Runner(graph=True)), '
+                                'the weight-norm chain rule and small reductions'}
     # the same step with the weight-gradient contraction on the f32-input MFMA (round 2's default; VQN_WGRAD=f32).  The default since
     # round 3 is the exact three-way bf16 split (csrc/wgrad_x3.hip: six bf16 MFMAs per product down to 2^-24), which passes the
     # reference-gradient goldens at the same 5e-3 bound.
@@ -1040,7 +1050,8 @@ def main_train(args, dev, rank, world, backend):
     result = {
         'metric': 'rays/sec (train) 2560 rays/step/GPU of 800x800 views, 64+64 samples/ray, NeuS SDF 8x256 + colour 4x256',
         'value': B * world / step_s, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': step_s * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'ms_per_step': step_s * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32 (layer products as exact bf16 piece triples, six bf16 MFMAs each, f32 accumulation; VQN_TRAIN_FWD/BWD=fused: f32-input MFMA)',
         'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1] / configs[3] training step: nerf.conf batch of 2560 rays per rank (random pixels of '
                                'synthetic 800x800 views), L1 colour + 0.1 eikonal + 0.1 mask BCE, Adam; data parallel over ranks with ONE '
@@ -1050,6 +1061,9 @@ def main_train(args, dev, rank, world, backend):
                                                 'colour backward + SDF backward with the second-order terms)',
                      'achieved': flop_prog / t_prog / 1e12, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': flop_prog / t_prog / 1e12 / F32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                     'frac_of_bf16_mfma_peak_at_6_mfma_per_product': 6.0 * flop_prog / t_prog / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                     'note': 'f32-equivalent FLOPs over the f32-input MFMA peak (what the f32 kernels of rounds 1-2 were priced against); the default '
+                             'kernels since round 3 run on the bf16 pipe at six MFMAs per product -- the second fraction is their share of THAT peak',
                      'whole_step_tflops': flop / step_s / 1e12, 'whole_step_frac': flop / step_s / 1e12 / F32_MFMA_PEAK_TFLOPS},
         'kernel_ms_per_step': {k: v[1] / args.steps for k, v in sorted(clock.items())},
         'all_reduce': dict(_collective_report(clock, args.steps), grad_bucket_bytes=bucket_bytes),
