@@ -819,3 +819,81 @@ def test_hip_adam_is_torch_adam(amsgrad, tensor_lr, wd):
             a, b = sa[k][name].float(), sb[k][name].float()
             assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max())), (k, name)
     ob.load_state_dict(oa.state_dict())                          # interchangeable checkpoints
+
+
+@pytest.mark.parametrize('mode', ['x3', 'f32'])
+def test_training_backward_is_linear_in_the_adjoints_at_a_large_point_count(mode):
+    """A size-independent property of the backward kernels at a point count the interpreter comparison does not reach (65,537 points =
+    2,049 point tiles: more than eight passes of the persistent workgroups, an odd tile count): every output of vqn_neus_train_bwd(_x3)
+    is linear in the incoming adjoints (d rgb, d n, d sdf) -- bwd(a g1 + b g2) = a bwd(g1) + b bwd(g2) -- and zero for zero adjoints."""
+    from tests.test_gpu_neus_render import _build
+    cfg, sdf, col, var, ren = _build('full')
+    eng = ren._train_engine(sdf, col)
+    dev, P = torch.device('cuda'), 65537
+    g = torch.Generator(device='cuda').manual_seed(7)
+    x = torch.rand(P, 3, device=dev, generator=g) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(P, 3, device=dev, generator=g), dim=-1)
+    adj = [[torch.randn(P, k, device=dev, generator=g) for k in (3, 3, 1)] for _ in range(2)]
+    a, b = 0.75, -1.5
+    sl = [getattr(sdf, 'lin%d' % l) for l in range(sdf.num_layers - 1)]
+    cl = [getattr(col, 'lin%d' % l) for l in range(col.num_layers - 1)]
+    outs = ['DC%d' % l for l in range(eng.nC + 1)] + ['GOUTF', 'ED'] + ['UD%d' % (l + 1) for l in range(eng.nL)] + \
+        ['AB%d' % l for l in range(eng.nL)]
+    run = eng.run_fused_backward_x3 if mode == 'x3' else eng.run_fused_backward
+    with torch.no_grad():
+        wbuf, descs, flat = eng.pack([m.effective_weight().float() for m in sl], [m.bias.float() for m in sl],
+                                     [m.effective_weight().float() for m in cl], [m.bias.float() for m in cl], want_flat=True)
+        T = eng.alloc_tensors(P, dev)
+        T['X'].copy_(x)
+        T['DIRS'].copy_(d)
+        eng.run_fused_forward(flat, T, P)
+        res = []
+        for gr in (adj[0], adj[1], [a * u + b * v for u, v in zip(adj[0], adj[1])], [torch.zeros_like(u) for u in adj[0]]):
+            for n in outs:
+                T[n].fill_(float('nan'))
+            run(flat, T, P, gr[0].contiguous(), gr[1].contiguous(), gr[2].contiguous())
+            res.append({n: T[n].clone() for n in outs})
+    for n in outs:
+        lin = a * res[0][n] + b * res[1][n]
+        scale = max(float(lin.abs().max()), 1e-6)
+        assert torch.isfinite(res[2][n]).all(), n
+        assert float((res[2][n] - lin).abs().max()) <= 2e-5 * scale, (n, float((res[2][n] - lin).abs().max()), scale)
+        assert float(res[3][n].abs().max()) == 0.0, n
+
+
+@pytest.mark.parametrize('mode', ['x3', 'f32'])
+def test_training_forward_outputs_are_the_render_kernels(mode):
+    """vqn_neus_train_fwd(_x3) is the fine render kernel with extra stores: at 65,537 points its sdf / normals / colours equal
+    vqn_neus_fine_points(_x3) on the networks' own packs (the training packs -- one gather from the flat vector, or the
+    library's builder -- are the render packs), and the saved U_8 reproduces the sdf through the last layer."""
+    from vqnerf_release_amd import _C
+    from tests.test_gpu_neus_render import _build
+    cfg, sdf, col, var, ren = _build('full')
+    eng = ren._train_engine(sdf, col)
+    dev, P = torch.device('cuda'), 65537
+    g = torch.Generator(device='cuda').manual_seed(11)
+    x = torch.rand(P, 3, device=dev, generator=g) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(P, 3, device=dev, generator=g), dim=-1)
+    sl = [getattr(sdf, 'lin%d' % l) for l in range(sdf.num_layers - 1)]
+    cl = [getattr(col, 'lin%d' % l) for l in range(col.num_layers - 1)]
+    with torch.no_grad():
+        W, b = [m.effective_weight().float() for m in sl], [m.bias.float() for m in sl]
+        Wc, bc = [m.effective_weight().float() for m in cl], [m.bias.float() for m in cl]
+        T = eng.alloc_tensors(P, dev)
+        T['X'].copy_(x)
+        T['DIRS'].copy_(d)
+        if mode == 'x3':
+            eng.run_fused_forward_x3(W, b, Wc, bc, T, P)
+        else:
+            eng.run_fused_forward(eng.pack(W, b, Wc, bc, want_flat=True)[2], T, P)
+        m = 'x3' if mode == 'x3' else 'f32'
+        wb_s, d_s = sdf.packs(max_tiles=col.max_tiles(), mode=m)
+        wb_c, d_c = col.packs(feat_tiles=sdf.plan(mode=m).tiles[-1], mode=m)
+        s_ref, n_ref, c_ref = _C.neus_fine_points(d_s, wb_s, d_c, wb_c, pts=x, dirs=d, mode=m)
+    # (the sdf bit for bit; normals and colours to an ulp-level bound: the two instantiations of the kernel template may contract
+    #  w * (1 - e) of the reverse sweep's first step into an fma differently, since one of them also stores the product)
+    assert torch.equal(T['SDF'].reshape(-1), s_ref)
+    assert float((T['N'] - n_ref).abs().max()) <= 5e-6 * float(n_ref.abs().max()) and float((T['RGB'] - c_ref).abs().max()) <= 5e-6
+    # OUTF row 0 is the raw sdf output: sdf * scale
+    outf0 = T['OUTF'].permute(0, 3, 1, 2).reshape(-1, T['OUTF'].shape[1] * 32)[:P, 0]
+    assert float((outf0 / float(sdf.scale) - s_ref).abs().max()) <= 1e-6 * max(1.0, float(s_ref.abs().max()))
