@@ -626,7 +626,7 @@ class NeusTrainEngine:
         if want not in ('fused', 'x3') or os.environ.get('VQN_NEUS_TILE32') is not None:
             return None
         mt = max(self.sdf_net.plan(max_tiles=self.col_net.max_tiles()).max_tiles, self.col_net.max_tiles())
-        if not (5 <= mt <= 9 and self.skip != 0):
+        if not (5 <= mt <= 9 and self.skip != 0 and self.E <= 64 and self.X <= 64):      # (embedding / extras: at most two feature tiles)
             return None
         return 'x3' if (want == 'x3' and mt <= 8) else 'f32'
 
@@ -799,7 +799,7 @@ class NeusTrainEngine:
         if os.environ.get('VQN_NEUS_TILE32') is not None:
             return False
         mt = max(self._tiles(w) for w in self.out[:self.nL] + self.cout[:self.nC] + [self.F - 1])
-        return 5 <= mt <= 8 and self.skip != 0 and self.nL >= 2 and self.nC >= 1 and max(self.nL, self.nC) < self.TB_MAX_L
+        return 5 <= mt <= 8 and self.skip != 0 and self.nL >= 2 and self.nC >= 1 and max(self.nL, self.nC) < self.TB_MAX_L and self.E <= 64 and self.X <= 64
 
     def _bwd_static(self, device):
         """Gather index (into the flat source vector of pack()) of the backward kernel's weight pack + its int32 descriptor
