@@ -131,7 +131,8 @@ __global__ __launch_bounds__(512, 1) void neus_train_bwd_x3_kernel(const TrainBw
   };
   // epilogue operands of this wave's tile, both images, requested right before the K loop.  (The f32 kernel's refinement -- the NEXT GEMM's
   // operands requested in place from inside the current epilogue -- measured slower here: 6.80 -> 7.19 ms, 39 -> 99 spilled VGPRs: the
-  // operands would live across commit() and the ring refills, and this engine has no registers to spare.)
+  // operands would live across commit() and the ring refills, and this engine has no registers to spare.  Requesting them half way through
+  // the K loop instead (a hook inside gemm_tiles_x3_ring2): 6.7 -> 7.0 ms, 39 -> 91 spilled VGPRs -- the same verdict.)
   float au[2][16], ab[2][16];
 
   for (long pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
