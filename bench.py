@@ -479,6 +479,15 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     out['vq_assign_k64'] = {'rows': Nv, 'D': D, 'K': K64, 'bound': 'hbm', 'achieved': by_a64 / t_a64 / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                             'frac': by_a64 / t_a64 / 1e9 / 8000.0, 'ms': t_a64 * 1e3, 'rows_per_s': Nv / t_a64,
                             'kernel': 'vq_assign_split_kernel (f16-pair prefilter, exact re-evaluation of the candidates: bit-identical indices)'}
+    # the same call on rows that lie NEAR codes (code + 5 % noise, normalised: what a trained encoder hands the quantiser).  The kernel's
+    # cost depends on the data: a row whose two best codes are closer than the prefilter's error margin is re-evaluated exactly (f32 chain),
+    # and the uniform positive rows above -- every row and code shares a large mean component, distances crowd together -- send most
+    # 16-row groups there.  scripts/debug/vq_k64_paths.py: uniform rows 3.5 TB/s, gaussian rows 4.0, rows near codes 5.1.
+    near = torch.nn.functional.normalize(C64.t()[torch.randint(0, K64, (Nv,), device=dev)] + 0.05 * torch.randn(Nv, D, device=dev), dim=1).contiguous()
+    t_n64 = _time_gpu(lambda: _C.vq_assign(near, C64, want_quant=False), 10)
+    out['vq_assign_k64']['rows_near_codes'] = {'achieved': by_a64 / t_n64 / 1e9, 'frac': by_a64 / t_n64 / 1e9 / 8000.0, 'ms': t_n64 * 1e3,
+                                               'note': 'rows = code + 5 % noise, normalised; the headline of this entry keeps the uniform rows of rounds 1-2'}
+    del near
     xr = torch.rand(Nv, D, device=dev)                       # un-normalised rows: the fused quantiser normalises them itself
     from vqnerf_release_amd.decomp.nerfactor.networks.vq_layers import VectorQuantizerEMA
     vql = VectorQuantizerEMA(embedding_dim=D, num_embeddings=K64, commitment_cost=0.1, seed=0).to(dev)
