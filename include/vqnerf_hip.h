@@ -502,13 +502,16 @@ int vqn_wgrad_finalize(int count, const float* const* ws, const int32_t* n, cons
  * gradient bucket of the data-parallel step, trainvali.py:469-477). */
 int vqn_multi_copy(int count, const float* const* src, float* const* dst, const int64_t* n, void* stream);
 
-/* torch.optim.Adam's update (exp_runner.py:72; train_nfr.py:121-139 Keras Adam(amsgrad=True)) for `count` f32 tensors in one
- * launch per 56 tensors: steps[i] a device float holding tensor i's step count AFTER this step's increment, lr_dev a device scalar
- * (NULL: the host value lr), max_exp_avg_sq NULL without AMSGrad.  exp_avg = b1 m + (1 - b1) g, exp_avg_sq = b2 v + (1 - b2) g^2,
- * p -= (lr / (1 - b1^t)) m / (sqrt(max v) / sqrt(1 - b2^t) + eps); weight_decay is L2 (added to g), maximize negates g. */
+/* The Adam / AMSGrad update of the reference's optimisers for `count` f32 tensors in one launch per 56 tensors: steps[i] a device
+ * float holding tensor i's step count AFTER this step's increment, lr_dev a device scalar (NULL: the host value lr),
+ * max_exp_avg_sq NULL without AMSGrad.  exp_avg = b1 m + (1 - b1) g, exp_avg_sq = b2 v + (1 - b2) g^2, then
+ *   eps_mode 0 -- torch.optim.Adam (geo/NeuS-ours2/nerf_runner.py:72): p -= (lr / (1 - b1^t)) m / (sqrt(max v) / sqrt(1 - b2^t) + eps)
+ *   eps_mode 1 -- Keras Adam(amsgrad=True) (decomp/nerfvq_nfr3/nerfactor/train_nfr.py:121-139; TensorFlow 2.4.1
+ *                 ResourceApplyAdamWithAmsgrad): p -= (lr sqrt(1 - b2^t) / (1 - b1^t)) m / (sqrt(max v) + eps)
+ * weight_decay is L2 (added to g), maximize negates g.  Both are restated in oracle/optim.py. */
 int vqn_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                   float* const* max_exp_avg_sq, const float* const* steps, const int64_t* numel, const float* lr_dev, double lr,
-                  double beta1, double beta2, double eps, double weight_decay, int maximize, void* stream);
+                  double beta1, double beta2, double eps, double weight_decay, int maximize, int eps_mode, void* stream);
 
 #ifdef __cplusplus
 }

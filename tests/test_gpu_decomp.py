@@ -294,8 +294,14 @@ def test_training_step_grads_vs_oracle(setup, backend):
               else od.T(v).requires_grad_(True)) for k, v in p.items()}
     ob = {k: od.T(v) for k, v in pts.items()}
     want = od.model_call(pt, specs, ob, setup['lxyz'], setup['lareas'], od.EMA(0.999, (15,)), od.EMA(0.999, (256, 15)), mode='train')
-    wl, _ = od.compute_loss(want, ob['rgb'], pt['codebook_raw'], mode='train')
+    # compute_loss reads the codebook AFTER the EMA move of call() (vq_nfr.py:582-583, :956): its gradient -- the code-separation term
+    # (:958-971) is the only path into `_codebook` -- is taken at the moved values
+    cb_leaf = want['vq']['update'].detach().clone().requires_grad_(True)
+    wl, _ = od.compute_loss(want, ob['rgb'], cb_leaf, mode='train')
     wl.sum().div(N).backward()
+    ref = cb_leaf.grad.numpy()
+    assert np.abs(ref).max() > 0 and model._codebook.grad is not None
+    assert np.abs(_np(model._codebook.grad) - ref).max() <= 2e-3 * np.abs(ref).max(), '_codebook.grad vs the oracle'
     for name, net in model.net.items():
         for layer, (W, b) in zip(net.layers, pt[name]):
             for got, ref in ((layer.kernel.grad, W.grad), (layer.bias.grad, b.grad)):

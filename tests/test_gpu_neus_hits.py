@@ -128,7 +128,16 @@ def wgrad(request):
     tp.wgrad_mode(old)
 
 
-def test_hits_training_grads_vs_reference(hits, wgrad):
+@pytest.fixture(params=['x3', 'fused', 'prog'])
+def engine(request, monkeypatch):
+    """The three forward / backward engines of the training step against the reference's gradients: the exact-split
+    kernels (default), the f32-input MFMA two-image kernels, the interpreted tile programs -- same 5e-3 bound."""
+    monkeypatch.setenv('VQN_TRAIN_FWD', request.param)
+    monkeypatch.setenv('VQN_TRAIN_BWD', request.param)
+    return request.param
+
+
+def test_hits_training_grads_vs_reference(hits, wgrad, engine):
     """Gradients of L1(colour) + 0.1 * eikonal wrt every parameter, HIP tile-program engine vs the REAL reference's autograd,
     on rays that hit the surface: <= 5e-3 of each tensor's largest entry (the oracle itself holds 5e-3 against the same fixture)."""
     g, ren = hits['g'], hits['ren']
@@ -143,6 +152,9 @@ def test_hits_training_grads_vs_reference(hits, wgrad):
         loss.backward()
     assert ren.last_train_backend == 'hip' and (rec.ran('vqn_tile_program:prog_sbwd') or rec.ran('vqn_neus_train_bwd')) and rec.ran('vqn_wgrad_partials')
     assert rec.ran('vqn_wgrad_partials_x3') == (wgrad == 'bf16x3')
+    # (the fixture's networks are the full-size ones: the selected engine is the one that ran)
+    assert rec.ran('vqn_neus_train_bwd_x3') == (engine == 'x3') and rec.ran('vqn_tile_program:prog_sbwd') == (engine == 'prog')
+    assert rec.ran('vqn_neus_train_fwd_x3') == (engine == 'x3') and rec.ran('vqn_tile_program:prog_fwd') == (engine == 'prog')
     np.testing.assert_allclose(loss.item(), float(g['bwd_loss']), rtol=2e-4)
     worst = 0.0
     for name, m in (('sdf', hits['sdf']), ('col', hits['col']), ('var', hits['var'])):

@@ -152,7 +152,16 @@ def wgrad(request):
     tp.wgrad_mode(old)
 
 
-def test_training_path_grads_vs_reference(case, wgrad):
+@pytest.fixture(params=['x3', 'fused', 'prog'])
+def engine(request, monkeypatch):
+    """The three forward / backward engines of the training step against the reference's gradients: the exact-split
+    kernels (default), the f32-input MFMA two-image kernels, the interpreted tile programs -- same 5e-3 bound."""
+    monkeypatch.setenv('VQN_TRAIN_FWD', request.param)
+    monkeypatch.setenv('VQN_TRAIN_BWD', request.param)
+    return request.param
+
+
+def test_training_path_grads_vs_reference(case, wgrad, engine):
     """Training path of the boundary class (tile-program engine + compositing backward kernel): grads of L1(colour) +
     0.1 * eikonal wrt every parameter against the REAL reference's autograd, <= 5e-3 of each tensor's largest entry."""
     from tests.gpu_util import launches

@@ -821,6 +821,48 @@ def test_hip_adam_is_torch_adam(amsgrad, tensor_lr, wd):
     ob.load_state_dict(oa.state_dict())                          # interchangeable checkpoints
 
 
+@pytest.mark.parametrize('eps_mode,amsgrad', [('keras', True), ('keras', False), ('torch', True)])
+def test_hip_adam_against_the_oracle_statements(eps_mode, amsgrad):
+    """vqn_adam_step against oracle/optim.py: Keras Adam(amsgrad) -- epsilon on the UN-debiased sqrt(vhat), the
+    reflectance trainer's optimiser (train_nfr.py:127-138) -- and torch.optim.Adam, three steps whose gradients span 1e-9 .. 1 so
+    that the epsilon placement is what is being tested (at |g| ~ eps the two updates differ by up to 16 x at t = 1)."""
+    from oracle import optim as oo
+    from vqnerf_release_amd.optim import HipAdam
+    rng = np.random.default_rng(5)
+    shapes = [(1000,), (64, 33), (5,)]
+    init = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+    ps = [torch.nn.Parameter(torch.tensor(a, device='cuda')) for a in init]
+    lr = 2e-3
+    opt = HipAdam(ps, lr=torch.tensor(lr, device='cuda'), eps=1e-7, amsgrad=amsgrad, eps_mode=eps_mode)
+    st = [[a.copy(), 0 * a, 0 * a, 0 * a] for a in init]
+    step = oo.keras_adam_step if eps_mode == 'keras' else oo.torch_adam_step
+    for t in range(1, 4):
+        for k, (p, s) in enumerate(zip(ps, shapes)):
+            g = (rng.standard_normal(s) * 10.0 ** rng.integers(-9, 1, size=s)).astype(np.float32)
+            p.grad = torch.tensor(g, device='cuda')
+            st[k] = list(step(*st[k][:1], g, *st[k][1:], t, lr, eps=1e-7, amsgrad=amsgrad))
+        with launches() as rec:
+            opt.step()
+        assert rec.counts['vqn_adam_step'] == 1
+        for k, p in enumerate(ps):
+            got, want = p.detach().cpu().numpy(), st[k][0]
+            assert np.abs(got - want).max() <= 2e-7 * max(1.0, np.abs(want).max()) + lr * 2e-6, (eps_mode, t, k)
+            assert np.allclose(opt.state[p]['exp_avg_sq'].cpu().numpy(), st[k][2], rtol=3e-6, atol=1e-30)
+    if eps_mode == 'keras':                                  # and the placement is visible: the torch-placement update is NOT the same
+        other = [torch.nn.Parameter(torch.tensor(a, device='cuda')) for a in init]
+        o2 = HipAdam(other, lr=lr, eps=1e-7, amsgrad=amsgrad, eps_mode='torch')
+        g = torch.full((1000,), 1e-7, device='cuda')
+        other[0].grad = g
+        o2.step()
+        mine = [torch.nn.Parameter(torch.tensor(a, device='cuda')) for a in init]
+        o3 = HipAdam(mine, lr=lr, eps=1e-7, amsgrad=amsgrad, eps_mode='keras')
+        mine[0].grad = g
+        o3.step()
+        d_t = float((other[0].detach().cpu() - torch.tensor(init[0])).abs().mean())
+        d_k = float((mine[0].detach().cpu() - torch.tensor(init[0])).abs().mean())
+        assert 0.05 < d_k / d_t < 0.07, (d_k, d_t)           # lr g / (|g| + eps / sqrt(1 - b2)) vs lr g / (|g| + eps) at |g| = eps: 0.0613
+
+
 @pytest.mark.parametrize('mode', ['x3', 'f32'])
 def test_training_backward_is_linear_in_the_adjoints_at_a_large_point_count(mode):
     """A size-independent property of the backward kernels at a point count the interpreter comparison does not reach (65,537 points =

@@ -209,7 +209,8 @@ __global__ __launch_bounds__(256) void vq_ema_update_kernel(const float* __restr
   __syncthreads();
   const float om = (float)(1.0 - decay);        // (1 - decay) taken in double, then rounded: what the framework statement multiplies by
   for (int k = tid; k < K; k += 256) {
-    const float hdn = hid_cs[k] - (hid_cs[k] - counts[k]) * om;
+    const float hdn = __fsub_rn(hid_cs[k], __fmul_rn(__fsub_rn(hid_cs[k], counts[k]), om));      // (each step rounded as the framework
+                                                                                               //  statement rounds it: no contraction into an fma)
     hid_cs[k] = hdn;
     const float a = (float)((double)hdn / deb[0]);
     avg_cs[k] = a;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void vq_ema_update_kernel(const float* __restr
   const double d1 = deb[1];
   for (int i = tid; i < D * K; i += 256) {
     const int k = i % K;
-    const float hdn = hid_dw[i] - (hid_dw[i] - dw[i]) * om;
+    const float hdn = __fsub_rn(hid_dw[i], __fmul_rn(__fsub_rn(hid_dw[i], dw[i]), om));
     hid_dw[i] = hdn;
     const float a = (float)((double)hdn / d1);
     avg_dw[i] = a;

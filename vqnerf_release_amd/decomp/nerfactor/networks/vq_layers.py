@@ -187,7 +187,7 @@ class VectorQuantizerEMA(torch.nn.Module):
             local_counts = counts
             if self.stats_all_reduce is not None:
                 counts, dw = self.stats_all_reduce(counts, dw)
-            if self.fuse_ema_update and cb.dtype == torch.float32 and self.ema_dw.hidden.is_cuda:
+            if self.fuse_ema_update and cb.dtype == torch.float32 and self.ema_dw.hidden.is_cuda and K <= 1024 and cb.is_contiguous():
                 # both moving averages, the Laplace-smoothed cluster sizes and the codebook move in ONE launch (vqn_vq_ema_update)
                 ret['update'] = _C.vq_ema_update(counts.contiguous(), dw.contiguous(), cb, self.decay, self.epsilon,
                                                  self.ema_cluster_size, self.ema_dw)

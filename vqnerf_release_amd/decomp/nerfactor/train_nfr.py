@@ -13,19 +13,18 @@ from vqnerf_release_amd import parallel
 
 
 def make_optimizer(config, params, capturable=False):
-    """Keras Adam(lr, amsgrad=True) (train_nfr.py:121-139): epsilon 1e-7 (Keras default, torch's is 1e-8), optional
+    """Keras Adam(lr, amsgrad=True) (train_nfr.py:121-139): epsilon 1e-7 (Keras default) added to the UN-debiased sqrt(vhat) as
+    TensorFlow's kernel does (optim.HipAdam(eps_mode='keras'); oracle/optim.py: keras_adam_step), optional
     ExponentialDecay(lr_decay_steps, lr_decay_rate) -> returned as a LambdaLR, clipnorm / clipvalue as a closure.
-    `capturable`: step counters and lr live on the device, as `Trainer(graph=True)` needs, and the update is one launch
-    (optim.HipAdam on a GPU: torch's fused multi-tensor kernel takes 2 x 85 us for these ~1 M parameters, 16 workgroups each)."""
+    `capturable`: the lr lives on the device as well as the step counters, as `Trainer(graph=True)` needs.  On a GPU the update is one
+    launch (csrc/adam.hip; torch's fused multi-tensor kernel takes 2 x 85 us for these ~1 M parameters, 16 workgroups each); CPU
+    parameters (the gloo tests) take the framework statement of the same update."""
+    from vqnerf_release_amd.optim import HipAdam
     lr = config.getfloat('DEFAULT', 'lr')
     params = list(params)
     if capturable:
         lr = torch.tensor(lr, dtype=torch.float32, device=params[0].device)
-    if capturable and params[0].is_cuda:
-        from vqnerf_release_amd.optim import HipAdam
-        opt = HipAdam(params, lr=lr, eps=1e-7, amsgrad=True)           # the same update as ONE launch (csrc/adam.hip)
-    else:
-        opt = torch.optim.Adam(params, lr=lr, eps=1e-7, amsgrad=True, capturable=capturable, fused=bool(capturable))
+    opt = HipAdam(params, lr=lr, eps=1e-7, amsgrad=True, eps_mode='keras', capturable=True if capturable else None)
     decay_steps = config.getint('DEFAULT', 'lr_decay_steps', fallback=-1)
     sched = None
     if decay_steps > 0:

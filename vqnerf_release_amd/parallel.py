@@ -162,7 +162,32 @@ class FlatBucket:
         self.flat.zero_()
         for p, v in zip(self.params, self.views):
             p.grad = v
+        self._reset_overlap()
         return self
+
+    def _reset_overlap(self):
+        """Forget slices in flight (waiting for them first): a step that raised between backward and all_reduce(), or a second
+        backward before the reduce, must not leave stale work handles or a half-counted slice behind."""
+        if getattr(self, '_slices', None) is not None:
+            for w in self._pending.values():
+                w.wait()
+            self._pending, self._left = {}, [sl['n_params'] for sl in self._slices]
+
+    def disable_overlap(self):
+        """Remove the post-accumulate hooks (a second bucket / Trainer on the same model would otherwise fire this one's collectives)."""
+        for h in getattr(self, '_hooks', []):
+            h.remove()
+        self._hooks = []
+        if getattr(self, '_slices', None) is not None:
+            self._reset_overlap()
+        self._slices = None
+
+    def __del__(self):
+        try:
+            for h in getattr(self, '_hooks', []):
+                h.remove()
+        except Exception:
+            pass
 
     def gather_grads(self):
         """For parameters whose .grad is not (or no longer) a view of the bucket."""
@@ -181,7 +206,11 @@ class FlatBucket:
         others.  The backward pass reaches the parameters roughly in reverse order, so the slices complete back to front; the
         extras (loss terms, written after backward) travel with whatever is reduced at `all_reduce()`, which also reduces every
         slice whose hooks did not all fire (an unused parameter).  Sums are slice-local, element-wise: the result is bit-identical
-        to the single all-reduce.  Not used while a SegmentedCapture records (a collective cuts the graph there)."""
+        to the single all-reduce.  Not used while a SegmentedCapture records (a collective cuts the graph there).
+        CONTRACT: every rank must run the same autograd graph -- the slices go out in hook-firing order, and a parameter that is unused
+        on ONE rank only would make the ranks' collective sequences differ (a hang).  Callers that cannot promise that keep the single
+        all-reduce (do not call this).  One backward per all_reduce(): a second backward that reaches a slice already in flight (gradient
+        accumulation) raises -- the slice left with the first pass's sums only."""
         if getattr(self, '_slices', None) is not None:
             return self
         target = max(1, -(-self.n_grad // max(1, n_buckets)))
@@ -205,13 +234,19 @@ class FlatBucket:
                     v.copy_(p.grad)
                     p.grad = v
                 self._left[k] -= 1
+                if self._left[k] < 0:                  # a second backward before all_reduce(): the slice is already in flight with
+                    w = self._pending.pop(k, None)     # the FIRST pass's sums -- take it back (wait) and let all_reduce() send the
+                    if w is not None:                  # accumulated gradients as part of its own run
+                        w.wait()
+                        raise RuntimeError('FlatBucket.enable_overlap: a second backward reached a slice that had already been sent; '
+                                           'accumulate gradients with the single all-reduce (do not enable the overlap)')
+                    return
                 if self._left[k] == 0:
                     sl = self._slices[k]
                     with _clock('all_reduce:grad_bucket[%d]' % k):
                         self._pending[k] = dist.all_reduce(self.flat[sl['lo']:sl['hi']], op=dist.ReduceOp.SUM, group=group, async_op=True)
             return hook
-        for i, p in enumerate(self.params):
-            p.register_post_accumulate_grad_hook(make_hook(i, self._slice_of[id(p)]))
+        self._hooks = [p.register_post_accumulate_grad_hook(make_hook(i, self._slice_of[id(p)])) for i, p in enumerate(self.params)]
         return self
 
     def all_reduce(self, average_grads=False, group=None):
