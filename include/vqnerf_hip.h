@@ -502,6 +502,30 @@ int vqn_wgrad_finalize(int count, const float* const* ws, const int32_t* n, cons
  * gradient bucket of the data-parallel step, trainvali.py:469-477). */
 int vqn_multi_copy(int count, const float* const* src, float* const* dst, const int64_t* n, void* stream);
 
+/* ---- training passes of the reflectance Dense stacks on the exact-split engine (round 4; csrc/refl_train_x3.hip) ----
+ * Replace `tape.gradient` through `_pred_enc_at` / `_pred_{diff,spec,rough}_at` (decomp/nerfvq_nfr3/nerfactor/models/vq_nfr.py:771-828,
+ * nfr_unit.py:329-391 over networks/{embedder,mlp,seq}.py) under train_nfr.py:562-576: the forward keeping what the backward needs, and
+ * the backward down to every Dense layer's per-point adjoint (the weight gradients are vqn_wgrad_partials_batched over those tensors).
+ * One stack: [posenc -> n_enc Dense layers with one skip-concat of the encoding -> z] (n_enc = 0: the input is z rows) -> up to three
+ * heads Dense(w0) relu -> Dense(w1) relu -> Dense(c <= 3) sigmoid over [y1 ; z].  Layers of at most 256 outputs; every f32 operand as
+ * three bf16 pieces, six bf16 MFMAs per product, f32 accumulation (f32-level results).
+ * desc: vqn_refl_train_desc_ints() int32 words (decomp/train_programs.py: ReflTrainEngine builds it; csrc/refl_train_x3.hip: ReflDesc);
+ * wbuf_pieces: the GEMM matrices as bf16 piece triples in x3 A-fragment order (vqn_pack_x3_gather); wbuf_f32: biases in accumulator
+ * order, the heads' last layers as row-dot images and accumulator-order columns.  Tensors in the tile format are
+ * [ceil(P/32)][feature tiles][32 features][32 points] f32.
+ * forward -- saved (written): with an encoder [E, Y_0 .. Y_{n_enc-1}] (Y_{n_enc-1} = z), without [ZT = the input rows' tile-format
+ *   copy]; then [H0_k, H1_k] per head.  z_rows_out [P, z_feats] (optional, with an encoder); head_out[k] [P, c_k].
+ * backward -- g_out[k] / head_out[k] [P, c_k]; g_z_rows [P, z_feats]: adjoint of z from outside the heads (optional; required for an
+ *   encoder alone); saved [Y_0 .. Y_{n_enc-1}] then [H0_k, H1_k]; outs (written) [D_0 .. D_{n_enc-1}] then [D0_k, D1_k, D2_k] per
+ *   head; gz_rows_out [P, z_feats]: d / d input rows (required without an encoder).  Adjoints of points past P are zero. */
+int vqn_refl_train_desc_ints(void);
+int vqn_refl_train_fwd_x3(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, const float* pts, const float* z_rows,
+                          int64_t P, float* const* saved, int n_saved, float* z_rows_out, float* const* head_out, void* stream);
+int64_t vqn_refl_train_bwd_x3_scratch_bytes(const int32_t* desc);
+int vqn_refl_train_bwd_x3(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, int64_t P, const float* const* g_out,
+                          const float* const* head_out, const float* g_z_rows, const float* const* saved, int n_saved,
+                          float* const* outs, int n_outs, float* gz_rows_out, void* scratch, int64_t scratch_bytes, void* stream);
+
 /* The Adam / AMSGrad update of the reference's optimisers for `count` f32 tensors in one launch per 56 tensors: steps[i] a device
  * float holding tensor i's step count AFTER this step's increment, lr_dev a device scalar (NULL: the host value lr),
  * max_exp_avg_sq NULL without AMSGrad.  exp_avg = b1 m + (1 - b1) g, exp_avg_sq = b2 v + (1 - b2) g^2, then

@@ -1,0 +1,51 @@
+"""Which Python lines issue the torch ops INSIDE the captured reflectance training step (2048 points)?  TorchDispatchMode + traceback
+around the capturing call of Trainer(graph=True); also the per-kernel launch census of one replay (torch profiler)."""
+import sys, collections, traceback
+sys.path.insert(0, '.')
+import torch, bench
+from torch.utils._python_dispatch import TorchDispatchMode
+dev = torch.device('cuda:0')
+model, tr, step = bench.decomp_train_setup(dev, 0, 1, graph=True)
+sites = collections.Counter()
+class Log(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if not any(s in name for s in ('view', 'reshape', 'detach', 'alias', 'expand', 'slice', 'select', 'unsqueeze', 'squeeze', 'as_strided', 't.default', 'transpose', 'permute', 'empty', 'size', 'stride', '_local_scalar')):
+            site = 'autograd-engine'
+            for fr in reversed(traceback.extract_stack()):
+                if 'vqnerf_release_amd/' in fr.filename:
+                    site = f"{fr.filename.split('vqnerf_release_amd/')[-1]}:{fr.lineno}"
+                    break
+            sites[(site, name)] += 1
+        return func(*args, **(kwargs or {}))
+n = 0
+while tr._captured is None and n < 8:
+    if n >= tr.GRAPH_WARMUP:
+        with Log():
+            step()
+    else:
+        step()
+    n += 1
+torch.cuda.synchronize()
+print('captured after', n, 'calls; torch ops during the capturing call:', sum(sites.values()))
+by_site = collections.Counter()
+for (s, nm), c in sites.items():
+    by_site[s] += c
+for s, c in by_site.most_common(60):
+    ops = ', '.join(f'{nm.replace("aten.", "")}x{k}' for (ss, nm), k in sorted(sites.items(), key=lambda kv: -kv[1]) if ss == s)[:170]
+    print(f'{c:4d}  {s:60s} {ops}')
+from torch.profiler import profile, ProfilerActivity
+for _ in range(3): step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    step()
+    torch.cuda.synchronize()
+ks = collections.Counter()
+tot = collections.Counter()
+for e in prof.events():
+    if e.device_type == torch.autograd.DeviceType.CUDA:
+        ks[e.name[:90]] += 1
+        tot[e.name[:90]] += e.device_time if hasattr(e, 'device_time') else e.cuda_time
+print('kernels in one replay:', sum(ks.values()))
+for k, c in ks.most_common(80):
+    print(f'{c:4d} {tot[k]:9.1f} us  {k}')

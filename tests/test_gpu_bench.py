@@ -61,5 +61,5 @@ def test_two_rank_train_mode_times_the_dp_step():
     assert abs(res['value'] - 2 * 2560 / (res['ms_per_step'] * 1e-3)) < 1e-6 * res['value']
     assert res['all_reduce']['grad_bucket']['calls_per_step'] == 1 and res['all_reduce']['total_us_per_step'] > 0
     assert res['last_train_backend'] == 'hip' and res['roofline']['bound'] == 'mfma'
-    assert any(k.startswith(('vqn_tile_program', 'vqn_neus_train_')) for k in res['kernel_ms_per_step'])
+    assert any(k.startswith(('vqn_tile_program', 'vqn_neus_train_', 'vqn_refl_train_')) for k in res['kernel_ms_per_step'])
     assert res['extra']['decomp_train_dp']['all_reduce']['vq_stats']['calls_per_step'] == 1

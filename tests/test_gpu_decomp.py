@@ -270,14 +270,18 @@ def test_model_call_vs_oracle(setup, mode):
     np.testing.assert_allclose(_np(loss), wl.numpy(), rtol=1e-4, atol=2e-6)
 
 
-@pytest.mark.parametrize('backend', ['hip', 'torch'])
-def test_training_step_grads_vs_oracle(setup, backend):
-    """Training path of the model -- 'hip': encoder / heads forward + backward tile programs (`vqn_tile_program`,
-    `vqn_wgrad_partials`) and the fused shading forward / backward kernels under autograd, 'torch': torch statements only;
-    both with the HIP VQ kernels -- d loss / d parameters vs the CPU oracle.  Asserts which kernels each backend launched."""
+@pytest.mark.parametrize('backend', ['hip', 'hip-prog', 'torch'])
+def test_training_step_grads_vs_oracle(setup, backend, monkeypatch):
+    """Training path of the model -- 'hip': encoder / heads forward + backward on the dedicated exact-split kernels
+    (`vqn_refl_train_fwd_x3` / `_bwd_x3`, round 4), 'hip-prog': on the interpreted tile programs (`vqn_tile_program`), both with the
+    batched contractions (`vqn_wgrad_partials`) and the fused shading forward / backward kernels under autograd; 'torch': torch
+    statements only; all with the HIP VQ kernels -- d loss / d parameters vs the CPU oracle.  Asserts which kernels each backend launched."""
     od, p, specs = setup['od'], setup['p'], setup['specs']
     from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
     model = load_oracle_params(get_model_class('vq_nfr')(make_config()), p, 'cuda')
+    if backend == 'hip-prog':
+        monkeypatch.setenv('VQN_REFL_TRAIN', 'prog')
+    prog, backend = backend == 'hip-prog', backend.split('-')[0]
     model.train_backend = backend
     N = 256
     pts = od.make_points(N, seed=9)
@@ -287,7 +291,8 @@ def test_training_step_grads_vs_oracle(setup, backend):
         loss, _ = model.compute_loss(pred, gt, **dict(lk))
         loss.sum().div(N).backward()
     hip = backend == 'hip'
-    assert rec.ran('vqn_tile_program') == hip and rec.ran('vqn_brdf_shade_bwd') == hip and rec.ran('vqn_wgrad_partials') == hip
+    assert rec.ran('vqn_tile_program') == (hip and prog) and rec.ran('vqn_refl_train_bwd_x3') == (hip and not prog)
+    assert rec.ran('vqn_refl_train_fwd_x3') == (hip and not prog) and rec.ran('vqn_brdf_shade_bwd') == hip and rec.ran('vqn_wgrad_partials') == hip
     assert rec.ran('vqn_vq_assign')
     # oracle with torch autograd on the CPU
     pt = {k: ([(od.T(W).requires_grad_(True), od.T(b).requires_grad_(True)) for W, b in v] if isinstance(v, list)

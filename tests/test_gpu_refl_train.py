@@ -1,0 +1,157 @@
+"""GPU: the dedicated training kernels of the reflectance Dense stacks (csrc/refl_train_x3.hip, decomp/refl_train.py) -- forward values,
+saved tensors and every gradient against the torch statement of the same networks (networks/mlp.py -- the statement the oracle tests pin
+to the reference's vq_nfr.py:771-828) under torch autograd, and against the interpreted tile programs they replace.  Model-level parity
+with the oracle runs in tests/test_gpu_decomp.py::test_training_step_grads_vs_oracle under this engine (the default)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.decomp_util import make_config
+from tests.gpu_util import launches
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(seed=5, **over):
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    m = get_model_class('vq_nfr')(make_config(**over))
+    m.build_nets(device='cuda', seed=seed).to('cuda')
+    # away from the glorot start: every activation pattern (dead relus, saturating sigmoids) should occur
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.05 * torch.randn(p.shape, device='cuda', generator=g))
+    return m
+
+
+def _pts(N, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1, 1, (N, 3))
+    return torch.tensor(x / np.linalg.norm(x, axis=1, keepdims=True) * rng.uniform(0.4, 1.0, (N, 1)), dtype=torch.float32, device='cuda')
+
+
+def _rel(a, b):
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+
+
+@pytest.mark.parametrize('N', [1, 33, 600, 4113])
+def test_encoder_and_heads_stack_against_torch_autograd(N):
+    """A = posenc -> fine_enc -> bottleneck -> z -> three continuous heads: outputs to 3e-6, parameter gradients to 1e-4 of each tensor's
+    largest entry (x3 products are exact to 2^-24; the order of the sums differs from torch's GEMMs), with an adjoint flowing into z from
+    outside the heads as the VQ branch does."""
+    from vqnerf_release_amd.decomp.refl_train import ReflStackEngine, ReflStackFunction
+    m = _model()
+    names = ['diff_main', 'spec_main', 'rough_main']
+    enc = [m.net['fine_enc'], m.net['bottleneck']]
+    eng = ReflStackEngine(enc, m.embedder['xyz'].n_freqs, [m.net[n] for n in names], m.z_dim, 'cuda')
+    x = _pts(N, 1)
+    g = torch.Generator(device='cuda').manual_seed(2)
+    w_z = torch.randn(N, 256, device='cuda', generator=g)
+    w_o = [torch.randn(N, m.net[n].widths[2], device='cuda', generator=g) for n in names]
+
+    def loss_of(z, outs):
+        return (z * w_z).sum() + sum((o * w).sum() for o, w in zip(outs, w_o))
+    # torch statement
+    m.zero_grad(set_to_none=True)
+    z_t = m.net['bottleneck'](m.net['fine_enc'](m.embedder['xyz'](x)))
+    outs_t = [m.net[n](z_t) for n in names]
+    loss_of(z_t, outs_t).backward()
+    want = [p.grad.detach().clone() for p in eng.params()]
+    m.zero_grad(set_to_none=True)
+    with launches() as rec:
+        res = ReflStackFunction.apply(eng, x, *eng.params())
+        loss_of(res[0], res[1:]).backward()
+    assert rec.counts['vqn_refl_train_fwd_x3'] == 1 and rec.counts['vqn_refl_train_bwd_x3'] == 1 and not rec.ran('vqn_tile_program')
+    assert float((res[0] - z_t).abs().max()) < 3e-6
+    for a, b in zip(res[1:], outs_t):
+        assert float((a - b).abs().max()) < 3e-6
+    for p, w in zip(eng.params(), want):
+        assert p.grad is not None and _rel(p.grad, w) < 1e-4, (tuple(p.shape), _rel(p.grad, w))
+
+
+@pytest.mark.parametrize('N', [2, 95, 2048])
+def test_vq_heads_stack_against_torch_autograd(N):
+    """B = the three VQ heads on quantised rows (spec_vq has three outputs): outputs, parameter gradients and d / d rows."""
+    from vqnerf_release_amd.decomp.refl_train import ReflStackEngine, ReflStackFunction
+    m = _model(seed=7)
+    names = ['diff_vq', 'spec_vq', 'rough_vq']
+    eng = ReflStackEngine(None, 0, [m.net[n] for n in names], m.z_dim, 'cuda')
+    g = torch.Generator(device='cuda').manual_seed(3)
+    z0 = torch.nn.functional.normalize(torch.rand(N, 256, device='cuda', generator=g), dim=-1)
+    w_o = [torch.randn(N, m.net[n].widths[2], device='cuda', generator=g) for n in names]
+    z_a = z0.clone().requires_grad_(True)
+    sum((m.net[n](z_a) * w).sum() for n, w in zip(names, w_o)).backward()
+    want = [p.grad.detach().clone() for p in eng.params()]
+    outs_t = [m.net[n](z0) for n in names]
+    m.zero_grad(set_to_none=True)
+    z_b = z0.clone().requires_grad_(True)
+    res = ReflStackFunction.apply(eng, z_b, *eng.params())
+    sum((o * w).sum() for o, w in zip(res, w_o)).backward()
+    for a, b in zip(res, outs_t):
+        assert float((a - b).abs().max()) < 3e-6
+    assert _rel(z_b.grad, z_a.grad) < 1e-4
+    for p, w in zip(eng.params(), want):
+        assert _rel(p.grad, w) < 1e-4, (tuple(p.shape), _rel(p.grad, w))
+
+
+def test_saved_tensors_and_adjoints_are_the_interpreted_programs(monkeypatch):
+    """Layer outputs and per-point adjoints left for the contraction, against decomp/train_programs.py's interpreter on the f32-input
+    MFMA (the engine of rounds 1-3): 2e-5 of each tensor's largest entry (the bound the geo x3 kernels hold against their interpreter),
+    zero rows for the points past N in the ragged last tile."""
+    from vqnerf_release_amd.decomp.refl_train import ReflStackEngine
+    from vqnerf_release_amd.decomp.train_programs import EncoderEngine, HeadsEngine
+    m = _model(seed=11)
+    N = 4113
+    names = ['diff_main', 'spec_main', 'rough_main']
+    enc_nets = [m.net['fine_enc'], m.net['bottleneck']]
+    eng = ReflStackEngine(enc_nets, m.embedder['xyz'].n_freqs, [m.net[n] for n in names], m.z_dim, 'cuda')
+    x = _pts(N, 4)
+    g = torch.Generator(device='cuda').manual_seed(5)
+    g_outs = [torch.randn(N, m.net[n].widths[2], device='cuda', generator=g) for n in names]
+    g_z = torch.randn(N, 256, device='cuda', generator=g)
+    pad = torch.ones(((N + 31) // 32) * 32, device='cuda')
+    pad[N:] = 0.0
+    pad = pad.reshape(-1, 1, 1, 32)                                # [point tile, 1, 1, point]: 0 on the ragged tile's padding columns
+
+    def _relm(a, b):                                                # (layer OUTPUTS of padding points are don't-cares: their adjoints are zero)
+        a, b = a * pad, b * pad
+        return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+    with torch.no_grad():
+        S, zrows, outs = eng.forward(x, [p.detach() for p in eng.params()])
+        # the interpreter: encoder, then heads on its z
+        ee = EncoderEngine(enc_nets[0], enc_nets[1], m.embedder['xyz'].n_freqs, 'cuda')
+        layers = list(enc_nets[0].layers) + list(enc_nets[1].layers)
+        T, wbuf, descs = ee.forward(x, [l.kernel.detach() for l in layers], [l.bias.detach() for l in layers])
+        for l in range(eng.nE):
+            assert _relm(S['Y'][l], T['Y%d' % l]) < 2e-5, l
+        assert _relm(S['E'], T['E']) < 1e-6
+        he = HeadsEngine([m.net[n] for n in names], m.z_dim, 'cuda')
+        W = [[l.kernel.detach() for l in m.net[n].layers] for n in names]
+        b = [[l.bias.detach() for l in m.net[n].layers] for n in names]
+        TH, wb2, d2 = he.forward(zrows, W, b)
+        for k in range(3):
+            assert _relm(S['H0'][k], TH['Y%d_0' % k]) < 2e-5 and _relm(S['H1'][k], TH['Y%d_1' % k]) < 2e-5
+        gz_h, dW_h, db_h = he.backward(TH, wb2, d2, g_outs, N)
+        dW_e, db_e = ee.backward(T, wbuf, descs, (gz_h + g_z).contiguous(), N)
+        _, grads = eng.backward(S, g_z, g_outs)
+    ref = []
+    for w, bb in zip(dW_e, db_e):
+        ref += [w, bb]
+    for k in range(3):
+        for j in range(3):
+            ref += [dW_h[3 * k + j], db_h[3 * k + j]]
+    assert len(ref) == len(grads)
+    for a, w in zip(grads, ref):
+        assert a.shape == w.shape and _rel(a, w) < 5e-4, (tuple(a.shape), _rel(a, w))      # (relu units within rounding of zero flip between the engines: the torch-autograd tests above are the tight ones)
+
+
+def test_stacks_outside_the_kernels_shape_keep_the_interpreter():
+    """A 512-wide stage-3 head (ref_nfr) is outside the x3 engine's 256-feature image: `supports` says so and the model keeps the
+    interpreted programs for it."""
+    from vqnerf_release_amd.decomp.refl_train import ReflStackEngine
+    from vqnerf_release_amd.decomp.nerfactor.networks import mlp
+    wide = mlp.Network([512, 256, 3], act=['relu', 'relu', 'sigmoid'], skip_at=[1])
+    assert not ReflStackEngine.supports(None, [wide], 512)
+    ok = mlp.Network([256, 128, 3], act=['relu', 'relu', 'sigmoid'], skip_at=[1])
+    assert ReflStackEngine.supports(None, [ok], 256)
+    assert not ReflStackEngine.supports(None, [mlp.Network([256, 128, 3], act=['relu', 'relu', None], skip_at=[1])], 256)

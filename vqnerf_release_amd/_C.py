@@ -783,3 +783,44 @@ def brdf_shade_bwd(xyz, normal, rayo, lvis, lxyz, lareas, light, materials, g_su
                                    *[_ptr(t) for t in flat_out], _ptr(part), _stream())
     _check(rc, 'vqn_brdf_shade_bwd')
     return outs, part.sum(0)
+
+
+# -------------------------------------------------------------------------------------- reflectance training passes (round 4)
+def refl_train_fwd_x3(desc, wbuf_pieces, wbuf_f32, pts, z_rows, P, saved, z_rows_out, head_out):
+    """Forward of a reflectance stack (optional encoder + up to three heads) on the exact-split engine, keeping what the backward
+    needs (csrc/refl_train_x3.hip: vqn_refl_train_fwd_x3)."""
+    _f32c(wbuf_f32, 'wbuf_f32')
+    for t in list(saved) + list(head_out) + [t for t in (pts, z_rows, z_rows_out) if t is not None]:
+        _f32c(t, 'tensor')
+    d, dp = _i32(desc)
+    sp = (ctypes.c_void_p * len(saved))(*[t.data_ptr() for t in saved])
+    hp = (ctypes.c_void_p * max(1, len(head_out)))(*[t.data_ptr() for t in head_out])
+    with _clock('vqn_refl_train_fwd_x3'):
+        rc = lib().vqn_refl_train_fwd_x3(dp, _ptr(wbuf_pieces), _ptr(wbuf_f32), _ptr(pts), _ptr(z_rows), ctypes.c_int64(P), sp,
+                                         ctypes.c_int(len(saved)), _ptr(z_rows_out), hp, _stream())
+    _check(rc, 'vqn_refl_train_fwd_x3')
+
+
+def refl_train_bwd_x3(desc, wbuf_pieces, wbuf_f32, P, g_out, head_out, g_z_rows, saved, outs, gz_rows_out):
+    """Backward of the same stack (vqn_refl_train_bwd_x3): fills `outs` with every layer's per-point adjoint in the tile format."""
+    _f32c(wbuf_f32, 'wbuf_f32')
+    for t in list(saved) + list(outs) + list(g_out) + list(head_out) + [t for t in (g_z_rows, gz_rows_out) if t is not None]:
+        _f32c(t, 'tensor')
+    d, dp = _i32(desc)
+    dev = wbuf_f32.device
+    L = lib()
+    L.vqn_refl_train_bwd_x3_scratch_bytes.restype = ctypes.c_int64
+    need = int(L.vqn_refl_train_bwd_x3_scratch_bytes(dp))
+    if need <= 0:
+        raise VqnError('vqn_refl_train_bwd_x3_scratch_bytes: invalid descriptor')
+    key = (str(dev), torch.cuda.current_stream().cuda_stream, 'refl_bwd')
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty((need,), dtype=torch.uint8, device=dev)
+        _scratch[key] = buf
+    arr = lambda ts: (ctypes.c_void_p * max(1, len(ts)))(*[t.data_ptr() for t in ts])
+    with _clock('vqn_refl_train_bwd_x3'):
+        rc = L.vqn_refl_train_bwd_x3(dp, _ptr(wbuf_pieces), _ptr(wbuf_f32), ctypes.c_int64(P), arr(g_out), arr(head_out), _ptr(g_z_rows),
+                                     arr(saved), ctypes.c_int(len(saved)), arr(outs), ctypes.c_int(len(outs)), _ptr(gz_rows_out), _ptr(buf),
+                                     ctypes.c_int64(buf.numel()), _stream())
+    _check(rc, 'vqn_refl_train_bwd_x3')

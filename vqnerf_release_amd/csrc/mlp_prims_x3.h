@@ -163,6 +163,62 @@ __device__ __forceinline__ void gemm_tiles_x3_ring2(const f32x4* __restrict__ ld
   }
 }
 
+// One-image form of the same GEMM for layers of at most NW / 2 output tiles (the 128-wide layers of the reflectance stacks): with one
+// tile per wave such a layer would leave half of the eight waves without work, so the waves split by IMAGE instead -- waves 0..3
+// take tile (wave & 3) of image 0, waves 4..7 the same tiles of image 1 (6 MFMAs per step; a weight fragment is fetched by two waves:
+// these layers have K <= 256, a small share of the stream).  `lds_img`: the wave's own image; `ot` wave-uniform.  Ring handling as above
+// (`next_wp` / `next_nb`: the wave's first tile of its next GEMM call).
+template <int R = 2, class Init, class Epi>
+__device__ __forceinline__ void gemm_tile_x3_ring1(const f32x4* __restrict__ lds_img, const KSegs ks, const f32x4* __restrict__ w,
+                                                   const int ot, const int lane, f32x4 (&A)[R][6],
+                                                   const f32x4* __restrict__ next_wp, const int next_nb, Init init, Epi epi) {
+  const int nr = ks.nA + ks.nB, ns = nr / 3, nb = (ns + 1) >> 1, nbp = ((nb + R - 1) / R) * R;
+  auto bstep = [&](int st) {
+    const int r = 3 * min(st, ns - 1);
+    return ((r < ks.nA) ? (ks.rowA + r) : (ks.rowB + (r - ks.nA))) * 64 + lane;
+  };
+  const f32x4* __restrict__ wp = w + (size_t)ot * nb * 384 + lane;
+  f32x16 acc;
+  f32x4 B[2][3];
+  {
+    const int a = bstep(0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) B[0][q] = lds_img[a + 64 * q];
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  init(acc);
+  __builtin_amdgcn_s_setprio(1);
+  for (int bi = 0; bi < nbp; bi += R) {
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const int blk = bi + u;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int a = bstep(blk * 2 + j + 1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) B[(j + 1) & 1][q] = lds_img[a + 64 * q];
+        if (blk < nb) {
+          const f32x4 w0 = A[u][3 * j], w1 = A[u][3 * j + 1], w2 = A[u][3 * j + 2];
+          acc = mma_x3(w2, B[j][0], acc);                    // smallest terms first
+          acc = mma_x3(w1, B[j][1], acc);
+          acc = mma_x3(w0, B[j][2], acc);
+          acc = mma_x3(w1, B[j][0], acc);
+          acc = mma_x3(w0, B[j][1], acc);
+          acc = mma_x3(w0, B[j][0], acc);
+        }
+      }
+      const int pos = blk + R;
+      const bool own = pos < nb, nxt = pos >= nbp;
+      const f32x4* __restrict__ src = nxt ? next_wp : wp;
+      const int sb = own ? pos : (nxt ? min(u, next_nb - 1) : nb - 1);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) A[u][i] = src[(sb * 6 + i) * 64];
+    }
+  }
+  __builtin_amdgcn_s_setprio(0);
+  epi(acc);
+}
+
 // an output tile (16 values per lane in accumulator-register order) -> its six piece fragments (2 steps x 3 pieces), in registers
 __device__ __forceinline__ void split_tile_x3(const float (&v)[16], f32x4 (&o)[6]) {
 #pragma unroll

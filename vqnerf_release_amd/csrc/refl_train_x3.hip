@@ -1,0 +1,658 @@
+// Training passes of the reflectance Dense stacks on the exact-split engine (csrc/mlp_prims_x3.h) -- round 4.
+//
+// What they stand for in the reference: `tape.gradient` through `_pred_enc_at` / `_pred_{diff,spec,rough}_at`
+// (decomp/nerfvq_nfr3/nerfactor/models/vq_nfr.py:771-828 over networks/{embedder,mlp,seq}.py) under train_nfr.py:562-576 -- the
+// forward with everything the backward needs kept, and the backward down to the per-point adjoints of every Dense layer (the
+// weight gradients themselves are the contractions of csrc/wgrad*.hip over the tensors these kernels leave).  Rounds 1-3 ran these
+// passes as interpreted tile programs on the f32-input MFMA (csrc/tile_vm.hip: 10 of the 19 ms of a 262,144-point step).
+//
+// One stack shape, two uses (ReflDesc):
+//   [positional encoding -> encoder layers (one skip-concat of the encoding) -> z]   optional (n_enc = 0: the input is z rows)
+//   -> up to three heads on z: Dense(w0) relu -> Dense(w1) relu -> Dense(c <= 3) sigmoid over [y1 ; z]  (mlp.Network(skip_at = [1]))
+// A = encoder + continuous heads of vq_nfr / nfr_unit, B = the VQ heads on the quantised rows.
+//
+// Kernel shape = the NeuS exact-split kernels': one 512-thread workgroup per CU holds TWO 32-point images as bf16 piece triples,
+// layers run IN PLACE (finished tiles wait in registers for the barrier), weights stream through the register ring along a table of the
+// pass's GEMM calls.  Layers of more than four output tiles: wave w owns tile w for both images (gemm_tiles_x3_ring2); layers of at
+// most four (the 128-wide ones): the waves split by image (gemm_tile_x3_ring1) so that all eight have a tile.  The 1..3-output last
+// layer of a head never touches the matrix pipe: forward row dots, backward rank-c updates on the vector ALU.
+// Saved tensors and adjoints are f32 in the tile format [point tile][feature tile][32 features][32 points] the contraction reads.
+#include "mlp_prims_x3.h"
+#include "vqnerf_hip.h"
+
+using namespace eng;
+
+namespace {
+
+constexpr int E0 = 0;
+constexpr int E_ROWS = 12;
+constexpr int X0 = E_ROWS;
+constexpr int RING = 2;
+constexpr int NW = 8;
+constexpr int RT_MAX_L = 8;
+constexpr int RT_MAX_H = 3;
+constexpr int MAX_CALLS = RT_MAX_L + 2 * RT_MAX_H;
+
+struct ReflDesc {
+  int n_enc, skip, emb_rows, emb_feats, e_tiles, max_tiles, n_heads, z_tiles;
+  int z_feats, rsv[7];
+  int te[RT_MAX_L], act[RT_MAX_L], offW[RT_MAX_L], offBias[RT_MAX_L], offWb[RT_MAX_L];
+  int t0[RT_MAX_H], t1[RT_MAX_H], c[RT_MAX_H], offW0[RT_MAX_H], offW1[RT_MAX_H], offB0[RT_MAX_H], offB1[RT_MAX_H], offW2y[RT_MAX_H],
+      offW2z[RT_MAX_H], offB2[RT_MAX_H], offW1b[RT_MAX_H], offW0b[RT_MAX_H], offA2y[RT_MAX_H], offA2z[RT_MAX_H];
+};
+constexpr int RT_DESC_INTS = 16 + 5 * RT_MAX_L + 14 * RT_MAX_H;
+static_assert(sizeof(ReflDesc) == RT_DESC_INTS * 4, "descriptor layout");
+
+struct ReflFwdPtrs {
+  const float* X; const float* ZR;          // points [N, 3] (n_enc > 0) | input rows [N, z_feats] (n_enc = 0)
+  float* E; float* Y[RT_MAX_L];             // saved: encoding, every encoder layer's output (the last one is z)
+  float* ZT;                                // z in the tile format: Y[n_enc - 1] with an encoder, else the copy this kernel writes
+  float* ZROWS;                             // z as rows [N, z_feats] (with an encoder; may be NULL)
+  float* H0[RT_MAX_H]; float* H1[RT_MAX_H]; float* OUT[RT_MAX_H];
+};
+
+struct ReflBwdPtrs {
+  const float* G_OUT[RT_MAX_H]; const float* OUT[RT_MAX_H]; const float* H0[RT_MAX_H]; const float* H1[RT_MAX_H];
+  float* D2[RT_MAX_H]; float* D1[RT_MAX_H]; float* D0[RT_MAX_H];
+  const float* G_Z;                         // rows [N, z_feats]: adjoint of z from outside the heads (may be NULL)
+  float* GZ_ROWS;                           // n_enc = 0: d / d input rows [N, z_feats]
+  const float* Y[RT_MAX_L]; float* D[RT_MAX_L];
+};
+
+struct SmallsR {
+  float pts[2][96], part[2][4 * 32 * 3], h2z[RT_MAX_H][2][96], d2[2][96];
+  int tab[MAX_CALLS * 4];                   // GEMM calls of one tile pair in program order: {float4 offset, K blocks, out tiles, 0}
+  int n_calls;
+};
+
+// accumulator tile <-> tile format: register i of lane (p, h) is feature (i & 3) + 8 (i >> 2) + 4 h of the feature tile
+__device__ __forceinline__ void tf_store_acc(float* __restrict__ T, const long ptile, const int n_ft, const int ot, const int lane, const float (&v)[16]) {
+  float* base = T + ((ptile * n_ft + ot) * 32 + 4 * (lane >> 5)) * 32 + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) __builtin_nontemporal_store(v[i], base + ((i & 3) + 8 * (i >> 2)) * 32);
+}
+__device__ __forceinline__ void tf_load_acc(const float* __restrict__ T, const long ptile, const int n_ft, const int ot, const int lane, float (&v)[16]) {
+  const float* base = T + ((ptile * n_ft + ot) * 32 + 4 * (lane >> 5)) * 32 + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = base[((i & 3) + 8 * (i >> 2)) * 32];
+}
+// a K step of an image: slot jj of lane (p, h) is feature 16 sl + 8 (jj >> 2) + 4 h + (jj & 3)
+__device__ __forceinline__ void tf_store_step(float* __restrict__ T, const long ptile, const int n_ft, const int sl, const int lane, const float (&x)[8]) {
+  float* base = T + ((ptile * n_ft + (sl >> 1)) * 32 + 16 * (sl & 1) + 4 * (lane >> 5)) * 32 + (lane & 31);
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) __builtin_nontemporal_store(x[jj], base + (8 * (jj >> 2) + (jj & 3)) * 32);
+}
+
+__device__ __forceinline__ void act_apply(const int act, const f32x16& acc, float (&v)[16]) {
+  if (act == ACT_RELU) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc[i], 0.f);
+  } else if (act == ACT_SIGMOID) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = act_fwd<ACT_SIGMOID>(acc[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = acc[i];
+  }
+}
+// v *= act'(y) with the derivative taken from the layer's OUTPUT y
+__device__ __forceinline__ void dact_mul(const int act, const float (&y)[16], float (&v)[16]) {
+  if (act == ACT_RELU) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = y[i] > 0.f ? v[i] : 0.f;
+  } else if (act == ACT_SIGMOID) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] *= y[i] * (1.f - y[i]);
+  }
+}
+
+// shared pieces of the two kernels --------------------------------------------------------------------------------------------
+#define REFL_PROLOGUE()                                                                                      \
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];                                                \
+  const int MT = rd.max_tiles;                                                                               \
+  const int IMG = E_ROWS + 6 * MT, IS = IMG * 64;                                                            \
+  SmallsR* sm = reinterpret_cast<SmallsR*>(lds + (size_t)2 * IS);                                            \
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;                                \
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                 \
+  const int img = wave >> 2, w4 = wave & 3;                                                                  \
+  f32x4* ldsi = lds + (size_t)img * IS;                                                                      \
+  const long n_tiles = (P + 31) >> 5, n_pairs = (n_tiles + 1) >> 1;                                          \
+  auto blocks_of = [](int krows) { return (krows / 3 + 1) >> 1; };                                           \
+  (void)ldsi; (void)h; (void)p; (void)blocks_of;
+
+// the wave's first tile of the next GEMM call (after `idx`, wrapping into the next tile pair) in which it owns one
+#define REFL_STREAM()                                                                                        \
+  const int n_calls = __builtin_amdgcn_readfirstlane(sm->n_calls);                                           \
+  auto next_stream = [&](int idx, const f32x4*& nwp, int& nnb) {                                             \
+    nwp = wx + lane; nnb = 1;                                                                                \
+    for (int k = 1; k <= n_calls; ++k) {                                                                     \
+      const int m = (idx + k) % n_calls;                                                                     \
+      const int tiles = __builtin_amdgcn_readfirstlane(sm->tab[4 * m + 2]);                                  \
+      const int mine = tiles <= 4 ? w4 : wave;                                                               \
+      if (mine < tiles) {                                                                                    \
+        const int off = __builtin_amdgcn_readfirstlane(sm->tab[4 * m]);                                      \
+        nnb = __builtin_amdgcn_readfirstlane(sm->tab[4 * m + 1]);                                            \
+        nwp = wx + off + (size_t)mine * nnb * 384 + lane;                                                    \
+        return;                                                                                              \
+      }                                                                                                      \
+    }                                                                                                        \
+  };                                                                                                         \
+  f32x4 ring[RING][6];                                                                                       \
+  {                                                                                                          \
+    const f32x4* wp0; int nb0;                                                                               \
+    next_stream(n_calls - 1, wp0, nb0);                                                                      \
+    ring_prime_x3<RING>(ring, wp0, nb0);                                                                     \
+  }                                                                                                          \
+  int call = 0;                                                                                              \
+  /* init(ot, im, slot, acc) / epi(ot, im, slot, acc) once per (tile, image) the wave owns; `slot` (a compile-time constant    \
+     after inlining: 0 in the split form, the image in the two-image form) indexes the per-image REGISTER arrays (o, au) -- a      \
+     run-time index would send them to scratch */                                                                               \
+  auto G = [&](const int off, const KSegs ks, const int tiles, auto init, auto epi) {                        \
+    const f32x4* nwp; int nnb;                                                                               \
+    next_stream(call, nwp, nnb);                                                                             \
+    ++call;                                                                                                  \
+    if (tiles <= 4) {                                                                                        \
+      if (w4 < tiles)                                                                                        \
+        gemm_tile_x3_ring1<RING>(ldsi, ks, wx + off, w4, lane, ring, nwp, nnb,                               \
+                                 [&](f32x16& acc) { init(w4, img, 0, acc); }, [&](const f32x16& acc) { epi(w4, img, 0, acc); }); \
+    } else {                                                                                                 \
+      gemm_tiles_x3_ring2<NW, RING, 1>(lds, IS, ks, wx + off, tiles, wave, lane, ring, nwp, nnb,             \
+                                       [&](int ot, int im, f32x16& acc) { if (im == 0) init(ot, 0, 0, acc); else init(ot, 1, 1, acc); },        \
+                                       [&](int ot, int im, const f32x16& acc) { if (im == 0) epi(ot, 0, 0, acc); else epi(ot, 1, 1, acc); });   \
+    }                                                                                                        \
+  };                                                                                                         \
+  f32x4 o[2][6];                                                                                             \
+  /* finished tiles (in `o`) over the layer's own input once every wave is out of its K loop */              \
+  auto commit = [&](const int tiles) {                                                                       \
+    __syncthreads();                                                                                         \
+    if (tiles <= 4) {                                                                                        \
+      if (w4 < tiles) store_frags_x3(ldsi, X0 + 6 * w4, lane, o[0]);                                         \
+    } else if (wave < tiles) {                                                                               \
+      store_frags_x3(lds, X0 + 6 * wave, lane, o[0]);                                                        \
+      store_frags_x3(lds + IS, X0 + 6 * wave, lane, o[1]);                                                   \
+    }                                                                                                        \
+    __syncthreads();                                                                                         \
+  };                                                                                                         \
+  /* fn(ot, im, slot) for every (tile, image) this wave owns in a `tiles`-tile tensor (the GEMMs' ownership) */ \
+  auto owned = [&](const int tiles, auto fn) {                                                               \
+    if (tiles <= 4) { if (w4 < tiles) fn(w4, img, 0); }                                                      \
+    else if (wave < tiles) { fn(wave, 0, 0); fn(wave, 1, 1); }                                               \
+  };
+
+// ================================================================ forward ================================================================
+__global__ __launch_bounds__(512, 1) void refl_train_fwd_x3_kernel(const ReflDesc rd, const f32x4* __restrict__ wx, const f32x4* __restrict__ wf,
+                                                                   const ReflFwdPtrs tp, const long P) {
+  REFL_PROLOGUE();
+  const int nE = rd.n_enc, nH = rd.n_heads, ZT = rd.z_tiles;
+  if (tid == 0) {
+    int n = 0;
+    auto add = [&](int off, int krows, int tiles) { sm->tab[4 * n] = off; sm->tab[4 * n + 1] = blocks_of(krows); sm->tab[4 * n + 2] = tiles; sm->tab[4 * n + 3] = 0; ++n; };
+    for (int l = 0; l < nE; ++l) add(rd.offW[l], l == 0 ? rd.emb_rows : 6 * rd.te[l - 1] + (l == rd.skip ? rd.emb_rows : 0), rd.te[l]);
+    for (int k = 0; k < nH; ++k) { add(rd.offW0[k], 6 * ZT, rd.t0[k]); add(rd.offW1[k], 6 * rd.t0[k], rd.t1[k]); }
+    sm->n_calls = n;
+  }
+  __syncthreads();
+  REFL_STREAM();
+
+  for (long pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+    call = 0;
+    const long ptile_w = 2 * pair + img;
+    const bool live_w = ptile_w < n_tiles;
+    if (nE > 0) {
+      // ---------------- points -> positional encoding -> E rows ----------------
+      if (tid < 64) {
+        const int im = tid >> 5, t = tid & 31;
+        long pt = ((2 * pair + im) << 5) + t;
+        if (pt >= P) pt = P - 1;
+        sm->pts[im][t * 3 + 0] = tp.X[pt * 3 + 0]; sm->pts[im][t * 3 + 1] = tp.X[pt * 3 + 1]; sm->pts[im][t * 3 + 2] = tp.X[pt * 3 + 2];
+      }
+      __syncthreads();
+      const float xs = sm->pts[img][p * 3 + 0], ys = sm->pts[img][p * 3 + 1], zs = sm->pts[img][p * 3 + 2];
+      for (int sl = w4; sl < 2 * rd.e_tiles; sl += 4) {
+        float x[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const int f = step_feat(sl, h, jj);
+          x[jj] = (sl < rd.emb_rows / 3 && f < rd.emb_feats) ? posenc_feat(f, xs, ys, zs) : 0.f;
+        }
+        if (live_w) tf_store_step(tp.E, ptile_w, rd.e_tiles, sl, lane, x);
+        if (sl < rd.emb_rows / 3) {
+          f32x4 q0, q1, q2;
+          split3x8(x, q0, q1, q2);
+          ldsi[(E0 + 3 * sl) * 64 + lane] = q0; ldsi[(E0 + 3 * sl + 1) * 64 + lane] = q1; ldsi[(E0 + 3 * sl + 2) * 64 + lane] = q2;
+        }
+      }
+      __syncthreads();
+      // ---------------- encoder layers (in place) ----------------
+      for (int l = 0; l < nE; ++l) {
+        const KSegs ks = (l == 0) ? KSegs{E0, rd.emb_rows, 0, 0} : KSegs{X0, 6 * rd.te[l - 1], E0, (l == rd.skip) ? rd.emb_rows : 0};
+        const int n_ot = rd.te[l], act = rd.act[l];
+        const f32x4* bp = wf + rd.offBias[l];
+        float* const t_y = tp.Y[l];
+        const bool top = l == nE - 1;
+        G(rd.offW[l], ks, n_ot,
+          [&](int ot, int, int, f32x16& acc) { init_bias_f16s(bp, ot, lane, acc); },
+          [&](int ot, int im, int sl_, const f32x16& acc) {
+            float v[16];
+            act_apply(act, acc, v);
+            const long ptile = 2 * pair + im;
+            if (ptile < n_tiles) {
+              tf_store_acc(t_y, ptile, n_ot, ot, lane, v);
+              if (top && tp.ZROWS != nullptr) {
+                const long pt = (ptile << 5) + p;
+                if (pt < P) {
+                  float* row = tp.ZROWS + pt * (long)rd.z_feats + 32 * ot + 4 * h;
+#pragma unroll
+                  for (int q = 0; q < 4; ++q)
+                    if (32 * ot + 8 * q + 4 * h < rd.z_feats)
+                      *reinterpret_cast<f32x4*>(row + 8 * q) = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                }
+              }
+            }
+            split_tile_x3(v, o[sl_]);
+          });
+        commit(n_ot);
+      }
+    } else {
+      // ---------------- input rows -> X (piece triples) + their tile-format copy ----------------
+      const long pt = (ptile_w << 5) + p;
+      const bool valid = pt < P;
+      const float* row = tp.ZR + (valid ? pt : P - 1) * (long)rd.z_feats;
+      for (int sl = w4; sl < 2 * ZT; sl += 4) {
+        float x[8];
+        const int f0 = 16 * sl + 4 * h;
+        const f32x4 a = (f0 < rd.z_feats) ? *reinterpret_cast<const f32x4*>(row + f0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 b = (f0 + 8 < rd.z_feats) ? *reinterpret_cast<const f32x4*>(row + f0 + 8) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
+        if (!valid) {
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) x[jj] = 0.f;
+        }
+        if (live_w) tf_store_step(tp.ZT, ptile_w, ZT, sl, lane, x);
+        f32x4 q0, q1, q2;
+        split3x8(x, q0, q1, q2);
+        ldsi[(X0 + 3 * sl) * 64 + lane] = q0; ldsi[(X0 + 3 * sl + 1) * 64 + lane] = q1; ldsi[(X0 + 3 * sl + 2) * 64 + lane] = q2;
+      }
+      __syncthreads();
+    }
+
+    // ---------------- heads ----------------
+    // the z share of every head's last layer while z is in the buffer: part -> h2z[k][img][p * 3 + c]
+    for (int k = 0; k < nH; ++k) {
+      if (rd.c[k] == 1) rowdot_x3<1>(ldsi, X0, 6 * ZT, wf + rd.offW2z[k], sm->part[img], w4, lane);
+      else rowdot_x3<3>(ldsi, X0, 6 * ZT, wf + rd.offW2z[k], sm->part[img], w4, lane);
+      __syncthreads();
+      const int nc = rd.c[k] == 1 ? 1 : 3;
+      if (tid < 64 * nc) {
+        const int im = tid / (32 * nc), r = tid - 32 * nc * im, pp = r % 32, c = r / 32;
+        const float* pr = sm->part[im];
+        sm->h2z[k][im][pp * 3 + c] = (pr[(0 * 32 + pp) * nc + c] + pr[(1 * 32 + pp) * nc + c]) + (pr[(2 * 32 + pp) * nc + c] + pr[(3 * 32 + pp) * nc + c]);
+      }
+      __syncthreads();
+    }
+    for (int k = 0; k < nH; ++k) {
+      if (k > 0) {                                       // z back into the buffer (the previous head ran over it)
+        owned(ZT, [&](int ot, int im, int sl_) {
+          float v[16];
+          const long ptile = 2 * pair + im;
+          if (ptile < n_tiles) tf_load_acc(tp.ZT, ptile, ZT, ot, lane, v);
+          else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = 0.f;
+          }
+          store_tile_x3(lds + (size_t)im * IS, X0 + 6 * ot, lane, v);
+        });
+        __syncthreads();
+      }
+      {
+        const int n_ot = rd.t0[k];
+        const f32x4* bp = wf + rd.offB0[k];
+        float* const t_y = tp.H0[k];
+        G(rd.offW0[k], KSegs{X0, 6 * ZT, 0, 0}, n_ot,
+          [&](int ot, int, int, f32x16& acc) { init_bias_f16s(bp, ot, lane, acc); },
+          [&](int ot, int im, int sl_, const f32x16& acc) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc[i], 0.f);
+            if (2 * pair + im < n_tiles) tf_store_acc(t_y, 2 * pair + im, n_ot, ot, lane, v);
+            split_tile_x3(v, o[sl_]);
+          });
+        commit(n_ot);
+      }
+      {
+        const int n_ot = rd.t1[k];
+        const f32x4* bp = wf + rd.offB1[k];
+        float* const t_y = tp.H1[k];
+        G(rd.offW1[k], KSegs{X0, 6 * rd.t0[k], 0, 0}, n_ot,
+          [&](int ot, int, int, f32x16& acc) { init_bias_f16s(bp, ot, lane, acc); },
+          [&](int ot, int im, int sl_, const f32x16& acc) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc[i], 0.f);
+            if (2 * pair + im < n_tiles) tf_store_acc(t_y, 2 * pair + im, n_ot, ot, lane, v);
+            split_tile_x3(v, o[sl_]);
+          });
+        commit(n_ot);
+      }
+      // last layer: row dots over y1, + the z share, + bias -> sigmoid
+      if (rd.c[k] == 1) rowdot_x3<1>(ldsi, X0, 6 * rd.t1[k], wf + rd.offW2y[k], sm->part[img], w4, lane);
+      else rowdot_x3<3>(ldsi, X0, 6 * rd.t1[k], wf + rd.offW2y[k], sm->part[img], w4, lane);
+      __syncthreads();
+      {
+        const int nc = rd.c[k] == 1 ? 1 : 3, cc = rd.c[k];
+        if (tid < 64 * nc) {
+          const int im = tid / (32 * nc), r = tid - 32 * nc * im, pp = r % 32, c = r / 32;
+          const float* pr = sm->part[im];
+          const float s = ((pr[(0 * 32 + pp) * nc + c] + pr[(1 * 32 + pp) * nc + c]) + (pr[(2 * 32 + pp) * nc + c] + pr[(3 * 32 + pp) * nc + c]))
+                          + sm->h2z[k][im][pp * 3 + c] + wf[rd.offB2[k]][c];
+          const long pt = ((2 * pair + im) << 5) + pp;
+          if (pt < P && c < cc) tp.OUT[k][pt * cc + c] = act_fwd<ACT_SIGMOID>(s);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ================================================================ backward ================================================================
+__global__ __launch_bounds__(512, 1) void refl_train_bwd_x3_kernel(const ReflDesc rd, const f32x4* __restrict__ wx, const f32x4* __restrict__ wf,
+                                                                   const ReflBwdPtrs tp, const long P, f32x4* __restrict__ scratch) {
+  REFL_PROLOGUE();
+  const int nE = rd.n_enc, nH = rd.n_heads, ZT = rd.z_tiles;
+  const size_t per_img = (size_t)4 * ZT * 64;                    // the d / d z accumulator between heads (accumulator-order quads)
+  f32x4* save0 = scratch + (size_t)blockIdx.x * 2 * per_img;
+  if (tid == 0) {
+    int n = 0;
+    auto add = [&](int off, int krows, int tiles) { sm->tab[4 * n] = off; sm->tab[4 * n + 1] = blocks_of(krows); sm->tab[4 * n + 2] = tiles; sm->tab[4 * n + 3] = 0; ++n; };
+    for (int k = 0; k < nH; ++k) { add(rd.offW1b[k], 6 * rd.t1[k], rd.t0[k]); add(rd.offW0b[k], 6 * rd.t0[k], ZT); }
+    for (int l = nE - 1; l >= 1; --l) add(rd.offWb[l], 6 * rd.te[l], rd.te[l - 1]);
+    sm->n_calls = n;
+  }
+  __syncthreads();
+  REFL_STREAM();
+  float au[2][16];
+
+  for (long pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+    call = 0;
+    // top of the stack, what happens to a finished d / d z tile: d_top = (gz [+ G_Z rows]) act'(z) -> the encoder backward (with an
+    // encoder), or d / d input rows (without)
+    auto top_tile = [&](const int ot, const int im, const int sl_, float (&v)[16]) {
+      const long ptile = 2 * pair + im;
+      const long pt = (ptile << 5) + p;
+      const bool valid = pt < P;
+      if (tp.G_Z != nullptr && valid) {
+        const float* row = tp.G_Z + pt * (long)rd.z_feats + 32 * ot + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (32 * ot + 8 * q + 4 * h < rd.z_feats) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(row + 8 * q);
+            v[4 * q] += g[0]; v[4 * q + 1] += g[1]; v[4 * q + 2] += g[2]; v[4 * q + 3] += g[3];
+          }
+      }
+      if (!valid) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = 0.f;
+      }
+      if (nE > 0) {
+        if (ptile < n_tiles) {
+          float y[16];
+          tf_load_acc(tp.Y[nE - 1], ptile, ZT, ot, lane, y);
+          dact_mul(rd.act[nE - 1], y, v);
+          tf_store_acc(tp.D[nE - 1], ptile, ZT, ot, lane, v);
+        }
+        split_tile_x3(v, o[sl_]);
+      } else if (valid) {
+        float* row = tp.GZ_ROWS + pt * (long)rd.z_feats + 32 * ot + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (32 * ot + 8 * q + 4 * h < rd.z_feats)
+            *reinterpret_cast<f32x4*>(row + 8 * q) = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+      }
+    };
+
+    for (int k = 0; k < nH; ++k) {
+      const int cc = rd.c[k], T0 = rd.t0[k], T1 = rd.t1[k];
+      // ---------------- delta_2 = g_out out (1 - out)  [c values per point] ----------------
+      if (tid < 64) {
+        const int im = tid >> 5, t = tid & 31;
+        const long ptile = 2 * pair + im, pt = (ptile << 5) + t;
+        float d[3] = {0.f, 0.f, 0.f};
+        if (pt < P)
+          for (int c = 0; c < cc; ++c) {
+            const float y = tp.OUT[k][pt * cc + c];
+            d[c] = tp.G_OUT[k][pt * cc + c] * y * (1.f - y);
+          }
+        sm->d2[im][t * 3 + 0] = d[0]; sm->d2[im][t * 3 + 1] = d[1]; sm->d2[im][t * 3 + 2] = d[2];
+        if (ptile < n_tiles) {
+          float* base = tp.D2[k] + ptile * 1024 + t;
+          for (int f = 0; f < 32; ++f) base[f * 32] = f < cc ? d[f < 3 ? f : 0] : 0.f;
+        }
+      }
+      __syncthreads();
+      const float dd0 = sm->d2[0][p * 3 + 0], dd1 = sm->d2[0][p * 3 + 1], dd2 = sm->d2[0][p * 3 + 2];
+      const float de0 = sm->d2[1][p * 3 + 0], de1 = sm->d2[1][p * 3 + 1], de2 = sm->d2[1][p * 3 + 2];
+      // acc += sum_c img_c[tile] d2[im][c]  (the last layer's transpose as rank-c updates on the vector ALU)
+      auto rank_c = [&](const f32x4* imgs, const int tiles, const int ot, const int im, f32x16& acc) {
+        for (int c = 0; c < cc; ++c) {
+          f32x16 wv;
+          init_bias_f16s(imgs + (size_t)c * tiles * 8, ot, lane, wv);
+          const float d = im == 0 ? (c == 0 ? dd0 : (c == 1 ? dd1 : dd2)) : (c == 0 ? de0 : (c == 1 ? de1 : de2));
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[i] = fmaf(wv[i], d, acc[i]);
+        }
+      };
+      // ---------------- delta_1 = (W2[:w1] delta_2) relu'(y1) -> X ----------------
+      owned(T1, [&](int ot, int im, int sl_) {
+        f32x16 acc;
+        init_zero(acc);
+        rank_c(wf + rd.offA2y[k], T1, ot, im, acc);
+        float v[16], y[16];
+        const long ptile = 2 * pair + im;
+        if (ptile < n_tiles) tf_load_acc(tp.H1[k], ptile, T1, ot, lane, y);
+        else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) y[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = y[i] > 0.f ? acc[i] : 0.f;
+        if (ptile < n_tiles) tf_store_acc(tp.D1[k], ptile, T1, ot, lane, v);
+        split_tile_x3(v, o[sl_]);
+      });
+      commit(T1);
+      // ---------------- delta_0 = (W1 delta_1) relu'(y0) ----------------
+      {
+        const float* const t_y = tp.H0[k];
+        float* const t_d = tp.D0[k];
+        G(rd.offW1b[k], KSegs{X0, 6 * T1, 0, 0}, T0,
+          [&](int ot, int im, int sl_, f32x16& acc) {
+            if (2 * pair + im < n_tiles) tf_load_acc(t_y, 2 * pair + im, T0, ot, lane, au[sl_]);
+            else {
+#pragma unroll
+              for (int i = 0; i < 16; ++i) au[sl_][i] = 0.f;
+            }
+            init_zero(acc);
+          },
+          [&](int ot, int im, int sl_, const f32x16& acc) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = au[sl_][i] > 0.f ? acc[i] : 0.f;
+            if (2 * pair + im < n_tiles) tf_store_acc(t_d, 2 * pair + im, T0, ot, lane, v);
+            split_tile_x3(v, o[sl_]);
+          });
+        commit(T0);
+      }
+      // ---------------- d / d z += W0 delta_0 + W2[w1:] delta_2 ----------------
+      {
+        const bool first = k == 0, last = k == nH - 1;
+        G(rd.offW0b[k], KSegs{X0, 6 * T0, 0, 0}, ZT,
+          [&](int ot, int im, int sl_, f32x16& acc) {
+            if (first) init_zero(acc);
+            else {
+              const f32x4* sv = save0 + (size_t)im * per_img;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f32x4 t = ld_stream(sv + (ot * 4 + q) * 64 + lane);
+                acc[4 * q] = t[0]; acc[4 * q + 1] = t[1]; acc[4 * q + 2] = t[2]; acc[4 * q + 3] = t[3];
+              }
+            }
+            rank_c(wf + rd.offA2z[k], ZT, ot, im, acc);
+          },
+          [&](int ot, int im, int sl_, const f32x16& acc) {
+            if (!last) {
+              f32x4* sv = save0 + (size_t)im * per_img;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) st_stream(sv + (ot * 4 + q) * 64 + lane, (f32x4){acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
+            } else {
+              float v[16];
+#pragma unroll
+              for (int i = 0; i < 16; ++i) v[i] = acc[i];
+              top_tile(ot, im, sl_, v);
+            }
+          });
+        if (last && nE > 0) commit(ZT);
+        else __syncthreads();                                  // (the next head's delta_1 goes over this GEMM's input)
+      }
+    }
+    if (nH == 0 && nE > 0) {                                   // an encoder alone: d_top from the incoming rows
+      owned(ZT, [&](int ot, int im, int sl_) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = 0.f;
+        top_tile(ot, im, sl_, v);
+      });
+      commit(ZT);
+    }
+    // ---------------- encoder layers, top down: delta_{l-1} = (W_l[y part] delta_l) act'_{l-1}(y_{l-1}) ----------------
+    for (int l = nE - 1; l >= 1; --l) {
+      const int n_ot = rd.te[l - 1], act = rd.act[l - 1];
+      const float* const t_y = tp.Y[l - 1];
+      float* const t_d = tp.D[l - 1];
+      G(rd.offWb[l], KSegs{X0, 6 * rd.te[l], 0, 0}, n_ot,
+        [&](int ot, int im, int sl_, f32x16& acc) {
+          if (2 * pair + im < n_tiles) tf_load_acc(t_y, 2 * pair + im, n_ot, ot, lane, au[sl_]);
+          else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) au[sl_][i] = 0.f;
+          }
+          init_zero(acc);
+        },
+        [&](int ot, int im, int sl_, const f32x16& acc) {
+          float v[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] = acc[i];
+          dact_mul(act, au[sl_], v);
+          if (2 * pair + im < n_tiles) tf_store_acc(t_d, 2 * pair + im, n_ot, ot, lane, v);
+          split_tile_x3(v, o[sl_]);
+        });
+      commit(n_ot);
+    }
+  }
+}
+
+size_t lds_bytes_r(int MT) { return (size_t)2 * (E_ROWS + 6 * MT) * 1024 + sizeof(SmallsR); }
+
+int load_desc_r(const int32_t* desc, ReflDesc& rd) {
+  memcpy(&rd, desc, sizeof(ReflDesc));
+  if (rd.n_enc < 0 || rd.n_enc > RT_MAX_L || rd.n_heads < 0 || rd.n_heads > RT_MAX_H || (rd.n_enc == 0 && rd.n_heads == 0)) return 1;
+  if (rd.max_tiles < 1 || rd.max_tiles > NW || lds_bytes_r(rd.max_tiles) > 160 * 1024) return 2;
+  if (rd.z_tiles < 1 || rd.z_tiles > rd.max_tiles || rd.z_feats < 1 || rd.z_feats > 32 * rd.z_tiles || (rd.z_feats & 3)) return 3;
+  if (rd.n_enc > 0) {
+    if (rd.emb_feats < 3 || rd.emb_feats > 64 || rd.emb_rows != x3_rows(rd.emb_feats) || rd.emb_rows > E_ROWS || rd.e_tiles < 1 || rd.e_tiles > 2 ||
+        2 * rd.e_tiles * 3 < rd.emb_rows) return 4;
+    if (rd.skip < 0 || rd.skip >= rd.n_enc) return 5;
+    for (int l = 0; l < rd.n_enc; ++l)
+      if (rd.te[l] < 1 || rd.te[l] > rd.max_tiles || rd.act[l] < 0 || rd.act[l] > 3 || rd.act[l] == ACT_SOFTPLUS100) return 6;
+    if (rd.te[rd.n_enc - 1] != rd.z_tiles) return 7;
+  }
+  for (int k = 0; k < rd.n_heads; ++k)
+    if (rd.t0[k] < 1 || rd.t0[k] > rd.max_tiles || rd.t1[k] < 1 || rd.t1[k] > rd.max_tiles || rd.c[k] < 1 || rd.c[k] > 3) return 8;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int vqn_refl_train_desc_ints(void) { return RT_DESC_INTS; }
+
+extern "C" int vqn_refl_train_fwd_x3(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, const float* pts, const float* z_rows,
+                                     int64_t P, float* const* saved, int n_saved, float* z_rows_out, float* const* head_out, void* stream) {
+  VQN_CHECK_ARG(desc && wbuf_pieces && wbuf_f32 && saved, "null pointer");
+  VQN_CHECK_ARG(P >= 1, "P >= 1");
+  ReflDesc rd;
+  VQN_CHECK_SHAPE(load_desc_r(desc, rd) == 0, "invalid reflectance stack descriptor (layers of at most 256 outputs, at most 8 encoder layers, 3 heads)");
+  const int nE = rd.n_enc, nH = rd.n_heads;
+  VQN_CHECK_ARG((nE > 0) ? (pts != nullptr) : (z_rows != nullptr), "pts with an encoder, z_rows without");
+  // saved: with an encoder [E, Y_0..Y_{nE-1}], without [ZT]; then per head [H0, H1]
+  VQN_CHECK_ARG(n_saved == (nE > 0 ? 1 + nE : 1) + 2 * nH, "saved: [E, Y_0..] | [ZT], then [H0_k, H1_k] per head");
+  VQN_CHECK_ARG(nH == 0 || head_out != nullptr, "head_out");
+  for (int i = 0; i < n_saved; ++i) VQN_CHECK_ARG(saved[i] != nullptr, "null saved tensor");
+  ReflFwdPtrs tp;
+  memset(&tp, 0, sizeof(tp));
+  tp.X = pts; tp.ZR = z_rows; tp.ZROWS = z_rows_out;
+  int s = 0;
+  if (nE > 0) {
+    tp.E = saved[s++];
+    for (int l = 0; l < nE; ++l) tp.Y[l] = saved[s++];
+    tp.ZT = tp.Y[nE - 1];
+  } else tp.ZT = saved[s++];
+  for (int k = 0; k < nH; ++k) {
+    tp.H0[k] = saved[s++]; tp.H1[k] = saved[s++];
+    VQN_CHECK_ARG(head_out[k] != nullptr, "null head output");
+    tp.OUT[k] = head_out[k];
+  }
+  const long n_tiles = (P + 31) / 32;
+  const size_t lds = lds_bytes_r(rd.max_tiles);
+  VQN_HIP(hipFuncSetAttribute((const void*)refl_train_fwd_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  long grid = (long)vqn_num_cus();
+  if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;
+  hipLaunchKernelGGL(refl_train_fwd_x3_kernel, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, rd, reinterpret_cast<const f32x4*>(wbuf_pieces),
+                     reinterpret_cast<const f32x4*>(wbuf_f32), tp, (long)P);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
+
+extern "C" int64_t vqn_refl_train_bwd_x3_scratch_bytes(const int32_t* desc) {
+  if (!desc) return -1;
+  ReflDesc rd;
+  if (load_desc_r(desc, rd) != 0) return -1;
+  return (int64_t)vqn_num_cus() * 2 * 4 * rd.z_tiles * 1024;
+}
+
+extern "C" int vqn_refl_train_bwd_x3(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, int64_t P, const float* const* g_out,
+                                     const float* const* head_out, const float* g_z_rows, const float* const* saved, int n_saved,
+                                     float* const* outs, int n_outs, float* gz_rows_out, void* scratch, int64_t scratch_bytes, void* stream) {
+  VQN_CHECK_ARG(desc && wbuf_pieces && wbuf_f32 && saved && outs && scratch, "null pointer");
+  VQN_CHECK_ARG(P >= 1, "P >= 1");
+  ReflDesc rd;
+  VQN_CHECK_SHAPE(load_desc_r(desc, rd) == 0, "invalid reflectance stack descriptor (layers of at most 256 outputs, at most 8 encoder layers, 3 heads)");
+  const int nE = rd.n_enc, nH = rd.n_heads;
+  // saved: [Y_0..Y_{nE-1}], then per head [H0, H1]; outs: [D_0..D_{nE-1}], then per head [D0, D1, D2]
+  VQN_CHECK_ARG(n_saved == nE + 2 * nH, "saved: [Y_0..Y_{nE-1}], then [H0_k, H1_k] per head");
+  VQN_CHECK_ARG(n_outs == nE + 3 * nH, "outs: [D_0..D_{nE-1}], then [D0_k, D1_k, D2_k] per head");
+  VQN_CHECK_ARG(nH == 0 || (g_out && head_out), "g_out / head_out");
+  VQN_CHECK_ARG(nE > 0 || gz_rows_out != nullptr, "gz_rows_out without an encoder");
+  VQN_CHECK_ARG(nH > 0 || g_z_rows != nullptr, "an encoder alone needs g_z_rows");
+  for (int i = 0; i < n_saved; ++i) VQN_CHECK_ARG(saved[i] != nullptr, "null saved tensor");
+  for (int i = 0; i < n_outs; ++i) VQN_CHECK_ARG(outs[i] != nullptr, "null output tensor");
+  ReflBwdPtrs tp;
+  memset(&tp, 0, sizeof(tp));
+  tp.G_Z = g_z_rows; tp.GZ_ROWS = gz_rows_out;
+  for (int l = 0; l < nE; ++l) { tp.Y[l] = saved[l]; tp.D[l] = outs[l]; }
+  for (int k = 0; k < nH; ++k) {
+    VQN_CHECK_ARG(g_out[k] && head_out[k], "null head adjoint / output");
+    tp.G_OUT[k] = g_out[k]; tp.OUT[k] = head_out[k];
+    tp.H0[k] = saved[nE + 2 * k]; tp.H1[k] = saved[nE + 2 * k + 1];
+    tp.D0[k] = outs[nE + 3 * k]; tp.D1[k] = outs[nE + 3 * k + 1]; tp.D2[k] = outs[nE + 3 * k + 2];
+  }
+  const long n_tiles = (P + 31) / 32;
+  const int64_t per_wg = (int64_t)2 * 4 * rd.z_tiles * 1024;
+  const size_t lds = lds_bytes_r(rd.max_tiles);
+  VQN_HIP(hipFuncSetAttribute((const void*)refl_train_bwd_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  long grid = (long)vqn_num_cus();
+  if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;
+  if ((int64_t)grid * per_wg > scratch_bytes) grid = (long)(scratch_bytes / per_wg);
+  VQN_CHECK_ARG(grid >= 1, "scratch too small (see vqn_refl_train_bwd_x3_scratch_bytes)");
+  hipLaunchKernelGGL(refl_train_bwd_x3_kernel, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, rd, reinterpret_cast<const f32x4*>(wbuf_pieces),
+                     reinterpret_cast<const f32x4*>(wbuf_f32), tp, (long)P, reinterpret_cast<f32x4*>(scratch));
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}

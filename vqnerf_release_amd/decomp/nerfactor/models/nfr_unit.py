@@ -379,6 +379,12 @@ class BrdfModel(ShapeModel):
             z, (d, s_, r) = self._fused_enc_heads(pts, names)
             return (self._numerics(z, 'Z'), self._numerics(self._albedo_affine(d), 'Albedo'), self._numerics(s_, 'Specular'),
                     self._numerics(r, 'Roughness'))
+        eng = self._stack_engine(names, pts, with_encoder=True)
+        if eng is not None:                                   # training: encoder + the three heads, one launch each way (round 4)
+            from vqnerf_release_amd.decomp.refl_train import ReflStackFunction
+            z, d, s_, r = ReflStackFunction.apply(eng, pts, *eng.params())
+            return (self._numerics(z, 'Z'), self._numerics(self._albedo_affine(d), 'Albedo'), self._numerics(s_, 'Specular'),
+                    self._numerics(r, 'Roughness'))
         z = self._pred_bias_at(pts)
         return (z,) + tuple(self._all_heads(z, suffix))
 
@@ -399,6 +405,28 @@ class BrdfModel(ShapeModel):
     # ------------------------------------------------------------------ training engines (tile programs)
     def _train_hip(self, x):
         return self.train_backend == 'hip' and x.is_cuda and getattr(self.embedder['xyz'], 'fused_ok', lambda: False)()
+
+    # 'x3': the dedicated exact-split kernels of csrc/refl_train_x3.hip (decomp/refl_train.py) wherever the stack has their shape;
+    # 'prog': the interpreted tile programs of rounds 1-3 (decomp/train_programs.py).  VQN_REFL_TRAIN overrides.
+    REFL_TRAIN_DEFAULT = 'x3'
+
+    def _stack_engine(self, names, x, with_encoder):
+        """The dedicated training engine for (encoder +) the `names` heads, or None when this call is not a HIP training call or the
+        stack is outside what the kernels run (then the interpreted programs / torch statements take it)."""
+        if not (self._train_hip(x) and not self._fused(x) and os.environ.get('VQN_REFL_TRAIN', self.REFL_TRAIN_DEFAULT) == 'x3'):
+            return None
+        key = ('stack', with_encoder) + tuple(names)
+        if key not in self._engines:
+            from vqnerf_release_amd.decomp.refl_train import ReflStackEngine
+            enc = [self.net['fine_enc'], self.net['bottleneck']] if with_encoder else None
+            heads = [self.net[n] for n in names]
+            emb = self.embedder['xyz']
+            ok = ReflStackEngine.supports(enc, heads, self.z_dim, getattr(emb, 'out_dims', 0) if with_encoder else 0)
+            self._engines[key] = ReflStackEngine(enc, emb.n_freqs if with_encoder else 0, heads, self.z_dim, x.device) if ok else None
+        eng = self._engines[key]
+        if eng is None or (not with_encoder and x.shape[1] != self.z_dim):
+            return None
+        return eng if any(p.requires_grad for p in eng.params()) or x.requires_grad else None
 
     def _enc_engine(self, device):
         if 'enc' not in self._engines:
@@ -460,6 +488,10 @@ class BrdfModel(ShapeModel):
         names = [h + '_' + suffix for h in self.HEADS]
         if self._fused(z):
             d, s, r = self._fused_heads(z, names)
+        elif self._stack_engine(names, z, with_encoder=False) is not None:
+            from vqnerf_release_amd.decomp.refl_train import ReflStackFunction
+            eng = self._stack_engine(names, z, with_encoder=False)
+            d, s, r = ReflStackFunction.apply(eng, z, *eng.params())
         elif self._train_hip(z):
             from vqnerf_release_amd.decomp.train_programs import HeadsFunction
             nets = [self.net[n] for n in names]

@@ -1,0 +1,268 @@
+"""Training passes of the reflectance Dense stacks on the exact-split engine (csrc/refl_train_x3.hip) -- round 4.
+
+What the reference gets from `tape.gradient` through `_pred_enc_at` and the three `_pred_*_at` heads (vq_nfr.py:771-828, nfr_unit.py:329-391
+over networks/mlp.py:24-50) under train_nfr.py:562-576, as TWO launches per stack and direction instead of interpreted tile programs:
+
+  ReflStackEngine(enc_nets=[fine_enc, bottleneck], heads=[diff, spec, rough])   xyz -> posenc -> ... -> z -> three heads   ("A")
+  ReflStackEngine(enc_nets=None,                   heads=[diff_vq, spec_vq, rough_vq])   z_vq rows -> three heads          ("B")
+
+`forward` leaves every layer's output in the tile format the weight-gradient contraction reads, `backward` every layer's per-point
+adjoint; the contractions are the batched ones of geo/train_programs.py (WgradBatch).  Weights keep the Keras layout (kernel [in, out]).
+Packs: ONE gather + exact three-way split launch (vqn_pack_x3_gather) for all GEMM matrices of both directions and one gather of the
+thin f32 images, from the flat parameter vector; the index arrays and the descriptor do not depend on the weight values (cached).
+Stacks this engine does not cover (layers wider than 256: the stage-3 `ref_nfr` heads) keep decomp/train_programs.py's interpreter."""
+import ctypes
+
+import numpy as np
+import torch
+
+from vqnerf_release_amd import _C
+from vqnerf_release_amd.geo import packing
+from vqnerf_release_amd.geo.train_programs import FlatLayout, WgradBatch, _ident
+
+ACTS = {None: 0, 'relu': 1, 'sigmoid': 3}
+RT_MAX_L, RT_MAX_H = 8, 3
+DESC_INTS = 16 + 5 * RT_MAX_L + 14 * RT_MAX_H
+
+
+def _tl(f):
+    return (f + 31) // 32
+
+
+class ReflStackEngine:
+    n_split = 256
+
+    @staticmethod
+    def supports(enc_nets, heads, z_dim, emb_feats=0):
+        """the shapes csrc/refl_train_x3.hip runs: layers of at most 256 outputs, at most one skip-concat (of the encoding), standard heads"""
+        if z_dim > 256 or z_dim % 4 or len(heads) > RT_MAX_H:
+            return False
+        for net in heads:
+            if not (len(net.widths) == 3 and net.skip_at == [1] and net.act == ['relu', 'relu', 'sigmoid'] and net.widths[0] <= 256
+                    and net.widths[1] <= 256 and 1 <= net.widths[2] <= 3):
+                return False
+        if enc_nets:
+            if not (3 <= emb_feats <= 64):
+                return False
+            n, skips = 0, 0
+            for ni, net in enumerate(enc_nets):
+                for li, (w, a) in enumerate(zip(net.widths, net.act)):
+                    if w > 256 or a not in ACTS:
+                        return False
+                    if net.skip_at is not None and (li - 1) in net.skip_at:
+                        skips += 1
+                        if ni != 0 or n == 0:
+                            return False
+                    n += 1
+            if n > RT_MAX_L or skips > 1 or enc_nets[-1].widths[-1] != z_dim:
+                return False
+        return bool(enc_nets) or bool(heads)
+
+    def __init__(self, enc_nets, n_freqs, heads, z_dim, device):
+        self.device, self.Z, self.heads = device, z_dim, list(heads)
+        self.enc_nets = list(enc_nets) if enc_nets else []
+        self.E = 3 + 6 * n_freqs if self.enc_nets else 0
+        self.layers, d_prev = [], self.E
+        for ni, net in enumerate(self.enc_nets):
+            for li, (w, a) in enumerate(zip(net.widths, net.act)):
+                skip_in = net.skip_at is not None and (li - 1) in net.skip_at
+                self.layers.append(dict(in_y=d_prev, out=w, act=ACTS[a], skip=skip_in))
+                d_prev = w
+        self.nE, self.nH = len(self.layers), len(self.heads)
+        assert self.supports(self.enc_nets, self.heads, z_dim, self.E)
+        self._dev = None
+
+    # ------------------------------------------------------------------ parameters
+    def params(self):
+        """[kernel_0, bias_0, kernel_1, ...] of the encoder layers, then of every head's three layers -- the order of forward()'s `params`"""
+        ps = []
+        for net in self.enc_nets + self.heads:
+            for layer in net.layers:
+                ps += [layer.kernel, layer.bias]
+        return ps
+
+    def layout(self):
+        shp = []
+        for l, L in enumerate(self.layers):
+            shp += [('W%d' % l, (L['in_y'] + (self.E if L['skip'] else 0), L['out'])), ('b%d' % l, (L['out'],))]
+        for k, net in enumerate(self.heads):
+            w0, w1, c = net.widths
+            shp += [('H%d_W0' % k, (self.Z, w0)), ('H%d_b0' % k, (w0,)), ('H%d_W1' % k, (w0, w1)), ('H%d_b1' % k, (w1,)),
+                    ('H%d_W2' % k, (w1 + self.Z, c)), ('H%d_b2' % k, (c,))]
+        return FlatLayout(shp)
+
+    def _static(self):
+        """(layout, int32 gather index of the piece pack, its K-step count, int64 gather index of the f32 images, descriptor)"""
+        if self._dev is not None:
+            return self._dev
+        L = self.layout()
+        chunks, off, fch, foff = [], [0], [], [0]
+
+        def add(view, idx):                                   # -> float4 offset inside the PIECE pack (192 float4 per tile and K step)
+            src = np.append(np.ascontiguousarray(view).reshape(-1), L.zero)
+            c = src[idx.reshape(-1)]
+            o4 = off[0]
+            chunks.append(c)
+            off[0] += (c.size // 512) * 192
+            return o4
+
+        def addf(view, idx):                                  # -> float4 offset inside the f32 image buffer
+            src = np.append(np.ascontiguousarray(view).reshape(-1), L.zero)
+            c = src[idx.reshape(-1)]
+            assert c.size % 4 == 0
+            o4 = foff[0] // 4
+            fch.append(c)
+            foff[0] += c.size
+            return o4
+
+        gx = packing.gemm_index_x3
+        emb_rows = packing.emb_rows_for_x3(self.E) if self.nE else 0
+        d = np.zeros(DESC_INTS, np.int32)
+        skip = 0
+        for l, Ly in enumerate(self.layers):
+            if Ly['skip']:
+                skip = l
+        mt = max([_tl(Ly['out']) for Ly in self.layers] + [_tl(self.Z)] + [_tl(w) for net in self.heads for w in net.widths[:2]])
+        d[0:9] = [self.nE, skip, emb_rows, self.E, _tl(self.E) if self.nE else 0, mt, self.nH, _tl(self.Z), self.Z]
+        o_te, o_act, o_w, o_b, o_wb = 16, 16 + RT_MAX_L, 16 + 2 * RT_MAX_L, 16 + 3 * RT_MAX_L, 16 + 4 * RT_MAX_L
+        for l, Ly in enumerate(self.layers):
+            n_in = Ly['in_y'] + (self.E if Ly['skip'] else 0)
+            if l == 0:
+                segs = [(emb_rows, _ident(self.E))]
+            elif Ly['skip']:
+                segs = [(6 * _tl(Ly['in_y']), _ident(Ly['in_y'])), (emb_rows, _ident(self.E, base=Ly['in_y']))]
+            else:
+                segs = [(6 * _tl(Ly['in_y']), _ident(Ly['in_y']))]
+            d[o_te + l], d[o_act + l] = _tl(Ly['out']), Ly['act']
+            d[o_w + l] = add(L['W%d' % l].T, gx(Ly['out'], n_in, segs))
+            d[o_b + l] = addf(L['b%d' % l], packing.bias_index_f16s(Ly['out']))
+            if l >= 1:                                        # backward: delta_{l-1} = W_l[y part] delta_l  (rows = inputs, K = outputs)
+                d[o_wb + l] = add(L['W%d' % l][:Ly['in_y'], :], gx(Ly['in_y'], Ly['out'], [(6 * _tl(Ly['out']), _ident(Ly['out']))]))
+        oh = 16 + 5 * RT_MAX_L
+        H = lambda field, k: oh + field * RT_MAX_H + k
+        zrows = 6 * _tl(self.Z)
+        for k, net in enumerate(self.heads):
+            w0, w1, c = net.widths
+            nout = 1 if c == 1 else 3
+            W0, W1, W2 = L['H%d_W0' % k], L['H%d_W1' % k], L['H%d_W2' % k]
+            d[H(0, k)], d[H(1, k)], d[H(2, k)] = _tl(w0), _tl(w1), c
+            d[H(3, k)] = add(W0.T, gx(w0, self.Z, [(zrows, _ident(self.Z))]))
+            d[H(4, k)] = add(W1.T, gx(w1, w0, [(6 * _tl(w0), _ident(w0))]))
+            d[H(5, k)] = addf(L['H%d_b0' % k], packing.bias_index_f16s(w0))
+            d[H(6, k)] = addf(L['H%d_b1' % k], packing.bias_index_f16s(w1))
+            pad = lambda m: np.concatenate([m, np.full((nout - c, m.shape[1]), L.zero, m.dtype)], 0) if nout > c else m
+            d[H(7, k)] = addf(pad(W2[:w1].T), packing.rowdot_index_x3(nout, 6 * _tl(w1), w1))
+            d[H(8, k)] = addf(pad(W2[w1:].T), packing.rowdot_index_x3(nout, zrows, self.Z))
+            d[H(9, k)] = addf(L['H%d_b2' % k], np.where(np.arange(4) < c, np.arange(4), c))
+            d[H(10, k)] = add(W1, gx(w0, w1, [(6 * _tl(w1), _ident(w1))]))
+            d[H(11, k)] = add(W0, gx(self.Z, w0, [(6 * _tl(w0), _ident(w0))]))
+            offs = [addf(W2[:w1, j], packing.bias_index_f16s(w1)) for j in range(c)]
+            d[H(12, k)] = offs[0]
+            assert all(o == offs[0] + j * _tl(w1) * 8 for j, o in enumerate(offs))
+            offs = [addf(W2[w1:, j], packing.bias_index_f16s(self.Z)) for j in range(c)]
+            d[H(13, k)] = offs[0]
+        gidx = np.concatenate(chunks)
+        assert gidx.size % 512 == 0 and gidx.max() < 2 ** 31
+        dev = self.device
+        self._dev = (L, torch.from_numpy(gidx.astype(np.int32)).to(dev), gidx.size // 512, torch.from_numpy(np.concatenate(fch)).to(dev), d)
+        return self._dev
+
+    # ------------------------------------------------------------------ passes
+    def _tensor(self, nt, tiles, dev):
+        return torch.empty((nt, tiles, 32, 32), dtype=torch.float32, device=dev)
+
+    def forward(self, x, params):
+        """x: xyz [N, 3] (with an encoder) | z rows [N, Z].  -> state dict (saved tensors, packs), z rows | None, head outputs."""
+        L, gidx, n_steps, fidx, desc = self._static()
+        N, dev = x.shape[0], x.device
+        nt = (N + 31) // 32
+        flat = L.flatten({n: p for n, p in zip(L.names, params)})
+        pieces = _C.pack_x3_gather(flat, gidx, n_steps)
+        wf = flat[fidx]
+        S = {'pieces': pieces, 'wf': wf, 'N': N}
+        saved = []
+        if self.nE:
+            S['E'] = self._tensor(nt, _tl(self.E), dev)
+            S['Y'] = [self._tensor(nt, _tl(Ly['out']), dev) for Ly in self.layers]
+            S['ZT'] = S['Y'][-1]
+            saved = [S['E']] + S['Y']
+            zrows = torch.empty((N, self.Z), dtype=torch.float32, device=dev)
+        else:
+            S['ZT'] = self._tensor(nt, _tl(self.Z), dev)
+            saved = [S['ZT']]
+            zrows = None
+        S['H0'] = [self._tensor(nt, _tl(net.widths[0]), dev) for net in self.heads]
+        S['H1'] = [self._tensor(nt, _tl(net.widths[1]), dev) for net in self.heads]
+        for a, b in zip(S['H0'], S['H1']):
+            saved += [a, b]
+        outs = [torch.empty((N, net.widths[2]), dtype=torch.float32, device=dev) for net in self.heads]
+        S['OUT'] = outs
+        _C.refl_train_fwd_x3(desc, pieces, wf, x if self.nE else None, None if self.nE else x, N, saved, zrows, outs)
+        return S, zrows, outs
+
+    def backward(self, S, g_z, g_outs):
+        """g_z [N, Z] | None: adjoint of z from outside the heads (with an encoder); g_outs: adjoints of the head outputs (None: zeros).
+        -> (d / d input rows | None, [dW, db, dW, db, ...] in params() order, Keras layout)."""
+        L, gidx, n_steps, fidx, desc = self._static()
+        N, dev = S['N'], S['wf'].device
+        nt = (N + 31) // 32
+        g_outs = [torch.zeros_like(o) if g is None else g.detach().float().contiguous() for g, o in zip(g_outs, S['OUT'])]
+        D = [self._tensor(nt, _tl(Ly['out']), dev) for Ly in self.layers]
+        D0 = [self._tensor(nt, _tl(net.widths[0]), dev) for net in self.heads]
+        D1 = [self._tensor(nt, _tl(net.widths[1]), dev) for net in self.heads]
+        D2 = [self._tensor(nt, 1, dev) for net in self.heads]
+        outs = list(D)
+        for a, b, c in zip(D0, D1, D2):
+            outs += [a, b, c]
+        saved = list(S['Y']) if self.nE else []
+        for a, b in zip(S['H0'], S['H1']):
+            saved += [a, b]
+        gz_rows = None if self.nE else torch.empty((N, self.Z), dtype=torch.float32, device=dev)
+        if g_z is not None:
+            g_z = g_z.detach().float().contiguous()
+        elif self.nE and not self.nH:
+            g_z = torch.zeros((N, self.Z), dtype=torch.float32, device=dev)
+        _C.refl_train_bwd_x3(desc, S['pieces'], S['wf'], N, g_outs, S['OUT'], g_z if self.nE else None, saved, outs, gz_rows)
+        # ---- weight gradients: contractions over the points, straight into the Keras layout [in, out] ----
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        batch = WgradBatch(self.n_split)
+        grads = []
+        for l, Ly in enumerate(self.layers):
+            n_in, n_out = Ly['in_y'] + (self.E if Ly['skip'] else 0), Ly['out']
+            G, b = new(n_in, n_out), new(n_out)
+            src = S['E'] if l == 0 else S['Y'][l - 1]
+            batch.contract(D[l], src, n_out, Ly['in_y'], G, 1, n_out, bias_dst=b)
+            if Ly['skip']:
+                batch.contract(D[l], S['E'], n_out, self.E, G[Ly['in_y']:], 1, n_out)
+            grads += [G, b]
+        for k, net in enumerate(self.heads):
+            w0, w1, c = net.widths
+            g0, g1, g2, b0, b1, b2 = new(self.Z, w0), new(w0, w1), new(w1 + self.Z, c), new(w0), new(w1), new(c)
+            batch.contract(D0[k], S['ZT'], w0, self.Z, g0, 1, w0, bias_dst=b0)
+            batch.contract(D1[k], S['H0'][k], w1, w0, g1, 1, w1, bias_dst=b1)
+            batch.contract(D2[k], S['H1'][k], c, w1, g2, 1, c, bias_dst=b2)
+            batch.contract(D2[k], S['ZT'], c, self.Z, g2[w1:], 1, c)
+            grads += [g0, b0, g1, b1, g2, b2]
+        batch.flush()
+        return gz_rows, grads
+
+
+class ReflStackFunction(torch.autograd.Function):
+    """(engine, x, *engine.params()) -> (z rows, head outputs ...) with an encoder, (head outputs ...) without."""
+
+    @staticmethod
+    def forward(ctx, engine, x, *params):
+        with torch.no_grad():
+            S, zrows, outs = engine.forward(x.detach().float().contiguous(), [p.detach().float() for p in params])
+        ctx.engine, ctx.S = engine, S
+        ctx.x_needs = x.requires_grad and not engine.nE
+        return ((zrows,) if engine.nE else ()) + tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        eng = ctx.engine
+        g_z, g_outs = (gs[0], gs[1:]) if eng.nE else (None, gs)
+        with torch.no_grad():
+            gz_rows, grads = eng.backward(ctx.S, g_z, list(g_outs))
+        ctx.S = None
+        return (None, gz_rows if not eng.nE else None) + tuple(grads)
