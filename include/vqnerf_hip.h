@@ -515,16 +515,23 @@ int vqn_multi_copy(int count, const float* const* src, float* const* dst, const 
  * [ceil(P/32)][feature tiles][32 features][32 points] f32.
  * forward -- saved (written): with an encoder [E, Y_0 .. Y_{n_enc-1}] (Y_{n_enc-1} = z), without [ZT = the input rows' tile-format
  *   copy]; then [H0_k, H1_k] per head.  z_rows_out [P, z_feats] (optional, with an encoder); head_out[k] [P, c_k].
- * backward -- g_out[k] / head_out[k] [P, c_k]; g_z_rows [P, z_feats]: adjoint of z from outside the heads (optional; required for an
- *   encoder alone); saved [Y_0 .. Y_{n_enc-1}] then [H0_k, H1_k]; outs (written) [D_0 .. D_{n_enc-1}] then [D0_k, D1_k, D2_k] per
- *   head; gz_rows_out [P, z_feats]: d / d input rows (required without an encoder).  Adjoints of points past P are zero. */
+ * backward -- g_out[k] / head_out[k] [P, c_k]; g_z_rows: up to four [P, z_feats] adjoints of z from outside this launch's heads (summed
+ *   in order); saved [Y_0 .. Y_{n_enc-1}] then [H0_k, H1_k]; outs (written) [D_0 .. D_{n_enc-1}] then [D0_k, D1_k, D2_k] per head.
+ *   run_heads / run_enc select the part of the stack the launch walks: both = the whole backward; heads only = d / d z rows into
+ *   gz_rows_out; encoder only = from g_z_rows down.  Adjoints of points past P are zero.
+ * Small batches (the reference's 2048 points are 64 tiles, a quarter of the CUs): the kernels switch by themselves to one 32-point
+ *   image per workgroup when tile pairs would fill less than half of the chip, and split_heads != 0 gives every head its own
+ *   workgroup row (forward: each row evaluates the encoder, row 0 writes its tensors; backward: heads only, gz_rows_out then holds
+ *   n_heads slices [P, z_feats], one per head, for the caller -- or the encoder-only launch's g_z_rows -- to sum). */
 int vqn_refl_train_desc_ints(void);
 int vqn_refl_train_fwd_x3(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, const float* pts, const float* z_rows,
-                          int64_t P, float* const* saved, int n_saved, float* z_rows_out, float* const* head_out, void* stream);
+                          int64_t P, float* const* saved, int n_saved, float* z_rows_out, float* const* head_out, int split_heads,
+                          void* stream);
 int64_t vqn_refl_train_bwd_x3_scratch_bytes(const int32_t* desc);
 int vqn_refl_train_bwd_x3(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, int64_t P, const float* const* g_out,
-                          const float* const* head_out, const float* g_z_rows, const float* const* saved, int n_saved,
-                          float* const* outs, int n_outs, float* gz_rows_out, void* scratch, int64_t scratch_bytes, void* stream);
+                          const float* const* head_out, const float* const* g_z_rows, int n_gz, const float* const* saved, int n_saved,
+                          float* const* outs, int n_outs, float* gz_rows_out, int run_heads, int run_enc, int split_heads,
+                          void* scratch, int64_t scratch_bytes, void* stream);
 
 /* The Adam / AMSGrad update of the reference's optimisers for `count` f32 tensors in one launch per 56 tensors: steps[i] a device
  * float holding tensor i's step count AFTER this step's increment, lr_dev a device scalar (NULL: the host value lr),

@@ -34,8 +34,18 @@ def _rel(a, b):
     return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
 
 
+@pytest.fixture(params=['auto', 'two-images', 'one-image', 'one-image+split', 'two-images+split'])
+def form(request, monkeypatch):
+    """The kernel forms: two 32-point images per workgroup (large batches) / one (small batches), heads in one workgroup / one workgroup
+    row per head (small batches; the backward then takes two launches with an encoder).  'auto' = what the batch size selects."""
+    if request.param != 'auto':
+        monkeypatch.setenv('VQN_REFL_NIMG', '2' if request.param.startswith('two') else '1')
+        monkeypatch.setenv('VQN_REFL_SPLIT', '1' if request.param.endswith('split') else '0')
+    return request.param
+
+
 @pytest.mark.parametrize('N', [1, 33, 600, 4113])
-def test_encoder_and_heads_stack_against_torch_autograd(N):
+def test_encoder_and_heads_stack_against_torch_autograd(N, form):
     """A = posenc -> fine_enc -> bottleneck -> z -> three continuous heads: outputs to 3e-6, parameter gradients to 1e-4 of each tensor's
     largest entry (x3 products are exact to 2^-24; the order of the sums differs from torch's GEMMs), with an adjoint flowing into z from
     outside the heads as the VQ branch does."""
@@ -61,7 +71,8 @@ def test_encoder_and_heads_stack_against_torch_autograd(N):
     with launches() as rec:
         res = ReflStackFunction.apply(eng, x, *eng.params())
         loss_of(res[0], res[1:]).backward()
-    assert rec.counts['vqn_refl_train_fwd_x3'] == 1 and rec.counts['vqn_refl_train_bwd_x3'] == 1 and not rec.ran('vqn_tile_program')
+    split = form.endswith('split') or (form == 'auto' and ((N + 31) // 32) * 3 <= 384)
+    assert rec.counts['vqn_refl_train_fwd_x3'] == 1 and rec.counts['vqn_refl_train_bwd_x3'] == (2 if split else 1) and not rec.ran('vqn_tile_program')
     assert float((res[0] - z_t).abs().max()) < 3e-6
     for a, b in zip(res[1:], outs_t):
         assert float((a - b).abs().max()) < 3e-6
@@ -70,7 +81,7 @@ def test_encoder_and_heads_stack_against_torch_autograd(N):
 
 
 @pytest.mark.parametrize('N', [2, 95, 2048])
-def test_vq_heads_stack_against_torch_autograd(N):
+def test_vq_heads_stack_against_torch_autograd(N, form):
     """B = the three VQ heads on quantised rows (spec_vq has three outputs): outputs, parameter gradients and d / d rows."""
     from vqnerf_release_amd.decomp.refl_train import ReflStackEngine, ReflStackFunction
     m = _model(seed=7)
@@ -94,7 +105,7 @@ def test_vq_heads_stack_against_torch_autograd(N):
         assert _rel(p.grad, w) < 1e-4, (tuple(p.shape), _rel(p.grad, w))
 
 
-def test_saved_tensors_and_adjoints_are_the_interpreted_programs(monkeypatch):
+def test_saved_tensors_and_adjoints_are_the_interpreted_programs(form):
     """Layer outputs and per-point adjoints left for the contraction, against decomp/train_programs.py's interpreter on the f32-input
     MFMA (the engine of rounds 1-3): 2e-5 of each tensor's largest entry (the bound the geo x3 kernels hold against their interpreter),
     zero rows for the points past N in the ragged last tile."""
@@ -143,6 +154,35 @@ def test_saved_tensors_and_adjoints_are_the_interpreted_programs(monkeypatch):
     assert len(ref) == len(grads)
     for a, w in zip(grads, ref):
         assert a.shape == w.shape and _rel(a, w) < 5e-4, (tuple(a.shape), _rel(a, w))      # (relu units within rounding of zero flip between the engines: the torch-autograd tests above are the tight ones)
+
+
+def test_large_batch_linearity_and_zero_adjoints(monkeypatch):
+    """Size-independent properties at a batch of 40,001 points (1,251 point tiles: five passes of the persistent two-image workgroups, an odd
+    tile count): the backward is linear in the incoming adjoints and zero for zero adjoints; forward outputs do not depend on the batch a
+    point sits in (the first 4,113 points alone give the same rows, bit for bit)."""
+    from vqnerf_release_amd.decomp.refl_train import ReflStackEngine
+    monkeypatch.setenv('VQN_REFL_NIMG', '2')          # (the small batch in the form of the large one: the forms differ in the order of the
+    monkeypatch.setenv('VQN_REFL_SPLIT', '0')         #  last layer's row-dot partial sums, 8 waves per image against 4)
+    m = _model(seed=13)
+    names = ['diff_main', 'spec_main', 'rough_main']
+    eng = ReflStackEngine([m.net['fine_enc'], m.net['bottleneck']], m.embedder['xyz'].n_freqs, [m.net[n] for n in names], m.z_dim, 'cuda')
+    N = 40001
+    x = _pts(N, 6)
+    g = torch.Generator(device='cuda').manual_seed(7)
+    ps = [p.detach() for p in eng.params()]
+    mk = lambda: ([torch.randn(N, m.net[n].widths[2], device='cuda', generator=g) for n in names], torch.randn(N, 256, device='cuda', generator=g))
+    (go1, gz1), (go2, gz2) = mk(), mk()
+    with torch.no_grad():
+        S, zrows, outs = eng.forward(x, ps)
+        S2, z_small, outs_small = eng.forward(x[:4113].contiguous(), ps)
+        assert torch.equal(z_small, zrows[:4113]) and all(torch.equal(a, b[:4113]) for a, b in zip(outs_small, outs))
+        _, ga = eng.backward(S, gz1, go1)
+        _, gb = eng.backward(S, gz2, go2)
+        _, gc = eng.backward(S, 2.0 * gz1 - 0.5 * gz2, [2.0 * a - 0.5 * b for a, b in zip(go1, go2)])
+        _, g0 = eng.backward(S, torch.zeros_like(gz1), [torch.zeros_like(a) for a in go1])
+    for a, b, c, z in zip(ga, gb, gc, g0):
+        assert float(z.abs().max()) == 0.0
+        assert _rel(c, 2.0 * a - 0.5 * b) < 2e-5
 
 
 def test_stacks_outside_the_kernels_shape_keep_the_interpreter():

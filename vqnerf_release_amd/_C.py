@@ -786,9 +786,9 @@ def brdf_shade_bwd(xyz, normal, rayo, lvis, lxyz, lareas, light, materials, g_su
 
 
 # -------------------------------------------------------------------------------------- reflectance training passes (round 4)
-def refl_train_fwd_x3(desc, wbuf_pieces, wbuf_f32, pts, z_rows, P, saved, z_rows_out, head_out):
+def refl_train_fwd_x3(desc, wbuf_pieces, wbuf_f32, pts, z_rows, P, saved, z_rows_out, head_out, split_heads=False):
     """Forward of a reflectance stack (optional encoder + up to three heads) on the exact-split engine, keeping what the backward
-    needs (csrc/refl_train_x3.hip: vqn_refl_train_fwd_x3)."""
+    needs (csrc/refl_train_x3.hip: vqn_refl_train_fwd_x3).  split_heads: one workgroup row per head (small batches)."""
     _f32c(wbuf_f32, 'wbuf_f32')
     for t in list(saved) + list(head_out) + [t for t in (pts, z_rows, z_rows_out) if t is not None]:
         _f32c(t, 'tensor')
@@ -797,14 +797,18 @@ def refl_train_fwd_x3(desc, wbuf_pieces, wbuf_f32, pts, z_rows, P, saved, z_rows
     hp = (ctypes.c_void_p * max(1, len(head_out)))(*[t.data_ptr() for t in head_out])
     with _clock('vqn_refl_train_fwd_x3'):
         rc = lib().vqn_refl_train_fwd_x3(dp, _ptr(wbuf_pieces), _ptr(wbuf_f32), _ptr(pts), _ptr(z_rows), ctypes.c_int64(P), sp,
-                                         ctypes.c_int(len(saved)), _ptr(z_rows_out), hp, _stream())
+                                         ctypes.c_int(len(saved)), _ptr(z_rows_out), hp, ctypes.c_int(int(split_heads)), _stream())
     _check(rc, 'vqn_refl_train_fwd_x3')
 
 
-def refl_train_bwd_x3(desc, wbuf_pieces, wbuf_f32, P, g_out, head_out, g_z_rows, saved, outs, gz_rows_out):
-    """Backward of the same stack (vqn_refl_train_bwd_x3): fills `outs` with every layer's per-point adjoint in the tile format."""
+def refl_train_bwd_x3(desc, wbuf_pieces, wbuf_f32, P, g_out, head_out, g_z_rows, saved, outs, gz_rows_out, run_heads=True, run_enc=True,
+                      split_heads=False):
+    """Backward of the same stack (vqn_refl_train_bwd_x3): fills `outs` with every layer's per-point adjoint in the tile format.
+    g_z_rows: list of up to four [P, z] adjoints flowing into z from outside this launch's heads; run_heads / run_enc select the part
+    of the stack walked; split_heads (heads only): gz_rows_out holds one [P, z] slice per head."""
     _f32c(wbuf_f32, 'wbuf_f32')
-    for t in list(saved) + list(outs) + list(g_out) + list(head_out) + [t for t in (g_z_rows, gz_rows_out) if t is not None]:
+    g_z_rows = [t for t in (g_z_rows or []) if t is not None]
+    for t in list(saved) + list(outs) + list(g_out) + list(head_out) + g_z_rows + [t for t in (gz_rows_out,) if t is not None]:
         _f32c(t, 'tensor')
     d, dp = _i32(desc)
     dev = wbuf_f32.device
@@ -820,7 +824,8 @@ def refl_train_bwd_x3(desc, wbuf_pieces, wbuf_f32, P, g_out, head_out, g_z_rows,
         _scratch[key] = buf
     arr = lambda ts: (ctypes.c_void_p * max(1, len(ts)))(*[t.data_ptr() for t in ts])
     with _clock('vqn_refl_train_bwd_x3'):
-        rc = L.vqn_refl_train_bwd_x3(dp, _ptr(wbuf_pieces), _ptr(wbuf_f32), ctypes.c_int64(P), arr(g_out), arr(head_out), _ptr(g_z_rows),
-                                     arr(saved), ctypes.c_int(len(saved)), arr(outs), ctypes.c_int(len(outs)), _ptr(gz_rows_out), _ptr(buf),
-                                     ctypes.c_int64(buf.numel()), _stream())
+        rc = L.vqn_refl_train_bwd_x3(dp, _ptr(wbuf_pieces), _ptr(wbuf_f32), ctypes.c_int64(P), arr(g_out), arr(head_out), arr(g_z_rows),
+                                     ctypes.c_int(len(g_z_rows)), arr(saved), ctypes.c_int(len(saved)), arr(outs), ctypes.c_int(len(outs)),
+                                     _ptr(gz_rows_out), ctypes.c_int(int(run_heads)), ctypes.c_int(int(run_enc)), ctypes.c_int(int(split_heads)),
+                                     _ptr(buf), ctypes.c_int64(buf.numel()), _stream())
     _check(rc, 'vqn_refl_train_bwd_x3')

@@ -199,20 +199,30 @@ __device__ __forceinline__ void gemm_tile_x3_ring1(const f32x4* __restrict__ lds
         for (int q = 0; q < 3; ++q) B[(j + 1) & 1][q] = lds_img[a + 64 * q];
         if (blk < nb) {
           const f32x4 w0 = A[u][3 * j], w1 = A[u][3 * j + 1], w2 = A[u][3 * j + 2];
+#ifdef VQN_DIAG_NO_MFMA      // timing only
+          asm volatile("" ::"v"(w0), "v"(w1), "v"(w2), "v"(B[j][0]), "v"(B[j][1]), "v"(B[j][2]));
+#else
           acc = mma_x3(w2, B[j][0], acc);                    // smallest terms first
           acc = mma_x3(w1, B[j][1], acc);
           acc = mma_x3(w0, B[j][2], acc);
           acc = mma_x3(w1, B[j][0], acc);
           acc = mma_x3(w0, B[j][1], acc);
           acc = mma_x3(w0, B[j][0], acc);
+#endif
         }
       }
       const int pos = blk + R;
       const bool own = pos < nb, nxt = pos >= nbp;
       const f32x4* __restrict__ src = nxt ? next_wp : wp;
       const int sb = own ? pos : (nxt ? min(u, next_nb - 1) : nb - 1);
+#ifdef VQN_DIAG_W_L1         // timing only: every weight fragment from the same L1-resident 6 KB
+#pragma unroll
+      for (int i = 0; i < 6; ++i) A[u][i] = w[i * 64 + lane];
+      (void)src; (void)sb;
+#else
 #pragma unroll
       for (int i = 0; i < 6; ++i) A[u][i] = src[(sb * 6 + i) * 64];
+#endif
     }
   }
   __builtin_amdgcn_s_setprio(0);

@@ -19,8 +19,11 @@
 // Saved tensors and adjoints are f32 in the tile format [point tile][feature tile][32 features][32 points] the contraction reads.
 #include "mlp_prims_x3.h"
 #include "vqnerf_hip.h"
+#include <stdlib.h>
+#include <type_traits>
 
 using namespace eng;
+template <int I> using IC = std::integral_constant<int, I>;
 
 namespace {
 
@@ -32,6 +35,19 @@ constexpr int NW = 8;
 constexpr int RT_MAX_L = 8;
 constexpr int RT_MAX_H = 3;
 constexpr int MAX_CALLS = RT_MAX_L + 2 * RT_MAX_H;
+
+// In-kernel phase timing of the backward (diagnostic build -DVQN_RT_STAMPS only; scripts/debug/refl_stamps.py): wave 0 of every
+// workgroup accumulates shader-clock cycles per phase.
+#ifdef VQN_RT_STAMPS
+__device__ unsigned long long g_rt_stamps[8 * 16];      // [wave][phase]
+#define RT_STAMP_DECL unsigned long long st_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_prev = __builtin_amdgcn_s_memtime(); const unsigned long long st_begin = st_prev;
+#define RT_STAMP(i) { const unsigned long long st_now = __builtin_amdgcn_s_memtime(); st_[i] += st_now - st_prev; st_prev = st_now; }
+#define RT_STAMP_FLUSH if ((threadIdx.x & 63) == 0) { st_[9] = __builtin_amdgcn_s_memtime() - st_begin; unsigned long long* g_ = g_rt_stamps + 16 * (threadIdx.x >> 6); for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_[i_], st_[i_]); atomicAdd(&g_[10], 1ull); }
+#else
+#define RT_STAMP_DECL
+#define RT_STAMP(i) {}
+#define RT_STAMP_FLUSH
+#endif
 
 struct ReflDesc {
   int n_enc, skip, emb_rows, emb_feats, e_tiles, max_tiles, n_heads, z_tiles;
@@ -54,24 +70,34 @@ struct ReflFwdPtrs {
 struct ReflBwdPtrs {
   const float* G_OUT[RT_MAX_H]; const float* OUT[RT_MAX_H]; const float* H0[RT_MAX_H]; const float* H1[RT_MAX_H];
   float* D2[RT_MAX_H]; float* D1[RT_MAX_H]; float* D0[RT_MAX_H];
-  const float* G_Z;                         // rows [N, z_feats]: adjoint of z from outside the heads (may be NULL)
-  float* GZ_ROWS;                           // n_enc = 0: d / d input rows [N, z_feats]
+  const float* G_Z[4]; int n_gz;            // rows [N, z_feats]: adjoints of z from outside this launch's heads, summed in order
+  int run_heads, run_enc;                   // which part of the stack this launch walks (both: the whole backward in one launch)
+  float* GZ_ROWS;                           // without the encoder part: d / d z rows [gridDim.y][N, z_feats] (one slice per head when split)
   const float* Y[RT_MAX_L]; float* D[RT_MAX_L];
 };
 
 struct SmallsR {
-  float pts[2][96], part[2][4 * 32 * 3], h2z[RT_MAX_H][2][96], d2[2][96];
-  int tab[MAX_CALLS * 4];                   // GEMM calls of one tile pair in program order: {float4 offset, K blocks, out tiles, 0}
+  float pts[2][96], part[2 * 4 * 32 * 3], h2z[RT_MAX_H][2][96], d2[2][96];
+  int tab[MAX_CALLS * 4];                   // GEMM calls of one unit in program order: {float4 offset, K blocks, out tiles, 0}
   int n_calls;
 };
 
 // accumulator tile <-> tile format: register i of lane (p, h) is feature (i & 3) + 8 (i >> 2) + 4 h of the feature tile
 __device__ __forceinline__ void tf_store_acc(float* __restrict__ T, const long ptile, const int n_ft, const int ot, const int lane, const float (&v)[16]) {
+#ifdef VQN_DIAG_RT_NO_ST        // timing only
+  asm volatile("" ::"v"(v[0]), "v"(v[5]), "v"(v[10]), "v"(v[15]));
+  return;
+#endif
   float* base = T + ((ptile * n_ft + ot) * 32 + 4 * (lane >> 5)) * 32 + (lane & 31);
 #pragma unroll
   for (int i = 0; i < 16; ++i) __builtin_nontemporal_store(v[i], base + ((i & 3) + 8 * (i >> 2)) * 32);
 }
 __device__ __forceinline__ void tf_load_acc(const float* __restrict__ T, const long ptile, const int n_ft, const int ot, const int lane, float (&v)[16]) {
+#ifdef VQN_DIAG_RT_NO_LD        // timing only
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = 0.5f + 0.001f * (float)(lane + i);
+  return;
+#endif
   const float* base = T + ((ptile * n_ft + ot) * 32 + 4 * (lane >> 5)) * 32 + (lane & 31);
 #pragma unroll
   for (int i = 0; i < 16; ++i) v[i] = base[((i & 3) + 8 * (i >> 2)) * 32];
@@ -107,20 +133,34 @@ __device__ __forceinline__ void dact_mul(const int act, const float (&y)[16], fl
 }
 
 // shared pieces of the two kernels --------------------------------------------------------------------------------------------
+// NIMG = 2: a workgroup holds two 32-point images (a "unit" = a tile pair), every weight fragment serves both; layers of at most four
+// output tiles split the waves by image.  NIMG = 1 (small batches: fewer tile pairs than CUs): one image per workgroup, wave w owns
+// output tile w -- twice the workgroups, half the matrix time per layer.  gridDim.y > 1 (small batches again): one HEAD per workgroup
+// row, the encoder (forward) evaluated by each of them -- the reference batch of 2048 points is 64 tiles, a quarter of the chip.
 #define REFL_PROLOGUE()                                                                                      \
   extern __shared__ __attribute__((aligned(16))) f32x4 lds[];                                                \
   const int MT = rd.max_tiles;                                                                               \
   const int IMG = E_ROWS + 6 * MT, IS = IMG * 64;                                                            \
-  SmallsR* sm = reinterpret_cast<SmallsR*>(lds + (size_t)2 * IS);                                            \
+  SmallsR* sm = reinterpret_cast<SmallsR*>(lds + (size_t)NIMG * IS);                                         \
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;                                \
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                 \
-  const int img = wave >> 2, w4 = wave & 3;                                                                  \
+  constexpr int NWI = NIMG == 1 ? 8 : 4;                /* waves per image in the vector-ALU phases */        \
+  const int img = NIMG == 1 ? 0 : (wave >> 2), w4 = NIMG == 1 ? wave : (wave & 3);                           \
   f32x4* ldsi = lds + (size_t)img * IS;                                                                      \
-  const long n_tiles = (P + 31) >> 5, n_pairs = (n_tiles + 1) >> 1;                                          \
+  float* part_i = sm->part + img * (4 * 32 * 3);        /* (NIMG = 1: all 8 x 32 x 3 floats are image 0's) */ \
+  const long n_tiles = (P + 31) >> 5, n_units = NIMG == 1 ? n_tiles : ((n_tiles + 1) >> 1);                  \
+  const int k_lo = gridDim.y > 1 ? (int)blockIdx.y : 0, k_hi = gridDim.y > 1 ? k_lo + 1 : rd.n_heads;       \
   auto blocks_of = [](int krows) { return (krows / 3 + 1) >> 1; };                                           \
-  (void)ldsi; (void)h; (void)p; (void)blocks_of;
+  auto ptile_of = [&](long unit, int im) { return NIMG == 1 ? unit : 2 * unit + im; };                       \
+  (void)ldsi; (void)h; (void)p; (void)blocks_of; (void)part_i; (void)k_hi; (void)NWI;
 
-// the wave's first tile of the next GEMM call (after `idx`, wrapping into the next tile pair) in which it owns one
+// sum of the NWI per-wave partial row dots of (point pp, output c)
+#define REFL_PART_SUM(pr, pp, nc, c)                                                                         \
+  (NIMG == 1 ? (((pr)[(0 * 32 + (pp)) * (nc) + (c)] + (pr)[(1 * 32 + (pp)) * (nc) + (c)]) + ((pr)[(2 * 32 + (pp)) * (nc) + (c)] + (pr)[(3 * 32 + (pp)) * (nc) + (c)])) + \
+               (((pr)[(4 * 32 + (pp)) * (nc) + (c)] + (pr)[(5 * 32 + (pp)) * (nc) + (c)]) + ((pr)[(6 * 32 + (pp)) * (nc) + (c)] + (pr)[(7 * 32 + (pp)) * (nc) + (c)])) \
+             : (((pr)[(0 * 32 + (pp)) * (nc) + (c)] + (pr)[(1 * 32 + (pp)) * (nc) + (c)]) + ((pr)[(2 * 32 + (pp)) * (nc) + (c)] + (pr)[(3 * 32 + (pp)) * (nc) + (c)])))
+
+// the wave's first tile of the next GEMM call (after `idx`, wrapping into the next unit) in which it owns one
 #define REFL_STREAM()                                                                                        \
   const int n_calls = __builtin_amdgcn_readfirstlane(sm->n_calls);                                           \
   auto next_stream = [&](int idx, const f32x4*& nwp, int& nnb) {                                             \
@@ -128,7 +168,7 @@ __device__ __forceinline__ void dact_mul(const int act, const float (&y)[16], fl
     for (int k = 1; k <= n_calls; ++k) {                                                                     \
       const int m = (idx + k) % n_calls;                                                                     \
       const int tiles = __builtin_amdgcn_readfirstlane(sm->tab[4 * m + 2]);                                  \
-      const int mine = tiles <= 4 ? w4 : wave;                                                               \
+      const int mine = (NIMG == 2 && tiles <= 4) ? w4 : wave;                                                \
       if (mine < tiles) {                                                                                    \
         const int off = __builtin_amdgcn_readfirstlane(sm->tab[4 * m]);                                      \
         nnb = __builtin_amdgcn_readfirstlane(sm->tab[4 * m + 1]);                                            \
@@ -138,84 +178,98 @@ __device__ __forceinline__ void dact_mul(const int act, const float (&y)[16], fl
     }                                                                                                        \
   };                                                                                                         \
   f32x4 ring[RING][6];                                                                                       \
-  {                                                                                                          \
+  if (n_calls > 0) {                                                                                         \
     const f32x4* wp0; int nb0;                                                                               \
     next_stream(n_calls - 1, wp0, nb0);                                                                      \
     ring_prime_x3<RING>(ring, wp0, nb0);                                                                     \
   }                                                                                                          \
   int call = 0;                                                                                              \
   /* init(ot, im, slot, acc) / epi(ot, im, slot, acc) once per (tile, image) the wave owns; `slot` (a compile-time constant    \
-     after inlining: 0 in the split form, the image in the two-image form) indexes the per-image REGISTER arrays (o, au) -- a      \
+     after inlining: 0 in the one-tile forms, the image in the two-image form) indexes the per-image REGISTER arrays (o, au) -- a  \
      run-time index would send them to scratch */                                                                               \
-  auto G = [&](const int off, const KSegs ks, const int tiles, auto init, auto epi) {                        \
+  auto Gx = [&](const int off, const KSegs ks, const int tiles, auto commit_c, auto init, auto epi) __attribute__((always_inline)) { \
+    constexpr bool COMMIT = decltype(commit_c)::value != 0;                                                  \
     const f32x4* nwp; int nnb;                                                                               \
     next_stream(call, nwp, nnb);                                                                             \
     ++call;                                                                                                  \
-    if (tiles <= 4) {                                                                                        \
-      if (w4 < tiles)                                                                                        \
-        gemm_tile_x3_ring1<RING>(ldsi, ks, wx + off, w4, lane, ring, nwp, nnb,                               \
-                                 [&](f32x16& acc) { init(w4, img, 0, acc); }, [&](const f32x16& acc) { epi(w4, img, 0, acc); }); \
+    /* COMMIT (a layer IN PLACE): the wave's accumulators stay where the K loop left them, a barrier sees every wave out of its K   \
+       loop -- the input rows are dead --, then the epilogues write their tiles straight over the input (store_tile_x3) and a second  \
+       barrier publishes them.  Waves without a tile in this GEMM arrive at the same two barriers from the else branches.  (Parking  \
+       the finished, already split tiles in registers across the barrier instead -- 48 of them -- ended in scratch: every commit     \
+       re-read 18 x 16 B per lane behind the epilogue's global stores, a third of the backward's time.) */                          \
+    if constexpr (NIMG == 1) {                                                                               \
+      if (wave < tiles)                                                                                      \
+        gemm_tile_x3_ring1<RING>(lds, ks, wx + off, wave, lane, ring, nwp, nnb,                              \
+                                 [&](f32x16& acc) __attribute__((always_inline)) { init(wave, 0, IC<0>{}, acc); },                 \
+                                 [&](const f32x16& acc) __attribute__((always_inline)) { if (COMMIT) __syncthreads(); epi(wave, 0, IC<0>{}, acc); }); \
+      else if (COMMIT) __syncthreads();                                                                      \
     } else {                                                                                                 \
-      gemm_tiles_x3_ring2<NW, RING, 1>(lds, IS, ks, wx + off, tiles, wave, lane, ring, nwp, nnb,             \
-                                       [&](int ot, int im, f32x16& acc) { if (im == 0) init(ot, 0, 0, acc); else init(ot, 1, 1, acc); },        \
-                                       [&](int ot, int im, const f32x16& acc) { if (im == 0) epi(ot, 0, 0, acc); else epi(ot, 1, 1, acc); });   \
+      if (tiles <= 4) {                                                                                      \
+        if (w4 < tiles)                                                                                      \
+          gemm_tile_x3_ring1<RING>(ldsi, ks, wx + off, w4, lane, ring, nwp, nnb,                             \
+                                   [&](f32x16& acc) __attribute__((always_inline)) { init(w4, img, IC<0>{}, acc); },               \
+                                   [&](const f32x16& acc) __attribute__((always_inline)) { if (COMMIT) __syncthreads(); epi(w4, img, IC<0>{}, acc); }); \
+        else if (COMMIT) __syncthreads();                                                                    \
+      } else {                                                                                               \
+        gemm_tiles_x3_ring2<NW, RING, 1>(lds, IS, ks, wx + off, tiles, wave, lane, ring, nwp, nnb,           \
+                                         [&](int ot, int im, f32x16& acc) __attribute__((always_inline)) { if (im == 0) init(ot, 0, IC<0>{}, acc); else init(ot, 1, IC<1>{}, acc); }, \
+                                         [&](int ot, int im, const f32x16& acc) __attribute__((always_inline)) {                                       \
+                                           if (im == 0) { if (COMMIT) __syncthreads(); epi(ot, 0, IC<0>{}, acc); } else epi(ot, 1, IC<1>{}, acc); });    \
+        if (COMMIT && wave >= tiles) __syncthreads();                                                        \
+      }                                                                                                      \
     }                                                                                                        \
+    if (COMMIT) __syncthreads();                                                                             \
   };                                                                                                         \
-  f32x4 o[2][6];                                                                                             \
-  /* finished tiles (in `o`) over the layer's own input once every wave is out of its K loop */              \
-  auto commit = [&](const int tiles) {                                                                       \
-    __syncthreads();                                                                                         \
-    if (tiles <= 4) {                                                                                        \
-      if (w4 < tiles) store_frags_x3(ldsi, X0 + 6 * w4, lane, o[0]);                                         \
-    } else if (wave < tiles) {                                                                               \
-      store_frags_x3(lds, X0 + 6 * wave, lane, o[0]);                                                        \
-      store_frags_x3(lds + IS, X0 + 6 * wave, lane, o[1]);                                                   \
-    }                                                                                                        \
-    __syncthreads();                                                                                         \
-  };                                                                                                         \
+  auto G = [&](const int off, const KSegs ks, const int tiles, auto init, auto epi) __attribute__((always_inline)) { Gx(off, ks, tiles, IC<0>{}, init, epi); };  \
+  auto GC = [&](const int off, const KSegs ks, const int tiles, auto init, auto epi) __attribute__((always_inline)) { Gx(off, ks, tiles, IC<1>{}, init, epi); }; \
   /* fn(ot, im, slot) for every (tile, image) this wave owns in a `tiles`-tile tensor (the GEMMs' ownership) */ \
-  auto owned = [&](const int tiles, auto fn) {                                                               \
-    if (tiles <= 4) { if (w4 < tiles) fn(w4, img, 0); }                                                      \
-    else if (wave < tiles) { fn(wave, 0, 0); fn(wave, 1, 1); }                                               \
+  auto owned = [&](const int tiles, auto fn) __attribute__((always_inline)) {                                                               \
+    if constexpr (NIMG == 1) { if (wave < tiles) fn(wave, 0, IC<0>{}); }                                           \
+    else {                                                                                                   \
+      if (tiles <= 4) { if (w4 < tiles) fn(w4, img, IC<0>{}); }                                                    \
+      else if (wave < tiles) { fn(wave, 0, IC<0>{}); fn(wave, 1, IC<1>{}); }                                             \
+    }                                                                                                        \
   };
 
 // ================================================================ forward ================================================================
+template <int NIMG>
 __global__ __launch_bounds__(512, 1) void refl_train_fwd_x3_kernel(const ReflDesc rd, const f32x4* __restrict__ wx, const f32x4* __restrict__ wf,
                                                                    const ReflFwdPtrs tp, const long P) {
   REFL_PROLOGUE();
-  const int nE = rd.n_enc, nH = rd.n_heads, ZT = rd.z_tiles;
+  const int nE = rd.n_enc, ZT = rd.z_tiles;
+  const bool wr_shared = blockIdx.y == 0;             // (heads split over blockIdx.y: the encoder's tensors are written by row 0 only)
   if (tid == 0) {
     int n = 0;
     auto add = [&](int off, int krows, int tiles) { sm->tab[4 * n] = off; sm->tab[4 * n + 1] = blocks_of(krows); sm->tab[4 * n + 2] = tiles; sm->tab[4 * n + 3] = 0; ++n; };
     for (int l = 0; l < nE; ++l) add(rd.offW[l], l == 0 ? rd.emb_rows : 6 * rd.te[l - 1] + (l == rd.skip ? rd.emb_rows : 0), rd.te[l]);
-    for (int k = 0; k < nH; ++k) { add(rd.offW0[k], 6 * ZT, rd.t0[k]); add(rd.offW1[k], 6 * rd.t0[k], rd.t1[k]); }
+    for (int k = k_lo; k < k_hi; ++k) { add(rd.offW0[k], 6 * ZT, rd.t0[k]); add(rd.offW1[k], 6 * rd.t0[k], rd.t1[k]); }
     sm->n_calls = n;
   }
   __syncthreads();
   REFL_STREAM();
 
-  for (long pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+  for (long unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
     call = 0;
-    const long ptile_w = 2 * pair + img;
+    const long ptile_w = ptile_of(unit, img);
     const bool live_w = ptile_w < n_tiles;
     if (nE > 0) {
       // ---------------- points -> positional encoding -> E rows ----------------
-      if (tid < 64) {
+      if (tid < 32 * NIMG) {
         const int im = tid >> 5, t = tid & 31;
-        long pt = ((2 * pair + im) << 5) + t;
+        long pt = (ptile_of(unit, im) << 5) + t;
         if (pt >= P) pt = P - 1;
         sm->pts[im][t * 3 + 0] = tp.X[pt * 3 + 0]; sm->pts[im][t * 3 + 1] = tp.X[pt * 3 + 1]; sm->pts[im][t * 3 + 2] = tp.X[pt * 3 + 2];
       }
       __syncthreads();
       const float xs = sm->pts[img][p * 3 + 0], ys = sm->pts[img][p * 3 + 1], zs = sm->pts[img][p * 3 + 2];
-      for (int sl = w4; sl < 2 * rd.e_tiles; sl += 4) {
+      for (int sl = w4; sl < 2 * rd.e_tiles; sl += NWI) {
         float x[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
           const int f = step_feat(sl, h, jj);
           x[jj] = (sl < rd.emb_rows / 3 && f < rd.emb_feats) ? posenc_feat(f, xs, ys, zs) : 0.f;
         }
-        if (live_w) tf_store_step(tp.E, ptile_w, rd.e_tiles, sl, lane, x);
+        if (live_w && wr_shared) tf_store_step(tp.E, ptile_w, rd.e_tiles, sl, lane, x);
         if (sl < rd.emb_rows / 3) {
           f32x4 q0, q1, q2;
           split3x8(x, q0, q1, q2);
@@ -230,13 +284,14 @@ __global__ __launch_bounds__(512, 1) void refl_train_fwd_x3_kernel(const ReflDes
         const f32x4* bp = wf + rd.offBias[l];
         float* const t_y = tp.Y[l];
         const bool top = l == nE - 1;
-        G(rd.offW[l], ks, n_ot,
-          [&](int ot, int, int, f32x16& acc) { init_bias_f16s(bp, ot, lane, acc); },
-          [&](int ot, int im, int sl_, const f32x16& acc) {
+        GC(rd.offW[l], ks, n_ot,
+          [&](int ot, int, auto, f32x16& acc) __attribute__((always_inline)) { init_bias_f16s(bp, ot, lane, acc); },
+          [&](int ot, int im, auto slc_, const f32x16& acc) __attribute__((always_inline)) {
+            constexpr int sl_ = decltype(slc_)::value;
             float v[16];
             act_apply(act, acc, v);
-            const long ptile = 2 * pair + im;
-            if (ptile < n_tiles) {
+            const long ptile = ptile_of(unit, im);
+            if (ptile < n_tiles && wr_shared) {
               tf_store_acc(t_y, ptile, n_ot, ot, lane, v);
               if (top && tp.ZROWS != nullptr) {
                 const long pt = (ptile << 5) + p;
@@ -249,16 +304,15 @@ __global__ __launch_bounds__(512, 1) void refl_train_fwd_x3_kernel(const ReflDes
                 }
               }
             }
-            split_tile_x3(v, o[sl_]);
+            store_tile_x3(lds + (size_t)im * IS, X0 + 6 * ot, lane, v);
           });
-        commit(n_ot);
       }
     } else {
       // ---------------- input rows -> X (piece triples) + their tile-format copy ----------------
       const long pt = (ptile_w << 5) + p;
       const bool valid = pt < P;
       const float* row = tp.ZR + (valid ? pt : P - 1) * (long)rd.z_feats;
-      for (int sl = w4; sl < 2 * ZT; sl += 4) {
+      for (int sl = w4; sl < 2 * ZT; sl += NWI) {
         float x[8];
         const int f0 = 16 * sl + 4 * h;
         const f32x4 a = (f0 < rd.z_feats) ? *reinterpret_cast<const f32x4*>(row + f0) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -268,7 +322,7 @@ __global__ __launch_bounds__(512, 1) void refl_train_fwd_x3_kernel(const ReflDes
 #pragma unroll
           for (int jj = 0; jj < 8; ++jj) x[jj] = 0.f;
         }
-        if (live_w) tf_store_step(tp.ZT, ptile_w, ZT, sl, lane, x);
+        if (live_w && wr_shared) tf_store_step(tp.ZT, ptile_w, ZT, sl, lane, x);
         f32x4 q0, q1, q2;
         split3x8(x, q0, q1, q2);
         ldsi[(X0 + 3 * sl) * 64 + lane] = q0; ldsi[(X0 + 3 * sl + 1) * 64 + lane] = q1; ldsi[(X0 + 3 * sl + 2) * 64 + lane] = q2;
@@ -278,23 +332,23 @@ __global__ __launch_bounds__(512, 1) void refl_train_fwd_x3_kernel(const ReflDes
 
     // ---------------- heads ----------------
     // the z share of every head's last layer while z is in the buffer: part -> h2z[k][img][p * 3 + c]
-    for (int k = 0; k < nH; ++k) {
-      if (rd.c[k] == 1) rowdot_x3<1>(ldsi, X0, 6 * ZT, wf + rd.offW2z[k], sm->part[img], w4, lane);
-      else rowdot_x3<3>(ldsi, X0, 6 * ZT, wf + rd.offW2z[k], sm->part[img], w4, lane);
+    for (int k = k_lo; k < k_hi; ++k) {
+      if (rd.c[k] == 1) rowdot_x3<1, NWI>(ldsi, X0, 6 * ZT, wf + rd.offW2z[k], part_i, w4, lane);
+      else rowdot_x3<3, NWI>(ldsi, X0, 6 * ZT, wf + rd.offW2z[k], part_i, w4, lane);
       __syncthreads();
       const int nc = rd.c[k] == 1 ? 1 : 3;
-      if (tid < 64 * nc) {
+      if (tid < 32 * NIMG * nc) {
         const int im = tid / (32 * nc), r = tid - 32 * nc * im, pp = r % 32, c = r / 32;
-        const float* pr = sm->part[im];
-        sm->h2z[k][im][pp * 3 + c] = (pr[(0 * 32 + pp) * nc + c] + pr[(1 * 32 + pp) * nc + c]) + (pr[(2 * 32 + pp) * nc + c] + pr[(3 * 32 + pp) * nc + c]);
+        const float* pr = sm->part + im * (4 * 32 * 3);
+        sm->h2z[k][im][pp * 3 + c] = REFL_PART_SUM(pr, pp, nc, c);
       }
       __syncthreads();
     }
-    for (int k = 0; k < nH; ++k) {
-      if (k > 0) {                                       // z back into the buffer (the previous head ran over it)
-        owned(ZT, [&](int ot, int im, int sl_) {
+    for (int k = k_lo; k < k_hi; ++k) {
+      if (k > k_lo) {                                    // z back into the buffer (the previous head ran over it)
+        owned(ZT, [&](int ot, int im, auto) __attribute__((always_inline)) {
           float v[16];
-          const long ptile = 2 * pair + im;
+          const long ptile = ptile_of(unit, im);
           if (ptile < n_tiles) tf_load_acc(tp.ZT, ptile, ZT, ot, lane, v);
           else {
 #pragma unroll
@@ -308,44 +362,43 @@ __global__ __launch_bounds__(512, 1) void refl_train_fwd_x3_kernel(const ReflDes
         const int n_ot = rd.t0[k];
         const f32x4* bp = wf + rd.offB0[k];
         float* const t_y = tp.H0[k];
-        G(rd.offW0[k], KSegs{X0, 6 * ZT, 0, 0}, n_ot,
-          [&](int ot, int, int, f32x16& acc) { init_bias_f16s(bp, ot, lane, acc); },
-          [&](int ot, int im, int sl_, const f32x16& acc) {
+        GC(rd.offW0[k], KSegs{X0, 6 * ZT, 0, 0}, n_ot,
+          [&](int ot, int, auto, f32x16& acc) __attribute__((always_inline)) { init_bias_f16s(bp, ot, lane, acc); },
+          [&](int ot, int im, auto slc_, const f32x16& acc) __attribute__((always_inline)) {
+            constexpr int sl_ = decltype(slc_)::value;
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc[i], 0.f);
-            if (2 * pair + im < n_tiles) tf_store_acc(t_y, 2 * pair + im, n_ot, ot, lane, v);
-            split_tile_x3(v, o[sl_]);
+            if (ptile_of(unit, im) < n_tiles) tf_store_acc(t_y, ptile_of(unit, im), n_ot, ot, lane, v);
+            store_tile_x3(lds + (size_t)im * IS, X0 + 6 * ot, lane, v);
           });
-        commit(n_ot);
       }
       {
         const int n_ot = rd.t1[k];
         const f32x4* bp = wf + rd.offB1[k];
         float* const t_y = tp.H1[k];
-        G(rd.offW1[k], KSegs{X0, 6 * rd.t0[k], 0, 0}, n_ot,
-          [&](int ot, int, int, f32x16& acc) { init_bias_f16s(bp, ot, lane, acc); },
-          [&](int ot, int im, int sl_, const f32x16& acc) {
+        GC(rd.offW1[k], KSegs{X0, 6 * rd.t0[k], 0, 0}, n_ot,
+          [&](int ot, int, auto, f32x16& acc) __attribute__((always_inline)) { init_bias_f16s(bp, ot, lane, acc); },
+          [&](int ot, int im, auto slc_, const f32x16& acc) __attribute__((always_inline)) {
+            constexpr int sl_ = decltype(slc_)::value;
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc[i], 0.f);
-            if (2 * pair + im < n_tiles) tf_store_acc(t_y, 2 * pair + im, n_ot, ot, lane, v);
-            split_tile_x3(v, o[sl_]);
+            if (ptile_of(unit, im) < n_tiles) tf_store_acc(t_y, ptile_of(unit, im), n_ot, ot, lane, v);
+            store_tile_x3(lds + (size_t)im * IS, X0 + 6 * ot, lane, v);
           });
-        commit(n_ot);
       }
       // last layer: row dots over y1, + the z share, + bias -> sigmoid
-      if (rd.c[k] == 1) rowdot_x3<1>(ldsi, X0, 6 * rd.t1[k], wf + rd.offW2y[k], sm->part[img], w4, lane);
-      else rowdot_x3<3>(ldsi, X0, 6 * rd.t1[k], wf + rd.offW2y[k], sm->part[img], w4, lane);
+      if (rd.c[k] == 1) rowdot_x3<1, NWI>(ldsi, X0, 6 * rd.t1[k], wf + rd.offW2y[k], part_i, w4, lane);
+      else rowdot_x3<3, NWI>(ldsi, X0, 6 * rd.t1[k], wf + rd.offW2y[k], part_i, w4, lane);
       __syncthreads();
       {
         const int nc = rd.c[k] == 1 ? 1 : 3, cc = rd.c[k];
-        if (tid < 64 * nc) {
+        if (tid < 32 * NIMG * nc) {
           const int im = tid / (32 * nc), r = tid - 32 * nc * im, pp = r % 32, c = r / 32;
-          const float* pr = sm->part[im];
-          const float s = ((pr[(0 * 32 + pp) * nc + c] + pr[(1 * 32 + pp) * nc + c]) + (pr[(2 * 32 + pp) * nc + c] + pr[(3 * 32 + pp) * nc + c]))
-                          + sm->h2z[k][im][pp * 3 + c] + wf[rd.offB2[k]][c];
-          const long pt = ((2 * pair + im) << 5) + pp;
+          const float* pr = sm->part + im * (4 * 32 * 3);
+          const float s = REFL_PART_SUM(pr, pp, nc, c) + sm->h2z[k][im][pp * 3 + c] + wf[rd.offB2[k]][c];
+          const long pt = (ptile_of(unit, im) << 5) + pp;
           if (pt < P && c < cc) tp.OUT[k][pt * cc + c] = act_fwd<ACT_SIGMOID>(s);
         }
       }
@@ -355,40 +408,49 @@ __global__ __launch_bounds__(512, 1) void refl_train_fwd_x3_kernel(const ReflDes
 }
 
 // ================================================================ backward ================================================================
+template <int NIMG>
 __global__ __launch_bounds__(512, 1) void refl_train_bwd_x3_kernel(const ReflDesc rd, const f32x4* __restrict__ wx, const f32x4* __restrict__ wf,
                                                                    const ReflBwdPtrs tp, const long P, f32x4* __restrict__ scratch) {
   REFL_PROLOGUE();
-  const int nE = rd.n_enc, nH = rd.n_heads, ZT = rd.z_tiles;
-  const size_t per_img = (size_t)4 * ZT * 64;                    // the d / d z accumulator between heads (accumulator-order quads)
-  f32x4* save0 = scratch + (size_t)blockIdx.x * 2 * per_img;
+  RT_STAMP_DECL
+  const int ZT = rd.z_tiles;
+  const int nE = tp.run_enc ? rd.n_enc : 0;                    // (the encoder part is walked only when asked for)
+  const bool heads = tp.run_heads != 0 && k_hi > k_lo;
+  const size_t per_img = (size_t)4 * ZT * 64;                  // the d / d z accumulator between heads (accumulator-order quads)
+  f32x4* save0 = scratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NIMG * per_img;
   if (tid == 0) {
     int n = 0;
     auto add = [&](int off, int krows, int tiles) { sm->tab[4 * n] = off; sm->tab[4 * n + 1] = blocks_of(krows); sm->tab[4 * n + 2] = tiles; sm->tab[4 * n + 3] = 0; ++n; };
-    for (int k = 0; k < nH; ++k) { add(rd.offW1b[k], 6 * rd.t1[k], rd.t0[k]); add(rd.offW0b[k], 6 * rd.t0[k], ZT); }
+    if (heads)
+      for (int k = k_lo; k < k_hi; ++k) { add(rd.offW1b[k], 6 * rd.t1[k], rd.t0[k]); add(rd.offW0b[k], 6 * rd.t0[k], ZT); }
     for (int l = nE - 1; l >= 1; --l) add(rd.offWb[l], 6 * rd.te[l], rd.te[l - 1]);
     sm->n_calls = n;
   }
   __syncthreads();
   REFL_STREAM();
-  float au[2][16];
+  float au[NIMG][16];
+  float* const gz_rows = tp.GZ_ROWS != nullptr ? tp.GZ_ROWS + (size_t)blockIdx.y * P * rd.z_feats : nullptr;
 
-  for (long pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+  for (long unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
     call = 0;
-    // top of the stack, what happens to a finished d / d z tile: d_top = (gz [+ G_Z rows]) act'(z) -> the encoder backward (with an
-    // encoder), or d / d input rows (without)
-    auto top_tile = [&](const int ot, const int im, const int sl_, float (&v)[16]) {
-      const long ptile = 2 * pair + im;
+    RT_STAMP(0)
+    // top of the stack, what happens to a finished d / d z tile: d_top = (gz + the incoming rows) act'(z) -> the encoder backward (when
+    // this launch walks the encoder), or d / d z rows (when it does not)
+    auto top_tile = [&](const int ot, const int im, auto slc_, float (&v)[16]) __attribute__((always_inline)) {
+      constexpr int sl_ = decltype(slc_)::value;
+      const long ptile = ptile_of(unit, im);
       const long pt = (ptile << 5) + p;
       const bool valid = pt < P;
-      if (tp.G_Z != nullptr && valid) {
-        const float* row = tp.G_Z + pt * (long)rd.z_feats + 32 * ot + 4 * h;
+      if (valid)
+        for (int j = 0; j < tp.n_gz; ++j) {
+          const float* row = tp.G_Z[j] + pt * (long)rd.z_feats + 32 * ot + 4 * h;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (32 * ot + 8 * q + 4 * h < rd.z_feats) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(row + 8 * q);
-            v[4 * q] += g[0]; v[4 * q + 1] += g[1]; v[4 * q + 2] += g[2]; v[4 * q + 3] += g[3];
-          }
-      }
+          for (int q = 0; q < 4; ++q)
+            if (32 * ot + 8 * q + 4 * h < rd.z_feats) {
+              const f32x4 g = *reinterpret_cast<const f32x4*>(row + 8 * q);
+              v[4 * q] += g[0]; v[4 * q + 1] += g[1]; v[4 * q + 2] += g[2]; v[4 * q + 3] += g[3];
+            }
+        }
       if (!valid) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = 0.f;
@@ -400,9 +462,9 @@ __global__ __launch_bounds__(512, 1) void refl_train_bwd_x3_kernel(const ReflDes
           dact_mul(rd.act[nE - 1], y, v);
           tf_store_acc(tp.D[nE - 1], ptile, ZT, ot, lane, v);
         }
-        split_tile_x3(v, o[sl_]);
+        store_tile_x3(lds + (size_t)im * IS, X0 + 6 * ot, lane, v);
       } else if (valid) {
-        float* row = tp.GZ_ROWS + pt * (long)rd.z_feats + 32 * ot + 4 * h;
+        float* row = gz_rows + pt * (long)rd.z_feats + 32 * ot + 4 * h;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (32 * ot + 8 * q + 4 * h < rd.z_feats)
@@ -410,12 +472,13 @@ __global__ __launch_bounds__(512, 1) void refl_train_bwd_x3_kernel(const ReflDes
       }
     };
 
-    for (int k = 0; k < nH; ++k) {
+    if (heads)
+    for (int k = k_lo; k < k_hi; ++k) {
       const int cc = rd.c[k], T0 = rd.t0[k], T1 = rd.t1[k];
       // ---------------- delta_2 = g_out out (1 - out)  [c values per point] ----------------
-      if (tid < 64) {
+      if (tid < 32 * NIMG) {
         const int im = tid >> 5, t = tid & 31;
-        const long ptile = 2 * pair + im, pt = (ptile << 5) + t;
+        const long ptile = ptile_of(unit, im), pt = (ptile << 5) + t;
         float d[3] = {0.f, 0.f, 0.f};
         if (pt < P)
           for (int c = 0; c < cc; ++c) {
@@ -429,25 +492,30 @@ __global__ __launch_bounds__(512, 1) void refl_train_bwd_x3_kernel(const ReflDes
         }
       }
       __syncthreads();
-      const float dd0 = sm->d2[0][p * 3 + 0], dd1 = sm->d2[0][p * 3 + 1], dd2 = sm->d2[0][p * 3 + 2];
-      const float de0 = sm->d2[1][p * 3 + 0], de1 = sm->d2[1][p * 3 + 1], de2 = sm->d2[1][p * 3 + 2];
-      // acc += sum_c img_c[tile] d2[im][c]  (the last layer's transpose as rank-c updates on the vector ALU)
-      auto rank_c = [&](const f32x4* imgs, const int tiles, const int ot, const int im, f32x16& acc) {
+      RT_STAMP(1)
+      float dd[NIMG][3];
+#pragma unroll
+      for (int im = 0; im < NIMG; ++im) { dd[im][0] = sm->d2[im][p * 3 + 0]; dd[im][1] = sm->d2[im][p * 3 + 1]; dd[im][2] = sm->d2[im][p * 3 + 2]; }
+      // acc += sum_c img_c[tile] d2[slot][c]  (the last layer's transpose as rank-c updates on the vector ALU)
+      auto rank_c = [&](const f32x4* imgs, const int tiles, const int ot, const int im, f32x16& acc) __attribute__((always_inline)) {
         for (int c = 0; c < cc; ++c) {
           f32x16 wv;
           init_bias_f16s(imgs + (size_t)c * tiles * 8, ot, lane, wv);
-          const float d = im == 0 ? (c == 0 ? dd0 : (c == 1 ? dd1 : dd2)) : (c == 0 ? de0 : (c == 1 ? de1 : de2));
+          float d;
+          if constexpr (NIMG == 1) d = c == 0 ? dd[0][0] : (c == 1 ? dd[0][1] : dd[0][2]);
+          else d = im == 0 ? (c == 0 ? dd[0][0] : (c == 1 ? dd[0][1] : dd[0][2])) : (c == 0 ? dd[NIMG - 1][0] : (c == 1 ? dd[NIMG - 1][1] : dd[NIMG - 1][2]));
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[i] = fmaf(wv[i], d, acc[i]);
         }
       };
       // ---------------- delta_1 = (W2[:w1] delta_2) relu'(y1) -> X ----------------
-      owned(T1, [&](int ot, int im, int sl_) {
+      owned(T1, [&](int ot, int im, auto slc_) __attribute__((always_inline)) {
+        constexpr int sl_ = decltype(slc_)::value;
         f32x16 acc;
         init_zero(acc);
         rank_c(wf + rd.offA2y[k], T1, ot, im, acc);
         float v[16], y[16];
-        const long ptile = 2 * pair + im;
+        const long ptile = ptile_of(unit, im);
         if (ptile < n_tiles) tf_load_acc(tp.H1[k], ptile, T1, ot, lane, y);
         else {
 #pragma unroll
@@ -456,36 +524,45 @@ __global__ __launch_bounds__(512, 1) void refl_train_bwd_x3_kernel(const ReflDes
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = y[i] > 0.f ? acc[i] : 0.f;
         if (ptile < n_tiles) tf_store_acc(tp.D1[k], ptile, T1, ot, lane, v);
-        split_tile_x3(v, o[sl_]);
+        store_tile_x3(lds + (size_t)im * IS, X0 + 6 * ot, lane, v);
       });
-      commit(T1);
+      __syncthreads();
+      RT_STAMP(2)
       // ---------------- delta_0 = (W1 delta_1) relu'(y0) ----------------
       {
         const float* const t_y = tp.H0[k];
         float* const t_d = tp.D0[k];
-        G(rd.offW1b[k], KSegs{X0, 6 * T1, 0, 0}, T0,
-          [&](int ot, int im, int sl_, f32x16& acc) {
-            if (2 * pair + im < n_tiles) tf_load_acc(t_y, 2 * pair + im, T0, ot, lane, au[sl_]);
+        GC(rd.offW1b[k], KSegs{X0, 6 * T1, 0, 0}, T0,
+          [&](int ot, int im, auto slc_, f32x16& acc) __attribute__((always_inline)) {
+            constexpr int sl_ = decltype(slc_)::value;
+            if (sl_ == 0) RT_STAMP(3)
+            if (ptile_of(unit, im) < n_tiles) tf_load_acc(t_y, ptile_of(unit, im), T0, ot, lane, au[sl_]);
             else {
 #pragma unroll
               for (int i = 0; i < 16; ++i) au[sl_][i] = 0.f;
             }
             init_zero(acc);
+            RT_STAMP(4)
           },
-          [&](int ot, int im, int sl_, const f32x16& acc) {
+          [&](int ot, int im, auto slc_, const f32x16& acc) __attribute__((always_inline)) {
+            constexpr int sl_ = decltype(slc_)::value;
+            if (sl_ == 0) RT_STAMP(5)
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = au[sl_][i] > 0.f ? acc[i] : 0.f;
-            if (2 * pair + im < n_tiles) tf_store_acc(t_d, 2 * pair + im, T0, ot, lane, v);
-            split_tile_x3(v, o[sl_]);
+            if (ptile_of(unit, im) < n_tiles) tf_store_acc(t_d, ptile_of(unit, im), T0, ot, lane, v);
+            store_tile_x3(lds + (size_t)im * IS, X0 + 6 * ot, lane, v);
+            RT_STAMP(6)
           });
-        commit(T0);
+        RT_STAMP(7)
       }
       // ---------------- d / d z += W0 delta_0 + W2[w1:] delta_2 ----------------
       {
-        const bool first = k == 0, last = k == nH - 1;
-        G(rd.offW0b[k], KSegs{X0, 6 * T0, 0, 0}, ZT,
-          [&](int ot, int im, int sl_, f32x16& acc) {
+        const bool first = k == k_lo, last = k == k_hi - 1;
+        GC(rd.offW0b[k], KSegs{X0, 6 * T0, 0, 0}, ZT,
+          [&](int ot, int im, auto slc_, f32x16& acc) __attribute__((always_inline)) {
+            constexpr int sl_ = decltype(slc_)::value;
+            if (sl_ == 0) RT_STAMP(3)
             if (first) init_zero(acc);
             else {
               const f32x4* sv = save0 + (size_t)im * per_img;
@@ -496,8 +573,11 @@ __global__ __launch_bounds__(512, 1) void refl_train_bwd_x3_kernel(const ReflDes
               }
             }
             rank_c(wf + rd.offA2z[k], ZT, ot, im, acc);
+            RT_STAMP(4)
           },
-          [&](int ot, int im, int sl_, const f32x16& acc) {
+          [&](int ot, int im, auto slc_, const f32x16& acc) __attribute__((always_inline)) {
+            constexpr int sl_ = decltype(slc_)::value;
+            if (sl_ == 0) RT_STAMP(5)
             if (!last) {
               f32x4* sv = save0 + (size_t)im * per_img;
 #pragma unroll
@@ -506,55 +586,64 @@ __global__ __launch_bounds__(512, 1) void refl_train_bwd_x3_kernel(const ReflDes
               float v[16];
 #pragma unroll
               for (int i = 0; i < 16; ++i) v[i] = acc[i];
-              top_tile(ot, im, sl_, v);
+              top_tile(ot, im, slc_, v);
             }
+            RT_STAMP(6)
           });
-        if (last && nE > 0) commit(ZT);
-        else __syncthreads();                                  // (the next head's delta_1 goes over this GEMM's input)
+        RT_STAMP(7)
       }
     }
-    if (nH == 0 && nE > 0) {                                   // an encoder alone: d_top from the incoming rows
-      owned(ZT, [&](int ot, int im, int sl_) {
+    if (!heads && nE > 0) {                                    // the encoder part alone: d_top from the incoming rows
+      owned(ZT, [&](int ot, int im, auto slc_) __attribute__((always_inline)) {
+        constexpr int sl_ = decltype(slc_)::value;
         float v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = 0.f;
-        top_tile(ot, im, sl_, v);
+        top_tile(ot, im, slc_, v);
       });
-      commit(ZT);
+      __syncthreads();
     }
     // ---------------- encoder layers, top down: delta_{l-1} = (W_l[y part] delta_l) act'_{l-1}(y_{l-1}) ----------------
     for (int l = nE - 1; l >= 1; --l) {
       const int n_ot = rd.te[l - 1], act = rd.act[l - 1];
       const float* const t_y = tp.Y[l - 1];
       float* const t_d = tp.D[l - 1];
-      G(rd.offWb[l], KSegs{X0, 6 * rd.te[l], 0, 0}, n_ot,
-        [&](int ot, int im, int sl_, f32x16& acc) {
-          if (2 * pair + im < n_tiles) tf_load_acc(t_y, 2 * pair + im, n_ot, ot, lane, au[sl_]);
+      GC(rd.offWb[l], KSegs{X0, 6 * rd.te[l], 0, 0}, n_ot,
+        [&](int ot, int im, auto slc_, f32x16& acc) __attribute__((always_inline)) {
+            constexpr int sl_ = decltype(slc_)::value;
+          if (sl_ == 0) RT_STAMP(3)
+          if (ptile_of(unit, im) < n_tiles) tf_load_acc(t_y, ptile_of(unit, im), n_ot, ot, lane, au[sl_]);
           else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) au[sl_][i] = 0.f;
           }
           init_zero(acc);
+          RT_STAMP(4)
         },
-        [&](int ot, int im, int sl_, const f32x16& acc) {
+        [&](int ot, int im, auto slc_, const f32x16& acc) __attribute__((always_inline)) {
+            constexpr int sl_ = decltype(slc_)::value;
+          if (sl_ == 0) RT_STAMP(5)
           float v[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) v[i] = acc[i];
           dact_mul(act, au[sl_], v);
-          if (2 * pair + im < n_tiles) tf_store_acc(t_d, 2 * pair + im, n_ot, ot, lane, v);
-          split_tile_x3(v, o[sl_]);
+          if (ptile_of(unit, im) < n_tiles) tf_store_acc(t_d, ptile_of(unit, im), n_ot, ot, lane, v);
+          store_tile_x3(lds + (size_t)im * IS, X0 + 6 * ot, lane, v);
+          RT_STAMP(6)
         });
-      commit(n_ot);
+      RT_STAMP(7)
     }
   }
+  RT_STAMP(0)
+  RT_STAMP_FLUSH
 }
 
-size_t lds_bytes_r(int MT) { return (size_t)2 * (E_ROWS + 6 * MT) * 1024 + sizeof(SmallsR); }
+size_t lds_bytes_r(int MT, int nimg) { return (size_t)nimg * (E_ROWS + 6 * MT) * 1024 + sizeof(SmallsR); }
 
 int load_desc_r(const int32_t* desc, ReflDesc& rd) {
   memcpy(&rd, desc, sizeof(ReflDesc));
   if (rd.n_enc < 0 || rd.n_enc > RT_MAX_L || rd.n_heads < 0 || rd.n_heads > RT_MAX_H || (rd.n_enc == 0 && rd.n_heads == 0)) return 1;
-  if (rd.max_tiles < 1 || rd.max_tiles > NW || lds_bytes_r(rd.max_tiles) > 160 * 1024) return 2;
+  if (rd.max_tiles < 1 || rd.max_tiles > NW || lds_bytes_r(rd.max_tiles, 2) > 160 * 1024) return 2;
   if (rd.z_tiles < 1 || rd.z_tiles > rd.max_tiles || rd.z_feats < 1 || rd.z_feats > 32 * rd.z_tiles || (rd.z_feats & 3)) return 3;
   if (rd.n_enc > 0) {
     if (rd.emb_feats < 3 || rd.emb_feats > 64 || rd.emb_rows != x3_rows(rd.emb_feats) || rd.emb_rows > E_ROWS || rd.e_tiles < 1 || rd.e_tiles > 2 ||
@@ -569,12 +658,21 @@ int load_desc_r(const int32_t* desc, ReflDesc& rd) {
   return 0;
 }
 
+// one image per workgroup when the two-image form would leave more than half of the CUs without a tile pair (VQN_REFL_NIMG = 1 | 2
+// forces a form: tests and A/B timings)
+int images_per_wg(long n_tiles) {
+  const char* e = getenv("VQN_REFL_NIMG");                       // (read per call: the tests switch it)
+  if (e && (e[0] == '1' || e[0] == '2')) return e[0] - '0';
+  return (n_tiles + 1) / 2 * 2 <= (long)vqn_num_cus() ? 1 : 2;
+}
+
 }  // namespace
 
 extern "C" int vqn_refl_train_desc_ints(void) { return RT_DESC_INTS; }
 
 extern "C" int vqn_refl_train_fwd_x3(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, const float* pts, const float* z_rows,
-                                     int64_t P, float* const* saved, int n_saved, float* z_rows_out, float* const* head_out, void* stream) {
+                                     int64_t P, float* const* saved, int n_saved, float* z_rows_out, float* const* head_out, int split_heads,
+                                     void* stream) {
   VQN_CHECK_ARG(desc && wbuf_pieces && wbuf_f32 && saved, "null pointer");
   VQN_CHECK_ARG(P >= 1, "P >= 1");
   ReflDesc rd;
@@ -600,11 +698,15 @@ extern "C" int vqn_refl_train_fwd_x3(const int32_t* desc, const void* wbuf_piece
     tp.OUT[k] = head_out[k];
   }
   const long n_tiles = (P + 31) / 32;
-  const size_t lds = lds_bytes_r(rd.max_tiles);
-  VQN_HIP(hipFuncSetAttribute((const void*)refl_train_fwd_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int nimg = images_per_wg(n_tiles);
+  const size_t lds = lds_bytes_r(rd.max_tiles, nimg);
+  auto kern = nimg == 1 ? refl_train_fwd_x3_kernel<1> : refl_train_fwd_x3_kernel<2>;
+  VQN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const long units = nimg == 1 ? n_tiles : (n_tiles + 1) / 2;
   long grid = (long)vqn_num_cus();
-  if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;
-  hipLaunchKernelGGL(refl_train_fwd_x3_kernel, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, rd, reinterpret_cast<const f32x4*>(wbuf_pieces),
+  if (grid > units) grid = units;
+  const unsigned gy = (split_heads && nH > 1) ? (unsigned)nH : 1u;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid, gy), dim3(512), lds, (hipStream_t)stream, rd, reinterpret_cast<const f32x4*>(wbuf_pieces),
                      reinterpret_cast<const f32x4*>(wbuf_f32), tp, (long)P);
   VQN_LAUNCH_CHECK();
   return VQN_OK;
@@ -614,45 +716,68 @@ extern "C" int64_t vqn_refl_train_bwd_x3_scratch_bytes(const int32_t* desc) {
   if (!desc) return -1;
   ReflDesc rd;
   if (load_desc_r(desc, rd) != 0) return -1;
-  return (int64_t)vqn_num_cus() * 2 * 4 * rd.z_tiles * 1024;
+  return (int64_t)vqn_num_cus() * RT_MAX_H * 2 * 4 * rd.z_tiles * 1024;
 }
 
 extern "C" int vqn_refl_train_bwd_x3(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, int64_t P, const float* const* g_out,
-                                     const float* const* head_out, const float* g_z_rows, const float* const* saved, int n_saved,
-                                     float* const* outs, int n_outs, float* gz_rows_out, void* scratch, int64_t scratch_bytes, void* stream) {
+                                     const float* const* head_out, const float* const* g_z_rows, int n_gz, const float* const* saved, int n_saved,
+                                     float* const* outs, int n_outs, float* gz_rows_out, int run_heads, int run_enc, int split_heads,
+                                     void* scratch, int64_t scratch_bytes, void* stream) {
   VQN_CHECK_ARG(desc && wbuf_pieces && wbuf_f32 && saved && outs && scratch, "null pointer");
   VQN_CHECK_ARG(P >= 1, "P >= 1");
   ReflDesc rd;
   VQN_CHECK_SHAPE(load_desc_r(desc, rd) == 0, "invalid reflectance stack descriptor (layers of at most 256 outputs, at most 8 encoder layers, 3 heads)");
   const int nE = rd.n_enc, nH = rd.n_heads;
+  run_heads = run_heads && nH > 0;
+  run_enc = run_enc && nE > 0;
+  VQN_CHECK_ARG(run_heads || run_enc, "nothing to run");
   // saved: [Y_0..Y_{nE-1}], then per head [H0, H1]; outs: [D_0..D_{nE-1}], then per head [D0, D1, D2]
   VQN_CHECK_ARG(n_saved == nE + 2 * nH, "saved: [Y_0..Y_{nE-1}], then [H0_k, H1_k] per head");
   VQN_CHECK_ARG(n_outs == nE + 3 * nH, "outs: [D_0..D_{nE-1}], then [D0_k, D1_k, D2_k] per head");
-  VQN_CHECK_ARG(nH == 0 || (g_out && head_out), "g_out / head_out");
-  VQN_CHECK_ARG(nE > 0 || gz_rows_out != nullptr, "gz_rows_out without an encoder");
-  VQN_CHECK_ARG(nH > 0 || g_z_rows != nullptr, "an encoder alone needs g_z_rows");
+  VQN_CHECK_ARG(!run_heads || (g_out && head_out), "g_out / head_out");
+  VQN_CHECK_ARG(n_gz >= 0 && n_gz <= 4 && (n_gz == 0 || g_z_rows != nullptr), "at most four incoming z-adjoint row tensors");
+  VQN_CHECK_ARG(run_enc || gz_rows_out != nullptr, "gz_rows_out when the encoder part is not walked");
+  VQN_CHECK_ARG(run_heads || n_gz > 0, "the encoder part alone needs incoming z adjoints");
+  const bool split = split_heads && run_heads && nH > 1;
+  VQN_CHECK_ARG(!(split && run_enc), "heads split over workgroup rows cannot continue into the encoder in the same launch");
   for (int i = 0; i < n_saved; ++i) VQN_CHECK_ARG(saved[i] != nullptr, "null saved tensor");
   for (int i = 0; i < n_outs; ++i) VQN_CHECK_ARG(outs[i] != nullptr, "null output tensor");
   ReflBwdPtrs tp;
   memset(&tp, 0, sizeof(tp));
-  tp.G_Z = g_z_rows; tp.GZ_ROWS = gz_rows_out;
+  tp.n_gz = n_gz; tp.run_heads = run_heads; tp.run_enc = run_enc; tp.GZ_ROWS = gz_rows_out;
+  for (int j = 0; j < n_gz; ++j) { VQN_CHECK_ARG(g_z_rows[j] != nullptr, "null z adjoint"); tp.G_Z[j] = g_z_rows[j]; }
   for (int l = 0; l < nE; ++l) { tp.Y[l] = saved[l]; tp.D[l] = outs[l]; }
   for (int k = 0; k < nH; ++k) {
-    VQN_CHECK_ARG(g_out[k] && head_out[k], "null head adjoint / output");
-    tp.G_OUT[k] = g_out[k]; tp.OUT[k] = head_out[k];
+    if (run_heads) { VQN_CHECK_ARG(g_out[k] && head_out[k], "null head adjoint / output"); tp.G_OUT[k] = g_out[k]; tp.OUT[k] = head_out[k]; }
     tp.H0[k] = saved[nE + 2 * k]; tp.H1[k] = saved[nE + 2 * k + 1];
     tp.D0[k] = outs[nE + 3 * k]; tp.D1[k] = outs[nE + 3 * k + 1]; tp.D2[k] = outs[nE + 3 * k + 2];
   }
   const long n_tiles = (P + 31) / 32;
-  const int64_t per_wg = (int64_t)2 * 4 * rd.z_tiles * 1024;
-  const size_t lds = lds_bytes_r(rd.max_tiles);
-  VQN_HIP(hipFuncSetAttribute((const void*)refl_train_bwd_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int nimg = images_per_wg(n_tiles);
+  const unsigned gy = split ? (unsigned)nH : 1u;
+  const int64_t per_wg = (int64_t)nimg * 4 * rd.z_tiles * 1024;
+  const size_t lds = lds_bytes_r(rd.max_tiles, nimg);
+  auto kern = nimg == 1 ? refl_train_bwd_x3_kernel<1> : refl_train_bwd_x3_kernel<2>;
+  VQN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const long units = nimg == 1 ? n_tiles : (n_tiles + 1) / 2;
   long grid = (long)vqn_num_cus();
-  if (grid > (n_tiles + 1) / 2) grid = (n_tiles + 1) / 2;
-  if ((int64_t)grid * per_wg > scratch_bytes) grid = (long)(scratch_bytes / per_wg);
+  if (grid > units) grid = units;
+  if ((int64_t)grid * gy * per_wg > scratch_bytes) grid = (long)(scratch_bytes / (per_wg * gy));
   VQN_CHECK_ARG(grid >= 1, "scratch too small (see vqn_refl_train_bwd_x3_scratch_bytes)");
-  hipLaunchKernelGGL(refl_train_bwd_x3_kernel, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, rd, reinterpret_cast<const f32x4*>(wbuf_pieces),
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid, gy), dim3(512), lds, (hipStream_t)stream, rd, reinterpret_cast<const f32x4*>(wbuf_pieces),
                      reinterpret_cast<const f32x4*>(wbuf_f32), tp, (long)P, reinterpret_cast<f32x4*>(scratch));
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }
+
+#ifdef VQN_RT_STAMPS
+extern "C" int vqn_debug_read_rt_stamps(unsigned long long* out, int reset) {
+  VQN_HIP(hipDeviceSynchronize());
+  VQN_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rt_stamps), sizeof(unsigned long long) * 128));
+  if (reset) {
+    unsigned long long z[128] = {0};
+    VQN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rt_stamps), z, sizeof(z)));
+  }
+  return VQN_OK;
+}
+#endif

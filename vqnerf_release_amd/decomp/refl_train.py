@@ -29,6 +29,16 @@ def _tl(f):
     return (f + 31) // 32
 
 
+_CUS = {}
+
+
+def _num_cus(device):
+    k = str(device)
+    if k not in _CUS:
+        _CUS[k] = int(torch.cuda.get_device_properties(device).multi_processor_count) if torch.device(device).type == 'cuda' else 256
+    return _CUS[k]
+
+
 class ReflStackEngine:
     n_split = 256
 
@@ -197,8 +207,19 @@ class ReflStackEngine:
             saved += [a, b]
         outs = [torch.empty((N, net.widths[2]), dtype=torch.float32, device=dev) for net in self.heads]
         S['OUT'] = outs
-        _C.refl_train_fwd_x3(desc, pieces, wf, x if self.nE else None, None if self.nE else x, N, saved, zrows, outs)
+        S['split'] = self._split_heads(nt)
+        _C.refl_train_fwd_x3(desc, pieces, wf, x if self.nE else None, None if self.nE else x, N, saved, zrows, outs, split_heads=S['split'])
         return S, zrows, outs
+
+    def _split_heads(self, nt):
+        """Small batches: one workgroup row per head while that still fits the chip (the reference batch of 2048 points is 64 point
+        tiles on 256 CUs).  VQN_REFL_SPLIT = 0 | 1 overrides."""
+        import os
+        force = os.environ.get('VQN_REFL_SPLIT')
+        if force is not None:
+            return force != '0' and self.nH > 1
+        cus = _num_cus(self.device)
+        return self.nH > 1 and nt * self.nH <= (3 * cus) // 2
 
     def backward(self, S, g_z, g_outs):
         """g_z [N, Z] | None: adjoint of z from outside the heads (with an encoder); g_outs: adjoints of the head outputs (None: zeros).
@@ -217,12 +238,23 @@ class ReflStackEngine:
         saved = list(S['Y']) if self.nE else []
         for a, b in zip(S['H0'], S['H1']):
             saved += [a, b]
-        gz_rows = None if self.nE else torch.empty((N, self.Z), dtype=torch.float32, device=dev)
         if g_z is not None:
             g_z = g_z.detach().float().contiguous()
         elif self.nE and not self.nH:
             g_z = torch.zeros((N, self.Z), dtype=torch.float32, device=dev)
-        _C.refl_train_bwd_x3(desc, S['pieces'], S['wf'], N, g_outs, S['OUT'], g_z if self.nE else None, saved, outs, gz_rows)
+        gz_rows = None
+        args = (desc, S['pieces'], S['wf'], N, g_outs, S['OUT'])
+        if S['split'] and self.nH > 1:
+            # one workgroup row per head -> one d / d z slice per head; with an encoder a second launch walks it from their sum
+            part = torch.empty((self.nH, N, self.Z), dtype=torch.float32, device=dev)
+            _C.refl_train_bwd_x3(*args, [], saved, outs, part, run_heads=True, run_enc=False, split_heads=True)
+            if self.nE:
+                _C.refl_train_bwd_x3(*args, [g_z] + [part[k] for k in range(self.nH)], saved, outs, None, run_heads=False, run_enc=True)
+            else:
+                gz_rows = part.sum(0)
+        else:
+            gz_rows = None if self.nE else torch.empty((N, self.Z), dtype=torch.float32, device=dev)
+            _C.refl_train_bwd_x3(*args, [g_z] if self.nE else [], saved, outs, gz_rows)
         # ---- weight gradients: contractions over the points, straight into the Keras layout [in, out] ----
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         batch = WgradBatch(self.n_split)
