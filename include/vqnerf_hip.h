@@ -498,6 +498,15 @@ int vqn_wgrad_finalize(int count, const float* const* ws, const int32_t* n, cons
                        const int32_t* cols_valid, float* const* dst, const int64_t* dst_row_stride, const int64_t* dst_col_stride, const float* scale,
                        void* stream);
 
+/* Thin contractions (round 4; csrc/wgrad_thin.hip): out[r][f] = sum_p A[r][p] B[f][p] for rows r < a_rows[i] <= 8 of ONE feature tile
+ * (a_t0[i]) of A against b_nt[i] feature tiles of B -- the weight gradient of a reflectance head's 1..3-output last layer
+ * (nfr_unit.py:110-129).  A stream over B on the vector ALU (f32 FMA chains in point order), no matrix pipe.  Partial blocks
+ * ws[i]: [n][8][32 b_nt] (rows >= a_rows are zero), row sums rowsum_ws[i] (may be NULL): [n][32]; n = the return value =
+ * min(n_split, n_point_tiles), summed by vqn_wgrad_finalize with src_rows = 8. */
+int vqn_wgrad_thin_batched(int count, const float* const* A, const int32_t* a_tiles, const int32_t* a_t0, const int32_t* a_rows,
+                           const float* const* B, const int32_t* b_tiles, const int32_t* b_t0, const int32_t* b_nt,
+                           int64_t n_point_tiles, int n_split, float* const* ws, float* const* rowsum_ws, void* stream);
+
 /* count contiguous f32 copies dst[i][0..n[i]) = src[i][0..n[i]) in one launch (the per-parameter gradients into the flat
  * gradient bucket of the data-parallel step, trainvali.py:469-477). */
 int vqn_multi_copy(int count, const float* const* src, float* const* dst, const int64_t* n, void* stream);

@@ -187,10 +187,12 @@ def test_decomp_trainer_trains():
     assert set(ld2) >= {'rgb', 'vqrgb', 'chromaticity'}
 
 
-def test_batched_weight_gradients_are_the_per_weight_sequence_bit_for_bit():
+def test_batched_weight_gradients_are_the_per_weight_sequence_bit_for_bit(monkeypatch):
     """vqn_wgrad_finalize (one launch per backward pass: ordered sums of every contraction's partial blocks, written transposed /
     sliced / scaled where they belong) against the per-weight sequence it replaces (vqn_reduce_partials + torch transpose / cat /
-    scale): identical gradients, bit for bit, for the reflectance trainer and for the geometry networks."""
+    scale): identical gradients, bit for bit, for the reflectance trainer (on the interpreted programs, which keep both tails; the
+    dedicated kernels of round 4 only have the batched one) and for the geometry networks."""
+    monkeypatch.setenv('VQN_REFL_TRAIN', 'prog')
     from oracle import decomp as od
     from oracle import geo as og
     from vqnerf_release_amd.geo import train_programs as tp

@@ -98,6 +98,8 @@ __device__ __forceinline__ void tf_load_acc(const float* __restrict__ T, const l
   for (int i = 0; i < 16; ++i) v[i] = 0.5f + 0.001f * (float)(lane + i);
   return;
 #endif
+  // (streaming `nt` loads here -- so that the saved tensors, 14 KB per point passing through once, leave the weight packs in L2 --
+  //  measured no better: backward 3.18 -> 3.26 ms per 262,144 points)
   const float* base = T + ((ptile * n_ft + ot) * 32 + 4 * (lane >> 5)) * 32 + (lane & 31);
 #pragma unroll
   for (int i = 0; i < 16; ++i) v[i] = base[((i & 3) + 8 * (i >> 2)) * 32];
@@ -221,7 +223,7 @@ __device__ __forceinline__ void dact_mul(const int act, const float (&y)[16], fl
     if (COMMIT) __syncthreads();                                                                             \
   };                                                                                                         \
   auto G = [&](const int off, const KSegs ks, const int tiles, auto init, auto epi) __attribute__((always_inline)) { Gx(off, ks, tiles, IC<0>{}, init, epi); };  \
-  auto GC = [&](const int off, const KSegs ks, const int tiles, auto init, auto epi) __attribute__((always_inline)) { Gx(off, ks, tiles, IC<1>{}, init, epi); }; \
+  auto GC = [&](const int off, const KSegs ks, const int tiles, auto init, auto epi) __attribute__((always_inline)) { Gx(off, ks, tiles, IC<1>{}, init, epi); }; (void)G; \
   /* fn(ot, im, slot) for every (tile, image) this wave owns in a `tiles`-tile tensor (the GEMMs' ownership) */ \
   auto owned = [&](const int tiles, auto fn) __attribute__((always_inline)) {                                                               \
     if constexpr (NIMG == 1) { if (wave < tiles) fn(wave, 0, IC<0>{}); }                                           \
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(512, 1) void refl_train_fwd_x3_kernel(const ReflDes
         GC(rd.offW[l], ks, n_ot,
           [&](int ot, int, auto, f32x16& acc) __attribute__((always_inline)) { init_bias_f16s(bp, ot, lane, acc); },
           [&](int ot, int im, auto slc_, const f32x16& acc) __attribute__((always_inline)) {
-            constexpr int sl_ = decltype(slc_)::value;
+            constexpr int sl_ = decltype(slc_)::value; (void)sl_;
             float v[16];
             act_apply(act, acc, v);
             const long ptile = ptile_of(unit, im);
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(512, 1) void refl_train_fwd_x3_kernel(const ReflDes
         GC(rd.offW0[k], KSegs{X0, 6 * ZT, 0, 0}, n_ot,
           [&](int ot, int, auto, f32x16& acc) __attribute__((always_inline)) { init_bias_f16s(bp, ot, lane, acc); },
           [&](int ot, int im, auto slc_, const f32x16& acc) __attribute__((always_inline)) {
-            constexpr int sl_ = decltype(slc_)::value;
+            constexpr int sl_ = decltype(slc_)::value; (void)sl_;
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc[i], 0.f);
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(512, 1) void refl_train_fwd_x3_kernel(const ReflDes
         GC(rd.offW1[k], KSegs{X0, 6 * rd.t0[k], 0, 0}, n_ot,
           [&](int ot, int, auto, f32x16& acc) __attribute__((always_inline)) { init_bias_f16s(bp, ot, lane, acc); },
           [&](int ot, int im, auto slc_, const f32x16& acc) __attribute__((always_inline)) {
-            constexpr int sl_ = decltype(slc_)::value;
+            constexpr int sl_ = decltype(slc_)::value; (void)sl_;
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc[i], 0.f);
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(512, 1) void refl_train_bwd_x3_kernel(const ReflDes
     // top of the stack, what happens to a finished d / d z tile: d_top = (gz + the incoming rows) act'(z) -> the encoder backward (when
     // this launch walks the encoder), or d / d z rows (when it does not)
     auto top_tile = [&](const int ot, const int im, auto slc_, float (&v)[16]) __attribute__((always_inline)) {
-      constexpr int sl_ = decltype(slc_)::value;
+      constexpr int sl_ = decltype(slc_)::value; (void)sl_;
       const long ptile = ptile_of(unit, im);
       const long pt = (ptile << 5) + p;
       const bool valid = pt < P;
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(512, 1) void refl_train_bwd_x3_kernel(const ReflDes
       };
       // ---------------- delta_1 = (W2[:w1] delta_2) relu'(y1) -> X ----------------
       owned(T1, [&](int ot, int im, auto slc_) __attribute__((always_inline)) {
-        constexpr int sl_ = decltype(slc_)::value;
+        constexpr int sl_ = decltype(slc_)::value; (void)sl_;
         f32x16 acc;
         init_zero(acc);
         rank_c(wf + rd.offA2y[k], T1, ot, im, acc);
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(512, 1) void refl_train_bwd_x3_kernel(const ReflDes
         float* const t_d = tp.D0[k];
         GC(rd.offW1b[k], KSegs{X0, 6 * T1, 0, 0}, T0,
           [&](int ot, int im, auto slc_, f32x16& acc) __attribute__((always_inline)) {
-            constexpr int sl_ = decltype(slc_)::value;
+            constexpr int sl_ = decltype(slc_)::value; (void)sl_;
             if (sl_ == 0) RT_STAMP(3)
             if (ptile_of(unit, im) < n_tiles) tf_load_acc(t_y, ptile_of(unit, im), T0, ot, lane, au[sl_]);
             else {
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(512, 1) void refl_train_bwd_x3_kernel(const ReflDes
             RT_STAMP(4)
           },
           [&](int ot, int im, auto slc_, const f32x16& acc) __attribute__((always_inline)) {
-            constexpr int sl_ = decltype(slc_)::value;
+            constexpr int sl_ = decltype(slc_)::value; (void)sl_;
             if (sl_ == 0) RT_STAMP(5)
             float v[16];
 #pragma unroll
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(512, 1) void refl_train_bwd_x3_kernel(const ReflDes
         const bool first = k == k_lo, last = k == k_hi - 1;
         GC(rd.offW0b[k], KSegs{X0, 6 * T0, 0, 0}, ZT,
           [&](int ot, int im, auto slc_, f32x16& acc) __attribute__((always_inline)) {
-            constexpr int sl_ = decltype(slc_)::value;
+            constexpr int sl_ = decltype(slc_)::value; (void)sl_;
             if (sl_ == 0) RT_STAMP(3)
             if (first) init_zero(acc);
             else {
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(512, 1) void refl_train_bwd_x3_kernel(const ReflDes
             RT_STAMP(4)
           },
           [&](int ot, int im, auto slc_, const f32x16& acc) __attribute__((always_inline)) {
-            constexpr int sl_ = decltype(slc_)::value;
+            constexpr int sl_ = decltype(slc_)::value; (void)sl_;
             if (sl_ == 0) RT_STAMP(5)
             if (!last) {
               f32x4* sv = save0 + (size_t)im * per_img;
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(512, 1) void refl_train_bwd_x3_kernel(const ReflDes
     }
     if (!heads && nE > 0) {                                    // the encoder part alone: d_top from the incoming rows
       owned(ZT, [&](int ot, int im, auto slc_) __attribute__((always_inline)) {
-        constexpr int sl_ = decltype(slc_)::value;
+        constexpr int sl_ = decltype(slc_)::value; (void)sl_;
         float v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = 0.f;
@@ -610,7 +612,7 @@ __global__ __launch_bounds__(512, 1) void refl_train_bwd_x3_kernel(const ReflDes
       float* const t_d = tp.D[l - 1];
       GC(rd.offWb[l], KSegs{X0, 6 * rd.te[l], 0, 0}, n_ot,
         [&](int ot, int im, auto slc_, f32x16& acc) __attribute__((always_inline)) {
-            constexpr int sl_ = decltype(slc_)::value;
+            constexpr int sl_ = decltype(slc_)::value; (void)sl_;
           if (sl_ == 0) RT_STAMP(3)
           if (ptile_of(unit, im) < n_tiles) tf_load_acc(t_y, ptile_of(unit, im), n_ot, ot, lane, au[sl_]);
           else {
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(512, 1) void refl_train_bwd_x3_kernel(const ReflDes
           RT_STAMP(4)
         },
         [&](int ot, int im, auto slc_, const f32x16& acc) __attribute__((always_inline)) {
-            constexpr int sl_ = decltype(slc_)::value;
+            constexpr int sl_ = decltype(slc_)::value; (void)sl_;
           if (sl_ == 0) RT_STAMP(5)
           float v[16];
 #pragma unroll

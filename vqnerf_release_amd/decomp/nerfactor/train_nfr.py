@@ -106,11 +106,15 @@ class Trainer:
             raise ValueError('the captured step was recorded %s code dropout' % ('without' if self._static_thres is None else 'with'))
         if thres is not None:
             self._static_thres.copy_(thres)
+        pairs = []
         for dst, src in zip(self._static_in, batch):
             if torch.is_tensor(dst):
                 if dst.shape != src.shape:
                     raise ValueError(f'captured step takes batches of shape {tuple(dst.shape)}, got {tuple(src.shape)}')
-                dst.copy_(src)
+                if dst.data_ptr() != src.data_ptr():
+                    pairs.append((dst, src))
+        if pairs:                                      # the batch into the graph's static inputs: one launch, not one per tensor
+            parallel.multi_copy([d for d, _ in pairs], [s for _, s in pairs])
         self._captured.replay()
         self.model.weights_changed()       # a replay moves weights and codebook without bumping any tensor `_version`
         if self.sched is not None:
@@ -150,10 +154,12 @@ class Trainer:
         loss_kwargs.pop('pretrain', None), loss_kwargs.pop('env', None)
         per_example, loss_dict = model.compute_loss(pred, gt, **loss_kwargs)
         weighted = compute_average_loss(per_example, global_bs)
-        if leaves is None:
-            weighted.backward()
+        if leaves is None and (parallel.is_dist() or not self.bucket.flat.is_cuda):
+            weighted.backward()                      # (data parallel: the bucket's post-accumulate hooks start its slices' all-reduces)
         else:
-            grads = torch.autograd.grad(weighted, leaves, allow_unused=True)
+            # the gradients as VALUES, moved into the bucket by one multi-tensor copy: `backward()` accumulates into every
+            # parameter's `.grad` view with a launch of its own (52 of them per step)
+            grads = torch.autograd.grad(weighted, leaves if leaves is not None else self.bucket.params, allow_unused=True)
             with torch.no_grad():
                 # one multi-tensor copy for all gradients (a launch per parameter is ~40 of the captured step's launches)
                 have = [(v, g) for v, g in zip(self.bucket.views, grads) if g is not None]

@@ -257,7 +257,7 @@ class ReflStackEngine:
             _C.refl_train_bwd_x3(*args, [g_z] if self.nE else [], saved, outs, gz_rows)
         # ---- weight gradients: contractions over the points, straight into the Keras layout [in, out] ----
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        batch = WgradBatch(self.n_split)
+        batch = WgradBatch(self.n_split, thin=True)          # (the heads' 1..3-output last layers: vqn_wgrad_thin_batched)
         grads = []
         for l, Ly in enumerate(self.layers):
             n_in, n_out = Ly['in_y'] + (self.E if Ly['skip'] else 0), Ly['out']

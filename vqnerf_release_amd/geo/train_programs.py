@@ -62,9 +62,10 @@ class WgradBatch:
     each result where it belongs -- a slice of a concatenated matrix, transposed, scaled, two contractions added -- in ONE launch
     (vqn_wgrad_finalize) instead of a reduce + transpose + cat + scale kernel sequence per weight."""
 
-    def __init__(self, n_split):
+    def __init__(self, n_split, thin=False):
         self.n_split = n_split
-        self.e, self.keep, self.p, self.nt, self.ws_floats = [], [], [], None, 0
+        self.thin = thin          # contractions of at most 8 output rows on the vector-ALU stream kernel (vqn_wgrad_thin_batched)
+        self.e, self.keep, self.p, self.nt, self.ws_floats, self.pt = [], [], [], None, 0, []
 
     def _partials(self, A, B, at, a0, an, bt, b0, bn, nt, want_rs):
         """queue one partial-block problem; -> (workspace offset, row-sum workspace offset | None) in floats"""
@@ -85,6 +86,28 @@ class WgradBatch:
         also sum_p A[o][p].  A, B: TFMT tensors [point tiles, feature tiles, 32, 32]."""
         nt, at, bt = A.shape[0], A.shape[1], B.shape[1]
         a_nt_all, b_nt_all = (a_rows + 31) // 32, (b_cols + 31) // 32
+        if self.thin and a_rows <= 8 and A2 is None:
+            if self.nt is None:
+                self.nt = nt
+            assert nt == self.nt, 'one WgradBatch = contractions over the same points'
+            n_blocks = min(self.n_split, nt)
+            for b0 in range(0, b_nt_all, 8):
+                bn = min(8, b_nt_all - b0)
+                if col_first >= min(bn * 32, b_cols - b0 * 32) + b0 * 32:
+                    continue
+                ws, self.ws_floats = self.ws_floats, self.ws_floats + n_blocks * 8 * bn * 32
+                want_rs = bias_dst is not None and b0 == 0
+                rs = None
+                if want_rs:
+                    rs, self.ws_floats = self.ws_floats, self.ws_floats + n_blocks * 32
+                self.pt.append((A, at, 0, a_rows, B, bt, b0, bn, ws, rs))
+                self.e.append(dict(ws=ws, ws2=None, src_rows=8, src_cols=bn * 32, rows_valid=a_rows, col_first=max(0, col_first - b0 * 32),
+                                   cols_valid=min(bn * 32, b_cols - b0 * 32), dst=dst.data_ptr() + 4 * (b0 * 32 * sc), sr=sr, sc=sc, scale=scale))
+                if want_rs:
+                    self.e.append(dict(ws=rs, ws2=None, src_rows=1, src_cols=32, rows_valid=1, col_first=0, cols_valid=a_rows,
+                                       dst=bias_dst.data_ptr(), sr=0, sc=1, scale=1.0))
+            self.keep += [A, B, dst, bias_dst]
+            return
         for a0 in range(0, a_nt_all, 8):
             an = min(8, a_nt_all - a0)
             for b0 in range(0, b_nt_all, 8):
@@ -106,11 +129,25 @@ class WgradBatch:
 
     def flush(self):
         e, k, q, m = self.e, len(self.e), self.p, len(self.p)
-        if m:
-            buf = torch.empty(self.ws_floats, dtype=torch.float32, device=q[0][0].device)
+        qt, mt = self.pt, len(self.pt)
+        if m or mt:
+            buf = torch.empty(self.ws_floats, dtype=torch.float32, device=(q or qt)[0][0].device)
             base = buf.data_ptr()
             assert base % 16 == 0
             at = lambda off: 0 if off is None else base + 4 * off
+            n = min(self.n_split, self.nt)
+        if mt:
+            tpt = lambda j: (ctypes.c_void_p * mt)(*[x[j].data_ptr() for x in qt])
+            opt = lambda j: (ctypes.c_void_p * mt)(*[at(x[j]) for x in qt])
+            iat = [np.array([x[j] for x in qt], np.int32) for j in (1, 2, 3, 5, 6, 7)]
+            ipt = [a.ctypes.data_as(ctypes.c_void_p) for a in iat]
+            with _C._clock('vqn_wgrad_thin_batched'):
+                nthin = _C.lib().vqn_wgrad_thin_batched(ctypes.c_int(mt), tpt(0), ipt[0], ipt[1], ipt[2], tpt(4), ipt[3], ipt[4], ipt[5],
+                                                        ctypes.c_int64(self.nt), ctypes.c_int(self.n_split), opt(8), opt(9), _C._stream())
+            if nthin <= 0:
+                _C._check(nthin if nthin < 0 else -3, 'vqn_wgrad_thin_batched')
+            assert nthin == n
+        if m:
             tp = lambda j: (ctypes.c_void_p * m)(*[x[j].data_ptr() for x in q])
             op = lambda j: (ctypes.c_void_p * m)(*[at(x[j]) for x in q])
             ia = [np.array([x[j] for x in q], np.int32) for j in (1, 2, 3, 5, 6, 7)]
@@ -123,6 +160,7 @@ class WgradBatch:
             if n <= 0:
                 _C._check(n if n < 0 else -3, 'vqn_wgrad_partials_batched')
             assert n == min(self.n_split, self.nt)
+        if m or mt:
             vp = lambda key: (ctypes.c_void_p * k)(*[at(x[key]) for x in e])
             dp = (ctypes.c_void_p * k)(*[x['dst'] for x in e])
             i32 = lambda key: np.array([x[key] for x in e], np.int32)
@@ -135,7 +173,7 @@ class WgradBatch:
                 rc = _C.lib().vqn_wgrad_finalize(ctypes.c_int(k), vp('ws'), p[0], vp('ws2'), p[1], p[2], p[3], p[4], p[5], p[6], dp, p[7],
                                                  p[8], p[9], _C._stream())
             _C._check(rc, 'vqn_wgrad_finalize')
-        self.e, self.keep, self.p, self.nt, self.ws_floats = [], [], [], None, 0
+        self.e, self.keep, self.p, self.nt, self.ws_floats, self.pt = [], [], [], None, 0, []
 
 
 K_LD_POSENC, K_LD_POSENC_JVP, K_LD_T, K_LD_VEC, K_LD_EXTRAS, K_GEMM, K_ST_VEC, K_POSENC_VJP = 1, 2, 3, 4, 5, 6, 7, 8
