@@ -20,6 +20,7 @@
 //        = piece(W[out = 32 ot + (lane & 31)][in = feature(step, lane >> 5, jj)]), 3 KB per tile and step.
 #pragma once
 #include "mlp_prims_f16s.h"      // step_feat, init_bias_f16s (accumulator-order bias images are shared with the f16 pair engine)
+#include <type_traits>
 
 namespace eng {
 
@@ -74,7 +75,7 @@ __device__ __forceinline__ void ring_prime_x3(f32x4 (&A)[R][6], const f32x4* __r
 // Two-image GEMM of the engine: out[32 x 32-point tile `ot`] for BOTH images of the workgroup (`img_stride` float4 apart) over the K
 // row triples of `ks` (row counts multiples of 3); wave w owns tiles w, w + NW, ...; every weight fragment is applied to both images
 // (12 MFMAs per step).  ONE accumulator per image: the six terms of a step go in smallest first; the accumulate roundings are those
-// of an f32 accumulation (6 per 16 products instead of 16).  init(ot, img, acc) / epi(ot, img, acc) are called once per image.
+// of an f32 accumulation (6 per 16 products instead of 16).  init(ot, img, acc) / epi(ot, img, acc) are called once per image, img as std::integral_constant<int, 0 | 1>.
 // `wave` must be wave-uniform (readfirstlane).
 template <int NW = 8, int R = 2, int NACC = 1, class Init, class Epi>
 __device__ __forceinline__ void gemm_tiles_x3_ring2(const f32x4* __restrict__ lds, const int img_stride, const KSegs ks,
@@ -104,8 +105,10 @@ __device__ __forceinline__ void gemm_tiles_x3_ring2(const f32x4* __restrict__ ld
       for (int q = 0; q < 3; ++q) { B0[0][q] = lds[a + 64 * q]; B1[0][q] = lds[a + img_stride + 64 * q]; }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);        // one vmcnt(0) drain per tile: exact in-loop waits (see gemm_tiles_f16s_ring)
-    init(ot, 0, acc0);
-    init(ot, 1, acc1);
+    // (the image index travels as a TYPE: callers that keep per-image register arrays -- epilogue operands, parked tiles -- index them
+    //  with a compile-time constant; a run-time index, which is what a lambda that is not inlined twice sees, sends such arrays to scratch)
+    init(ot, std::integral_constant<int, 0>{}, acc0);
+    init(ot, std::integral_constant<int, 1>{}, acc1);
     __builtin_amdgcn_s_setprio(1);
     for (int bi = 0; bi < nbp; bi += R) {
 #pragma unroll
@@ -158,8 +161,8 @@ __device__ __forceinline__ void gemm_tiles_x3_ring2(const f32x4* __restrict__ ld
 #pragma unroll
       for (int i = 0; i < 16; ++i) { acc0[i] += sm0[i]; acc1[i] += sm1[i]; }
     }
-    epi(ot, 0, acc0);
-    epi(ot, 1, acc1);
+    epi(ot, std::integral_constant<int, 0>{}, acc0);
+    epi(ot, std::integral_constant<int, 1>{}, acc1);
   }
 }
 

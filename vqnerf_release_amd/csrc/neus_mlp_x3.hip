@@ -138,13 +138,20 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
     gemm_tiles_x3_ring2<NW, RING, NACC>(lds, IS, ks, wbase, tiles, wave, lane, ring, nwp, nnb, init, epi);
   };
   // a layer whose output tile `wave` goes over its own input (the X buffer): finished tiles wait in `o` for the barrier
-  f32x4 o[2][6];
-  auto commit = [&](const int tiles, const int dst_row0) {
-    __syncthreads();                                           // every wave is out of its K loop: the input rows are dead
-    if (wave < tiles) {
-      store_frags_x3(lds, dst_row0 + 6 * wave, lane, o[0]);
-      store_frags_x3(lds + IS, dst_row0 + 6 * wave, lane, o[1]);
-    }
+  // A layer IN PLACE (its output tile `wave` goes over its own input, the X buffer): the accumulators stay where the K loop left them,
+  // a barrier sees every wave out of its K loop -- the input rows are dead --, then the epilogues write their tiles straight over the
+  // input (store_tile_x3) and a second barrier publishes them; waves without a tile in this GEMM reach the same two barriers from
+  // the branch below.  (Rounds 3's form parked the finished, already split tiles in 48 registers across the barrier: they ended in
+  // scratch, and every layer re-read 18 x 16 B per lane behind the epilogue's global stores -- round 4, found with in-kernel stamps
+  // on csrc/refl_train_x3.hip, where the same change took a third off the backward.)
+  auto GC = [&](const f32x4* wbase, const KSegs ks, const int tiles, auto init, auto epi) {
+    const f32x4* nwp; int nnb;
+    next_stream(call, nwp, nnb);
+    ++call;
+    gemm_tiles_x3_ring2<NW, RING, NACC>(lds, IS, ks, wbase, tiles, wave, lane, ring, nwp, nnb, init,
+                                        [&](int ot, auto im_c, const f32x16& acc) __attribute__((always_inline)) {
+          if (decltype(im_c)::value == 0) __syncthreads(); epi(ot, im_c, acc); });
+    if (wave >= tiles) __syncthreads();
     __syncthreads();
   };
 
@@ -200,14 +207,15 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
       const bool do_save = FINE && (l < n_lin - 2);
       const f32x4* bp = wsdf + L.b_off;
       float* const t_u = TRAIN ? to.U[l + 1] : nullptr;
-      G(wsdf + L.w_off, ks, L.n_out_tiles,
-        [&](int ot, int, f32x16& acc) { init_bias_f16s(bp, ot, lane, acc); },
-        [&](int ot, int im, const f32x16& acc) {
+      GC(wsdf + L.w_off, ks, L.n_out_tiles,
+        [&](int ot, auto, f32x16& acc) __attribute__((always_inline)) { init_bias_f16s(bp, ot, lane, acc); },
+        [&](int ot, auto im_c, const f32x16& acc) __attribute__((always_inline)) {
+          constexpr int im = decltype(im_c)::value; (void)im;
           float v[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) v[i] = act_fwd<ACT_SOFTPLUS100>(acc[i]);
           if (TRAIN && 2 * pair + im < n_tiles) tfmt_store_acc(t_u, 2 * pair + im, L.n_out_tiles, ot, lane, v);
-          split_tile_x3(v, o[im]);
+          store_tile_x3(lds + (size_t)im * IS, X0 + 6 * ot, lane, v);
           if (do_save) {                            // what the reverse sweep needs of this layer: act'(x) = 1 - exp(-100 h)
             f32x4* sv = save0 + (size_t)im * per_img + (size_t)l * 4 * MT * 64;
 #pragma unroll
@@ -216,7 +224,6 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
                                                                act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q + 2]), act_bwd_from_out<ACT_SOFTPLUS100>(v[4 * q + 3])});
           }
         });
-      commit(L.n_out_tiles, X0);
     }
     const int hid_rows = 6 * sd.layers[n_lin - 2].n_out_tiles;
 
@@ -226,8 +233,9 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
       const LayerDesc L = sd.layers[n_lin - 1];
       const f32x4* bp = wsdf + L.b_off;
       G(wsdf + L.w_off, KSegs{X0, hid_rows, 0, 0}, L.n_out_tiles,
-        [&](int ot, int, f32x16& acc) { init_bias_f16s(bp, ot, lane, acc); },
-        [&](int ot, int im, const f32x16& acc) {
+        [&](int ot, auto, f32x16& acc) __attribute__((always_inline)) { init_bias_f16s(bp, ot, lane, acc); },
+        [&](int ot, auto im_c, const f32x16& acc) __attribute__((always_inline)) {
+          constexpr int im = decltype(im_c)::value; (void)im;
           f32x4* sv = save0 + (size_t)im * per_img + (size_t)feat_slot * 64;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
@@ -299,8 +307,9 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
       const KSegs ks{X0, 6 * L.n_out_tiles, 0, 0};
       if (l == sd.skip)                              // the embedding's share first: it reads X and writes E (nobody reads E now)
         G(wsdf + L.wTE_off, ks, emb_tiles,
-          [&](int, int, f32x16& acc) { init_zero(acc); },
-          [&](int ot, int im, const f32x16& acc) {
+          [&](int, auto, f32x16& acc) __attribute__((always_inline)) { init_zero(acc); },
+          [&](int ot, auto im_c, const f32x16& acc) __attribute__((always_inline)) {
+          constexpr int im = decltype(im_c)::value; (void)im;
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = acc[i];
@@ -309,24 +318,27 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
       const int tiles = sd.layers[l - 1].n_out_tiles;
 #ifdef VQN_X3_HV_EARLY       // stashed act' of the tile requested right after the drain (lands under the K loop) at the price of 32 registers
       f32x4 hv[2][4];
-      G(wsdf + L.wT_off, ks, tiles,
-        [&](int ot, int im, f32x16& acc) {
+      GC(wsdf + L.wT_off, ks, tiles,
+        [&](int ot, auto im_c, f32x16& acc) __attribute__((always_inline)) {
+          constexpr int im = decltype(im_c)::value; (void)im;
           const f32x4* sv = save0 + (size_t)im * per_img + (size_t)(l - 1) * 4 * MT * 64;
 #pragma unroll
           for (int q = 0; q < 4; ++q) hv[im][q] = ld_stream(sv + (ot * 4 + q) * 64 + lane);
           init_zero(acc);
         },
-        [&](int ot, int im, const f32x16& acc) {
+        [&](int ot, auto im_c, const f32x16& acc) __attribute__((always_inline)) {
+          constexpr int im = decltype(im_c)::value; (void)im;
           float v[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) v[i] = acc[i] * hv[im][i >> 2][i & 3];
           if (TRAIN && 2 * pair + im < n_tiles) tfmt_store_acc(to.GH[l - 1], 2 * pair + im, tiles, ot, lane, v);
-          split_tile_x3(v, o[im]);
+          store_tile_x3(lds + (size_t)im * IS, X0 + 6 * ot, lane, v);
         });
 #else                        // ... or in the epilogue itself: the kernel sits at the 256-register limit, and the other wave of the SIMD covers the wait
-      G(wsdf + L.wT_off, ks, tiles,
-        [&](int, int, f32x16& acc) { init_zero(acc); },
-        [&](int ot, int im, const f32x16& acc) {
+      GC(wsdf + L.wT_off, ks, tiles,
+        [&](int, auto, f32x16& acc) __attribute__((always_inline)) { init_zero(acc); },
+        [&](int ot, auto im_c, const f32x16& acc) __attribute__((always_inline)) {
+          constexpr int im = decltype(im_c)::value; (void)im;
           const f32x4* sv = save0 + (size_t)im * per_img + (size_t)(l - 1) * 4 * MT * 64;
           f32x4 hv[4];
 #pragma unroll
@@ -335,16 +347,16 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
 #pragma unroll
           for (int i = 0; i < 16; ++i) v[i] = acc[i] * hv[i >> 2][i & 3];
           if (TRAIN && 2 * pair + im < n_tiles) tfmt_store_acc(to.GH[l - 1], 2 * pair + im, tiles, ot, lane, v);
-          split_tile_x3(v, o[im]);
+          store_tile_x3(lds + (size_t)im * IS, X0 + 6 * ot, lane, v);
         });
 #endif
-      commit(tiles, X0);
     }
     {
       const LayerDesc L = sd.layers[0];
       const bool accumulate = sd.skip >= 1;
       G(wsdf + L.wTE_off, KSegs{X0, 6 * L.n_out_tiles, 0, 0}, emb_tiles,
-        [&](int ot, int im, f32x16& acc) {
+        [&](int ot, auto im_c, f32x16& acc) __attribute__((always_inline)) {
+          constexpr int im = decltype(im_c)::value; (void)im;
           if (accumulate) {
             float v[16];
             load_tile_x3(lds + (size_t)im * IS, E0 + ot * 6, lane, v);
@@ -352,7 +364,8 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
             for (int i = 0; i < 16; ++i) acc[i] = v[i];
           } else init_zero(acc);
         },
-        [&](int ot, int im, const f32x16& acc) {
+        [&](int ot, auto im_c, const f32x16& acc) __attribute__((always_inline)) {
+          constexpr int im = decltype(im_c)::value; (void)im;
           float v[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) v[i] = acc[i];
@@ -422,16 +435,16 @@ __global__ __launch_bounds__(512, 1) void neus_points_x3_kernel(
         const KSegs ks{X0, in_rows, E0, l == 0 ? cd.extra_rows : 0};
         const f32x4* bp = wcol + L.b_off;
         float* const t_c = TRAIN ? to.C[l + 1] : nullptr;
-        G(wcol + L.w_off, ks, L.n_out_tiles,
-          [&](int ot, int, f32x16& acc) { init_bias_f16s(bp, ot, lane, acc); },
-          [&](int ot, int im, const f32x16& acc) {
+        GC(wcol + L.w_off, ks, L.n_out_tiles,
+          [&](int ot, auto, f32x16& acc) __attribute__((always_inline)) { init_bias_f16s(bp, ot, lane, acc); },
+          [&](int ot, auto im_c, const f32x16& acc) __attribute__((always_inline)) {
+          constexpr int im = decltype(im_c)::value; (void)im;
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = act_fwd<ACT_RELU>(acc[i]);
             if (TRAIN && 2 * pair + im < n_tiles) tfmt_store_acc(t_c, 2 * pair + im, L.n_out_tiles, ot, lane, v);
-            split_tile_x3(v, o[im]);
+            store_tile_x3(lds + (size_t)im * IS, X0 + 6 * ot, lane, v);
           });
-        commit(L.n_out_tiles, X0);
         in_rows = 6 * L.n_out_tiles;
       }
       rowdot_x3<3>(ldsi, X0, in_rows, wcol + cd.last_w_off, sm->part[img], w4, lane);

@@ -120,13 +120,20 @@ __global__ __launch_bounds__(512, 1) void neus_train_bwd_x3_kernel(const TrainBw
     ++call;
     gemm_tiles_x3_ring2<NW, RING, NACC>(lds, IS, ks, wbase, tiles, wave, lane, ring, nwp, nnb, init, epi);
   };
-  f32x4 o[2][6];
-  auto commit = [&](const int tiles) {
-    __syncthreads();
-    if (wave < tiles) {
-      store_frags_x3(lds, X0 + 6 * wave, lane, o[0]);
-      store_frags_x3(lds + IS, X0 + 6 * wave, lane, o[1]);
-    }
+  // A layer IN PLACE (its output tile `wave` goes over its own input, the X buffer): the accumulators stay where the K loop left them,
+  // a barrier sees every wave out of its K loop -- the input rows are dead --, then the epilogues write their tiles straight over the
+  // input (store_tile_x3) and a second barrier publishes them; waves without a tile in this GEMM reach the same two barriers from
+  // the branch below.  (Rounds 3's form parked the finished, already split tiles in 48 registers across the barrier: they ended in
+  // scratch, and every layer re-read 18 x 16 B per lane behind the epilogue's global stores -- round 4, found with in-kernel stamps
+  // on csrc/refl_train_x3.hip, where the same change took a third off the backward.)
+  auto GC = [&](const f32x4* wbase, const KSegs ks, const int tiles, auto init, auto epi) {
+    const f32x4* nwp; int nnb;
+    next_stream(call, nwp, nnb);
+    ++call;
+    gemm_tiles_x3_ring2<NW, RING, NACC>(lds, IS, ks, wbase, tiles, wave, lane, ring, nwp, nnb, init,
+                                        [&](int ot, auto im_c, const f32x16& acc) __attribute__((always_inline)) {
+          if (decltype(im_c)::value == 0) __syncthreads(); epi(ot, im_c, acc); });
+    if (wave >= tiles) __syncthreads();
     __syncthreads();
   };
   // epilogue operands of this wave's tile, both images, requested right before the K loop.  (The f32 kernel's refinement -- the NEXT GEMM's
@@ -181,8 +188,9 @@ __global__ __launch_bounds__(512, 1) void neus_train_bwd_x3_kernel(const TrainBw
       const int n_ot = bd.tc[l - 1];
       const float* const t_c = tp.C[l];
       float* const t_dc = tp.DC[l - 1];
-      G(wx + bd.offCB[l], ks, n_ot,
-        [&](int ot, int im, f32x16& acc) {
+      GC(wx + bd.offCB[l], ks, n_ot,
+        [&](int ot, auto im_c, f32x16& acc) __attribute__((always_inline)) {
+          constexpr int im = decltype(im_c)::value; (void)im;
           if (2 * pair + im < n_tiles) tf_load_acc(t_c, 2 * pair + im, n_ot, ot, lane, au[im]);
           else {
 #pragma unroll
@@ -190,21 +198,22 @@ __global__ __launch_bounds__(512, 1) void neus_train_bwd_x3_kernel(const TrainBw
           }
           init_zero(acc);
         },
-        [&](int ot, int im, const f32x16& acc) {
+        [&](int ot, auto im_c, const f32x16& acc) __attribute__((always_inline)) {
+          constexpr int im = decltype(im_c)::value; (void)im;
           float v[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) v[i] = acc[i] * act_bwd_from_out<ACT_RELU>(au[im][i]);
           if (2 * pair + im < n_tiles) tf_store_acc(t_dc, 2 * pair + im, n_ot, ot, lane, v);
-          split_tile_x3(v, o[im]);
+          store_tile_x3(lds + (size_t)im * IS, X0 + 6 * ot, lane, v);
         });
-      commit(n_ot);
     }
     {
       const int in_rows = 6 * bd.tc[0];
       rowdot_x3<3>(ldsi, X0, in_rows, wf + bd.offCBnrm, sm->part[img], w4, lane);
       G(wx + bd.offCBfeat, KSegs{X0, in_rows, 0, 0}, bd.feat_tiles,
-        [&](int, int, f32x16& acc) { init_zero(acc); },
-        [&](int ot, int im, const f32x16& acc) {
+        [&](int, auto, f32x16& acc) __attribute__((always_inline)) { init_zero(acc); },
+        [&](int ot, auto im_c, const f32x16& acc) __attribute__((always_inline)) {
+          constexpr int im = decltype(im_c)::value; (void)im;
           f32x4* sv = save0 + (size_t)im * per_img + (size_t)feat_slot * 64;
 #pragma unroll
           for (int q = 0; q < 4; ++q) st_stream(sv + (ot * 4 + q) * 64 + lane, (f32x4){acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
@@ -266,8 +275,9 @@ __global__ __launch_bounds__(512, 1) void neus_train_bwd_x3_kernel(const TrainBw
       const float* const t_u = tp.U[l + 1];
       const float* const t_gh = tp.GH[l];
       float* const t_ud = tp.UD[l + 1];
-      G(wx + bd.offT[l], ks, n_ot,
-        [&](int ot, int im, f32x16& acc) {
+      GC(wx + bd.offT[l], ks, n_ot,
+        [&](int ot, auto im_c, f32x16& acc) __attribute__((always_inline)) {
+          constexpr int im = decltype(im_c)::value; (void)im;
           if (2 * pair + im < n_tiles) {
             tf_load_acc(t_u, 2 * pair + im, n_ot, ot, lane, au[im]);
             tf_load_acc(t_gh, 2 * pair + im, n_ot, ot, lane, ab[im]);
@@ -277,7 +287,8 @@ __global__ __launch_bounds__(512, 1) void neus_train_bwd_x3_kernel(const TrainBw
           }
           init_zero(acc);
         },
-        [&](int ot, int im, const f32x16& acc) {
+        [&](int ot, auto im_c, const f32x16& acc) __attribute__((always_inline)) {
+          constexpr int im = decltype(im_c)::value; (void)im;
           f32x4* sv = save0 + (size_t)im * per_img + (size_t)l * 4 * MT * 64;
           float v[16], s[16];
 #pragma unroll
@@ -290,9 +301,8 @@ __global__ __launch_bounds__(512, 1) void neus_train_bwd_x3_kernel(const TrainBw
 #pragma unroll
           for (int q = 0; q < 4; ++q) st_stream(sv + (ot * 4 + q) * 64 + lane, (f32x4){s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3]});
           if (2 * pair + im < n_tiles) tf_store_acc(t_ud, 2 * pair + im, n_ot, ot, lane, v);
-          split_tile_x3(v, o[im]);
+          store_tile_x3(lds + (size_t)im * IS, X0 + 6 * ot, lane, v);
         });
-      commit(n_ot);
     }
 
     // ---------------- reverse sweep ----------------
@@ -316,8 +326,9 @@ __global__ __launch_bounds__(512, 1) void neus_train_bwd_x3_kernel(const TrainBw
       const float* const t_u = tp.U[l];
       float* const t_ab = tp.AB[l - 1];
       const f32x4* const wrow = wf + bd.offWrow;
-      G(wx + (top ? bd.offBtop : bd.offB[l]), ks, n_ot,
-        [&](int ot, int im, f32x16& acc) {
+      GC(wx + (top ? bd.offBtop : bd.offB[l]), ks, n_ot,
+        [&](int ot, auto im_c, f32x16& acc) __attribute__((always_inline)) {
+          constexpr int im = decltype(im_c)::value; (void)im;
           const f32x4* sv = save0 + (size_t)im * per_img + (size_t)(l - 1) * 4 * MT * 64;
           if (2 * pair + im < n_tiles) tf_load_acc(t_u, 2 * pair + im, n_ot, ot, lane, au[im]);
           else {
@@ -336,14 +347,14 @@ __global__ __launch_bounds__(512, 1) void neus_train_bwd_x3_kernel(const TrainBw
             for (int i = 0; i < 16; ++i) acc[i] *= gs;
           } else init_zero(acc);
         },
-        [&](int ot, int im, const f32x16& acc) {
+        [&](int ot, auto im_c, const f32x16& acc) __attribute__((always_inline)) {
+          constexpr int im = decltype(im_c)::value; (void)im;
           float v[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) v[i] = acc[i] * act_bwd_from_out<ACT_SOFTPLUS100>(au[im][i]) + ab[im][i];
           if (2 * pair + im < n_tiles) tf_store_acc(t_ab, 2 * pair + im, n_ot, ot, lane, v);
-          split_tile_x3(v, o[im]);
+          store_tile_x3(lds + (size_t)im * IS, X0 + 6 * ot, lane, v);
         });
-      commit(n_ot);
     }
   }
 }
