@@ -101,6 +101,23 @@ def _time_gpu(fn, n, warm=1):
     return e0.elapsed_time(e1) / n * 1e-3
 
 
+def _time_windows(fn, n, windows=3, warm=0, clock=False):
+    """`windows` back-to-back windows of n calls each -> (median seconds per call, [ms per call of every window], kernel clock of the
+    median window | None).  Every secondary leg reports the MEDIAN and lists all windows (round 3 reported the fastest)."""
+    from vqnerf_release_amd import _C
+    res = []
+    for w in range(windows):
+        if clock:
+            _C.KernelClock.reset(True)
+        dt = _time_gpu(fn, n, warm=warm if w == 0 else 0)
+        res.append((dt, _C.KernelClock.summary() if clock else None))
+    if clock:
+        _C.KernelClock.reset(False)
+    order = sorted(range(windows), key=lambda i: res[i][0])
+    mid = order[(windows - 1) // 2]
+    return res[mid][0], [r[0] * 1e3 for r in res], res[mid][1]
+
+
 DECOMP_INI = dict(
     model='vq_nfr', data_type='nerf', white_bg='True', mlp_width=128, conv_width=256, pos_enc='True', n_freqs_xyz=10,
     n_freqs_ldir=4, n_freqs_vdir=4, light_h=16, light_init_val=0.5, num_embed=15, commitment_cost=0.1, vq_loss_weight=1.0,
@@ -138,15 +155,8 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
         opt.step()
     for _ in range(3):          # (the caching allocator settles on the step's workspaces over the first few steps)
         geo_train()
-    # two windows of 6 steps, the faster one: a one-off stall of 40-90 ms lands somewhere in steps 4-25 of a training process (measured
-    # with every contraction / kernel choice, scripts/debug/wgrad_f32_time.py: allocator growth and first-use code loading, not the step)
-    dt, clk = None, None
-    for _ in range(2):
-        _C.KernelClock.reset(True)
-        dtw = _time_gpu(geo_train, 6, warm=0)
-        if dt is None or dtw < dt:
-            dt, clk = dtw, _C.KernelClock.summary()
-    _C.KernelClock.reset(False)
+    # three windows of 6 steps: the median (all listed)
+    dt, geo_windows, clk = _time_windows(geo_train, 6, windows=3, clock=True)
     S_c, S_f = 64 + 48, 128
     # algorithmic FLOPs of one step: coarse SDF passes + [fwd, reverse sweep, tangent, reverse, 2 weight
     # contractions] of the SDF net + [fwd, reverse, weight contraction] of the colour net, per fine sample
@@ -164,9 +174,12 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     kfrac = {k: {'ms': clk[k][1] / 6, 'tflops': kflop[k] / (clk[k][1] / 6 * 1e-3) / 1e12,
                  'frac_of_f32_mfma_peak': kflop[k] / (clk[k][1] / 6 * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS} for k in kflop if k in clk}
     for k, v in kfrac.items():               # exact-split kernels: the pipe they run on is the bf16 one, six MFMAs per product
-        if k.endswith('_x3'):
-            v['frac_of_bf16_mfma_peak_at_6_mfma_per_product'] = 6.0 * v['tflops'] / BF16_MFMA_PEAK_TFLOPS
-    out['geo_train'] = {'rays_per_s': B / dt, 'ms_per_step': dt * 1e3, 'batch_rays': B,
+        if k.endswith('_x3'):                # -> `frac` is the bf16-pipe fraction; the f32-equivalent one stays as the secondary key
+            v['frac'] = v['frac_of_bf16_mfma_peak_at_6_mfma_per_product'] = 6.0 * v['tflops'] / BF16_MFMA_PEAK_TFLOPS
+            v['bound'] = 'bf16 mfma (6 issued per f32 product)'
+        else:
+            v['frac'] = v['frac_of_f32_mfma_peak']
+    out['geo_train'] = {'rays_per_s': B / dt, 'ms_per_step': dt * 1e3, 'windows_ms_per_step': geo_windows, 'batch_rays': B,
                         'achieved_tflops': flop / dt / 1e12, 'frac_of_f32_mfma_peak': flop / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
                         'kernel_ms_per_step': {k: v[1] / 6 for k, v in sorted(clk.items())}, 'kernel_roofline': kfrac,
                         'device_ms_outside_listed_kernels': dt * 1e3 - sum(v[1] / 6 for v in clk.values()),
@@ -188,17 +201,9 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
         out['geo_train']['wgrad_mode'] = wg_default
         _tp.wgrad_mode('f32')
         geo_train()
-        # (two windows, the faster one: a one-off stall of 40-90 ms lands somewhere in steps 12-25 of a training process -- measured in
-        # either contraction mode, scripts/debug/wgrad_f32_time.py -- and this leg's steps fall right there)
-        dt3, clk3 = None, None
-        for _ in range(2):
-            _C.KernelClock.reset(True)
-            dtw = _time_gpu(geo_train, 6, warm=0)
-            if dt3 is None or dtw < dt3:
-                dt3, clk3 = dtw, _C.KernelClock.summary()
-        _C.KernelClock.reset(False)
+        dt3, w3, clk3 = _time_windows(geo_train, 6, windows=3, clock=True)
         _tp.wgrad_mode(wg_default)
-        out['geo_train_wgrad_f32'] = {'rays_per_s': B / dt3, 'ms_per_step': dt3 * 1e3, 'achieved_tflops': flop / dt3 / 1e12,
+        out['geo_train_wgrad_f32'] = {'rays_per_s': B / dt3, 'ms_per_step': dt3 * 1e3, 'windows_ms_per_step': w3, 'achieved_tflops': flop / dt3 / 1e12,
                                       'frac_of_f32_mfma_peak': flop / dt3 / 1e12 / F32_MFMA_PEAK_TFLOPS,
                                       'wgrad_ms_per_step': clk3['vqn_wgrad_partials'][1] / 6,
                                       'note': 'the f32-input MFMA contraction (bit-for-bit a k-ordered fmaf chain), opt-in since round 3'}
@@ -212,8 +217,8 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
         g_runner, g_step = geo_train_setup(dev, 0, B, graph=True)
         for _ in range(g_runner.GRAPH_WARMUP + 2):
             g_step()
-        dtg = min(_time_gpu(g_step, 10, warm=0) for _ in range(2))       # (two windows, the faster: see PRIME_LAUNCHES)
-        out['geo_train_graph'] = {'rays_per_s': B / dtg, 'ms_per_step': dtg * 1e3, 'batch_rays': B, 'captured': g_runner._cap is not None,
+        dtg, wg, _ = _time_windows(g_step, 10, windows=3)
+        out['geo_train_graph'] = {'rays_per_s': B / dtg, 'ms_per_step': dtg * 1e3, 'windows_ms_per_step': wg, 'batch_rays': B, 'captured': g_runner._cap is not None,
                                   'achieved_tflops': flop / dtg / 1e12, 'frac_of_f32_mfma_peak': flop / dtg / 1e12 / F32_MFMA_PEAK_TFLOPS,
                                   'note': 'geo_train with the whole optimisation step (up-sampling passes, forward / backward tile programs, '
                                           'compositing, weight-gradient contractions, weight-norm chain rule, capturable Adam) replayed from one '
@@ -431,30 +436,47 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     del rel
     small = points(2048)
     model.get_codebook(); _ = model.light            # lazily created variables must exist before the optimiser is built
-    opt2 = torch.optim.Adam(model.trainable_variables, lr=5e-4, eps=1e-7, amsgrad=True)
-    tr = train_nfr.Trainer(model, opt2)
-    dt = _time_gpu(lambda: tr.train_iter(small, global_bs=1024), 5, warm=2)
+    # Keras Adam(amsgrad) as the reference builds it (train_nfr.py:121-139; epsilon outside the debiased root: optim.HipAdam(eps_mode='keras'))
+    opt2, _, clip2 = train_nfr.make_optimizer(config_from_dict(DECOMP_INI), model.trainable_variables)
+    tr = train_nfr.Trainer(model, opt2, clip=clip2)
+    dt, w_small, _ = _time_windows(lambda: tr.train_iter(small, global_bs=1024), 5, windows=3, warm=2)
     TRAIN_FLOP_PER_POINT = 3 * 2.0 * (enc_macs + head_macs)      # forward + reverse sweep + weight-gradient contraction of every Dense layer
     tfrac = lambda n, t: {'achieved_tflops': TRAIN_FLOP_PER_POINT * n / t / 1e12, 'flop_per_point': TRAIN_FLOP_PER_POINT,
-                          'frac_of_f32_mfma_peak': TRAIN_FLOP_PER_POINT * n / t / 1e12 / F32_MFMA_PEAK_TFLOPS}
-    out['decomp_train'] = {'points_per_s': 2048 / dt, 'ms_per_step': dt * 1e3, 'batch_points': 2048, 'roofline': tfrac(2048, dt),
-                           'note': 'all HIP: encoder / heads forward + backward tile programs, weight-gradient contraction, fused '
-                                   'shading forward + backward, VQ assign / EMA statistics; torch for the loss, Adam and glue '
-                                   '(launch-latency-bound at the reference batch of 2048 points)'}
+                          'frac_of_f32_mfma_peak': TRAIN_FLOP_PER_POINT * n / t / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                          # the pipe the step actually runs on: forward, backward and contraction as exact bf16 piece triples = six issued
+                          # bf16 MFMAs per f32 product
+                          'frac_of_bf16_mfma_peak_at_6_mfma_per_product': 6.0 * TRAIN_FLOP_PER_POINT * n / t / 1e12 / BF16_MFMA_PEAK_TFLOPS}
+    train_note = ('all HIP: encoder + continuous heads and the VQ heads forward / backward on the dedicated exact-split kernels '
+                  '(vqn_refl_train_fwd_x3 / _bwd_x3, round 4; the interpreted tile programs of rounds 1-3: VQN_REFL_TRAIN=prog), batched '
+                  'weight-gradient contractions (bf16x3 on the matrix pipe, the 1..3-output last layers as a vector-ALU stream), fused shading '
+                  'forward + backward, VQ assign / EMA statistics, loss terms, Keras-Adam as one launch; torch for the glue')
+    out['decomp_train'] = {'points_per_s': 2048 / dt, 'ms_per_step': dt * 1e3, 'windows_ms_per_step': w_small, 'batch_points': 2048,
+                           'roofline': tfrac(2048, dt), 'note': train_note + ' (eager: launch-latency-bound at the reference batch of 2048 points)'}
     big_tr = points(262144)
-    dt = _time_gpu(lambda: tr.train_iter(big_tr, global_bs=262144), 3, warm=1)
-    out['decomp_train_256k'] = {'points_per_s': 262144 / dt, 'ms_per_step': dt * 1e3, 'batch_points': 262144, 'roofline': tfrac(262144, dt),
-                                'note': 'same step on a 128x larger batch (what a data-parallel / large-batch run would use)'}
+    dt, w_big, clk_big = _time_windows(lambda: tr.train_iter(big_tr, global_bs=262144), 3, windows=3, warm=1, clock=True)
+    n_big = 262144
+    kf = {'vqn_refl_train_fwd_x3': 2.0 * (enc_macs + head_macs) * n_big, 'vqn_refl_train_bwd_x3': 2.0 * (enc_macs + head_macs) * n_big,
+          'vqn_wgrad_partials_x3': 2.0 * (enc_macs + head_macs) * n_big}
+    kroof = {}
+    for k, fl in kf.items():
+        if k in clk_big:
+            ms = clk_big[k][1] / 3
+            kroof[k] = {'ms': ms, 'tflops_f32_equivalent': fl / (ms * 1e-3) / 1e12, 'bound': 'bf16 mfma (6 issued per f32 product)',
+                        'frac': 6.0 * fl / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 'frac_of_f32_mfma_peak': fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
+    out['decomp_train_256k'] = {'points_per_s': n_big / dt, 'ms_per_step': dt * 1e3, 'windows_ms_per_step': w_big, 'batch_points': n_big,
+                                'roofline': tfrac(n_big, dt), 'kernel_ms_per_step': {k: v[1] / 3 for k, v in sorted(clk_big.items())},
+                                'kernel_roofline': kroof,
+                                'note': 'same step on a 128x larger batch (what a data-parallel / large-batch run would use); ' + train_note}
     # the same reference-size step captured once into a HIP graph and replayed (Trainer(graph=True)); last, as it switches
     # the model to its all-foreground statement
     opt3, _, clip3 = train_nfr.make_optimizer(config_from_dict(DECOMP_INI), model.trainable_variables, capturable=True)
     tr_g = train_nfr.Trainer(model, opt3, clip=clip3, graph=True)
-    # (three windows of 20 replays, the fastest: the capture stream's queue has a one-off launch-bookkeeping stall of its own, PRIME_LAUNCHES)
-    dt = min(_time_gpu(lambda: tr_g.train_iter(small, global_bs=1024), 20, warm=(train_nfr.Trainer.GRAPH_WARMUP + 2) if w == 0 else 0) for w in range(3))
-    out['decomp_train_graph'] = {'points_per_s': 2048 / dt, 'ms_per_step': dt * 1e3, 'batch_points': 2048, 'roofline': tfrac(2048, dt),
-                                 'captured': tr_g._captured is not None,
+    dt, w_graph, _ = _time_windows(lambda: tr_g.train_iter(small, global_bs=1024), 20, windows=3, warm=train_nfr.Trainer.GRAPH_WARMUP + 2)
+    out['decomp_train_graph'] = {'points_per_s': 2048 / dt, 'ms_per_step': dt * 1e3, 'windows_ms_per_step': w_graph, 'batch_points': 2048,
+                                 'roofline': tfrac(2048, dt), 'captured': tr_g._captured is not None,
                                  'note': 'decomp_train with the whole step (forward, loss, backward, EMA codebook move, Adam) '
-                                         'replayed from one captured HIP graph'}
+                                         'replayed from one captured HIP graph; one 32-point image per workgroup and one workgroup row per head '
+                                         '(64 point tiles x 3 heads on 256 CUs)'}
 
     # ---- standalone VQ nearest-code assignment + EMA statistics (HBM-bound) ----
     Nv, D, K = 1 << 20, 256, 15
@@ -488,6 +510,16 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     out['vq_assign_k64']['rows_near_codes'] = {'achieved': by_a64 / t_n64 / 1e9, 'frac': by_a64 / t_n64 / 1e9 / 8000.0, 'ms': t_n64 * 1e3,
                                                'note': 'rows = code + 5 % noise, normalised; the headline of this entry keeps the uniform rows of rounds 1-2'}
     del near
+    # SURVEY 8(d)'s rows: L2-normalised ENCODER outputs (the reflectance encoder on random surface points), the codebook cut from such
+    # rows (what the k-means initialisation hands the VQ stage)
+    with torch.no_grad():
+        xyz_e = torch.nn.functional.normalize(torch.randn(Nv, 3, device=dev), dim=-1) * (0.5 + 0.5 * torch.rand(Nv, 1, device=dev))
+        enc_rows = _C.l2_normalize_rows(model._pred_enc_at(xyz_e).contiguous())
+        C_enc = enc_rows[torch.randperm(Nv, device=dev)[:K64]].t().contiguous()
+    t_e64 = _time_gpu(lambda: _C.vq_assign(enc_rows, C_enc, want_quant=False), 10)
+    out['vq_assign_k64']['rows_encoder_outputs'] = {'achieved': by_a64 / t_e64 / 1e9, 'frac': by_a64 / t_e64 / 1e9 / 8000.0, 'ms': t_e64 * 1e3,
+                                                    'note': 'SURVEY 8(d) rows: l2-normalised outputs of the (random-init) encoder, codes = 64 of them'}
+    del enc_rows, xyz_e
     xr = torch.rand(Nv, D, device=dev)                       # un-normalised rows: the fused quantiser normalises them itself
     from vqnerf_release_amd.decomp.nerfactor.networks.vq_layers import VectorQuantizerEMA
     vql = VectorQuantizerEMA(embedding_dim=D, num_embeddings=K64, commitment_cost=0.1, seed=0).to(dev)
@@ -564,14 +596,18 @@ def _max_over_ranks(x, dev, world, backend):
     return float(t.item())
 
 
-PRIME_LAUNCHES = 4600      # a process's first ~4,100 kernel launches end in a one-off ~100 ms stall (scripts/debug/step_trace.py: step 13 of
-                           # the geo trainer, memory reservation flat -- the runtime's launch bookkeeping, not the step)
+PRIME_LAUNCHES = 4600      # Round 3 primed the training legs past a one-off ~100 ms stall around a process's 4,100th clocked launch.  Its cause
+                           # (round 4, scripts/debug/launch_stall.py): not launches -- 12,000 plain launches of either path show no stall --
+                           # but live HIP EVENTS: the runtime extends its event pool with a stall of tens of ms (37 ms at the 2,400th live
+                           # event), and _C.KernelClock kept two per clocked call alive.  The clock now pools its events (reserved up front
+                           # in _timed_steps); the priming stays as a belt (allocator growth of the first steps).
 
 
 def _timed_steps(fn, steps, warmup, dev, world, backend, prime=0):
     """W untimed + K timed calls bracketed by barrier + synchronize; returns (max-over-ranks seconds, kernel clock of the K calls).
     prime: extra untimed calls BEFORE the W warm-up calls, to carry a training process past its one-off launch-count stall."""
     from vqnerf_release_amd import _C
+    _C.KernelClock.reserve(4096)                # the timed region creates no events (see PRIME_LAUNCHES)
     for _ in range(prime):
         fn()
 
@@ -621,7 +657,7 @@ def geo_train_setup(dev, rank, batch_rays=2560, graph=False):
     return runner, step
 
 
-def decomp_train_setup(dev, rank, world, batch_points=2048, graph=False):
+def decomp_train_setup(dev, rank, world, batch_points=2048, graph=False, capturable=False):
     """The VQ-stage trainer (train_nfr.Trainer: n_rays_per_step = 1024 pixel pairs = 2048 surface points per rank, Keras-Adam with
     amsgrad; under N ranks the [counts || dw] codebook statistics are summed in the middle of the forward pass and the gradient
     bucket after the backward pass, the loss normaliser is the global batch)."""
@@ -639,8 +675,8 @@ def decomp_train_setup(dev, rank, world, batch_points=2048, graph=False):
         opt, _, clip = train_nfr.make_optimizer(config_from_dict(DECOMP_INI), model.trainable_variables, capturable=True)
         tr = train_nfr.Trainer(model, opt, clip=clip, graph=True)
     else:
-        opt = torch.optim.Adam(model.trainable_variables, lr=5e-4, eps=1e-7, amsgrad=True)
-        tr = train_nfr.Trainer(model, opt)
+        opt, _, clip = train_nfr.make_optimizer(config_from_dict(DECOMP_INI), model.trainable_variables, capturable=capturable)
+        tr = train_nfr.Trainer(model, opt, clip=clip)
     batch = synthetic_points(batch_points, dev, np.random.default_rng(100 + rank))      # this rank's points
     return model, tr, (lambda: tr.train_iter(batch, global_bs=(batch_points // 2) * world))
 
@@ -657,6 +693,45 @@ def synthetic_points(n, dev, rng):
     return (['v'] * 1, torch.zeros(n, 2, device=dev), T(np.tile(np.array([[0, 0, 4.0]], np.float32), (n, 1))),
             torch.zeros(n, 3, device=dev), T(rng.uniform(0, 1, (n, 3)).astype(np.float32)), one, one.clone(),
             T(xyz * rng.uniform(0.5, 1.0, (n, 1)).astype(np.float32)), T(nrm), lvis)
+
+
+def dp_graph_selfcheck(dev, rank, world, backend, steps=2):
+    """Eager data-parallel reflectance steps against the graph-segment replay of the same steps (train_nfr.Trainer(graph=True) under
+    N ranks: parallel.SegmentedCapture), from the same state, on this run's ranks and backend: GRAPH_WARMUP eager steps (both trainers
+    take them eagerly), the capturing step, then `steps` replays -- parameters, codebook and EMA state compared bit for bit on every
+    rank, the verdict reduced over ranks (MIN).  Never raises: an exception is part of the report."""
+    import torch.distributed as dist
+    rep = {'steps_compared': None, 'bit_identical': False}
+    try:
+        from vqnerf_release_amd.decomp.nerfactor import train_nfr
+        n_calls = train_nfr.Trainer.GRAPH_WARMUP + 1 + steps
+        m_e, tr_e, step_e = decomp_train_setup(dev, rank, world, graph=False, capturable=True)
+        for _ in range(n_calls):
+            step_e()
+        m_g, tr_g, step_g = decomp_train_setup(dev, rank, world, graph=True)
+        for _ in range(n_calls):
+            step_g()
+        torch.cuda.synchronize()
+        same = tr_g._captured is not None
+        worst = 0.0
+        for a, b in zip([m_e._codebook] + list(m_e.trainable_variables) + [m_e.vq_layer.ema_dw.hidden, m_e.vq_layer.ema_cluster_size.hidden],
+                        [m_g._codebook] + list(m_g.trainable_variables) + [m_g.vq_layer.ema_dw.hidden, m_g.vq_layer.ema_cluster_size.hidden]):
+            if not torch.equal(a.detach(), b.detach()):
+                same = False
+                worst = max(worst, float((a.detach() - b.detach()).abs().max()))
+        flag = torch.tensor([1.0 if same else 0.0], device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        rep.update(steps_compared=n_calls, bit_identical=bool(flag.item() == 1.0), captured=tr_g._captured is not None,
+                   graph_segments=len(tr_g._captured.graphs) if tr_g._captured is not None else 0, max_abs_diff_this_rank=worst)
+        del m_e, tr_e, step_e, m_g, tr_g, step_g
+    except Exception as e:                                      # noqa: BLE001
+        rep['error'] = repr(e)[:300]
+        try:                                                    # keep the ranks' collective sequences aligned
+            flag = torch.tensor([0.0], device=dev if backend == 'nccl' else 'cpu')
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        except Exception:                                       # noqa: BLE001
+            pass
+    return rep
 
 
 def dp_train_leg(dev, rank, world, backend, steps=10, warmup=3):
@@ -681,13 +756,18 @@ def dp_train_leg(dev, rank, world, backend, steps=10, warmup=3):
         out['decomp']['replicas_bit_identical_after_steps'] = True
     del model, tr, dstep
     # the same step replayed from HIP graphs: under N ranks three graphs with the two all-reduces between them
-    # (parallel.SegmentedCapture); guarded -- a failure here must not cost the run its headline line
-    # Under RCCL with more than one rank it runs only on request (VQN_BENCH_DP_GRAPH=1): it was validated on two gloo ranks sharing
-    # one card (tests/test_gpu_parallel.py, tests/test_gpu_bench.py) but never on a multi-GPU node, and a rank that hangs inside a
-    # collective here would take the whole line with it.
-    if world > 1 and backend != 'gloo' and os.environ.get('VQN_BENCH_DP_GRAPH') != '1':
-        out['decomp_graph'] = {'skipped': 'multi-rank RCCL: set VQN_BENCH_DP_GRAPH=1 to time the graph-segment replay of the DP step'}
+    # (parallel.SegmentedCapture).  Multi-rank RCCL: the run validates that path ITSELF before timing it -- the eager DP trainer and the
+    # graph-segment trainer step the same model from the same state on the same batches (same capturable Keras-Adam kernel on both
+    # sides), and every rank's parameters + codebook must agree bit for bit afterwards; only then are the graph legs timed, otherwise the
+    # line reports why not (the eager legs above are the fallback, the exit code stays 0).  VQN_BENCH_DP_GRAPH=0 skips the graph legs.
+    if world > 1 and backend != 'gloo' and os.environ.get('VQN_BENCH_DP_GRAPH') == '0':
+        out['dp_graph_selfcheck'] = {'skipped': 'VQN_BENCH_DP_GRAPH=0'}
         return out
+    if world > 1:
+        out['dp_graph_selfcheck'] = dp_graph_selfcheck(dev, rank, world, backend)
+        if not out['dp_graph_selfcheck'].get('bit_identical'):
+            out['decomp_graph'] = {'skipped': 'dp_graph_selfcheck did not pass: eager data-parallel legs only'}
+            return out
     try:
         model, tr, gstep2 = decomp_train_setup(dev, rank, world, graph=True)
         from vqnerf_release_amd.decomp.nerfactor import train_nfr
@@ -984,11 +1064,20 @@ def main():
             cores = len(os.sched_getaffinity(0))
         except Exception:
             pass
-        # a 1-GPU box shares its host: the CPU share of one GPU is 16 cores (more threads only oversubscribe)
-        cores = int(os.environ.get('VQN_CPU_THREADS', min(cores, 16)))
-        torch.set_num_threads(cores)
+        # every core this process may run on (os.cpu_count() / the affinity mask); the 16-thread figure -- the CPU share of
+        # one GPU of the box, what rounds 1-3 reported -- is measured beside it
+        cores_all = cores
+        cores = int(os.environ.get('VQN_CPU_THREADS', cores_all))
         cpu_call = lambda: og.render(p_sdf, p_col, torch.tensor(0.3), cfg, oc, dc, nc, fc, 2.0, background_rgb=torch.ones(1, 3),
                                      cos_anneal_ratio=1.0)
+        at16 = None
+        if cores > 16:
+            torch.set_num_threads(16)
+            cpu_call()
+            t0 = time.perf_counter()
+            cpu_call()
+            at16 = time.perf_counter() - t0
+        torch.set_num_threads(cores)
         cpu_call()                                                        # warm-up: one full call at the same batch
         times = []
         for _ in range(max(1, args.cpu_reps)):
@@ -1003,7 +1092,8 @@ def main():
                                   'sample': f'{n_cpu} rays spread over the whole 800x800 view (same weights) per oracle.geo.render call; '
                                             f'1 warm-up + {len(times)} timed calls, median {cpu_dt:.1f} s '
                                             f'(all: {", ".join("%.1f" % t for t in times)} s); torch {torch.__version__} CPU fp32, '
-                                            f'{cores} threads'}
+                                            f'{cores} threads (of {cores_all} available)',
+                                  'value_at_16_threads': (n_cpu / at16) if at16 else None}
         result['psnr_vs_oracle_db'] = -10.0 * math.log10(mse + 1e-20)
         result['psnr_sample'] = {'rays': n_cpu, 'frac_weight_sum_gt_0.5': float((ws_ref > 0.5).float().mean()),
                                  'frac_weight_sum_gt_0.9': float((ws_ref > 0.9).float().mean()),
@@ -1016,7 +1106,10 @@ def main():
         result['psnr_f16s_vs_oracle_db'] = -10.0 * math.log10(mse16 + 1e-20)
         result['psnr_x3_vs_oracle_db'] = -10.0 * math.log10(float(((got_x3 - ref['color_fine'].detach()) ** 2).mean()) + 1e-20)
         if not args.no_extras:
-            result['cpu_baseline_decomp'] = decomp_cpu_leg(dev, cores)
+            # the reference batch (2048 points) and a 65,536-point view share
+            result['cpu_baseline_decomp'] = decomp_cpu_leg(dev, cores, N=65536)
+            result['cpu_baseline_decomp']['at_2048_points'] = {k: v for k, v in decomp_cpu_leg(dev, cores, N=2048).items()
+                                                                if k in ('value', 'sample', 'gpu_points_per_s_same_sample', 'vq_idx_match_pct')}
     if extra:
         result['extra'] = extra
     print(json.dumps(result))

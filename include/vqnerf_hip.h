@@ -498,6 +498,16 @@ int vqn_wgrad_finalize(int count, const float* const* ws, const int32_t* n, cons
                        const int32_t* cols_valid, float* const* dst, const int64_t* dst_row_stride, const int64_t* dst_col_stride, const float* scale,
                        void* stream);
 
+/* Element-wise pieces of the reflectance training graph, one launch each (round 4; csrc/elementwise.hip).
+ * vqn_clip_preserve: y = x + (clip(x, lo, hi) - x), every step rounded -- tfp.math.clip_by_value_preserve_gradient in the
+ *   reference's own arithmetic (vq_nfr.py:731, :735-745); the gradient is the identity.
+ * vqn_ks_split_fwd: spec = ks basecolor, albedo = (1 - ks) basecolor (vq_nfr.py:590-592; basecolor [n, 3], ks [n, 1 | 3]);
+ * vqn_ks_split_bwd: their adjoints (g_albedo / g_spec may be NULL = zero). */
+int vqn_clip_preserve(const float* x, int64_t n, float lo, float hi, float* y, void* stream);
+int vqn_ks_split_fwd(const float* basecolor, const float* ks, int ks_channels, int64_t n, float* albedo, float* spec, void* stream);
+int vqn_ks_split_bwd(const float* basecolor, const float* ks, int ks_channels, int64_t n, const float* g_albedo, const float* g_spec,
+                     float* g_basecolor, float* g_ks, void* stream);
+
 /* Thin contractions (round 4; csrc/wgrad_thin.hip): out[r][f] = sum_p A[r][p] B[f][p] for rows r < a_rows[i] <= 8 of ONE feature tile
  * (a_t0[i]) of A against b_nt[i] feature tiles of B -- the weight gradient of a reflectance head's 1..3-output last layer
  * (nfr_unit.py:110-129).  A stream over B on the vector ALU (f32 FMA chains in point order), no matrix pipe.  Partial blocks

@@ -63,12 +63,31 @@ def _stream():
 
 class KernelClock:
     """Optional per-kernel device timing: HIP events recorded on the stream the kernel is launched on
-    (torch's current stream).  Off by default; bench.py switches it on for the timed region."""
+    (torch's current stream).  Off by default; bench.py switches it on for the timed region.
+    Events are POOLED: a process that keeps creating event pairs (two per clocked call, all alive until the summary) runs into a
+    one-off stall of tens of ms when the runtime extends its event pool -- scripts/debug/launch_stall.py: 37 ms at the 2,400th live
+    event, none for plain launches -- which round 3's bench had to prime its training legs past.  reset() hands the window's events
+    back to the free list instead of dropping them."""
     enabled = False
     pairs = {}
+    _free = []
+
+    @classmethod
+    def _event(cls):
+        return cls._free.pop() if cls._free else torch.cuda.Event(enable_timing=True)
+
+    @classmethod
+    def reserve(cls, n):
+        """create n events now (outside any timed region)"""
+        while len(cls._free) < n:
+            cls._free.append(torch.cuda.Event(enable_timing=True))
 
     @classmethod
     def reset(cls, enabled=True):
+        for v in cls.pairs.values():
+            for a, b in v:
+                cls._free.append(a)
+                cls._free.append(b)
         cls.enabled = enabled
         cls.pairs = {}
 
@@ -88,12 +107,12 @@ class _clock:
         if KernelClock.enabled and not self.on:
             KernelClock.pairs.setdefault(self.name + ' [captured]', [])
         if self.on:
-            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0 = KernelClock._event()
             self.e0.record()
 
     def __exit__(self, *exc):
         if self.on:
-            e1 = torch.cuda.Event(enable_timing=True)
+            e1 = KernelClock._event()
             e1.record()
             KernelClock.pairs.setdefault(self.name, []).append((self.e0, e1))
         return False
@@ -829,3 +848,36 @@ def refl_train_bwd_x3(desc, wbuf_pieces, wbuf_f32, P, g_out, head_out, g_z_rows,
                                      _ptr(gz_rows_out), ctypes.c_int(int(run_heads)), ctypes.c_int(int(run_enc)), ctypes.c_int(int(split_heads)),
                                      _ptr(buf), ctypes.c_int64(buf.numel()), _stream())
     _check(rc, 'vqn_refl_train_bwd_x3')
+
+
+# -------------------------------------------------------------------------------------- element-wise pieces (round 4)
+def clip_preserve(x, lo, hi):
+    """x + (clip(x) - x) in one launch (vqn_clip_preserve)."""
+    _f32c(x, 'x')
+    y = torch.empty_like(x)
+    with _clock('vqn_clip_preserve'):
+        rc = lib().vqn_clip_preserve(_ptr(x), ctypes.c_int64(x.numel()), ctypes.c_float(lo), ctypes.c_float(hi), _ptr(y), _stream())
+    _check(rc, 'vqn_clip_preserve')
+    return y
+
+
+def ks_split_fwd(basecolor, ks):
+    _f32c(basecolor, 'basecolor'); _f32c(ks, 'ks')
+    albedo, spec = torch.empty_like(basecolor), torch.empty_like(basecolor)
+    with _clock('vqn_ks_split_fwd'):
+        rc = lib().vqn_ks_split_fwd(_ptr(basecolor), _ptr(ks), ctypes.c_int(ks.shape[1]), ctypes.c_int64(basecolor.shape[0]), _ptr(albedo),
+                                    _ptr(spec), _stream())
+    _check(rc, 'vqn_ks_split_fwd')
+    return albedo, spec
+
+
+def ks_split_bwd(basecolor, ks, g_albedo, g_spec):
+    for t in (g_albedo, g_spec):
+        if t is not None:
+            _f32c(t, 'gradient')
+    g_bc, g_ks = torch.empty_like(basecolor), torch.empty_like(ks)
+    with _clock('vqn_ks_split_bwd'):
+        rc = lib().vqn_ks_split_bwd(_ptr(basecolor), _ptr(ks), ctypes.c_int(ks.shape[1]), ctypes.c_int64(basecolor.shape[0]), _ptr(g_albedo),
+                                    _ptr(g_spec), _ptr(g_bc), _ptr(g_ks), _stream())
+    _check(rc, 'vqn_ks_split_bwd')
+    return g_bc, g_ks

@@ -130,6 +130,32 @@ class ShadeFunction(torch.autograd.Function):
         return (None, g_light) + tuple(flat)
 
 
+class _KsSplit(torch.autograd.Function):
+    """(spec, albedo) = (ks basecolor, (1 - ks) basecolor) (vq_nfr.py:590-592, nfr_unit.py:215-217): one launch forward, one backward
+    (vqn_ks_split_fwd / _bwd) instead of three + six framework launches; the same roundings as the torch statement."""
+
+    @staticmethod
+    def forward(ctx, ks, basecolor):
+        k, b = ks.detach().float().contiguous(), basecolor.detach().float().contiguous()
+        ctx.save_for_backward(k, b)
+        albedo, spec = _C.ks_split_fwd(b, k)
+        return spec, albedo
+
+    @staticmethod
+    def backward(ctx, g_spec, g_albedo):
+        k, b = ctx.saved_tensors
+        c = lambda t: None if t is None else t.float().contiguous()
+        g_bc, g_ks = _C.ks_split_bwd(b, k, c(g_albedo), c(g_spec))
+        return g_ks, g_bc
+
+
+def ks_split(ks, basecolor):
+    """-> (spec, albedo)"""
+    if ks.is_cuda and ks.dtype == torch.float32 and basecolor.dtype == torch.float32 and basecolor.shape[1] == 3 and ks.shape[1] in (1, 3):
+        return _KsSplit.apply(ks, basecolor)
+    return ks * basecolor, (1 - ks) * basecolor
+
+
 class _PackCache:
     def __init__(self):
         self.key, self.value = None, None
@@ -612,8 +638,7 @@ class Model(BrdfModel):
         rayo, rgb_m, xyz_m, normal_m = take_rows(mask, rayo), take_rows(mask, rgb), take_rows(mask, xyz), take_rows(mask, normal)
         lvis_m = self.fg_lvis(lvis, mask, xyz_m)
         z_bias, basecolor, ks, rough = self.enc_and_heads(xyz_m, 'out')
-        spec = ks * basecolor
-        albedo = (1 - ks) * basecolor
+        spec, albedo = ks_split(ks, basecolor)
         if not self._fused(xyz_m, albedo, spec, rough) and self.train_backend == 'hip' and xyz_m.is_cuda and mode == 'train':
             sh = self._shade_train(xyz_m, normal_m, rayo, lvis_m, [(albedo, spec, rough)])
             rgb_pred, normal_pred = sh['rgb'][0], sh['normal']
