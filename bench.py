@@ -88,6 +88,14 @@ def macs_per_point(sdf, col):
     return m_sdf, m_col
 
 
+_T0 = time.perf_counter()
+
+
+def _log(msg):
+    """progress on stderr (stdout carries the ONE JSON line): a run that stays silent for minutes looks hung to its driver"""
+    print(f'[bench {time.perf_counter() - _T0:7.1f} s] {msg}', file=sys.stderr, flush=True)
+
+
 def _time_gpu(fn, n, warm=1):
     for _ in range(warm):
         fn()
@@ -136,6 +144,7 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     out = {}
     rng = np.random.default_rng(1)
 
+    _log('leg: geo training step')
     # ---- geo training step: nerf.conf batch (2560 rays), L1 colour + 0.1 eikonal + 0.1 mask BCE, Adam ----
     B = 2560
     ds = SyntheticDataset(device=dev, n_images=8)
@@ -212,6 +221,7 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     finally:
         _tp.wgrad_mode(os.environ.get('VQN_WGRAD', 'bf16x3'))
 
+    _log('leg: the same training step through the Runner, captured once into a HIP gr')
     # ---- the same training step through the Runner, captured once into a HIP graph and replayed (Runner(graph=True)) ----
     try:
         g_runner, g_step = geo_train_setup(dev, 0, B, graph=True)
@@ -227,6 +237,7 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     except Exception as e:                                      # noqa: BLE001
         out['geo_train_graph'] = {'error': repr(e)[:300]}
 
+    _log('leg: the headline render on the split-precision kernels')
     # ---- the headline render on the split-precision kernels (renderer.matrix_mode = 'f16s'), opt-in mode ----
     Bq = 80000
     o_np, d_np = image_rays(np.arange(0, 800, 8))             # 100 rows spread over the view: hits and misses
@@ -272,6 +283,7 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     except Exception as e:                                      # noqa: BLE001
         out['geo_render_x3'] = {'error': repr(e)[:300]}
 
+    _log('leg: the literal "x64 samples" headline of the metric string')
     # ---- the literal "x64 samples" headline of the metric string: n_samples = 64, n_importance = 0 -- no
     # coarse pass at all (renderer.py:335), 169.0 MFLOP/ray -- one whole 800x800 view per step ----
     from vqnerf_release_amd.geo.models.renderer import NeuSRenderer
@@ -297,6 +309,7 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
                 'SDF + gradient + colour launch over 64 section mid-points per ray; `value` is the shipped 64 + 64 configuration'}
     del o64, d64, n64, f64
 
+    _log('leg: light-visibility extraction')
     # ---- light-visibility extraction (gen_geo.py compute_vis): secondary rays surface -> light, occupancy only ----
     from vqnerf_release_amd.geo.gen_geo import GeoExtractor
     ex = GeoExtractor(ren, max_radius=2.0, light_h=16, max_rays=1 << 20)
@@ -334,6 +347,7 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
                           'note': 'all front-lit (point, light) pairs of a chunk in one batch; colour network skipped (weights_only); '
                                   'the reference walks 512 lights one by one with a host sync each (gen_geo.py:202-242)'}
 
+    _log('leg: reflectance model')
     # ---- reflectance model (vq_nfr): full-view inference and one training step ----
     model = get_model_class('vq_nfr')(config_from_dict(DECOMP_INI))
     model.build_nets(device=dev, seed=0).to(dev)
@@ -390,6 +404,7 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
                                              'peaks at half of it, transcendentals (rsq / rcp / sqrt: 9 per light for the two '
                                              'material sets together, counted) at an eighth; counters: valu_busy_frac 0.77'}},
         'kernel_launches_per_call': launches_per_call}
+    _log('leg: the same view on the split-precision MLP kernels')
     # ---- the same view on the split-precision MLP kernels (matrix_mode 'f16s': f16 hi/lo operands, 3 f16 MFMAs per product) ----
     with torch.no_grad():
         ref_pred = model.call(big, mode='vali')[0]
@@ -415,6 +430,7 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
         'max_abs_diff_vs_f32': {k: float((got_pred[k] - ref_pred[k]).abs().max()) for k in ('rgb', 'albedo', 'rough', 'vq_rgb')},
         'vq_idx_match_vs_f32_pct': 100.0 * float(same_code),
         'note': 'opt-in precision mode (model.matrix_mode = "f16s"); `value` and every other line are the f32 path'}
+    _log('leg: BASELINE.json configs[4]')
     # ---- BASELINE.json configs[4]: relighting one view under 16 probes (test.py pd_relit pass), f32 and split-precision MLP stacks ----
     model.novel_probes = {f'probe{i:02d}': torch.tensor(rng.uniform(0, 2, (16, 32, 3)).astype(np.float32), device=dev) for i in range(16)}
     rel = {}
@@ -453,7 +469,10 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     out['decomp_train'] = {'points_per_s': 2048 / dt, 'ms_per_step': dt * 1e3, 'windows_ms_per_step': w_small, 'batch_points': 2048,
                            'roofline': tfrac(2048, dt), 'note': train_note + ' (eager: launch-latency-bound at the reference batch of 2048 points)'}
     big_tr = points(262144)
-    dt, w_big, clk_big = _time_windows(lambda: tr.train_iter(big_tr, global_bs=262144), 3, windows=3, warm=1, clock=True)
+    # (the step is timed WITHOUT the per-kernel clock -- two HIP events around each of its ~100 launches cost the 14 ms step ~0.4 ms --
+    #  and the kernel breakdown comes from one more, clocked window)
+    dt, w_big, _ = _time_windows(lambda: tr.train_iter(big_tr, global_bs=262144), 3, windows=3, warm=1)
+    _, _, clk_big = _time_windows(lambda: tr.train_iter(big_tr, global_bs=262144), 3, windows=1, clock=True)
     n_big = 262144
     kf = {'vqn_refl_train_fwd_x3': 2.0 * (enc_macs + head_macs) * n_big, 'vqn_refl_train_bwd_x3': 2.0 * (enc_macs + head_macs) * n_big,
           'vqn_wgrad_partials_x3': 2.0 * (enc_macs + head_macs) * n_big}
@@ -478,6 +497,7 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
                                          'replayed from one captured HIP graph; one 32-point image per workgroup and one workgroup row per head '
                                          '(64 point tiles x 3 heads on 256 CUs)'}
 
+    _log('leg: standalone VQ nearest-code assignment + EMA statistics')
     # ---- standalone VQ nearest-code assignment + EMA statistics (HBM-bound) ----
     Nv, D, K = 1 << 20, 256, 15
     x = torch.rand(Nv, D, device=dev)
@@ -492,6 +512,7 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     out['vq_ema_stats'] = {'rows': Nv, 'bound': 'hbm', 'achieved': by_s / t_s / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                            'frac': by_s / t_s / 1e9 / 8000.0, 'ms': t_s * 1e3}
 
+    _log('leg: BASELINE.json configs[2]')
     # ---- BASELINE.json configs[2]: the full decomposition with a 64-entry codebook (VERDICT r02 missing #2) ----
     K64 = 64
     cb64 = rng.uniform(0, 1, (K64, 256)).astype(np.float32)
@@ -923,7 +944,9 @@ def main():
     # HBM-side traffic of the dominant kernel, measured live by child profiler passes -- before this process initialises the GPU
     measured_traffic = (None, 'not measured (--no-traffic, --mode train or a multi-rank run)')
     if world == 1 and not args.no_traffic and args.mode == 'render' and os.environ.get('VQN_BENCH_NO_TRAFFIC', '0') in ('', '0'):
+        _log('roofline.traffic: two child rocprofv3 --pmc passes')
         measured_traffic = live_traffic(args.rays)
+        _log('traffic passes done')
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback)'
     local_rank %= torch.cuda.device_count()        # (rehearsals put several ranks on one card; the driver gives one GPU per rank)
     torch.cuda.set_device(local_rank)
@@ -944,6 +967,7 @@ def main():
     if args.mode == 'train':
         return main_train(args, dev, rank, world, backend)
 
+    _log('leg: random-init weights of the shipped architecture')
     # ---- random-init weights of the shipped architecture (same seed on every rank) ----
     torch.manual_seed(0)
     sdf = SDFNetwork(**FULL['sdf'])
@@ -955,6 +979,7 @@ def main():
     ren = NeuSRenderer(None, sdf, var, col, **FULL['renderer'])
     S_f = FULL['renderer']['n_samples'] + FULL['renderer']['n_importance']
 
+    _log('leg: this ranks rays')
     # ---- this rank's rays: the rows of its own 800x800 view (camera turned by rank * 2 pi / world), resident in HBM ----
     n_rows = (args.rays + 799) // 800
     rows = np.arange(n_rows) % 800
@@ -970,7 +995,9 @@ def main():
         with torch.no_grad():
             out_box[0] = ren.render(o, d, near, far, 2.0, perturb_overwrite=0, background_rgb=bg, cos_anneal_ratio=1.0)
 
+    _log('headline render: warm-up + timed steps')
     dt, clock = _timed_steps(step, args.steps, args.warmup, dev, world, backend)
+    _log('headline render done')
     out = out_box[0]
     assert torch.isfinite(out['color_fine']).all()
 
@@ -1048,10 +1075,12 @@ def main():
     if world == 1 and not args.no_extras:
         # before the CPU legs: a spun-up host thread pool slows the launch-heavy training steps that follow it
         extra = secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col)
+        _log('dp_train legs')
         extra['dp_train'] = dp_train_leg(dev, 0, 1, backend, steps=6, warmup=2)      # the same legs a multi-rank run reports
     if dp is not None:
         extra['dp_train'] = dp
     if world == 1 and not args.no_cpu_baseline:
+        _log('CPU baseline (oracle) legs')
         from oracle import geo as og                      # CPU-baseline leg only (test infrastructure)
         cfg = dict(og.FULL_CFG)
         p_sdf = {k: v.float() for k, v in state['sdf'].items()}
@@ -1064,20 +1093,25 @@ def main():
             cores = len(os.sched_getaffinity(0))
         except Exception:
             pass
-        # every core this process may run on (os.cpu_count() / the affinity mask); the 16-thread figure -- the CPU share of
-        # one GPU of the box, what rounds 1-3 reported -- is measured beside it
+        # Threads.  The affinity mask of a 1-GPU box of this pool lists the whole host (256 hardware threads) while the job's CPU share is 16
+        # (the pool's own sizing rule; 8 such jobs share the host): a call with 256 threads did not finish in 7 minutes (round 4, measured --
+        # oversubscription), so `value` is measured at the 16-thread share as in rounds 1-3, and one call at host / 8 = 32 threads is
+        # reported beside it.  VQN_CPU_THREADS overrides the first figure.
         cores_all = cores
-        cores = int(os.environ.get('VQN_CPU_THREADS', cores_all))
+        cores = int(os.environ.get('VQN_CPU_THREADS', min(cores_all, 16)))
         cpu_call = lambda: og.render(p_sdf, p_col, torch.tensor(0.3), cfg, oc, dc, nc, fc, 2.0, background_rgb=torch.ones(1, 3),
                                      cos_anneal_ratio=1.0)
-        at16 = None
-        if cores > 16:
-            torch.set_num_threads(16)
+        wide = min(cores_all, max(32, cores_all // 8)) if cores_all > cores else 0
+        t_wide = None
+        if wide > cores:
+            torch.set_num_threads(wide)
+            _log(f'CPU baseline: one call at {wide} threads')
             cpu_call()
             t0 = time.perf_counter()
             cpu_call()
-            at16 = time.perf_counter() - t0
+            t_wide = time.perf_counter() - t0
         torch.set_num_threads(cores)
+        _log(f'CPU baseline: {cores} threads')
         cpu_call()                                                        # warm-up: one full call at the same batch
         times = []
         for _ in range(max(1, args.cpu_reps)):
@@ -1092,8 +1126,8 @@ def main():
                                   'sample': f'{n_cpu} rays spread over the whole 800x800 view (same weights) per oracle.geo.render call; '
                                             f'1 warm-up + {len(times)} timed calls, median {cpu_dt:.1f} s '
                                             f'(all: {", ".join("%.1f" % t for t in times)} s); torch {torch.__version__} CPU fp32, '
-                                            f'{cores} threads (of {cores_all} available)',
-                                  'value_at_16_threads': (n_cpu / at16) if at16 else None}
+                                            f'{cores} threads (affinity mask: {cores_all})',
+                                  'wider': ({'threads': wide, 'value': n_cpu / t_wide, 'calls': '1 warm-up + 1 timed'} if t_wide else None)}
         result['psnr_vs_oracle_db'] = -10.0 * math.log10(mse + 1e-20)
         result['psnr_sample'] = {'rays': n_cpu, 'frac_weight_sum_gt_0.5': float((ws_ref > 0.5).float().mean()),
                                  'frac_weight_sum_gt_0.9': float((ws_ref > 0.9).float().mean()),
@@ -1106,6 +1140,7 @@ def main():
         result['psnr_f16s_vs_oracle_db'] = -10.0 * math.log10(mse16 + 1e-20)
         result['psnr_x3_vs_oracle_db'] = -10.0 * math.log10(float(((got_x3 - ref['color_fine'].detach()) ** 2).mean()) + 1e-20)
         if not args.no_extras:
+            _log('CPU baseline of the reflectance model')
             # the reference batch (2048 points) and a 65,536-point view share
             result['cpu_baseline_decomp'] = decomp_cpu_leg(dev, cores, N=65536)
             result['cpu_baseline_decomp']['at_2048_points'] = {k: v for k, v in decomp_cpu_leg(dev, cores, N=2048).items()

@@ -277,15 +277,18 @@ struct ShadeBwdArgs {
   int n_sets;
 };
 
-// d/d a2 of G1(c) = 2c / (c + sqrt|a2 + (1 - a2) c^2|), with divide_no_nan semantics
+// d/d a2 of G1(c) = 2c / (c + sqrt|a2 + (1 - a2) c^2|), with divide_no_nan semantics.  Two quarter-rate instructions (rsq, rcp): the
+// root and its reciprocal both come from one v_rsq (round 4: the backward's inner loop was bound by its 14 transcendentals per light)
 __device__ __forceinline__ void g1_and_da2(float c, float a2, float* g1, float* dg1) {
   const float q = a2 + (1.f - a2) * c * c;
-  const float s = __builtin_amdgcn_sqrtf(fabsf(q));
+  const float aq = fabsf(q);
+  const float rs = aq > 0.f ? __builtin_amdgcn_rsqf(aq) : 0.f;          // 1 / sqrt|q|   (0 where the root is 0)
+  const float s = aq * rs;                                              // sqrt|q|
   const float den = c + s;
   if (den == 0.f) { *g1 = 0.f; *dg1 = 0.f; return; }
   const float rden = __builtin_amdgcn_rcpf(den);
   *g1 = 2.f * c * rden;
-  const float ds = s > 0.f ? (q >= 0.f ? 1.f : -1.f) * (1.f - c * c) * 0.5f * __builtin_amdgcn_rcpf(s) : 0.f;
+  const float ds = (q >= 0.f ? 0.5f : -0.5f) * (1.f - c * c) * rs;
   *dg1 = -2.f * c * rden * rden * ds;
 }
 
@@ -345,8 +348,9 @@ __global__ __launch_bounds__(256) void brdf_shade_bwd_kernel(const ShadeBwdArgs 
       dx *= il; dy *= il; dz *= il;
       const float cosl = dx * nx + dy * ny + dz * nz;
       const float vis = (cosl > 0.f ? 1.f : 0.f) * vis4[k >> 2][k & 3];
-      il = inv_norm(dx, dy, dz);
-      const float wx = dx * il, wy = dy * il, wz = dz * il;
+      // (the forward normalises the light direction a second time, as the reference does -- microfacet.py:18 on top of shape.py:103-119;
+      //  a unit vector's second normalisation moves it by an ulp, which the GRADIENT does not need: one rsq and eight instructions less)
+      const float wx = dx, wy = dy, wz = dz;
       float hx = wx + ux, hy = wy + uy, hz = wz + uz;
       const float ih = inv_norm(hx, hy, hz);
       hx *= ih; hy *= ih; hz *= ih;
@@ -363,12 +367,12 @@ __global__ __launch_bounds__(256) void brdf_shade_bwd_kernel(const ShadeBwdArgs 
       for (int s = 0; s < 2; ++s)
         if (s < a.n_sets) {
           const float t = cos_m * cos_m * (a2[s] - 1.f) + 1.f;
-          const float pd = PI_F * t * t;
           float D = 0.f, dD = 0.f;
-          if (pd != 0.f) {
-            const float rpd = __builtin_amdgcn_rcpf(pd);
+          if (t != 0.f) {                                             // (pi t^2 != 0)
+            const float rt = __builtin_amdgcn_rcpf(t);
+            const float rpd = rt * rt * (1.f / PI_F);                 // 1 / (pi t^2): one reciprocal for D and its derivative
             D = a2[s] * rpd;
-            dD = (t - 2.f * a2[s] * cos_m * cos_m) * rpd * __builtin_amdgcn_rcpf(t);
+            dD = (t - 2.f * a2[s] * cos_m * cos_m) * rpd * rt;
           }
           float g1l, dg1l;
           g1_and_da2(cl, a2[s], &g1l, &dg1l);

@@ -372,17 +372,31 @@ __global__ __launch_bounds__(256) void codebook_prep_kernel(const float* __restr
 }
 
 // out[0] = -w log(min_{i != j} |c_i - c_j|), out[1] = the min, out[2..3] = its pair (i < j) as floats.  One workgroup; cb [D, K] (codes = columns).
+// (round 4: the codebook is staged in LDS first when it fits -- every thread walked its two columns through 256 dependent global
+//  loads, 65 us of the captured 2048-point step's 760; same fmaf chain over d, the same value bit for bit)
+constexpr int SIM_LDS_FLOATS = 12288;        // 48 KB: K <= 48 at D = 256
 __global__ __launch_bounds__(256) void sim_smooth_fwd_kernel(const float* __restrict__ cb, int D, int K, float w, float* __restrict__ out) {
   __shared__ float best[256];
   __shared__ int bi[256];
+  __shared__ float cbs[SIM_LDS_FLOATS];
   const int t = threadIdx.x;
+  const bool staged = D * K <= SIM_LDS_FLOATS;
+  if (staged) {
+    for (int e = t; e < D * K; e += 256) cbs[e] = cb[e];
+    __syncthreads();
+  }
+  const float* __restrict__ src = staged ? cbs : cb;
   float bd = INFINITY;
   int bp = 0;
   for (int pr = t; pr < K * K; pr += 256) {
     const int i = pr / K, j = pr - i * K;
     if (i >= j) continue;
     float s = 0.f;
-    for (int d = 0; d < D; ++d) { const float dl = cb[(size_t)d * K + i] - cb[(size_t)d * K + j]; s = fmaf(dl, dl, s); }
+    if (staged) {
+      for (int d = 0; d < D; ++d) { const float dl = cbs[d * K + i] - cbs[d * K + j]; s = fmaf(dl, dl, s); }
+    } else {
+      for (int d = 0; d < D; ++d) { const float dl = src[(size_t)d * K + i] - src[(size_t)d * K + j]; s = fmaf(dl, dl, s); }
+    }
     const float dist = sqrtf(s);
     if (dist < bd || !(dist == dist)) { bd = dist; bp = pr; }
   }

@@ -156,12 +156,17 @@ __global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(const float* __restric
 // the step and parks the pieces in LDS (3 KB per tile, two step buffers), every wave then reads all eight tiles' pieces from there
 // (24 ds_read_b128 per step and wave).  Without it each wave fetches all of B itself, half a 128-byte line per instruction, and the
 // L2 -> L1 traffic (B four times over) binds the launch at 2.5x its matrix time.  One barrier per step.
-template <bool FULL>          // FULL: a_nt == b_nt == 8 -- no guards in the instruction stream
+// NOT = output tiles per wave: 2 (a_nt up to 8), or 1 for problems of a_nt <= 4 -- half the accumulators (128 registers), so that TWO
+// workgroups share a CU and one's operand splits, LDS parking and barrier waits run under the other's MFMAs (round 4: the 128-wide
+// layers of the reflectance stacks make most of their contractions such problems, and with one wave per SIMD they ran at 0.32 of the
+// matrix pipe, overhead-bound per 16-point step).
+template <bool FULL, int NOT_ = 2>          // FULL: a_nt == b_nt == 8 -- no guards in the instruction stream
 __device__ __forceinline__ void wgrad_x3_lds_body(const float* __restrict__ A, int a_tiles, int a_t0, int a_nt,
                                                   const float* __restrict__ B, int b_tiles, int b_t0, int b_nt, long n_ptiles,
                                                   float* __restrict__ ws, float* __restrict__ rowsum_ws) {
-  const bool two = FULL || (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + 4 < a_nt);      // this wave owns a second output tile
-  constexpr int NOT = 2, BT = 8;
+  constexpr int NOT = NOT_, BT = 8;
+  static_assert(!FULL || NOT_ == 2, "the 256 x 256 form has two output tiles per wave");
+  const bool two = NOT == 2 && (FULL || (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + 4 < a_nt));      // this wave owns a second output tile
   __shared__ u32x4 pieces[2][BT][3][64];                       // 48 KB
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -293,25 +298,32 @@ __device__ __forceinline__ void wgrad_x3_lds_body(const float* __restrict__ A, i
         const u32x4 b0 = n0, b1 = n1, b2 = n2;
         if (b + 1 < BT) { n0 = pieces[cur][b + 1][0][lane]; n1 = pieces[cur][b + 1][1][lane]; n2 = pieces[cur][b + 1][2][lane]; }   // one tile ahead of the MFMAs
         // the wave's two output tiles alternate MFMA by MFMA (one wave per SIMD: nothing else covers a dependent chain)
-        f32x16 c0 = acc[0][b], c1 = acc[1][b];
-        if (FULL || two) {
-          c0 = mma(pa[0].p2, b0, c0); c1 = mma(pa[1].p2, b0, c1);
-          c0 = mma(pa[0].p1, b1, c0); c1 = mma(pa[1].p1, b1, c1);
-          c0 = mma(pa[0].p0, b2, c0); c1 = mma(pa[1].p0, b2, c1);
-          c0 = mma(pa[0].p1, b0, c0); c1 = mma(pa[1].p1, b0, c1);
-          c0 = mma(pa[0].p0, b1, c0); c1 = mma(pa[1].p0, b1, c1);
-          c0 = mma(pa[0].p0, b0, c0); c1 = mma(pa[1].p0, b0, c1);
+        if constexpr (NOT == 2) {
+          f32x16 c0 = acc[0][b], c1 = acc[NOT - 1][b];
+          if (FULL || two) {
+            c0 = mma(pa[0].p2, b0, c0); c1 = mma(pa[NOT - 1].p2, b0, c1);
+            c0 = mma(pa[0].p1, b1, c0); c1 = mma(pa[NOT - 1].p1, b1, c1);
+            c0 = mma(pa[0].p0, b2, c0); c1 = mma(pa[NOT - 1].p0, b2, c1);
+            c0 = mma(pa[0].p1, b0, c0); c1 = mma(pa[NOT - 1].p1, b0, c1);
+            c0 = mma(pa[0].p0, b1, c0); c1 = mma(pa[NOT - 1].p0, b1, c1);
+            c0 = mma(pa[0].p0, b0, c0); c1 = mma(pa[NOT - 1].p0, b0, c1);
+          } else {
+            c0 = mma(pa[0].p2, b0, c0); c0 = mma(pa[0].p1, b1, c0); c0 = mma(pa[0].p0, b2, c0);
+            c0 = mma(pa[0].p1, b0, c0); c0 = mma(pa[0].p0, b1, c0); c0 = mma(pa[0].p0, b0, c0);
+          }
+          acc[0][b] = c0; acc[NOT - 1][b] = c1;
         } else {
+          f32x16 c0 = acc[0][b];
           c0 = mma(pa[0].p2, b0, c0); c0 = mma(pa[0].p1, b1, c0); c0 = mma(pa[0].p0, b2, c0);
           c0 = mma(pa[0].p1, b0, c0); c0 = mma(pa[0].p0, b1, c0); c0 = mma(pa[0].p0, b0, c0);
+          acc[0][b] = c0;
         }
-        acc[0][b] = c0; acc[1][b] = c1;
       }
     }
     park(cur ^ 1, bf[(slot + 1) % R]);
     __syncthreads();
   };
-  if (FULL) {
+  if constexpr (FULL) {
     for (long q = 0; q < n_q; q += R) {
       step_full(q, std::integral_constant<int, 0>{});
       step_full(q + 1, std::integral_constant<int, 1>{});
@@ -361,6 +373,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_x3_lds_batched_kernel(const WgTa
   const WgProblem& P = tab.p[blockIdx.y];
   wgrad_x3_lds_body<FULL>(P.A, P.a_tiles, P.a_t0, P.a_nt, P.B, P.b_tiles, P.b_t0, P.b_nt, n_ptiles, P.ws, P.rs);
 }
+// ... of at most four A tiles: one output tile per wave, two workgroups per CU
+__global__ __launch_bounds__(256, 2) void wgrad_x3_lds_batched_narrow_kernel(const WgTable tab, long n_ptiles) {
+  const WgProblem& P = tab.p[blockIdx.y];
+  wgrad_x3_lds_body<false, 1>(P.A, P.a_tiles, P.a_t0, P.a_nt, P.B, P.b_tiles, P.b_t0, P.b_nt, n_ptiles, P.ws, P.rs);
+}
 
 }  // namespace
 
@@ -379,9 +396,10 @@ extern "C" int vqn_wgrad_partials_batched(int count, const float* const* A, cons
   if (grid > n_point_tiles) grid = n_point_tiles;
   static const long small_from = [] { const char* e = getenv("VQN_WGRAD_X3_SMALL_TILES"); return (e && e[0]) ? atol(e) : 1024L; }();
   static const int no_lds = [] { const char* e = getenv("VQN_WGRAD_X3_NO_LDS"); return (e != nullptr && atoi(e) != 0) ? 1 : 0; }();
-  // classes 0..2: the f32 kernels by shape; 3 / 4: the x3 LDS kernel, full / guarded
-  WgProblem cls[5][WG_MAX];
-  int n_cls[5] = {0, 0, 0, 0, 0};
+  // classes 0..2: the f32 kernels by shape; 3 / 4 / 5: the x3 LDS kernel, full / guarded / guarded with at most four A tiles
+  static const int no_narrow = [] { const char* e = getenv("VQN_WGRAD_X3_NO_NARROW"); return (e != nullptr && atoi(e) != 0) ? 1 : 0; }();
+  WgProblem cls[6][WG_MAX];
+  int n_cls[6] = {0, 0, 0, 0, 0, 0};
   auto flush = [&](int c) -> int {
     if (n_cls[c] == 0) return VQN_OK;
     int rc = VQN_OK;
@@ -392,7 +410,8 @@ extern "C" int vqn_wgrad_partials_batched(int count, const float* const* A, cons
       for (int i = 0; i < n_cls[c]; ++i) tab.p[i] = cls[c][i];
       const dim3 g((unsigned)grid, (unsigned)n_cls[c]);
       if (c == 3) hipLaunchKernelGGL(wgrad_x3_lds_batched_kernel<true>, g, dim3(256), 0, (hipStream_t)stream, tab, (long)n_point_tiles);
-      else hipLaunchKernelGGL(wgrad_x3_lds_batched_kernel<false>, g, dim3(256), 0, (hipStream_t)stream, tab, (long)n_point_tiles);
+      else if (c == 4) hipLaunchKernelGGL(wgrad_x3_lds_batched_kernel<false>, g, dim3(256), 0, (hipStream_t)stream, tab, (long)n_point_tiles);
+      else hipLaunchKernelGGL(wgrad_x3_lds_batched_narrow_kernel, g, dim3(256), 0, (hipStream_t)stream, tab, (long)n_point_tiles);
       VQN_LAUNCH_CHECK();
     }
     n_cls[c] = 0;
@@ -410,11 +429,11 @@ extern "C" int vqn_wgrad_partials_batched(int count, const float* const* A, cons
       if (n < 0) return n;
       continue;
     }
-    const int c = f32 ? ((a_nt[i] <= 4 && b_nt[i] <= 4) ? 0 : (a_nt[i] <= 4 ? 1 : 2)) : ((a_nt[i] == 8 && b_nt[i] == 8) ? 3 : 4);
+    const int c = f32 ? ((a_nt[i] <= 4 && b_nt[i] <= 4) ? 0 : (a_nt[i] <= 4 ? 1 : 2)) : ((a_nt[i] == 8 && b_nt[i] == 8) ? 3 : ((a_nt[i] <= 4 && !no_narrow) ? 5 : 4));
     cls[c][n_cls[c]++] = WgProblem{A[i], B[i], ws[i], rowsum_ws[i], a_tiles[i], a_t0[i], a_nt[i], b_tiles[i], b_t0[i], b_nt[i]};
     if (n_cls[c] == WG_MAX) { const int rc = flush(c); if (rc != VQN_OK) return rc; }
   }
-  for (int c = 0; c < 5; ++c) { const int rc = flush(c); if (rc != VQN_OK) return rc; }
+  for (int c = 0; c < 6; ++c) { const int rc = flush(c); if (rc != VQN_OK) return rc; }
   return (int)grid;
 }
 
