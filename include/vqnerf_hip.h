@@ -124,6 +124,20 @@ int vqn_sim_smooth_bwd(const float* codebook, const float* fwd4, const float* g_
 int vqn_vq_quantize_rows(const float* z, int64_t N, int D, const float* codebook, int K, const float* sel_mask, float eps,
                          float loss_scale, float* ws, int64_t* idx, float* ste, float* loss, float* counts, void* stream);
 
+/* Backward of that chain in one pass per row (round 4): g_xn = g_ste + (xnorm - quant) (g_loss 2 / (N D)) -- the straight-through
+ * identity plus the commitment term's gradient (vq_layers.py:302, :327) -- then the l2-normalise backward of z at g_xn
+ * (util/math.py:63-64).  g_ste may be NULL (zero), g_loss a device scalar.  = vqn_vq_ste_loss_bwd followed by
+ * vqn_l2_normalize_rows_bwd, same roundings. */
+int vqn_vq_train_bwd(const float* z, const float* xnorm, const float* quant, const float* g_ste, const float* g_loss, int64_t N, int D,
+                     float eps, float* g_z, void* stream);
+
+/* vqn_vq_quantize_rows for the TRAINING path (round 4; vq_nfr.py:575-578 with is_training = True): the same single pass, and
+ * xnorm [N, D] additionally receives the l2-normalised rows -- the x of the EMA statistics (vq_layers.py:304-309, vqn_vq_ema_stats)
+ * and of the backward (vqn_vq_ste_loss_bwd, vqn_l2_normalize_rows_bwd).  Same indices / straight-through rows / loss / counts. */
+int vqn_vq_quantize_rows_train(const float* z, int64_t N, int D, const float* codebook, int K, const float* sel_mask, float eps,
+                               float loss_scale, float* ws, int64_t* idx, float* ste, float* loss, float* counts, float* xnorm,
+                               void* stream);
+
 /* ---- reflectance MLP stacks + shading (decomp/nerfvq_nfr3/nerfactor) ------------------------- */
 
 /* Generic fused Dense-stack evaluator: [posenc ->] Dense -> Dense ... with skip-concats and several
@@ -508,13 +522,14 @@ int vqn_ks_split_fwd(const float* basecolor, const float* ks, int ks_channels, i
 int vqn_ks_split_bwd(const float* basecolor, const float* ks, int ks_channels, int64_t n, const float* g_albedo, const float* g_spec,
                      float* g_basecolor, float* g_ks, void* stream);
 
-/* Thin contractions (round 4; csrc/wgrad_thin.hip): out[r][f] = sum_p A[r][p] B[f][p] for rows r < a_rows[i] <= 8 of ONE feature tile
- * (a_t0[i]) of A against b_nt[i] feature tiles of B -- the weight gradient of a reflectance head's 1..3-output last layer
- * (nfr_unit.py:110-129).  A stream over B on the vector ALU (f32 FMA chains in point order), no matrix pipe.  Partial blocks
- * ws[i]: [n][8][32 b_nt] (rows >= a_rows are zero), row sums rowsum_ws[i] (may be NULL): [n][32]; n = the return value =
- * min(n_split, n_point_tiles), summed by vqn_wgrad_finalize with src_rows = 8. */
-int vqn_wgrad_thin_batched(int count, const float* const* A, const int32_t* a_tiles, const int32_t* a_t0, const int32_t* a_rows,
-                           const float* const* B, const int32_t* b_tiles, const int32_t* b_t0, const int32_t* b_nt,
+/* Thin contractions (round 4; csrc/wgrad_thin.hip): out[r][f] = sum_p A[a_row0 + r][p] B[f][p] for r < a_rows[i] <= 8 rows of ONE
+ * feature tile (a_t0[i]) of A against b_nt[i] feature tiles of B -- the weight gradient of a reflectance head's 1..3-output last layer
+ * (nfr_unit.py:110-129; the heads of a family keep their rows in one tile: a_row0).  A stream over B on the vector ALU (f32 FMA chains
+ * in point order), no matrix pipe.  Partial blocks ws[i], TRANSPOSED: [n][32 b_nt][8] (columns >= a_rows are zero), row sums
+ * rowsum_ws[i] (may be NULL): [n][32] (entries >= a_rows zero); n = the return value = min(n_split, n_point_tiles).
+ * vqn_wgrad_finalize sums them with src_rows = 32 b_nt, src_cols = 8 (a column range picks a head's rows). */
+int vqn_wgrad_thin_batched(int count, const float* const* A, const int32_t* a_tiles, const int32_t* a_t0, const int32_t* a_row0,
+                           const int32_t* a_rows, const float* const* B, const int32_t* b_tiles, const int32_t* b_t0, const int32_t* b_nt,
                            int64_t n_point_tiles, int n_split, float* const* ws, float* const* rowsum_ws, void* stream);
 
 /* count contiguous f32 copies dst[i][0..n[i]) = src[i][0..n[i]) in one launch (the per-parameter gradients into the flat
@@ -537,7 +552,9 @@ int vqn_multi_copy(int count, const float* const* src, float* const* dst, const 
  * backward -- g_out[k] / head_out[k] [P, c_k]; g_z_rows: up to four [P, z_feats] adjoints of z from outside this launch's heads (summed
  *   in order); saved [Y_0 .. Y_{n_enc-1}] then [H0_k, H1_k]; outs (written) [D_0 .. D_{n_enc-1}] then [D0_k, D1_k, D2_k] per head.
  *   run_heads / run_enc select the part of the stack the launch walks: both = the whole backward; heads only = d / d z rows into
- *   gz_rows_out; encoder only = from g_z_rows down.  Adjoints of points past P are zero.
+ *   gz_rows_out; encoder only = from g_z_rows down.  Adjoints of points past P are zero.  d2_row0 (may be NULL): head k writes its
+ *   c_k rows of D2_k at row d2_row0[k] of the tile and nothing else -- the heads of a family then share ONE D2 tile tensor (all D2_k
+ *   the same pointer), which vqn_wgrad_thin_batched reads by row range; NULL: rows 0..c_k-1, the rest of the tile zeroed.
  * Small batches (the reference's 2048 points are 64 tiles, a quarter of the CUs): the kernels switch by themselves to one 32-point
  *   image per workgroup when tile pairs would fill less than half of the chip, and split_heads != 0 gives every head its own
  *   workgroup row (forward: each row evaluates the encoder, row 0 writes its tensors; backward: heads only, gz_rows_out then holds
@@ -549,8 +566,8 @@ int vqn_refl_train_fwd_x3(const int32_t* desc, const void* wbuf_pieces, const fl
 int64_t vqn_refl_train_bwd_x3_scratch_bytes(const int32_t* desc);
 int vqn_refl_train_bwd_x3(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, int64_t P, const float* const* g_out,
                           const float* const* head_out, const float* const* g_z_rows, int n_gz, const float* const* saved, int n_saved,
-                          float* const* outs, int n_outs, float* gz_rows_out, int run_heads, int run_enc, int split_heads,
-                          void* scratch, int64_t scratch_bytes, void* stream);
+                          float* const* outs, int n_outs, float* gz_rows_out, const int32_t* d2_row0, int run_heads, int run_enc,
+                          int split_heads, void* scratch, int64_t scratch_bytes, void* stream);
 
 /* The Adam / AMSGrad update of the reference's optimisers for `count` f32 tensors in one launch per 56 tensors: steps[i] a device
  * float holding tensor i's step count AFTER this step's increment, lr_dev a device scalar (NULL: the host value lr),

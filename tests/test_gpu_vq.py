@@ -338,6 +338,33 @@ def test_fused_quantize_equals_the_three_kernel_sequence(N, D, K, masked):
     assert ste_n is None and torch.equal(idx_n, idx_f)
 
 
+@pytest.mark.parametrize('N,D,K,masked', [(17, 256, 15, False), (4099, 256, 15, True), (3000, 256, 64, False), (2048, 128, 33, True)])
+def test_training_quantiser_is_the_four_kernel_sequence(N, D, K, masked):
+    """The training path's fused chain (VectorQuantizerEMA.train_from_raw: vqn_vq_quantize_rows_train) against the sequence it replaces
+    (l2_normalize_rows -> forward(is_training=True)): indices, straight-through rows, normalised rows (through the EMA statistics and the
+    codebook move they feed) bit for bit, loss to fp32 rounding, d / d z to 2e-6 of its largest entry."""
+    from vqnerf_release_amd.decomp.nerfactor.networks.vq_layers import VectorQuantizerEMA, l2_normalize_rows
+    rng = np.random.default_rng(N + K)
+    z0 = torch.tensor(rng.uniform(0, 1, (N, D)).astype(np.float32)).cuda()
+    C = rng.uniform(0, 1, (D, K)).astype(np.float32)
+    C = torch.tensor(C / np.linalg.norm(C, axis=0, keepdims=True)).cuda()
+    thres = ([0.0] * (K - 3) + [1.0, 1.0, 0.5]) if masked else None
+    roll = torch.full((1, K), 0.5).cuda() if masked else None
+    g = torch.Generator(device='cuda').manual_seed(1)
+    w = torch.randn(N, D, device='cuda', generator=g)
+    res = {}
+    for fused in (True, False):
+        layer = VectorQuantizerEMA(embedding_dim=D, num_embeddings=K, commitment_cost=0.25, seed=0).cuda()
+        z = z0.clone().requires_grad_(True)
+        vq = layer.train_from_raw(z, C, thres=thres, roll=roll) if fused else layer(l2_normalize_rows(z), C, is_training=True, thres=thres, roll=roll)
+        ((vq['quantize'] * w).sum() + 3.0 * vq['loss']).backward()
+        res[fused] = (vq['encoding_indices'], vq['quantize'].detach(), vq['loss'].detach(), vq['update'], z.grad, layer.ema_dw.hidden.clone())
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3]) and torch.equal(a[5], b[5])
+    np.testing.assert_allclose(float(a[2]), float(b[2]), rtol=2e-6)
+    assert float((a[4] - b[4]).abs().max()) <= 2e-6 * float(b[4].abs().max())
+
+
 @pytest.mark.parametrize('K', [15, 64])
 def test_model_call_is_bit_identical_with_and_without_the_fused_quantiser(K):
     """vq_nfr.Model.call / fast_render(gen_embed) / vq_test in inference mode: the one-kernel quantiser against the three-kernel

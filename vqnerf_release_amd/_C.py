@@ -301,6 +301,21 @@ def vq_ste_loss_bwd(x, quant, g_ste, g_loss):
     return gx
 
 
+def vq_train_bwd(z, xnorm, quant, g_ste, g_loss, eps=1e-6):
+    """Backward of the training quantiser in one pass (vqn_vq_train_bwd): straight-through + commitment adjoint, then the l2-normalise
+    backward of z."""
+    for t in (z, xnorm, quant, g_loss):
+        _f32c(t, 'tensor')
+    if g_ste is not None:
+        _f32c(g_ste, 'g_ste')
+    gz = torch.empty_like(z)
+    with _clock('vqn_vq_train_bwd'):
+        rc = lib().vqn_vq_train_bwd(_ptr(z), _ptr(xnorm), _ptr(quant), _ptr(g_ste), _ptr(g_loss), ctypes.c_int64(z.shape[0]), ctypes.c_int(z.shape[1]),
+                                    ctypes.c_float(eps), _ptr(gz), _stream())
+    _check(rc, 'vqn_vq_train_bwd')
+    return gz
+
+
 def l2_normalize_rows(x, eps=1e-6):
     """x [N,D] -> x / sqrt(max(sum_d x^2, eps)) row by row, in the defined summation order of vqn_vq_assign's |x|^2."""
     _f32c(x, 'x')
@@ -311,7 +326,7 @@ def l2_normalize_rows(x, eps=1e-6):
     return y
 
 
-def vq_quantize_rows(z, codebook, sel_mask=None, eps=1e-6, want_ste=True):
+def vq_quantize_rows(z, codebook, sel_mask=None, eps=1e-6, want_ste=True, want_xnorm=False):
     """Fused inference path: z [N,D] un-normalised, codebook [D,K] -> (idx int64 [N], ste [N,D] | None, mean((q - z^)^2) scalar
     tensor, counts [K]) in one pass over the rows (l2-normalise, nearest code, straight-through output, commitment term, usage)."""
     _f32c(z, 'z'); _f32c(codebook, 'codebook')
@@ -328,6 +343,14 @@ def vq_quantize_rows(z, codebook, sel_mask=None, eps=1e-6, want_ste=True):
         sel_mask = _f32c(sel_mask.reshape(-1).to(torch.float32).contiguous(), 'sel_mask')
         assert sel_mask.numel() == K
     n = N * D
+    if want_xnorm:                                         # the training form: the normalised rows are kept (EMA statistics, backward)
+        xnorm = torch.empty((N, D), dtype=torch.float32, device=dev)
+        with _clock('vqn_vq_quantize_rows_train'):
+            rc = lib().vqn_vq_quantize_rows_train(_ptr(z), ctypes.c_int64(N), ctypes.c_int(D), _ptr(codebook), ctypes.c_int(K), _ptr(sel_mask),
+                                                  ctypes.c_float(eps), ctypes.c_float(1.0 / n if n else 0.0), _ptr(ws), _ptr(idx), _ptr(ste),
+                                                  _ptr(loss), _ptr(counts), _ptr(xnorm), _stream())
+        _check(rc, 'vqn_vq_quantize_rows_train')
+        return idx, ste, loss, counts, xnorm
     with _clock('vqn_vq_quantize_rows'):
         rc = lib().vqn_vq_quantize_rows(_ptr(z), ctypes.c_int64(N), ctypes.c_int(D), _ptr(codebook), ctypes.c_int(K), _ptr(sel_mask),
                                         ctypes.c_float(eps), ctypes.c_float(1.0 / n if n else 0.0), _ptr(ws), _ptr(idx), _ptr(ste),
@@ -821,7 +844,7 @@ def refl_train_fwd_x3(desc, wbuf_pieces, wbuf_f32, pts, z_rows, P, saved, z_rows
 
 
 def refl_train_bwd_x3(desc, wbuf_pieces, wbuf_f32, P, g_out, head_out, g_z_rows, saved, outs, gz_rows_out, run_heads=True, run_enc=True,
-                      split_heads=False):
+                      split_heads=False, d2_row0=None):
     """Backward of the same stack (vqn_refl_train_bwd_x3): fills `outs` with every layer's per-point adjoint in the tile format.
     g_z_rows: list of up to four [P, z] adjoints flowing into z from outside this launch's heads; run_heads / run_enc select the part
     of the stack walked; split_heads (heads only): gz_rows_out holds one [P, z] slice per head."""
@@ -845,7 +868,8 @@ def refl_train_bwd_x3(desc, wbuf_pieces, wbuf_f32, P, g_out, head_out, g_z_rows,
     with _clock('vqn_refl_train_bwd_x3'):
         rc = L.vqn_refl_train_bwd_x3(dp, _ptr(wbuf_pieces), _ptr(wbuf_f32), ctypes.c_int64(P), arr(g_out), arr(head_out), arr(g_z_rows),
                                      ctypes.c_int(len(g_z_rows)), arr(saved), ctypes.c_int(len(saved)), arr(outs), ctypes.c_int(len(outs)),
-                                     _ptr(gz_rows_out), ctypes.c_int(int(run_heads)), ctypes.c_int(int(run_enc)), ctypes.c_int(int(split_heads)),
+                                     _ptr(gz_rows_out), None if d2_row0 is None else (ctypes.c_int32 * len(d2_row0))(*[int(v) for v in d2_row0]),
+                                     ctypes.c_int(int(run_heads)), ctypes.c_int(int(run_enc)), ctypes.c_int(int(split_heads)),
                                      _ptr(buf), ctypes.c_int64(buf.numel()), _stream())
     _check(rc, 'vqn_refl_train_bwd_x3')
 

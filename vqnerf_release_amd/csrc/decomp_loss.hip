@@ -309,7 +309,69 @@ __global__ __launch_bounds__(256) void ste_commit_bwd_kernel(const f32x4* __rest
   }
 }
 
+// the two above in one pass per row (round 4; the training quantiser's backward): g_xn = g_ste + (xn - q) (g_loss 2 / numel), then the
+// l2-normalise backward of x at g_xn.  One wave per row, D <= 1024, D % 4 == 0; same roundings as the two-kernel sequence.
+__global__ __launch_bounds__(256) void vq_train_bwd_kernel(const float* __restrict__ x, const float* __restrict__ xn, const float* __restrict__ q,
+                                                           const float* __restrict__ g_ste, const float* __restrict__ g_loss, float two_over_numel,
+                                                           long N, int D, float eps, float* __restrict__ gx) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const float t_c = __fmul_rn(g_loss[0], two_over_numel);
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * D);
+  const f32x4* nr = reinterpret_cast<const f32x4*>(xn + row * D);
+  const f32x4* qr = reinterpret_cast<const f32x4*>(q + row * D);
+  const f32x4* gr = g_ste != nullptr ? reinterpret_cast<const f32x4*>(g_ste + row * D) : nullptr;
+  f32x4* or_ = reinterpret_cast<f32x4*>(gx + row * D);
+  const int n4 = D >> 2;
+  f32x4 xv[4], gv[4];
+  float x2 = 0.f, xg = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = lane + 64 * k;
+    if (i < n4) {
+      xv[k] = xr[i];
+      const f32x4 a = nr[i], b = qr[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gv[k][j] = __fmul_rn(__fsub_rn(a[j], b[j]), t_c);
+      if (gr != nullptr) {
+        const f32x4 c = gr[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gv[k][j] = __fadd_rn(c[j], gv[k][j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { x2 = fmaf(xv[k][j], xv[k][j], x2); xg = fmaf(xv[k][j], gv[k][j], xg); }
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) { x2 += __shfl_xor(x2, m); xg += __shfl_xor(xg, m); }
+  const float s = 1.0f / sqrtf(fmaxf(x2, eps));
+  const float t = x2 > eps ? (s * s * s) * xg : 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = lane + 64 * k;
+    if (i < n4) {
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = gv[k][j] * s - xv[k][j] * t;
+      or_[i] = o;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int vqn_vq_train_bwd(const float* z, const float* xnorm, const float* quant, const float* g_ste, const float* g_loss, int64_t N, int D,
+                                float eps, float* g_z, void* stream) {
+  VQN_CHECK_ARG(N >= 0 && D > 0, "N >= 0, D > 0");
+  if (N == 0) return VQN_OK;
+  VQN_CHECK_ARG(z && xnorm && quant && g_loss && g_z, "null pointer");
+  VQN_CHECK_SHAPE(D % 4 == 0 && D <= 1024, "D a multiple of 4, at most 1024");
+  hipLaunchKernelGGL(vq_train_bwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z, xnorm, quant, g_ste, g_loss,
+                     (float)(2.0 / ((double)N * D)), (long)N, D, eps, g_z);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
 
 extern "C" int vqn_l2_normalize_rows_bwd(const float* x, const float* g, int64_t N, int D, float eps, float* gx, void* stream) {
   VQN_CHECK_ARG(N >= 0 && D > 0, "N >= 0, D > 0");

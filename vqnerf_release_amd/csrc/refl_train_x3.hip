@@ -72,6 +72,7 @@ struct ReflBwdPtrs {
   float* D2[RT_MAX_H]; float* D1[RT_MAX_H]; float* D0[RT_MAX_H];
   const float* G_Z[4]; int n_gz;            // rows [N, z_feats]: adjoints of z from outside this launch's heads, summed in order
   int run_heads, run_enc;                   // which part of the stack this launch walks (both: the whole backward in one launch)
+  int d2_shared, d2_row0[RT_MAX_H];         // shared: head k writes rows d2_row0[k].. of ONE delta_2 tile (nothing else); else rows 0.. + zeros
   float* GZ_ROWS;                           // without the encoder part: d / d z rows [gridDim.y][N, z_feats] (one slice per head when split)
   const float* Y[RT_MAX_L]; float* D[RT_MAX_L];
 };
@@ -490,7 +491,11 @@ __global__ __launch_bounds__(512, 1) void refl_train_bwd_x3_kernel(const ReflDes
         sm->d2[im][t * 3 + 0] = d[0]; sm->d2[im][t * 3 + 1] = d[1]; sm->d2[im][t * 3 + 2] = d[2];
         if (ptile < n_tiles) {
           float* base = tp.D2[k] + ptile * 1024 + t;
-          for (int f = 0; f < 32; ++f) base[f * 32] = f < cc ? d[f < 3 ? f : 0] : 0.f;
+          if (tp.d2_shared) {
+            for (int f = 0; f < cc; ++f) base[(tp.d2_row0[k] + f) * 32] = d[f];
+          } else {
+            for (int f = 0; f < 32; ++f) base[f * 32] = f < cc ? d[f < 3 ? f : 0] : 0.f;
+          }
         }
       }
       __syncthreads();
@@ -723,8 +728,8 @@ extern "C" int64_t vqn_refl_train_bwd_x3_scratch_bytes(const int32_t* desc) {
 
 extern "C" int vqn_refl_train_bwd_x3(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, int64_t P, const float* const* g_out,
                                      const float* const* head_out, const float* const* g_z_rows, int n_gz, const float* const* saved, int n_saved,
-                                     float* const* outs, int n_outs, float* gz_rows_out, int run_heads, int run_enc, int split_heads,
-                                     void* scratch, int64_t scratch_bytes, void* stream) {
+                                     float* const* outs, int n_outs, float* gz_rows_out, const int32_t* d2_row0, int run_heads, int run_enc,
+                                     int split_heads, void* scratch, int64_t scratch_bytes, void* stream) {
   VQN_CHECK_ARG(desc && wbuf_pieces && wbuf_f32 && saved && outs && scratch, "null pointer");
   VQN_CHECK_ARG(P >= 1, "P >= 1");
   ReflDesc rd;
@@ -747,6 +752,11 @@ extern "C" int vqn_refl_train_bwd_x3(const int32_t* desc, const void* wbuf_piece
   ReflBwdPtrs tp;
   memset(&tp, 0, sizeof(tp));
   tp.n_gz = n_gz; tp.run_heads = run_heads; tp.run_enc = run_enc; tp.GZ_ROWS = gz_rows_out;
+  tp.d2_shared = d2_row0 != nullptr;
+  for (int k = 0; k < nH && d2_row0 != nullptr; ++k) {
+    VQN_CHECK_ARG(d2_row0[k] >= 0 && d2_row0[k] + rd.c[k] <= 32, "d2_row0 outside the tile");
+    tp.d2_row0[k] = d2_row0[k];
+  }
   for (int j = 0; j < n_gz; ++j) { VQN_CHECK_ARG(g_z_rows[j] != nullptr, "null z adjoint"); tp.G_Z[j] = g_z_rows[j]; }
   for (int l = 0; l < nE; ++l) { tp.Y[l] = saved[l]; tp.D[l] = outs[l]; }
   for (int k = 0; k < nH; ++k) {

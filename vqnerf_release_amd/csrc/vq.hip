@@ -33,6 +33,7 @@ struct VqFuse {
   float eps;
   float* loss_part;
   float* counts;
+  float* xnorm;          // optional [N, D]: the l2-normalised rows (the training path keeps them: EMA statistics, backward)
 };
 
 template <int KT, bool MAXONLY, bool FUSE>
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
             const f32x4 dq = cq - av[i];
             lr = fmaf(dq[0], dq[0], lr); lr = fmaf(dq[1], dq[1], lr); lr = fmaf(dq[2], dq[2], lr); lr = fmaf(dq[3], dq[3], lr);
             if (rvalid && quant != nullptr) *reinterpret_cast<f32x4*>(quant + (size_t)(row0 + col) * D + 16 * i + 4 * q) = av[i] + dq;
+            if (rvalid && fuse.xnorm != nullptr) *reinterpret_cast<f32x4*>(fuse.xnorm + (size_t)(row0 + col) * D + 16 * i + 4 * q) = av[i];
           }
         }
         if (!rvalid) lr = 0.f;
@@ -563,6 +565,7 @@ __global__ __launch_bounds__(512, 1) void vq_assign_split_kernel(const float* __
           const f32x4 dq = cq - av[i];
           lr = fmaf(dq[0], dq[0], lr); lr = fmaf(dq[1], dq[1], lr); lr = fmaf(dq[2], dq[2], lr); lr = fmaf(dq[3], dq[3], lr);
           if (rvalid && quant != nullptr) *reinterpret_cast<f32x4*>(quant + (size_t)(row0 + col) * D + 16 * i + 4 * q) = av[i] + dq;
+          if (rvalid && fuse.xnorm != nullptr) *reinterpret_cast<f32x4*>(fuse.xnorm + (size_t)(row0 + col) * D + 16 * i + 4 * q) = av[i];
         }
       }
       if (!rvalid) lr = 0.f;
@@ -1037,7 +1040,7 @@ extern "C" int vqn_vq_assign(const float* x, int64_t N, int D, const float* code
   VQN_CHECK_SHAPE(((size_t)KTp * D16 * 256 + 3 * KTp * 16 + 4) * 4 <= 160 * 1024, "codebook does not fit in 160 KB of LDS");
   hipStream_t s = (hipStream_t)stream;
   long long* idx_ll = reinterpret_cast<long long*>(idx);
-  const VqFuse nf = {0.f, nullptr, nullptr};
+  const VqFuse nf = {0.f, nullptr, nullptr, nullptr};
   if (split_ok(K, D, sel_mask, dist))
     return KTp == 2 ? launch_split<2, false>(x, N, D, codebook, K, idx_ll, quant, nf, s)
                     : launch_split<4, false>(x, N, D, codebook, K, idx_ll, quant, nf, s);
@@ -1059,8 +1062,8 @@ extern "C" int vqn_l2_normalize_rows(const float* x, int64_t N, int D, float eps
   return VQN_OK;
 }
 
-extern "C" int vqn_vq_quantize_rows(const float* z, int64_t N, int D, const float* codebook, int K, const float* sel_mask, float eps,
-                                    float loss_scale, float* ws, int64_t* idx, float* ste, float* loss, float* counts, void* stream) {
+static int quantize_rows_impl(const float* z, int64_t N, int D, const float* codebook, int K, const float* sel_mask, float eps,
+                              float loss_scale, float* ws, int64_t* idx, float* ste, float* loss, float* counts, float* xnorm, void* stream) {
   VQN_CHECK_ARG(N >= 0 && D > 0 && K > 0, "N >= 0, D > 0, K > 0 required");
   VQN_CHECK_ARG(loss && counts && ws, "loss, counts and ws (VQN_QUANT_WS_FLOATS floats) must be non-null");
   hipStream_t s = (hipStream_t)stream;
@@ -1081,7 +1084,8 @@ extern "C" int vqn_vq_quantize_rows(const float* z, int64_t N, int D, const floa
   const bool split = split_ok(K, D, sel_mask, nullptr);
   const long blocks = split ? split_grid(N) : assign_grid(N);
   VQN_CHECK_SHAPE(blocks + 1 <= VQN_QUANT_WS_FLOATS, "workspace too small for this device");
-  const VqFuse fz = {eps, ws + 1, counts};             // ws[0]: the code-dropout maximum; ws[1 ..]: per-workgroup loss sums
+  VQN_CHECK_SHAPE(xnorm == nullptr || ((uintptr_t)xnorm % 16) == 0, "xnorm must be 16-byte aligned");
+  const VqFuse fz = {eps, ws + 1, counts, xnorm};      // ws[0]: the code-dropout maximum; ws[1 ..]: per-workgroup loss sums
   int rc;
   if (split)
     rc = KTp == 2 ? launch_split<2, true>(z, N, D, codebook, K, idx_ll, ste, fz, s) : launch_split<4, true>(z, N, D, codebook, K, idx_ll, ste, fz, s);
@@ -1095,6 +1099,20 @@ extern "C" int vqn_vq_quantize_rows(const float* z, int64_t N, int D, const floa
   hipLaunchKernelGGL(vq_ste_loss_final_kernel, dim3(1), dim3(64), 0, s, ws + 1, (int)blocks, loss_scale, loss);
   VQN_LAUNCH_CHECK();
   return VQN_OK;
+}
+
+extern "C" int vqn_vq_quantize_rows(const float* z, int64_t N, int D, const float* codebook, int K, const float* sel_mask, float eps,
+                                    float loss_scale, float* ws, int64_t* idx, float* ste, float* loss, float* counts, void* stream) {
+  return quantize_rows_impl(z, N, D, codebook, K, sel_mask, eps, loss_scale, ws, idx, ste, loss, counts, nullptr, stream);
+}
+
+// ... and the form the TRAINING path uses (round 4): the same pass also leaves the l2-normalised rows, which the EMA statistics
+// (vqn_vq_ema_stats) and the backward (vqn_vq_ste_loss_bwd, vqn_l2_normalize_rows_bwd) read.
+extern "C" int vqn_vq_quantize_rows_train(const float* z, int64_t N, int D, const float* codebook, int K, const float* sel_mask, float eps,
+                                          float loss_scale, float* ws, int64_t* idx, float* ste, float* loss, float* counts, float* xnorm,
+                                          void* stream) {
+  VQN_CHECK_ARG(N == 0 || xnorm != nullptr, "xnorm must be non-null");
+  return quantize_rows_impl(z, N, D, codebook, K, sel_mask, eps, loss_scale, ws, idx, ste, loss, counts, xnorm, stream);
 }
 
 extern "C" int64_t vqn_vq_ema_stats_ws_bytes(int64_t N, int D, int K) {

@@ -147,6 +147,9 @@ class Model(BrdfModel):
         on_kernels = z_enc.is_cuda and z_enc.shape[1] % 4 == 0
         if self.fuse_quantise and on_kernels and mode != 'train' and z_enc.shape[1] <= 256 and not self._needs_graph(z_enc):
             vq = self.vq_layer.infer_from_raw(z_enc, codebook, thres=th, roll=roll)
+        elif (self.fuse_quantise and on_kernels and mode == 'train' and z_enc.shape[1] <= 256 and z_enc.dtype == torch.float32
+              and self.train_backend == 'hip' and os.environ.get('VQN_VQ_TRAIN_FUSED', '1') != '0'):
+            vq = self.vq_layer(z_enc, codebook, is_training=True, thres=th, roll=roll, raw=True)     # (round 4: one pass instead of four)
         else:
             z_norm = l2_normalize_rows(z_enc) if on_kernels else mathutil.safe_l2_normalize(z_enc, axis=1)
             vq = self.vq_layer(z_norm, codebook, is_training=(mode == 'train'), thres=th, roll=roll)

@@ -71,6 +71,35 @@ class _SteAndCommitment(torch.autograd.Function):
         return g, None
 
 
+class _QuantiseTrain(torch.autograd.Function):
+    """The training path's normalise -> nearest code -> straight-through + commitment chain (vq_nfr.py:575-578, vq_layers.py:277-302,
+    :327) as ONE pass over the rows (`vqn_vq_quantize_rows_train`; was l2-normalise, assign, straight-through, loss-final: four launches
+    and 7 KB per row) -- bit-identical indices, straight-through rows and loss to that sequence (tests/test_gpu_vq.py).  Outputs:
+    straight-through rows, mean((sg(q) - x^)^2); `aux` receives idx / counts / the normalised rows (not differentiable).
+    Backward = the two kernels of the sequence (`vqn_vq_ste_loss_bwd`, `vqn_l2_normalize_rows_bwd`) as one pass (`vqn_vq_train_bwd`); it reads q back as the saved
+    straight-through rows x^ + (q - x^), equal to q to an ulp (the commitment gradient 2 beta (x^ - q) / numel sees a 1e-7 relative
+    difference)."""
+
+    @staticmethod
+    def forward(ctx, z_raw, cb, sel, eps, aux):
+        x = z_raw.detach().float().contiguous()
+        idx, ste, loss, counts, xnorm = _C.vq_quantize_rows(x, cb, sel_mask=sel, eps=eps, want_ste=True, want_xnorm=True)
+        aux.update(idx=idx, counts=counts, xnorm=xnorm)
+        ctx.save_for_backward(x, xnorm, ste)
+        ctx.eps = float(eps)
+        return ste, loss
+
+    @staticmethod
+    def backward(ctx, g_ste, g_loss):
+        x, xnorm, ste = ctx.saved_tensors
+        gs = None if g_ste is None else g_ste.float().contiguous()
+        gl = torch.zeros((), dtype=torch.float32, device=x.device) if g_loss is None else g_loss.float().contiguous()
+        if x.shape[1] <= 1024:
+            return _C.vq_train_bwd(x, xnorm, ste, gs, gl, ctx.eps), None, None, None, None         # (one pass: the two kernels below)
+        g_xn = _C.vq_ste_loss_bwd(xnorm, ste, gs, gl)
+        return _C.l2_normalize_rows_bwd(x, g_xn, ctx.eps), None, None, None, None
+
+
 class L2NormalizeRows(torch.autograd.Function):
     """`safe_l2_normalize(x, axis=1)` (util/math.py:63-64) on `vqn_l2_normalize_rows`: the sum of squares in the DEFINED order the
     VQ kernels use for |x|^2, so that the fused inference kernel (`vqn_vq_quantize_rows`) and this three-kernel sequence agree bit
@@ -166,7 +195,12 @@ class VectorQuantizerEMA(torch.nn.Module):
         return torch.rand((1, n), generator=self._gen).to(dev)
 
     def forward(self, inputs, codebook, is_training, thres=None, individual=True, roll=None,
-                return_distances=True):
+                return_distances=True, raw=False):
+        """`raw=True` (training only): `inputs` are the UN-normalised encoder rows and the layer normalises them itself, in the same
+        pass as the nearest-code search (`train_from_raw`); going through `forward` keeps module hooks working."""
+        if raw:
+            assert is_training, 'raw=True is the training form (inference: infer_from_raw)'
+            return self.train_from_raw(inputs, codebook, thres=thres, individual=individual, roll=roll)
         D, K = self.embedding_dim, self.num_embeddings
         flat = inputs.reshape(-1, D)
         x = flat.detach().contiguous()
@@ -210,6 +244,47 @@ class VectorQuantizerEMA(torch.nn.Module):
         ret.update({'quantize': quantized, 'loss': loss, 'encoding_indices': encoding_indices, 'distances': dist})
         # `encodings` (an [N, K] one-hot) and `perplexity` are computed when somebody reads them (nobody does in a training step)
         return LazyResult(ret, {'perplexity': perplexity, 'encodings': lambda: torch.nn.functional.one_hot(idx, K).to(flat.dtype)})
+
+    def train_from_raw(self, z_raw, codebook, thres=None, individual=True, roll=None, eps=1e-6):
+        """Training form taking the UN-normalised encoder output [N, D] (device, D % 4 == 0, D <= 256): the chain of `forward(
+        l2_normalize_rows(z_raw), codebook, is_training=True, ...)` with the normalise / assign / straight-through / commitment part as one
+        pass (`_QuantiseTrain`), then the EMA statistics and codebook move as before.  Same result keys (`distances` on first access)."""
+        D, K = self.embedding_dim, self.num_embeddings
+        cb = codebook.detach().contiguous()
+        sel = None
+        if thres is not None:
+            if roll is None:
+                roll = self.draw_roll(individual, z_raw.device)
+            thres_t = torch.as_tensor(thres, dtype=torch.float32, device=z_raw.device)
+            sel = (roll.to(z_raw.device) >= thres_t).to(torch.float32).expand(1, K).reshape(K).contiguous()
+        aux = {}
+        quantized, e_latent_loss = _QuantiseTrain.apply(z_raw.reshape(-1, D), cb, sel, float(eps), aux)
+        idx, x = aux['idx'], aux['xnorm']
+        counts, dw = _C.vq_ema_stats(x, idx, K)
+        local_counts = counts
+        ret = {}
+        if self.stats_all_reduce is not None:
+            counts, dw = self.stats_all_reduce(counts, dw)
+        if self.fuse_ema_update and cb.dtype == torch.float32 and self.ema_dw.hidden.is_cuda and K <= 1024 and cb.is_contiguous():
+            ret['update'] = _C.vq_ema_update(counts.contiguous(), dw.contiguous(), cb, self.decay, self.epsilon,
+                                             self.ema_cluster_size, self.ema_dw)
+        else:
+            cs = self.ema_cluster_size(counts)
+            ema_dw = self.ema_dw(dw)
+            n = cs.sum()
+            cs = (cs + self.epsilon) / (n + K * self.epsilon) * n
+            w = ema_dw / cs.reshape(1, -1)
+            used = (counts > 0).to(w.dtype)
+            ret['update'] = w * used[None, :] + cb * (1.0 - used[None, :])
+        counts = local_counts
+
+        def perplexity():
+            avg = counts / max(idx.numel(), 1)
+            return torch.exp(-torch.sum(avg * torch.log(avg + 1e-10)))
+        ret.update({'quantize': quantized.reshape(z_raw.shape), 'loss': self.commitment_cost * e_latent_loss,
+                    'encoding_indices': idx.reshape(z_raw.shape[:-1])})
+        return LazyResult(ret, {'perplexity': perplexity, 'encodings': lambda: torch.nn.functional.one_hot(idx, K).to(torch.float32),
+                                'distances': lambda: _C.vq_assign(x, cb, sel_mask=sel, want_quant=False, want_dist=True)[2]})
 
     @torch.no_grad()
     def infer_from_raw(self, z_raw, codebook, thres=None, individual=True, roll=None, eps=1e-6):

@@ -231,7 +231,15 @@ class ReflStackEngine:
         D = [self._tensor(nt, _tl(Ly['out']), dev) for Ly in self.layers]
         D0 = [self._tensor(nt, _tl(net.widths[0]), dev) for net in self.heads]
         D1 = [self._tensor(nt, _tl(net.widths[1]), dev) for net in self.heads]
-        D2 = [self._tensor(nt, 1, dev) for net in self.heads]
+        cs = [net.widths[2] for net in self.heads]
+        roff = [sum(cs[:k]) for k in range(self.nH)]
+        shared = self.nH > 0 and sum(cs) <= 8                  # the heads' delta_2 rows in ONE tile: z is streamed once for all of them
+        if shared:
+            d2all = self._tensor(nt, 1, dev)
+            D2 = [d2all] * self.nH
+        else:
+            D2 = [self._tensor(nt, 1, dev) for net in self.heads]
+        d2kw = {'d2_row0': roff} if shared else {}
         outs = list(D)
         for a, b, c in zip(D0, D1, D2):
             outs += [a, b, c]
@@ -247,14 +255,14 @@ class ReflStackEngine:
         if S['split'] and self.nH > 1:
             # one workgroup row per head -> one d / d z slice per head; with an encoder a second launch walks it from their sum
             part = torch.empty((self.nH, N, self.Z), dtype=torch.float32, device=dev)
-            _C.refl_train_bwd_x3(*args, [], saved, outs, part, run_heads=True, run_enc=False, split_heads=True)
+            _C.refl_train_bwd_x3(*args, [], saved, outs, part, run_heads=True, run_enc=False, split_heads=True, **d2kw)
             if self.nE:
                 _C.refl_train_bwd_x3(*args, [g_z] + [part[k] for k in range(self.nH)], saved, outs, None, run_heads=False, run_enc=True)
             else:
                 gz_rows = part.sum(0)
         else:
             gz_rows = None if self.nE else torch.empty((N, self.Z), dtype=torch.float32, device=dev)
-            _C.refl_train_bwd_x3(*args, [g_z] if self.nE else [], saved, outs, gz_rows)
+            _C.refl_train_bwd_x3(*args, [g_z] if self.nE else [], saved, outs, gz_rows, **d2kw)
         # ---- weight gradients: contractions over the points, straight into the Keras layout [in, out] ----
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         batch = WgradBatch(self.n_split, thin=True)          # (the heads' 1..3-output last layers: vqn_wgrad_thin_batched)
@@ -267,14 +275,21 @@ class ReflStackEngine:
             if Ly['skip']:
                 batch.contract(D[l], S['E'], n_out, self.E, G[Ly['in_y']:], 1, n_out)
             grads += [G, b]
+        z_targets = []
         for k, net in enumerate(self.heads):
             w0, w1, c = net.widths
             g0, g1, g2, b0, b1, b2 = new(self.Z, w0), new(w0, w1), new(w1 + self.Z, c), new(w0), new(w1), new(c)
             batch.contract(D0[k], S['ZT'], w0, self.Z, g0, 1, w0, bias_dst=b0)
             batch.contract(D1[k], S['H0'][k], w1, w0, g1, 1, w1, bias_dst=b1)
-            batch.contract(D2[k], S['H1'][k], c, w1, g2, 1, c, bias_dst=b2)
-            batch.contract(D2[k], S['ZT'], c, self.Z, g2[w1:], 1, c)
+            if shared:
+                batch.contract_thin_rows(D2[k], roff[k], c, S['H1'][k], w1, [(0, c, g2, 1, c, b2)])
+                z_targets.append((roff[k], c, g2[w1:], 1, c, None))
+            else:
+                batch.contract(D2[k], S['H1'][k], c, w1, g2, 1, c, bias_dst=b2)
+                batch.contract(D2[k], S['ZT'], c, self.Z, g2[w1:], 1, c)
             grads += [g0, b0, g1, b1, g2, b2]
+        if shared:
+            batch.contract_thin_rows(D2[0], 0, sum(cs), S['ZT'], self.Z, z_targets)
         batch.flush()
         return gz_rows, grads
 

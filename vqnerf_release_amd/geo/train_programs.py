@@ -86,27 +86,8 @@ class WgradBatch:
         also sum_p A[o][p].  A, B: TFMT tensors [point tiles, feature tiles, 32, 32]."""
         nt, at, bt = A.shape[0], A.shape[1], B.shape[1]
         a_nt_all, b_nt_all = (a_rows + 31) // 32, (b_cols + 31) // 32
-        if self.thin and a_rows <= 8 and A2 is None:
-            if self.nt is None:
-                self.nt = nt
-            assert nt == self.nt, 'one WgradBatch = contractions over the same points'
-            n_blocks = min(self.n_split, nt)
-            for b0 in range(0, b_nt_all, 8):
-                bn = min(8, b_nt_all - b0)
-                if col_first >= min(bn * 32, b_cols - b0 * 32) + b0 * 32:
-                    continue
-                ws, self.ws_floats = self.ws_floats, self.ws_floats + n_blocks * 8 * bn * 32
-                want_rs = bias_dst is not None and b0 == 0
-                rs = None
-                if want_rs:
-                    rs, self.ws_floats = self.ws_floats, self.ws_floats + n_blocks * 32
-                self.pt.append((A, at, 0, a_rows, B, bt, b0, bn, ws, rs))
-                self.e.append(dict(ws=ws, ws2=None, src_rows=8, src_cols=bn * 32, rows_valid=a_rows, col_first=max(0, col_first - b0 * 32),
-                                   cols_valid=min(bn * 32, b_cols - b0 * 32), dst=dst.data_ptr() + 4 * (b0 * 32 * sc), sr=sr, sc=sc, scale=scale))
-                if want_rs:
-                    self.e.append(dict(ws=rs, ws2=None, src_rows=1, src_cols=32, rows_valid=1, col_first=0, cols_valid=a_rows,
-                                       dst=bias_dst.data_ptr(), sr=0, sc=1, scale=1.0))
-            self.keep += [A, B, dst, bias_dst]
+        if self.thin and a_rows <= 8 and A2 is None and col_first == 0 and A.shape[1] == 1:
+            self.contract_thin_rows(A, 0, a_rows, B, b_cols, [(0, a_rows, dst, sr, sc, bias_dst)])
             return
         for a0 in range(0, a_nt_all, 8):
             an = min(8, a_nt_all - a0)
@@ -127,6 +108,35 @@ class WgradBatch:
                                        cols_valid=min(an * 32, a_rows - a0 * 32), dst=bias_dst.data_ptr() + 4 * a0 * 32, sr=0, sc=1, scale=1.0))
         self.keep += [A, B, A2, B2, dst, bias_dst]
 
+    def contract_thin_rows(self, A, a_row0, a_rows, B, b_cols, targets):
+        """Thin contraction (vqn_wgrad_thin_batched): rows a_row0 .. a_row0 + a_rows - 1 (a_rows <= 8) of the ONE feature tile of A against
+        the b_cols features of B, streamed once; targets = [(row_off, n_rows, dst, sr, sc, bias_dst)]: rows row_off .. row_off + n_rows - 1
+        of the result (local numbering) -> element (o, i) at dst.flatten()[o * sr + i * sc], their point sums -> bias_dst."""
+        nt, at, bt = A.shape[0], A.shape[1], B.shape[1]
+        assert at == 1 and a_rows <= 8
+        if self.nt is None:
+            self.nt = nt
+        assert nt == self.nt, 'one WgradBatch = contractions over the same points'
+        n_blocks = min(self.n_split, nt)
+        b_nt_all = (b_cols + 31) // 32
+        for b0 in range(0, b_nt_all, 8):
+            bn = min(8, b_nt_all - b0)
+            ws, self.ws_floats = self.ws_floats, self.ws_floats + n_blocks * 8 * bn * 32
+            want_rs = b0 == 0 and any(t[5] is not None for t in targets)
+            rs = None
+            if want_rs:
+                rs, self.ws_floats = self.ws_floats, self.ws_floats + n_blocks * 32
+            self.pt.append((A, at, 0, a_row0, a_rows, B, bt, b0, bn, ws, rs))
+            for row_off, n_rows, dst, sr, sc, bias_dst in targets:
+                # transposed partial blocks [features, 8]: finalize's row = the feature i, its column = the result row o
+                self.e.append(dict(ws=ws, ws2=None, src_rows=bn * 32, src_cols=8, rows_valid=min(bn * 32, b_cols - b0 * 32), col_first=row_off,
+                                   cols_valid=row_off + n_rows, dst=dst.data_ptr() + 4 * (b0 * 32 * sc - row_off * sr), sr=sc, sc=sr, scale=1.0))
+                if want_rs and bias_dst is not None:
+                    self.e.append(dict(ws=rs, ws2=None, src_rows=1, src_cols=32, rows_valid=1, col_first=row_off, cols_valid=row_off + n_rows,
+                                       dst=bias_dst.data_ptr() - 4 * row_off, sr=0, sc=1, scale=1.0))
+                self.keep += [dst, bias_dst]
+        self.keep += [A, B]
+
     def flush(self):
         e, k, q, m = self.e, len(self.e), self.p, len(self.p)
         qt, mt = self.pt, len(self.pt)
@@ -139,11 +149,11 @@ class WgradBatch:
         if mt:
             tpt = lambda j: (ctypes.c_void_p * mt)(*[x[j].data_ptr() for x in qt])
             opt = lambda j: (ctypes.c_void_p * mt)(*[at(x[j]) for x in qt])
-            iat = [np.array([x[j] for x in qt], np.int32) for j in (1, 2, 3, 5, 6, 7)]
+            iat = [np.array([x[j] for x in qt], np.int32) for j in (1, 2, 3, 4, 6, 7, 8)]
             ipt = [a.ctypes.data_as(ctypes.c_void_p) for a in iat]
             with _C._clock('vqn_wgrad_thin_batched'):
-                nthin = _C.lib().vqn_wgrad_thin_batched(ctypes.c_int(mt), tpt(0), ipt[0], ipt[1], ipt[2], tpt(4), ipt[3], ipt[4], ipt[5],
-                                                        ctypes.c_int64(self.nt), ctypes.c_int(self.n_split), opt(8), opt(9), _C._stream())
+                nthin = _C.lib().vqn_wgrad_thin_batched(ctypes.c_int(mt), tpt(0), ipt[0], ipt[1], ipt[2], ipt[3], tpt(5), ipt[4], ipt[5], ipt[6],
+                                                        ctypes.c_int64(self.nt), ctypes.c_int(self.n_split), opt(9), opt(10), _C._stream())
             if nthin <= 0:
                 _C._check(nthin if nthin < 0 else -3, 'vqn_wgrad_thin_batched')
             assert nthin == n
