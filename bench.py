@@ -430,6 +430,33 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
         'max_abs_diff_vs_f32': {k: float((got_pred[k] - ref_pred[k]).abs().max()) for k in ('rgb', 'albedo', 'rough', 'vq_rgb')},
         'vq_idx_match_vs_f32_pct': 100.0 * float(same_code),
         'note': 'opt-in precision mode (model.matrix_mode = "f16s"); `value` and every other line are the f32 path'}
+    _log('leg: the same view on the exact-split stack kernel')
+    # ---- the same view with the MLP stacks on the exact-split kernel of the trainers (matrix_mode 'x3': bf16 piece triples, 6 bf16 MFMAs
+    # per product, f32-level products with no operand-range caveat; csrc/refl_train_x3.hip with nothing kept for a backward) ----
+    with torch.no_grad():
+        model.matrix_mode = 'x3'
+        try:
+            got_x3 = model.call(big, mode='vali')[0]
+            _C.KernelClock.reset(True)
+            dtx3 = _time_gpu(lambda: model.call(big, mode='vali'), 3, warm=0)
+            clkx3 = _C.KernelClock.summary()
+        finally:
+            model.matrix_mode = 'f32'
+            _C.KernelClock.reset(False)
+    t_chainx3 = sum(v[1] for k, v in clkx3.items() if k == 'vqn_refl_train_fwd_x3') / 3 * 1e-3
+    effx3 = 2.0 * (enc_macs + head_macs) * N / max(t_chainx3, 1e-9) / 1e12
+    out['decomp_render_x3'] = {
+        'points_per_s': N / dtx3, 'ms_per_view': dtx3 * 1e3, 'points': N,
+        'mlp_chain': {'bound': 'mfma', 'achieved': effx3, 'unit': 'TFLOP/s (algorithmic f32 FLOPs)', 'ms': t_chainx3 * 1e3,
+                      'issued_bf16_tflops': 6.0 * effx3, 'peak': BF16_MFMA_PEAK_TFLOPS, 'frac': 6.0 * effx3 / BF16_MFMA_PEAK_TFLOPS,
+                      'frac_note': 'issued bf16 MFMA FLOPs (6 per algorithmic FLOP) over the dense bf16 peak',
+                      'f32_equivalent_frac': effx3 / F32_MFMA_PEAK_TFLOPS, 'speedup_vs_f32_kernel': t_chain / max(t_chainx3, 1e-9)},
+        'max_abs_diff_vs_f32': {k: float((got_x3[k] - ref_pred[k]).abs().max()) for k in ('rgb', 'albedo', 'rough', 'vq_rgb')},
+        'vq_idx_match_vs_f32_pct': 100.0 * float((got_x3['embed'] == ref_pred['embed']).float().mean()),
+        'kernel_launches_per_call': {k: v[0] // 3 for k, v in clkx3.items()},
+        'note': 'opt-in mode (model.matrix_mode = "x3"): encoder + main heads in one launch, quantiser, VQ heads in one launch, shading; '
+                '`value` and every other line are the f32 path'}
+    del got_x3
     _log('leg: BASELINE.json configs[4]')
     # ---- BASELINE.json configs[4]: relighting one view under 16 probes (test.py pd_relit pass), f32 and split-precision MLP stacks ----
     model.novel_probes = {f'probe{i:02d}': torch.tensor(rng.uniform(0, 2, (16, 32, 3)).astype(np.float32), device=dev) for i in range(16)}

@@ -518,6 +518,10 @@ int vqn_wgrad_finalize(int count, const float* const* ws, const int32_t* n, cons
  * vqn_ks_split_fwd: spec = ks basecolor, albedo = (1 - ks) basecolor (vq_nfr.py:590-592; basecolor [n, 3], ks [n, 1 | 3]);
  * vqn_ks_split_bwd: their adjoints (g_albedo / g_spec may be NULL = zero). */
 int vqn_clip_preserve(const float* x, int64_t n, float lo, float hi, float* y, void* stream);
+/* out[i] = the per-point training loss summed in the reference's order (vq_nfr.py:906-981): terms [n, 5] = rgb, vqrgb, chromaticity,
+ * chr_smooth, lambert; vqloss / sim device scalars (sim may be NULL); (((rgb + vqrgb) + vqloss) [+ chr] [+ smooth] [+ sim] [+ lambert]). */
+int vqn_loss_total(const float* terms, int64_t n, const float* vqloss, const float* sim, int use_chr, int use_smooth, int use_lambert,
+                   float* out, void* stream);
 int vqn_ks_split_fwd(const float* basecolor, const float* ks, int ks_channels, int64_t n, float* albedo, float* spec, void* stream);
 int vqn_ks_split_bwd(const float* basecolor, const float* ks, int ks_channels, int64_t n, const float* g_albedo, const float* g_spec,
                      float* g_basecolor, float* g_ks, void* stream);
@@ -548,7 +552,9 @@ int vqn_multi_copy(int count, const float* const* src, float* const* dst, const 
  * order, the heads' last layers as row-dot images and accumulator-order columns.  Tensors in the tile format are
  * [ceil(P/32)][feature tiles][32 features][32 points] f32.
  * forward -- saved (written): with an encoder [E, Y_0 .. Y_{n_enc-1}] (Y_{n_enc-1} = z), without [ZT = the input rows' tile-format
- *   copy]; then [H0_k, H1_k] per head.  z_rows_out [P, z_feats] (optional, with an encoder); head_out[k] [P, c_k].
+ *   copy]; then [H0_k, H1_k] per head.  z_rows_out [P, z_feats] (optional, with an encoder); head_out[k] [P, c_k].  save_tensors = 0:
+ *   INFERENCE on the same kernel (the exact-split reflectance chain, `model.matrix_mode = 'x3'`): nothing is kept but z's tile-format
+ *   tensor (Y_{n_enc-1} / ZT: heads 2 and 3 re-read it); the other `saved` entries may be NULL.
  * backward -- g_out[k] / head_out[k] [P, c_k]; g_z_rows: up to four [P, z_feats] adjoints of z from outside this launch's heads (summed
  *   in order); saved [Y_0 .. Y_{n_enc-1}] then [H0_k, H1_k]; outs (written) [D_0 .. D_{n_enc-1}] then [D0_k, D1_k, D2_k] per head.
  *   run_heads / run_enc select the part of the stack the launch walks: both = the whole backward; heads only = d / d z rows into
@@ -562,7 +568,7 @@ int vqn_multi_copy(int count, const float* const* src, float* const* dst, const 
 int vqn_refl_train_desc_ints(void);
 int vqn_refl_train_fwd_x3(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, const float* pts, const float* z_rows,
                           int64_t P, float* const* saved, int n_saved, float* z_rows_out, float* const* head_out, int split_heads,
-                          void* stream);
+                          int save_tensors, void* stream);
 int64_t vqn_refl_train_bwd_x3_scratch_bytes(const int32_t* desc);
 int vqn_refl_train_bwd_x3(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, int64_t P, const float* const* g_out,
                           const float* const* head_out, const float* const* g_z_rows, int n_gz, const float* const* saved, int n_saved,

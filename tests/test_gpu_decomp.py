@@ -9,6 +9,7 @@ import torch
 
 from tests.decomp_util import make_config, load_oracle_params, make_batch
 from tests.gpu_util import launches
+from vqnerf_release_amd import _C
 
 pytestmark = pytest.mark.gpu
 
@@ -123,6 +124,89 @@ def test_split_precision_chain_vs_fp64_oracle(setup, n):
         a32, a16 = np.abs(_np(g32) - w.numpy()).max(), np.abs(_np(g16) - w.numpy()).max()
         assert a16 <= 4 * a32 + 2e-6, (a16, a32)
     assert torch.equal(one, h16[5])                                   # one head per launch == three per launch, here too
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [1, 33, 2048, 5000])
+def test_exact_split_chain_vs_fp64_oracle(setup, n):
+    """matrix_mode = 'x3' (round 4): inference on the exact-split stack kernel of the trainers (vqn_refl_train_fwd_x3 with nothing kept
+    for a backward: bf16 piece triples, six bf16 MFMAs per product, f32 accumulate).  Its products are f32-exact up to the dropped
+    piece-pair terms (2^-24 relative), so against the oracle in float64 it must be as accurate as the f32 kernel: within 2x the f32
+    kernel's own error + 1e-6 of the output scale.  Encoder + three heads of a family in ONE launch, heads alone in ONE launch."""
+    od, model, p, specs = setup['od'], setup['model'], setup['p'], setup['specs']
+    pts = od.make_points(n, seed=60 + n)
+    xyz = torch.tensor(pts['xyz']).cuda()
+    p64 = {k: [(torch.tensor(W, dtype=torch.float64), torch.tensor(b, dtype=torch.float64)) for W, b in v]
+           for k, v in p.items() if isinstance(v, list)}
+    z64 = od.pred_enc(p64, specs, torch.tensor(pts['xyz'], dtype=torch.float64))
+    try:
+        with torch.no_grad():
+            z32 = model._pred_enc_at(xyz)
+            h32 = model._all_heads(z32, 'main') + model._all_heads(z32, 'vq')
+            model.matrix_mode = 'x3'
+            _C.KernelClock.reset(True)
+            zx = model._pred_enc_at(xyz)
+            hx = model._all_heads(z32, 'main') + model._all_heads(z32, 'vq')
+            one = model._pred_rough_at(z32, vq=True)
+            zf, a, s_, r = model.enc_and_heads(xyz, 'main')
+            torch.cuda.synchronize()
+            clk = _C.KernelClock.summary()
+    finally:
+        model.matrix_mode = 'f32'
+        _C.KernelClock.reset(False)
+    assert clk['vqn_refl_train_fwd_x3'][0] == 5 and 'vqn_mlp_chain_fwd' not in clk, clk      # enc | main heads | vq heads | one head | enc + heads
+    scale = float(z64.abs().max())
+    e32, ex = np.abs(_np(z32) - z64.numpy()).max(), np.abs(_np(zx) - z64.numpy()).max()
+    assert ex <= 2 * e32 + 1e-6 * scale, (ex, e32, scale)
+    assert zx.shape == z32.shape and not torch.equal(zx, z32)          # it really is the other kernel
+    assert torch.equal(zf, zx)                                         # the encoder rows do not depend on which heads ride along
+    z_at = torch.tensor(_np(z32), dtype=torch.float64)
+    want = od.heads(p64, specs, z_at, False) + od.heads(p64, specs, z_at, True)
+    for g32, gx, w in zip(h32, hx, want):
+        assert gx.shape == w.shape
+        a32, ax = np.abs(_np(g32) - w.numpy()).max(), np.abs(_np(gx) - w.numpy()).max()
+        assert ax <= 2 * a32 + 1e-6, (ax, a32)
+    assert np.abs(_np(one) - _np(hx[5])).max() <= 1e-6                # one head per launch vs three per launch: the same sums
+    # heads at the x3 encoder's own rows: enc + heads in one launch == the two launches
+    with torch.no_grad():
+        model.matrix_mode = 'x3'
+        try:
+            h_at = model._all_heads(zx, 'main')
+        finally:
+            model.matrix_mode = 'f32'
+    for got, sep in zip((a, s_, r), h_at):
+        assert np.abs(_np(got) - _np(sep)).max() <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['test', 'vali'])
+def test_exact_split_model_call_vs_f32(setup, mode):
+    """model.call with matrix_mode = 'x3' end to end (encoder + main heads, quantiser, VQ heads, shading): every output within f32
+    rounding of the f32 path, the same codes except at near-ties."""
+    od, model = setup['od'], setup['model']
+    batch = make_batch(od.make_points(3000, seed=77), 'cuda', bg_every=7)
+    with torch.no_grad():
+        ref = model.call(batch, mode=mode)[0]
+        model.matrix_mode = 'x3'
+        try:
+            _C.KernelClock.reset(True)
+            got = model.call(batch, mode=mode)[0]
+            torch.cuda.synchronize()
+            clk = _C.KernelClock.summary()
+        finally:
+            model.matrix_mode = 'f32'
+            _C.KernelClock.reset(False)
+    assert clk['vqn_refl_train_fwd_x3'][0] == 2 and 'vqn_mlp_chain_fwd' not in clk and 'vqn_mlp_chain_vq_fwd' not in clk, clk
+    same = (got['embed'] == ref['embed']).float().mean()
+    assert float(same) >= 0.995
+    ok = (got['embed'] == ref['embed']).reshape(-1)
+    checked = 0
+    for k in ('rgb', 'albedo', 'rough', 'spec', 'vq_rgb', 'vq_albedo'):
+        if k in ref and torch.is_tensor(ref[k]) and ref[k].shape[0] == ok.shape[0]:
+            d = (got[k] - ref[k]).abs()[ok]
+            assert float(d.max()) <= 5e-5, (k, float(d.max()))
+            checked += 1
+    assert checked >= 4
 
 
 def _oracle_shade(od, setup, pts, mats, light, with_lvis, dtype, gamma=None):

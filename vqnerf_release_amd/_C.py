@@ -828,18 +828,19 @@ def brdf_shade_bwd(xyz, normal, rayo, lvis, lxyz, lareas, light, materials, g_su
 
 
 # -------------------------------------------------------------------------------------- reflectance training passes (round 4)
-def refl_train_fwd_x3(desc, wbuf_pieces, wbuf_f32, pts, z_rows, P, saved, z_rows_out, head_out, split_heads=False):
+def refl_train_fwd_x3(desc, wbuf_pieces, wbuf_f32, pts, z_rows, P, saved, z_rows_out, head_out, split_heads=False, save=True):
     """Forward of a reflectance stack (optional encoder + up to three heads) on the exact-split engine, keeping what the backward
     needs (csrc/refl_train_x3.hip: vqn_refl_train_fwd_x3).  split_heads: one workgroup row per head (small batches)."""
     _f32c(wbuf_f32, 'wbuf_f32')
-    for t in list(saved) + list(head_out) + [t for t in (pts, z_rows, z_rows_out) if t is not None]:
+    for t in [t for t in saved if t is not None] + list(head_out) + [t for t in (pts, z_rows, z_rows_out) if t is not None]:
         _f32c(t, 'tensor')
     d, dp = _i32(desc)
-    sp = (ctypes.c_void_p * len(saved))(*[t.data_ptr() for t in saved])
+    sp = (ctypes.c_void_p * len(saved))(*[0 if t is None else t.data_ptr() for t in saved])
     hp = (ctypes.c_void_p * max(1, len(head_out)))(*[t.data_ptr() for t in head_out])
     with _clock('vqn_refl_train_fwd_x3'):
         rc = lib().vqn_refl_train_fwd_x3(dp, _ptr(wbuf_pieces), _ptr(wbuf_f32), _ptr(pts), _ptr(z_rows), ctypes.c_int64(P), sp,
-                                         ctypes.c_int(len(saved)), _ptr(z_rows_out), hp, ctypes.c_int(int(split_heads)), _stream())
+                                         ctypes.c_int(len(saved)), _ptr(z_rows_out), hp, ctypes.c_int(int(split_heads)), ctypes.c_int(int(save)),
+                                         _stream())
     _check(rc, 'vqn_refl_train_fwd_x3')
 
 
@@ -905,3 +906,15 @@ def ks_split_bwd(basecolor, ks, g_albedo, g_spec):
                                     _ptr(g_spec), _ptr(g_bc), _ptr(g_ks), _stream())
     _check(rc, 'vqn_ks_split_bwd')
     return g_bc, g_ks
+
+
+def loss_total(terms, vqloss, sim, use_chr, use_smooth, use_lambert):
+    _f32c(terms, 'terms'); _f32c(vqloss, 'vqloss')
+    if sim is not None:
+        _f32c(sim, 'sim')
+    out = torch.empty((terms.shape[0],), dtype=torch.float32, device=terms.device)
+    with _clock('vqn_loss_total'):
+        rc = lib().vqn_loss_total(_ptr(terms), ctypes.c_int64(terms.shape[0]), _ptr(vqloss), _ptr(sim), ctypes.c_int(int(use_chr)),
+                                  ctypes.c_int(int(use_smooth)), ctypes.c_int(int(use_lambert)), _ptr(out), _stream())
+    _check(rc, 'vqn_loss_total')
+    return out

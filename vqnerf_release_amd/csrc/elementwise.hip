@@ -47,6 +47,23 @@ __global__ __launch_bounds__(256) void ks_split_bwd_kernel(const float* __restri
   }
 }
 
+// loss[i] = ((((rgb + vqrgb) + vqloss) [+ chr]) [+ smooth]) [+ sim]) [+ lambert] in the reference's own order (vq_nfr.py:906-981):
+// terms [N, 5] = rgb, vqrgb, chromaticity, chr_smooth, lambert per point; vqloss / sim device scalars.
+__global__ __launch_bounds__(256) void loss_total_kernel(const float* __restrict__ terms, const long n, const float* __restrict__ vqloss,
+                                                         const float* __restrict__ sim, const int use_chr, const int use_smooth,
+                                                         const int use_lambert, float* __restrict__ out) {
+  const float vl = vqloss[0], sm = sim != nullptr ? sim[0] : 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float* t = terms + 5 * i;
+    float l = __fadd_rn(__fadd_rn(t[0], t[1]), vl);
+    if (use_chr) l = __fadd_rn(l, t[2]);
+    if (use_smooth) l = __fadd_rn(l, t[3]);
+    if (sim != nullptr) l = __fadd_rn(l, sm);
+    if (use_lambert) l = __fadd_rn(l, t[4]);
+    out[i] = l;
+  }
+}
+
 long grid_for(long n) {
   long blocks = (n + 255) / 256;
   const long cap = (long)vqn_num_cus() * 16;
@@ -81,6 +98,17 @@ extern "C" int vqn_ks_split_bwd(const float* basecolor, const float* ks, int ks_
   VQN_CHECK_ARG(basecolor && ks && g_basecolor && g_ks, "null pointer");
   hipLaunchKernelGGL(ks_split_bwd_kernel, dim3((unsigned)grid_for(n)), dim3(256), 0, (hipStream_t)stream, basecolor, ks, ks_channels, (long)n,
                      g_albedo, g_spec, g_basecolor, g_ks);
+  VQN_LAUNCH_CHECK();
+  return VQN_OK;
+}
+
+extern "C" int vqn_loss_total(const float* terms, int64_t n, const float* vqloss, const float* sim, int use_chr, int use_smooth, int use_lambert,
+                              float* out, void* stream) {
+  VQN_CHECK_ARG(n >= 0, "n >= 0");
+  if (n == 0) return VQN_OK;
+  VQN_CHECK_ARG(terms && vqloss && out, "null pointer");
+  hipLaunchKernelGGL(loss_total_kernel, dim3((unsigned)grid_for(n)), dim3(256), 0, (hipStream_t)stream, terms, (long)n, vqloss, sim, use_chr,
+                     use_smooth, use_lambert, out);
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }

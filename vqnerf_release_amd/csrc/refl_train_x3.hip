@@ -65,6 +65,7 @@ struct ReflFwdPtrs {
   float* ZT;                                // z in the tile format: Y[n_enc - 1] with an encoder, else the copy this kernel writes
   float* ZROWS;                             // z as rows [N, z_feats] (with an encoder; may be NULL)
   float* H0[RT_MAX_H]; float* H1[RT_MAX_H]; float* OUT[RT_MAX_H];
+  int save;                                 // 0: inference -- nothing is kept for a backward (only z's tile-format copy, which heads 2 and 3 re-read)
 };
 
 struct ReflBwdPtrs {
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(512, 1) void refl_train_fwd_x3_kernel(const ReflDes
           const int f = step_feat(sl, h, jj);
           x[jj] = (sl < rd.emb_rows / 3 && f < rd.emb_feats) ? posenc_feat(f, xs, ys, zs) : 0.f;
         }
-        if (live_w && wr_shared) tf_store_step(tp.E, ptile_w, rd.e_tiles, sl, lane, x);
+        if (live_w && wr_shared && tp.save) tf_store_step(tp.E, ptile_w, rd.e_tiles, sl, lane, x);
         if (sl < rd.emb_rows / 3) {
           f32x4 q0, q1, q2;
           split3x8(x, q0, q1, q2);
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(512, 1) void refl_train_fwd_x3_kernel(const ReflDes
             act_apply(act, acc, v);
             const long ptile = ptile_of(unit, im);
             if (ptile < n_tiles && wr_shared) {
-              tf_store_acc(t_y, ptile, n_ot, ot, lane, v);
+              if (tp.save || top) tf_store_acc(t_y, ptile, n_ot, ot, lane, v);
               if (top && tp.ZROWS != nullptr) {
                 const long pt = (ptile << 5) + p;
                 if (pt < P) {
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(512, 1) void refl_train_fwd_x3_kernel(const ReflDes
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc[i], 0.f);
-            if (ptile_of(unit, im) < n_tiles) tf_store_acc(t_y, ptile_of(unit, im), n_ot, ot, lane, v);
+            if (tp.save && ptile_of(unit, im) < n_tiles) tf_store_acc(t_y, ptile_of(unit, im), n_ot, ot, lane, v);
             store_tile_x3(lds + (size_t)im * IS, X0 + 6 * ot, lane, v);
           });
       }
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(512, 1) void refl_train_fwd_x3_kernel(const ReflDes
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc[i], 0.f);
-            if (ptile_of(unit, im) < n_tiles) tf_store_acc(t_y, ptile_of(unit, im), n_ot, ot, lane, v);
+            if (tp.save && ptile_of(unit, im) < n_tiles) tf_store_acc(t_y, ptile_of(unit, im), n_ot, ot, lane, v);
             store_tile_x3(lds + (size_t)im * IS, X0 + 6 * ot, lane, v);
           });
       }
@@ -679,7 +680,7 @@ extern "C" int vqn_refl_train_desc_ints(void) { return RT_DESC_INTS; }
 
 extern "C" int vqn_refl_train_fwd_x3(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, const float* pts, const float* z_rows,
                                      int64_t P, float* const* saved, int n_saved, float* z_rows_out, float* const* head_out, int split_heads,
-                                     void* stream) {
+                                     int save_tensors, void* stream) {
   VQN_CHECK_ARG(desc && wbuf_pieces && wbuf_f32 && saved, "null pointer");
   VQN_CHECK_ARG(P >= 1, "P >= 1");
   ReflDesc rd;
@@ -689,10 +690,12 @@ extern "C" int vqn_refl_train_fwd_x3(const int32_t* desc, const void* wbuf_piece
   // saved: with an encoder [E, Y_0..Y_{nE-1}], without [ZT]; then per head [H0, H1]
   VQN_CHECK_ARG(n_saved == (nE > 0 ? 1 + nE : 1) + 2 * nH, "saved: [E, Y_0..] | [ZT], then [H0_k, H1_k] per head");
   VQN_CHECK_ARG(nH == 0 || head_out != nullptr, "head_out");
-  for (int i = 0; i < n_saved; ++i) VQN_CHECK_ARG(saved[i] != nullptr, "null saved tensor");
+  // (save_tensors = 0, inference: only z's tile-format tensor -- Y_{n_enc-1} / ZT -- is written and must be given)
+  for (int i = 0; i < n_saved; ++i)
+    VQN_CHECK_ARG(saved[i] != nullptr || (!save_tensors && i != (nE > 0 ? nE : 0)), "null saved tensor");
   ReflFwdPtrs tp;
   memset(&tp, 0, sizeof(tp));
-  tp.X = pts; tp.ZR = z_rows; tp.ZROWS = z_rows_out;
+  tp.X = pts; tp.ZR = z_rows; tp.ZROWS = z_rows_out; tp.save = save_tensors != 0;
   int s = 0;
   if (nE > 0) {
     tp.E = saved[s++];

@@ -181,7 +181,8 @@ class BrdfModel(ShapeModel):
         self._light = None
         self._gamma_index, self._gamma_bias = None, None
         self._plans, self._packs, self._engines = {}, {}, {}
-        self.matrix_mode = 'f32'         # 'f16s': inference MLP stacks on the split-precision (f16 hi/lo MFMA) kernel, ~1e-6 relative
+        self.matrix_mode = 'f32'         # 'f16s': inference MLP stacks on the split-precision (f16 hi/lo MFMA) kernel, ~1e-6 relative;
+                                         # 'x3' (round 4): on the exact-split stack kernel (bf16 piece triples, f32-level products)
         self.assume_foreground = False   # True: callers promise alpha > 0 everywhere (vq_nfr.Model.call skips the boolean gathers)
         self.train_backend = 'hip'       # 'hip': fused shading fwd/bwd kernels under autograd; 'torch': torch statements
         # the reference's tf.debugging.check_numerics guards (vq_nfr.py:731, :783, :802, :815, :827, :985 and their twins in
@@ -307,10 +308,10 @@ class BrdfModel(ShapeModel):
 
     # ------------------------------------------------------------------ fused layer programs
     def _enc_program(self):
-        pkey = 'enc:' + self.matrix_mode
+        pkey = 'enc:' + self._chain_mode()
         if pkey not in self._plans:
             emb = self.embedder['xyz']
-            b = packing.ChainBuilder('posenc', emb.out_dims, n_freqs=emb.n_freqs, mode=self.matrix_mode)
+            b = packing.ChainBuilder('posenc', emb.out_dims, n_freqs=emb.n_freqs, mode=self._chain_mode())
             fe, bn = self.net['fine_enc'], self.net['bottleneck']
             y = b.mlp('fine_enc', fe.widths, fe.act, fe.skip_at, b.input)
             assert not isinstance(y, list)
@@ -320,11 +321,11 @@ class BrdfModel(ShapeModel):
 
     def _head_program(self, names, in_dim=None):
         in_dim = in_dim or self.z_dim
-        key = 'heads:%s:%d:' % (self.matrix_mode, in_dim) + ','.join(names)
+        key = 'heads:%s:%d:' % (self._chain_mode(), in_dim) + ','.join(names)
         if key not in self._plans:
-            b = packing.ChainBuilder('raw', in_dim, mode=self.matrix_mode)
+            b = packing.ChainBuilder('raw', in_dim, mode=self._chain_mode())
             x = b.input
-            resident = self.matrix_mode == 'f32' and all(self._is_std_head(self.net[n]) and self.net[n].widths[1] <= 128 for n in names)
+            resident = self._chain_mode() == 'f32' and all(self._is_std_head(self.net[n]) and self.net[n].widths[1] <= 128 for n in names)
             for slot, name in enumerate(names):
                 net = self.net[name]
                 if resident:
@@ -401,6 +402,12 @@ class BrdfModel(ShapeModel):
         """(z, basecolor | albedo, ks | spec, rough) of `pts`: `_pred_bias_at` followed by `_all_heads(z, suffix)`, as one fused
         program where the path allows it (no graph, f32 kernels, standard heads)."""
         names = [h + '_' + suffix for h in self.HEADS]
+        if self.matrix_mode == 'x3' and self._fused(pts):
+            res = self._x3_infer(names, pts, True)
+            if res is not None:
+                z, (d, s_, r) = res
+                return (self._numerics(z, 'Z'), self._numerics(self._albedo_affine(d), 'Albedo'), self._numerics(s_, 'Specular'),
+                        self._numerics(r, 'Roughness'))
         if self._fused(pts) and self._can_fuse_enc_heads(names) and self._plan_fits_two_workgroups(names):
             z, (d, s_, r) = self._fused_enc_heads(pts, names)
             return (self._numerics(z, 'Z'), self._numerics(self._albedo_affine(d), 'Albedo'), self._numerics(s_, 'Specular'),
@@ -418,15 +425,23 @@ class BrdfModel(ShapeModel):
         return self._enc_heads_program(names).n_waves == 4
 
     def _fused_enc(self, pts):
+        if self.matrix_mode == 'x3':
+            res = self._x3_infer([], pts, True)
+            if res is not None:
+                return res[0]
         plan = self._enc_program()
-        wbuf, desc = self._program_pack('enc:' + self.matrix_mode, plan, ['fine_enc', 'bottleneck'])
-        return _C.mlp_chain_fwd(desc, wbuf, pts.detach().float().contiguous(), [self.z_dim], mode=self.matrix_mode)[0]
+        wbuf, desc = self._program_pack('enc:' + self._chain_mode(), plan, ['fine_enc', 'bottleneck'])
+        return _C.mlp_chain_fwd(desc, wbuf, pts.detach().float().contiguous(), [self.z_dim], mode=self._chain_mode())[0]
 
     def _fused_heads(self, z, names):
+        if self.matrix_mode == 'x3':
+            res = self._x3_infer(list(names), z, False)
+            if res is not None:
+                return res[1]
         plan = self._head_program(names, z.shape[1])
-        wbuf, desc = self._program_pack('heads:%s:%d:' % (self.matrix_mode, z.shape[1]) + ','.join(names), plan, names)
+        wbuf, desc = self._program_pack('heads:%s:%d:' % (self._chain_mode(), z.shape[1]) + ','.join(names), plan, names)
         widths = [self.net[n].widths[-1] for n in names]
-        return _C.mlp_chain_fwd(desc, wbuf, z.detach().float().contiguous(), widths, mode=self.matrix_mode)
+        return _C.mlp_chain_fwd(desc, wbuf, z.detach().float().contiguous(), widths, mode=self._chain_mode())
 
     # ------------------------------------------------------------------ training engines (tile programs)
     def _train_hip(self, x):
@@ -453,6 +468,30 @@ class BrdfModel(ShapeModel):
         if eng is None or (not with_encoder and x.shape[1] != self.z_dim):
             return None
         return eng if any(p.requires_grad for p in eng.params()) or x.requires_grad else None
+
+    # ---- matrix_mode = 'x3' (round 4, opt-in like 'f16s'): inference on the exact-split stack kernel of the trainers
+    # (csrc/refl_train_x3.hip with nothing kept for a backward) -- f32-level products (six bf16 MFMAs each), no operand-range caveat
+    def _x3_infer(self, names, x, with_encoder):
+        """(z rows | None, head outputs) on the exact-split engine, or None when the stack is outside its shape (then the f32 chain)."""
+        key = ('stack', with_encoder) + tuple(names)
+        if key not in self._engines:
+            from vqnerf_release_amd.decomp.refl_train import ReflStackEngine
+            enc = [self.net['fine_enc'], self.net['bottleneck']] if with_encoder else None
+            heads = [self.net[n] for n in names]
+            emb = self.embedder['xyz']
+            ok = ReflStackEngine.supports(enc, heads, self.z_dim, getattr(emb, 'out_dims', 0) if with_encoder else 0)
+            self._engines[key] = ReflStackEngine(enc, emb.n_freqs if with_encoder else 0, heads, self.z_dim, x.device) if ok else None
+        eng = self._engines[key]
+        if eng is None or (not with_encoder and x.shape[1] != self.z_dim):
+            return None
+        cache = self._packs.setdefault(('x3',) + key, _PackCache())
+        packs = cache.get(eng.params(), lambda: eng.build_packs(eng.params()))
+        return eng.infer(x, packs)
+
+    def _chain_mode(self):
+        """mode of the descriptor-driven chain kernels: they have no exact-split variant ('x3' stacks outside the stack kernel's shape
+        run the f32 chain)"""
+        return 'f32' if self.matrix_mode == 'x3' else self.matrix_mode
 
     def _enc_engine(self, device):
         if 'enc' not in self._engines:

@@ -71,6 +71,29 @@ class FusedTrainLoss(torch.autograd.Function):
         return g_pred, g_vq, None, g_z, g_spec, None, None, None
 
 
+class _LossTotal(torch.autograd.Function):
+    """loss[i] = ((rgb + vqrgb) + vqloss) [+ chromaticity] [+ chr_smooth] [+ sim_smooth] [+ lambert], the reference's order
+    (vq_nfr.py:906-981), one launch; backward: the incoming [N] adjoint to the used columns, its sum to the two scalars."""
+
+    @staticmethod
+    def forward(ctx, terms, vqloss, sim, use_chr, use_smooth, use_lambert):
+        ctx.use = (bool(use_chr), bool(use_smooth), bool(use_lambert))
+        ctx.has_sim = sim is not None
+        key = (str(terms.device),) + ctx.use
+        if key not in _LossTotal._cols:           # (made outside any capture: a host-to-device copy cannot be recorded)
+            _LossTotal._cols[key] = torch.tensor([1.0, 1.0, float(ctx.use[0]), float(ctx.use[1]), float(ctx.use[2])], device=terms.device)
+        ctx.cols = _LossTotal._cols[key]
+        return _C.loss_total(terms.detach().float().contiguous(), vqloss.detach().float().reshape(1).contiguous(),
+                             None if sim is None else sim.detach().float().reshape(1).contiguous(), *ctx.use)
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = g.sum()
+        return g[:, None] * ctx.cols[None, :], gs, (gs if ctx.has_sim else None), None, None, None
+
+    _cols = {}
+
+
 class Model(BrdfModel):
     def __init__(self, config, debug=False):
         self.no_brdf_chunk = config.getboolean('DEFAULT', 'no_brdf_chunk', fallback=True)
@@ -439,23 +462,17 @@ class Model(BrdfModel):
         spec, rough = (kwargs.pop('spec'), kwargs.pop('rough')) if w['lambert'] > 0 else (None, None)
         terms = FusedTrainLoss.apply(rgb_pred, vq_rgb, rgb_gt, z_vq, spec, rough, self.data_type == 'nerf', w)
         ld = {'rgb': terms[:, 0], 'vqrgb': terms[:, 1], 'vqloss': cfg('vq_loss_weight') * kwargs.pop('vqloss')}
-        # the per-point total as ONE weighted row sum + the two scalar terms (the reference adds term by term, vq_nfr.py:906-981: the
-        # same sum up to the association of at most seven f32 additions): 3 launches forward instead of 7
-        use = [1.0, 1.0, float(w['chr'] > 0), float(w['smooth'] > 0), float(w['lambert'] > 0)]
-        scalar = ld['vqloss']
+        # the per-point total in the reference's own order, ONE launch (vqn_loss_total; seven framework launches before)
         if w['chr'] > 0:
             ld['chromaticity'] = terms[:, 2]
         if w['smooth'] > 0:
             ld['chr_smooth'] = terms[:, 3]
+        sim = None
         if cfg('sim_loss_weight') > 0:
-            ld['sim_smooth'] = self._sim_smooth(cfg)
-            scalar = scalar + ld['sim_smooth']
+            sim = ld['sim_smooth'] = self._sim_smooth(cfg)
         if w['lambert'] > 0:
             ld['lambert'] = terms[:, 4]
-        key = (terms.device, tuple(use))
-        if getattr(self, '_use_cols', (None,))[0] != key:
-            self._use_cols = (key, torch.tensor(use, dtype=torch.float32, device=terms.device))
-        loss = torch.addmv(scalar.reshape(1).expand(terms.shape[0]), terms, self._use_cols[1])
+        loss = _LossTotal.apply(terms, ld['vqloss'], sim, w['chr'] > 0, w['smooth'] > 0, w['lambert'] > 0)
         ld['loss'] = loss
         return self._numerics(loss, 'Loss'), ld
 

@@ -211,6 +211,34 @@ class ReflStackEngine:
         _C.refl_train_fwd_x3(desc, pieces, wf, x if self.nE else None, None if self.nE else x, N, saved, zrows, outs, split_heads=S['split'])
         return S, zrows, outs
 
+    @torch.no_grad()
+    def build_packs(self, params):
+        """(piece pack, f32 images) of the current weights: two launches + the flat copy; callers cache them per weights epoch."""
+        L, gidx, n_steps, fidx, desc = self._static()
+        flat = L.flatten({n: p.detach().float() for n, p in zip(L.names, params)})
+        return _C.pack_x3_gather(flat, gidx, n_steps), flat[fidx]
+
+    @torch.no_grad()
+    def infer(self, x, packs):
+        """Inference on the same kernel (`model.matrix_mode = 'x3'`: the exact-split reflectance chain): nothing is kept for a backward.
+        packs = build_packs(params).  -> (z rows | None, head outputs)."""
+        L, gidx, n_steps, fidx, desc = self._static()
+        x = x.detach().float().contiguous()
+        N, dev = x.shape[0], x.device
+        nt = (N + 31) // 32
+        pieces, wf = packs
+        zt = self._tensor(nt, _tl(self.Z), dev)
+        if self.nE:
+            saved = [None] * self.nE + [zt] + [None] * (2 * self.nH)
+            zrows = torch.empty((N, self.Z), dtype=torch.float32, device=dev)
+        else:
+            saved = [zt] + [None] * (2 * self.nH)
+            zrows = None
+        outs = [torch.empty((N, net.widths[2]), dtype=torch.float32, device=dev) for net in self.heads]
+        _C.refl_train_fwd_x3(desc, pieces, wf, x if self.nE else None, None if self.nE else x, N, saved, zrows, outs,
+                             split_heads=self._split_heads(nt), save=False)
+        return zrows, outs
+
     def _split_heads(self, nt):
         """Small batches: one workgroup row per head while that still fits the chip (the reference batch of 2048 points is 64 point
         tiles on 256 CUs).  VQN_REFL_SPLIT = 0 | 1 overrides."""
