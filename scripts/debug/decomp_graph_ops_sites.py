@@ -18,6 +18,21 @@ class Log(TorchDispatchMode):
                     break
             sites[(site, name)] += 1
         return func(*args, **(kwargs or {}))
+# the backward bodies run on the autograd engine's thread, where the mode above is not active: run each of them under its own Log()
+import vqnerf_release_amd.decomp.refl_train as _rt, vqnerf_release_amd.decomp.nerfactor.models.nfr_unit as _nu
+import vqnerf_release_amd.decomp.nerfactor.models.vq_nfr as _vn, vqnerf_release_amd.decomp.nerfactor.networks.vq_layers as _vl
+import vqnerf_release_amd.decomp.nerfactor.util.math as _um
+def _wrap(cls):
+    inner = cls.backward
+    def bw(ctx, *g):
+        with Log():
+            return inner(ctx, *g)
+    cls.backward = staticmethod(bw)
+for mod in (_rt, _nu, _vn, _vl, _um):
+    for name in dir(mod):
+        c = getattr(mod, name)
+        if isinstance(c, type) and issubclass(c, torch.autograd.Function) and c is not torch.autograd.Function and c.__module__ == mod.__name__:
+            _wrap(c)
 n = 0
 while tr._captured is None and n < 8:
     if n >= tr.GRAPH_WARMUP:
@@ -34,18 +49,3 @@ for (s, nm), c in sites.items():
 for s, c in by_site.most_common(60):
     ops = ', '.join(f'{nm.replace("aten.", "")}x{k}' for (ss, nm), k in sorted(sites.items(), key=lambda kv: -kv[1]) if ss == s)[:170]
     print(f'{c:4d}  {s:60s} {ops}')
-from torch.profiler import profile, ProfilerActivity
-for _ in range(3): step()
-torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CUDA]) as prof:
-    step()
-    torch.cuda.synchronize()
-ks = collections.Counter()
-tot = collections.Counter()
-for e in prof.events():
-    if e.device_type == torch.autograd.DeviceType.CUDA:
-        ks[e.name[:90]] += 1
-        tot[e.name[:90]] += e.device_time if hasattr(e, 'device_time') else e.cuda_time
-print('kernels in one replay:', sum(ks.values()))
-for k, c in ks.most_common(80):
-    print(f'{c:4d} {tot[k]:9.1f} us  {k}')

@@ -212,6 +212,43 @@ def test_full_image_properties():
         assert torch.equal(r1['color_fine'], rr['color_fine'][:3001])
 
 
+def test_full_view_640000_rays_properties():
+    """The bench workload itself (BASELINE.json configs[1]: one 800 x 800 view = 640,000 rays x 128 samples in ONE render call): the
+    size-independent invariants at the full size, and agreement of the one-call view with the same rays rendered in 80,000-ray chunks
+    (gen_geo.py:265-266 splits a view by batch_size) and with a permuted ray order."""
+    from oracle import geo as og
+    _, sdf, col, var, ren = _build('full')
+    B = 640000
+    o, d, near, far = [torch.tensor(a).cuda() for a in og.make_rays(B, 23)]
+    bg = torch.ones(1, 3).cuda()
+    kw = dict(perturb_overwrite=0, background_rgb=bg, cos_anneal_ratio=1.0)
+    with torch.no_grad():
+        rr = ren.render(o, d, near, far, 2.0, **kw)
+        c, w, ws = rr['color_fine'], rr['weights'], rr['weight_sum']
+        assert c.shape == (B, 3) and w.shape[0] == B
+        assert torch.isfinite(c).all() and torch.isfinite(w).all()
+        assert (w >= 0).all() and (ws <= 1 + 1e-4).all()
+        assert (c >= 0).all() and (c <= 1 + 1e-4).all()
+        torch.testing.assert_close(w.sum(-1, keepdim=True), ws, rtol=1e-5, atol=1e-5)
+        assert torch.equal(w.max(-1, keepdim=True)[0], rr['weight_max'])
+        assert float(ws.std()) > 0 and float(c.std()) > 0           # (not a constant image)
+        # chunking independence at the reference's own chunk size, first / middle / ragged last chunk
+        for a, b in ((0, 80000), (240000, 320000), (560000 + 37, 640000)):
+            rc = ren.render(o[a:b], d[a:b], near[a:b], far[a:b], 2.0, **kw)
+            assert torch.equal(rc['color_fine'], c[a:b])
+            assert torch.equal(rc['weights'], w[a:b])
+        del rc
+        # a checksum of checksums: per-chunk sums in f64 add up to the view's
+        tot = sum(float(c[i:i + 80000].double().sum()) for i in range(0, B, 80000))
+        assert abs(tot - float(c.double().sum())) <= 1e-6 * abs(tot)
+        # permutation equivariance over rays
+        perm = torch.randperm(B, device='cuda')
+        keep_c = c.clone()
+        del rr, w, ws
+        rp = ren.render(o[perm], d[perm], near[perm], far[perm], 2.0, **kw)
+        assert torch.equal(rp['color_fine'], keep_c[perm])
+
+
 def test_background_branch_runs_where_the_reference_raises():
     """n_outside > 0 (NeRF++ background, renderer.py:93-129, :309-331): dead in every shipped conf, and the reference's own
     render_core raises there (renderer.py:267 multiplies [B, n, 3] points by [B, n + n_outside] weights), so there are no

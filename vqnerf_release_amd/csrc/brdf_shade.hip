@@ -33,6 +33,47 @@ __device__ __forceinline__ float inv_norm(float x, float y, float z) {
 // a / b with tf.math.divide_no_nan semantics on the 1-ulp hardware reciprocal
 __device__ __forceinline__ float fdiv_no_nan(float a, float b) { return b == 0.f ? 0.f : a * __builtin_amdgcn_rcpf(b); }
 
+// Two lights per instruction (round 4): the per-light arithmetic is the same instruction stream for every light, so lights 2j and 2j + 1 of
+// a lane travel as the two halves of 64-bit register pairs -- v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do both at the issue cost of one
+// (the vector pipe's 157 TFLOP/s IS the packed rate; the scalar forms peak at half of it).  Not packable: min / max / compares and the
+// quarter-rate rsq / rcp / sqrt, issued per half.  Component-wise the operations are those of the scalar statement (explicit fma).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 max2(f32x2 a, float b) { return (f32x2){fmaxf(a[0], b), fmaxf(a[1], b)}; }
+__device__ __forceinline__ f32x2 clip01_2(f32x2 a) { return (f32x2){clip01(a[0]), clip01(a[1])}; }
+__device__ __forceinline__ f32x2 rsq2(f32x2 a) { return (f32x2){__builtin_amdgcn_rsqf(a[0]), __builtin_amdgcn_rsqf(a[1])}; }
+__device__ __forceinline__ f32x2 rcp2(f32x2 a) { return (f32x2){__builtin_amdgcn_rcpf(a[0]), __builtin_amdgcn_rcpf(a[1])}; }
+__device__ __forceinline__ f32x2 sqrt2(f32x2 a) { return (f32x2){__builtin_amdgcn_sqrtf(a[0]), __builtin_amdgcn_sqrtf(a[1])}; }
+__device__ __forceinline__ f32x2 abs2(f32x2 a) { return (f32x2){fabsf(a[0]), fabsf(a[1])}; }
+__device__ __forceinline__ f32x2 inv_norm2(f32x2 x, f32x2 y, f32x2 z) { return rsq2(max2(fma2(z, z, fma2(y, y, x * x)), 1e-6f)); }
+__device__ __forceinline__ f32x2 dot2(f32x2 ax, f32x2 ay, f32x2 az, float bx, float by, float bz) {
+  return fma2(az, splat2(bz), fma2(ay, splat2(by), ax * splat2(bx)));
+}
+
+// Sixteen per-lane values summed over the wave in ONE halving butterfly: across lane bits 32, 16, 8, 4 every lane keeps half of its
+// values and hands the other half over (8 + 4 + 2 + 1 exchanges), bits 2 and 1 finish the last value: 17 exchanges instead of the 96 of
+// sixteen separate six-step reductions.  Returns in lane l the total of value (l >> 2) & 15.
+__device__ __forceinline__ float wave_sum16(float (&v)[16], const int lane) {
+#pragma unroll
+  for (int half = 8; half >= 1; half >>= 1) {
+    const int bit = half << 2;
+    const bool up = (lane & bit) != 0;
+#pragma unroll
+    for (int i = 0; i < half; ++i) {
+      float lo = v[i], hi = v[i + half];
+      asm volatile("" : "+v"(lo), "+v"(hi));      // (values, not addresses: the optimiser otherwise selects the array INDEX and walks a 16-way compare chain per access)
+      const float keep = up ? hi : lo;
+      const float send = up ? lo : hi;
+      v[i] = keep + __shfl_xor(send, bit);
+    }
+  }
+  float t = v[0];
+  t += __shfl_xor(t, 2);
+  t += __shfl_xor(t, 1);
+  return t;
+}
+
 struct ShadeArgs {
   const float *xyz, *normal, *rayo, *lvis, *lxyz, *lareas, *light, *gamma;
   const float *albedo[2], *spec[2], *rough[2];
@@ -87,22 +128,23 @@ __global__ __launch_bounds__(PLDS ? (LQ == 4 ? 512 : 768) : 256) void brdf_shade
   }
 
   // ---- this lane's lights: light index = 256 g + 4 lane + e ----
-  float lx[LP], ly[LP], lz[LP], Ar[LP], Ag[LP], Ab[LP];      // A_c = radiance_c * solid angle
+  constexpr int LH = LP / 2;                       // light PAIRS per lane: pair j = lights (2 j, 2 j + 1) of the lane
+  f32x2 lx[LH], ly[LH], lz[LH], Ar[LH], Ag[LH], Ab[LH];      // A_c = radiance_c * solid angle
 #pragma unroll
   for (int g = 0; g < LQ; ++g)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int li = 256 * g + 4 * lane + e, k = 4 * g + e;
-      lx[k] = a.lxyz[li * 3 + 0]; ly[k] = a.lxyz[li * 3 + 1]; lz[k] = a.lxyz[li * 3 + 2];
+      lx[k >> 1][k & 1] = a.lxyz[li * 3 + 0]; ly[k >> 1][k & 1] = a.lxyz[li * 3 + 1]; lz[k >> 1][k & 1] = a.lxyz[li * 3 + 2];
       const float area = a.lareas[li];
-      Ar[k] = a.light[li * 3 + 0] * area; Ag[k] = a.light[li * 3 + 1] * area; Ab[k] = a.light[li * 3 + 2] * area;
+      Ar[k >> 1][k & 1] = a.light[li * 3 + 0] * area; Ag[k >> 1][k & 1] = a.light[li * 3 + 1] * area; Ab[k >> 1][k & 1] = a.light[li * 3 + 2] * area;
     }
-  float area_k[PROBES ? LP : 1];                    // only the relighting pass needs the bare solid angles
+  f32x2 area_k[PROBES ? LH : 1];                    // only the relighting pass needs the bare solid angles
   if (PROBES) {
 #pragma unroll
     for (int g = 0; g < LQ; ++g)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) area_k[4 * g + e] = a.lareas[256 * g + 4 * lane + e];
+      for (int e = 0; e < 4; ++e) area_k[(4 * g + e) >> 1][e & 1] = a.lareas[256 * g + 4 * lane + e];
   }
   float gam_b = 1.f, gam_i = 1.f;
   if (a.gamma) { gam_b = a.gamma[0]; gam_i = a.gamma[1]; }
@@ -148,71 +190,81 @@ __global__ __launch_bounds__(PLDS ? (LQ == 4 ? 512 : 768) : 256) void brdf_shade
         const float g1v = div_no_nan(2.f * c, c + sqrtf(fabsf(M[s].a2 + M[s].oma2 * c * c)));
         M[s].kv = div_no_nan(g1v, 2.f * fabsf(v_dot_n));
       }
-    float S[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};              // sum_l glossy_c * w_c per material set
-    float W[3] = {0.f, 0.f, 0.f};                                    // sum_l w_c  (Lambertian part, shared)
+    f32x2 S2[2][3], W2[3];                                           // sum_l glossy_c * w_c per material set; sum_l w_c (Lambertian part, shared): even / odd lights
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { S2[0][c] = splat2(0.f); S2[1][c] = splat2(0.f); W2[c] = splat2(0.f); }
     float wsp[PROBES ? LP : 1][3];                                   // relighting: set-0 brdf_c * vis * cos * area per light (per unit radiance)
 #pragma unroll
-    for (int k = 0; k < LP; ++k) {
+    for (int j = 0; j < LH; ++j) {
       // light direction (shape.py:103-110)
-      float dx = lx[k] - px, dy = ly[k] - py, dz = lz[k] - pz;
-      const float il = inv_norm(dx, dy, dz);
+      f32x2 dx = lx[j] - splat2(px), dy = ly[j] - splat2(py), dz = lz[j] - splat2(pz);
+      const f32x2 il = inv_norm2(dx, dy, dz);
       dx *= il; dy *= il; dz *= il;                                 // surf2l = l
-      const float cosl = dx * nx + dy * ny + dz * nz;               // vq_nfr.py:702 (un-renormalised normal)
-      const float l_dot_n = dx * mx + dy * my + dz * mz;
-      const float cw = (cosl > 0.f && l_dot_n > 0.f) ? cosl * vis4[k >> 2][k & 3] : 0.f;     // vis * cos
-      float hx = dx + ux, hy = dy + uy, hz = dz + uz;
-      const float ih = inv_norm(hx, hy, hz);
+      const f32x2 cosl = dot2(dx, dy, dz, nx, ny, nz);              // vq_nfr.py:702 (un-renormalised normal)
+      const f32x2 l_dot_n = dot2(dx, dy, dz, mx, my, mz);
+      const f32x2 visj = {vis4[j >> 1][2 * (j & 1)], vis4[j >> 1][2 * (j & 1) + 1]};
+      f32x2 cw = cosl * visj;                                       // vis * cos
+      cw[0] = (cosl[0] > 0.f && l_dot_n[0] > 0.f) ? cw[0] : 0.f;
+      cw[1] = (cosl[1] > 0.f && l_dot_n[1] > 0.f) ? cw[1] : 0.f;
+      f32x2 hx = dx + splat2(ux), hy = dy + splat2(uy), hz = dz + splat2(uz);
+      const f32x2 ih = inv_norm2(hx, hy, hz);
       hx *= ih; hy *= ih; hz *= ih;
-      const float cos_vh = clip01(hx * ux + hy * uy + hz * uz);
-      const float om = 1.f - cos_vh, om2 = om * om, om5 = om2 * om2 * om;
-      const float cos_m = clip01(hx * mx + hy * my + hz * mz);
-      const float cm2 = cos_m * cos_m;
-      const float cl = clip01(l_dot_n), cl2 = cl * cl;
-      const float wr = cw * Ar[k], wg = cw * Ag[k], wb = cw * Ab[k];
-      W[0] += wr; W[1] += wg; W[2] += wb;
+      const f32x2 cos_vh = clip01_2(dot2(hx, hy, hz, ux, uy, uz));
+      const f32x2 om = splat2(1.f) - cos_vh, om2 = om * om, om5 = om2 * om2 * om;
+      const f32x2 cos_m = clip01_2(dot2(hx, hy, hz, mx, my, mz));
+      const f32x2 cm2 = cos_m * cos_m;
+      const f32x2 cl = clip01_2(l_dot_n), cl2 = cl * cl;
+      const f32x2 wr = cw * Ar[j], wg = cw * Ag[j], wb = cw * Ab[j];
+      W2[0] += wr; W2[1] += wg; W2[2] += wb;
 #pragma unroll
       for (int s = 0; s < 2; ++s)
         if (s < NS) {
-          const float t = fmaf(cm2, -M[s].oma2, 1.f);                // cos_m^2 (a2 - 1) + 1
-          const float t2 = t * t;
+          const f32x2 t = fma2(cm2, splat2(-M[s].oma2), splat2(1.f));   // cos_m^2 (a2 - 1) + 1
+          const f32x2 t2 = t * t;
           // divide_no_nan (microfacet.py:57, :71-72): both denominators vanish only together with their numerators (t = 0 needs
           // a2 = 0; cl + sl = 0 needs cl = 0 and a2 = 0, where D = 0 too), so a floor on the denominator gives the same 0
-          const float D = M[s].a2_pi * __builtin_amdgcn_rcpf(fmaxf(t2, 1e-30f));
-          const float sl = __builtin_amdgcn_sqrtf(fabsf(fmaf(M[s].oma2, cl2, M[s].a2)));
-          const float gdi = D * M[s].kv * __builtin_amdgcn_rcpf(fmaxf(cl + sl, 1e-30f));
-          const float g0 = fmaf(M[s].omf0[0], om5, M[s].f0[0]) * gdi, g1 = fmaf(M[s].omf0[1], om5, M[s].f0[1]) * gdi,
-                      g2 = fmaf(M[s].omf0[2], om5, M[s].f0[2]) * gdi;
-          S[s][0] = fmaf(g0, wr, S[s][0]); S[s][1] = fmaf(g1, wg, S[s][1]); S[s][2] = fmaf(g2, wb, S[s][2]);
+          const f32x2 D = splat2(M[s].a2_pi) * rcp2(max2(t2, 1e-30f));
+          const f32x2 sl = sqrt2(abs2(fma2(splat2(M[s].oma2), cl2, splat2(M[s].a2))));
+          const f32x2 gdi = D * splat2(M[s].kv) * rcp2(max2(cl + sl, 1e-30f));
+          const f32x2 g0 = fma2(splat2(M[s].omf0[0]), om5, splat2(M[s].f0[0])) * gdi, g1 = fma2(splat2(M[s].omf0[1]), om5, splat2(M[s].f0[1])) * gdi,
+                      g2 = fma2(splat2(M[s].omf0[2]), om5, splat2(M[s].f0[2])) * gdi;
+          S2[s][0] = fma2(g0, wr, S2[s][0]); S2[s][1] = fma2(g1, wg, S2[s][1]); S2[s][2] = fma2(g2, wb, S2[s][2]);
           if (PROBES && s == 0) {
-            const float gw = cw * area_k[k];
-            wsp[k][0] = (g0 + M[0].a[0]) * gw; wsp[k][1] = (g1 + M[0].a[1]) * gw; wsp[k][2] = (g2 + M[0].a[2]) * gw;
+            const f32x2 gw = cw * area_k[j];
+            const f32x2 p0 = (g0 + splat2(M[0].a[0])) * gw, p1 = (g1 + splat2(M[0].a[1])) * gw, p2 = (g2 + splat2(M[0].a[2])) * gw;
+            wsp[2 * j][0] = p0[0]; wsp[2 * j][1] = p1[0]; wsp[2 * j][2] = p2[0];
+            wsp[2 * j + 1][0] = p0[1]; wsp[2 * j + 1][1] = p1[1]; wsp[2 * j + 1][2] = p2[1];
           }
         }
     }
+    float S[2][3], W[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { S[0][c] = S2[0][c][0] + S2[0][c][1]; S[1][c] = S2[1][c][0] + S2[1][c][1]; W[c] = W2[c][0] + W2[c][1]; }
     {
       // the (up to) 12 sums over lights of this point -- rgb of each material set, and set 0's diffuse / specular split: each is
       // reduced over the wave, then lane i takes value i and lanes 0..11 apply the gamma curve / clip to their own value (ONE powf
       // per wave instead of twelve: the curve of the 'dtu' / 'hw' data types cost half as much as the shading itself) and store it
-      float u[12];
+      float u[16];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        u[c] = wave_sum(fmaf(M[0].a[c], W[c], S[0][c]));
-        u[3 + c] = NS > 1 ? wave_sum(fmaf(M[1].a[c], W[c], S[1][c])) : 0.f;
-        u[6 + c] = split ? wave_sum(M[0].a[c] * W[c]) : 0.f;
-        u[9 + c] = split ? wave_sum(S[0][c]) : 0.f;
+        u[c] = fmaf(M[0].a[c], W[c], S[0][c]);
+        u[3 + c] = NS > 1 ? fmaf(M[1].a[c], W[c], S[1][c]) : 0.f;
+        u[6 + c] = split ? M[0].a[c] * W[c] : 0.f;
+        u[9 + c] = split ? S[0][c] : 0.f;
       }
-      float t = u[0];
-#pragma unroll
-      for (int i = 1; i < 12; ++i) t = lane == i ? u[i] : t;
+      u[12] = u[13] = u[14] = u[15] = 0.f;
+      float t = wave_sum16(u, lane);                                 // lane l: value (l >> 2) & 15
       if (!a.raw) {
         if (a.gamma) t = powf(t * gam_b, gam_i);
         t = clip01(t);
       }
       // (one store per output array, each from a uniform base pointer)
-      if (lane < 3) a.rgb[0][n * 3 + lane] = t;
-      if (NS > 1 && lane >= 3 && lane < 6) a.rgb[1][n * 3 + lane - 3] = t;
-      if (split && lane >= 6 && lane < 9) a.rgb_diff[n * 3 + lane - 6] = t;
-      if (split && lane >= 9 && lane < 12) a.rgb_spec[n * 3 + lane - 9] = t;
+      const int vi = lane >> 2;
+      const bool first = (lane & 3) == 0;
+      if (first && vi < 3) a.rgb[0][n * 3 + vi] = t;
+      if (NS > 1 && first && vi >= 3 && vi < 6) a.rgb[1][n * 3 + vi - 3] = t;
+      if (split && first && vi >= 6 && vi < 9) a.rgb_diff[n * 3 + vi - 6] = t;
+      if (split && first && vi >= 9 && vi < 12) a.rgb_spec[n * 3 + vi - 9] = t;
     }
     if (PROBES) {
       // all probes against the SAME per-light weights: the [N,L] x [L,3P] contraction of the relighting loop, 16 probes at a time.
@@ -299,16 +351,17 @@ __global__ __launch_bounds__(256) void brdf_shade_bwd_kernel(const ShadeBwdArgs 
   const int lane = threadIdx.x & 63;
   const long wave_id = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: per-point scalars by scalar loads
   const long n_waves = (long)gridDim.x * 4;
-  float lx[LP], ly[LP], lz[LP], area[LP], Lr[LP], Lg[LP], Lb[LP], gL[LP][3];
+  constexpr int LH = LP / 2;                       // light pairs per lane (see the forward kernel)
+  f32x2 lx[LH], ly[LH], lz[LH], area[LH], Lr[LH], Lg[LH], Lb[LH], gL[LH][3];
 #pragma unroll
   for (int g = 0; g < LQ; ++g)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int li = 256 * g + 4 * lane + e, k = 4 * g + e;
-      lx[k] = a.lxyz[li * 3 + 0]; ly[k] = a.lxyz[li * 3 + 1]; lz[k] = a.lxyz[li * 3 + 2];
-      area[k] = a.lareas[li];
-      Lr[k] = a.light[li * 3 + 0]; Lg[k] = a.light[li * 3 + 1]; Lb[k] = a.light[li * 3 + 2];
-      gL[k][0] = gL[k][1] = gL[k][2] = 0.f;
+      const int li = 256 * g + 4 * lane + e, k = 4 * g + e, j = k >> 1, o = k & 1;
+      lx[j][o] = a.lxyz[li * 3 + 0]; ly[j][o] = a.lxyz[li * 3 + 1]; lz[j][o] = a.lxyz[li * 3 + 2];
+      area[j][o] = a.lareas[li];
+      Lr[j][o] = a.light[li * 3 + 0]; Lg[j][o] = a.light[li * 3 + 1]; Lb[j][o] = a.light[li * 3 + 2];
+      gL[j][0][o] = gL[j][1][o] = gL[j][2][o] = 0.f;
     }
   for (long n = wave_id; n < a.N; n += n_waves) {
     f32x4 vis4[LQ];
@@ -327,80 +380,108 @@ __global__ __launch_bounds__(256) void brdf_shade_bwd_kernel(const ShadeBwdArgs 
     const float mx = nx * in_, my = ny * in_, mz = nz * in_;
     const float v_dot_n = ux * mx + uy * my + uz * mz;
     const float cv = clip01(v_dot_n);
-    float alb[2][3], f0[2][3], a2[2], g1v[2], dg1v[2], gs[2][3], rgh[2];
+    const float avn = fabsf(v_dot_n);
+    float alb_pi[2][3], f0[2][3], a2[2], g1v[2], dg1v[2], gs[2][3], rgh[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
       if (s < a.n_sets) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          alb[s][c] = a.albedo[s][n * 3 + c]; f0[s][c] = a.spec[s][n * 3 + c]; gs[s][c] = a.g_sum[s][n * 3 + c];
+          alb_pi[s][c] = a.albedo[s][n * 3 + c] / PI_F;           // (per point: an IEEE division is ten instructions, and this one sat in the light loop)
+          f0[s][c] = a.spec[s][n * 3 + c]; gs[s][c] = a.g_sum[s][n * 3 + c];
         }
         rgh[s] = a.rough[s][n];
         const float alpha = rgh[s] * rgh[s];
         a2[s] = alpha * alpha;
         g1_and_da2(cv, a2[s], &g1v[s], &dg1v[s]);
       }
-    float acc_alb[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, acc_f0[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, acc_a2[2] = {0.f, 0.f};
+    f32x2 acc_alb[2][3], acc_f0[2][3], acc_a2[2];
 #pragma unroll
-    for (int k = 0; k < LP; ++k) {
-      float dx = lx[k] - px, dy = ly[k] - py, dz = lz[k] - pz;
-      float il = inv_norm(dx, dy, dz);
+    for (int s = 0; s < 2; ++s) {
+      acc_a2[s] = splat2(0.f);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { acc_alb[s][c] = splat2(0.f); acc_f0[s][c] = splat2(0.f); }
+    }
+#pragma unroll
+    for (int j = 0; j < LH; ++j) {
+      f32x2 dx = lx[j] - splat2(px), dy = ly[j] - splat2(py), dz = lz[j] - splat2(pz);
+      const f32x2 il = inv_norm2(dx, dy, dz);
       dx *= il; dy *= il; dz *= il;
-      const float cosl = dx * nx + dy * ny + dz * nz;
-      const float vis = (cosl > 0.f ? 1.f : 0.f) * vis4[k >> 2][k & 3];
+      const f32x2 cosl = dot2(dx, dy, dz, nx, ny, nz);
+      const f32x2 visj = {vis4[j >> 1][2 * (j & 1)], vis4[j >> 1][2 * (j & 1) + 1]};
+      const f32x2 vis = {cosl[0] > 0.f ? visj[0] : 0.f, cosl[1] > 0.f ? visj[1] : 0.f};
       // (the forward normalises the light direction a second time, as the reference does -- microfacet.py:18 on top of shape.py:103-119;
       //  a unit vector's second normalisation moves it by an ulp, which the GRADIENT does not need: one rsq and eight instructions less)
-      const float wx = dx, wy = dy, wz = dz;
-      float hx = wx + ux, hy = wy + uy, hz = wz + uz;
-      const float ih = inv_norm(hx, hy, hz);
+      f32x2 hx = dx + splat2(ux), hy = dy + splat2(uy), hz = dz + splat2(uz);
+      const f32x2 ih = inv_norm2(hx, hy, hz);
       hx *= ih; hy *= ih; hz *= ih;
-      const float cos_vh = clip01(hx * ux + hy * uy + hz * uz);
-      const float om = 1.f - cos_vh, om2 = om * om, om5 = om2 * om2 * om;
-      const float cos_m = clip01(hx * mx + hy * my + hz * mz);
-      const float l_dot_n = wx * mx + wy * my + wz * mz;
-      const float cl = clip01(l_dot_n);
-      const float den = 4.f * fabsf(l_dot_n) * fabsf(v_dot_n);
-      const float inv_den = den == 0.f ? 0.f : __builtin_amdgcn_rcpf(den);
-      const float wgt = vis * cosl * area[k];                       // geometry weight of this light (without radiance)
-      const float Lc[3] = {Lr[k], Lg[k], Lb[k]};
+      const f32x2 cos_vh = clip01_2(dot2(hx, hy, hz, ux, uy, uz));
+      const f32x2 om = splat2(1.f) - cos_vh, om2 = om * om, om5 = om2 * om2 * om;
+      const f32x2 omo5 = splat2(1.f) - om5;
+      const f32x2 cos_m = clip01_2(dot2(hx, hy, hz, mx, my, mz));
+      const f32x2 cm2 = cos_m * cos_m;
+      const f32x2 l_dot_n = dot2(dx, dy, dz, mx, my, mz);
+      const f32x2 cl = clip01_2(l_dot_n);
+      const f32x2 den = splat2(4.f) * abs2(l_dot_n) * splat2(avn);
+      const f32x2 inv_den = {den[0] == 0.f ? 0.f : __builtin_amdgcn_rcpf(den[0]), den[1] == 0.f ? 0.f : __builtin_amdgcn_rcpf(den[1])};
+      const f32x2 wgt = vis * cosl * area[j];                      // geometry weight of this light (without radiance)
+      const f32x2 Lc[3] = {Lr[j], Lg[j], Lb[j]};
 #pragma unroll
       for (int s = 0; s < 2; ++s)
         if (s < a.n_sets) {
-          const float t = cos_m * cos_m * (a2[s] - 1.f) + 1.f;
-          float D = 0.f, dD = 0.f;
-          if (t != 0.f) {                                             // (pi t^2 != 0)
-            const float rt = __builtin_amdgcn_rcpf(t);
-            const float rpd = rt * rt * (1.f / PI_F);                 // 1 / (pi t^2): one reciprocal for D and its derivative
-            D = a2[s] * rpd;
-            dD = (t - 2.f * a2[s] * cos_m * cos_m) * rpd * rt;
-          }
-          float g1l, dg1l;
-          g1_and_da2(cl, a2[s], &g1l, &dg1l);
-          const float G = g1l * g1v[s];
-          const float dG = dg1l * g1v[s] + g1l * dg1v[s];
-          const float gd = G * D * inv_den, dgd = (dG * D + G * dD) * inv_den;
+          const f32x2 t = fma2(cm2, splat2(a2[s] - 1.f), splat2(1.f));
+          // (t = 0: D = dD = 0, as the reference's divide_no_nan -- a zero reciprocal gives both)
+          const f32x2 rt = {t[0] != 0.f ? __builtin_amdgcn_rcpf(t[0]) : 0.f, t[1] != 0.f ? __builtin_amdgcn_rcpf(t[1]) : 0.f};
+          const f32x2 rpd = rt * rt * splat2(1.f / PI_F);          // 1 / (pi t^2): one reciprocal for D and its derivative
+          const f32x2 D = splat2(a2[s]) * rpd;
+          const f32x2 dD = fma2(splat2(-2.f * a2[s]), cm2, t) * rpd * rt;
+          // G1(l.n) and its derivative in a2 (g1_and_da2, both halves)
+          const f32x2 q = fma2(splat2(1.f - a2[s]) * cl, cl, splat2(a2[s]));
+          const f32x2 aq = abs2(q);
+          const f32x2 rs = {aq[0] > 0.f ? __builtin_amdgcn_rsqf(aq[0]) : 0.f, aq[1] > 0.f ? __builtin_amdgcn_rsqf(aq[1]) : 0.f};
+          const f32x2 dn = fma2(aq, rs, cl);                       // c + sqrt|q|
+          const f32x2 rden = {dn[0] == 0.f ? 0.f : __builtin_amdgcn_rcpf(dn[0]), dn[1] == 0.f ? 0.f : __builtin_amdgcn_rcpf(dn[1])};
+          const f32x2 g1l = splat2(2.f) * cl * rden;
+          const f32x2 hs = {q[0] >= 0.f ? 0.5f : -0.5f, q[1] >= 0.f ? 0.5f : -0.5f};
+          const f32x2 ds = hs * fma2(-cl, cl, splat2(1.f)) * rs;
+          const f32x2 dg1l = splat2(-2.f) * cl * rden * rden * ds;
+          const f32x2 G = g1l * splat2(g1v[s]);
+          const f32x2 dG = fma2(dg1l, splat2(g1v[s]), g1l * splat2(dg1v[s]));
+          const f32x2 gd = G * D * inv_den, dgd = fma2(dG, D, G * dD) * inv_den;
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            const float F = f0[s][c] + (1.f - f0[s][c]) * om5;
-            const float gw = gs[s][c] * wgt;                        // d loss / d (brdf_c * radiance_c)  per unit radiance
-            const float glw = gw * Lc[c];
-            acc_alb[s][c] += glw * (1.f / PI_F);
-            acc_f0[s][c] += glw * (1.f - om5) * gd;
-            acc_a2[s] += glw * F * dgd;
-            gL[k][c] += gw * (F * gd + alb[s][c] / PI_F);
+            const f32x2 F = fma2(splat2(1.f - f0[s][c]), om5, splat2(f0[s][c]));
+            const f32x2 gw = splat2(gs[s][c]) * wgt;               // d loss / d (brdf_c * radiance_c)  per unit radiance
+            const f32x2 glw = gw * Lc[c];
+            acc_alb[s][c] = fma2(glw, splat2(1.f / PI_F), acc_alb[s][c]);
+            acc_f0[s][c] = fma2(glw * omo5, gd, acc_f0[s][c]);
+            acc_a2[s] = fma2(glw * F, dgd, acc_a2[s]);
+            gL[j][c] = fma2(gw, fma2(F, gd, splat2(alb_pi[s][c])), gL[j][c]);
           }
         }
     }
+    {
+      // the 14 sums over lights (albedo, f0: 3 each, a2: 1, per set): one butterfly; lane l gets value (l >> 2) & 15 = 7 s + i
+      float u[16];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-      if (s < a.n_sets) {
-        float r[7];
+      for (int s = 0; s < 2; ++s) {
+        const bool on = s < a.n_sets;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { r[c] = wave_sum(acc_alb[s][c]); r[3 + c] = wave_sum(acc_f0[s][c]); }
-        r[6] = wave_sum(acc_a2[s]) * 4.f * rgh[s] * rgh[s] * rgh[s];          // a2 = rough^4
-        if (lane < 3) { a.g_albedo[s][n * 3 + lane] = r[lane]; a.g_spec[s][n * 3 + lane] = r[3 + lane]; }
-        if (lane == 0) a.g_rough[s][n] = r[6];
+        for (int c = 0; c < 3; ++c) {
+          u[7 * s + c] = on ? acc_alb[s][c][0] + acc_alb[s][c][1] : 0.f;
+          u[7 * s + 3 + c] = on ? acc_f0[s][c][0] + acc_f0[s][c][1] : 0.f;
+        }
+        u[7 * s + 6] = on ? (acc_a2[s][0] + acc_a2[s][1]) : 0.f;
       }
+      u[14] = u[15] = 0.f;
+      const float t = wave_sum16(u, lane);
+      const int vi = lane >> 2, s_ = vi >= 7 ? 1 : 0, i = vi - 7 * s_;
+      if ((lane & 3) == 0 && vi < 14 && s_ < a.n_sets) {
+        if (i < 3) a.g_albedo[s_][n * 3 + i] = t;
+        else if (i < 6) a.g_spec[s_][n * 3 + i - 3] = t;
+        else a.g_rough[s_][n] = t * 4.f * rgh[s_] * rgh[s_] * rgh[s_];                          // a2 = rough^4
+      }
+    }
   }
   float* part = a.g_light_part + (size_t)wave_id * L * 3;
 #pragma unroll
@@ -408,7 +489,7 @@ __global__ __launch_bounds__(256) void brdf_shade_bwd_kernel(const ShadeBwdArgs 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int li = 256 * g + 4 * lane + e, k = 4 * g + e;
-      part[li * 3 + 0] = gL[k][0]; part[li * 3 + 1] = gL[k][1]; part[li * 3 + 2] = gL[k][2];
+      part[li * 3 + 0] = gL[k >> 1][0][k & 1]; part[li * 3 + 1] = gL[k >> 1][1][k & 1]; part[li * 3 + 2] = gL[k >> 1][2][k & 1];
     }
 }
 

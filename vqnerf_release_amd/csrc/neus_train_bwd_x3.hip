@@ -47,6 +47,10 @@ struct SmallsB {
 
 // accumulator tile <-> tile format: register i of lane (p, h) is feature (i & 3) + 8 (i >> 2) + 4 h of the feature tile
 __device__ __forceinline__ void tf_store_acc(float* __restrict__ T, const long ptile, const int n_ft, const int ot, const int lane, const float (&v)[16]) {
+#ifdef VQN_DIAG_RT_NO_ST        // timing only
+  asm volatile("" ::"v"(v[0]), "v"(v[3]), "v"(v[7]));
+  return;
+#endif
   float* base = T + ((ptile * n_ft + ot) * 32 + 4 * (lane >> 5)) * 32 + (lane & 31);
 #pragma unroll
   for (int i = 0; i < 16; ++i) __builtin_nontemporal_store(v[i], base + ((i & 3) + 8 * (i >> 2)) * 32);
@@ -58,6 +62,10 @@ __device__ __forceinline__ void tf_load_acc(const float* __restrict__ T, const l
 }
 // a K step of an image: slot jj of lane (p, h) is feature 16 sl + 8 (jj >> 2) + 4 h + (jj & 3)
 __device__ __forceinline__ void tf_store_step(float* __restrict__ T, const long ptile, const int n_ft, const int sl, const int lane, const float (&x)[8]) {
+#ifdef VQN_DIAG_RT_NO_ST        // timing only
+  asm volatile("" ::"v"(x[0]), "v"(x[3]), "v"(x[7]));
+  return;
+#endif
   float* base = T + ((ptile * n_ft + (sl >> 1)) * 32 + 16 * (sl & 1) + 4 * (lane >> 5)) * 32 + (lane & 31);
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) __builtin_nontemporal_store(x[jj], base + (8 * (jj >> 2) + (jj & 3)) * 32);

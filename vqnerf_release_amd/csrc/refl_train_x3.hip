@@ -236,8 +236,18 @@ __device__ __forceinline__ void dact_mul(const int act, const float (&y)[16], fl
   };
 
 // ================================================================ forward ================================================================
+// A/B of VERDICT r3 #2(a), -DVQN_REFL_OCC2: the one-image form compiled for FOUR waves per SIMD (128 registers) and launched as two
+// workgroups per CU, so that one workgroup's epilogue runs under the other's K loop (profiles/r04_refl_occ2_ab.txt has the outcome)
+#ifdef VQN_REFL_OCC2
+#define RT_WAVES_EU(N) ((N) == 1 ? 4 : 1)
+#define RT_WGS_PER_CU(N) ((N) == 1 ? 2 : 1)
+#else
+#define RT_WAVES_EU(N) 1
+#define RT_WGS_PER_CU(N) 1
+#endif
+
 template <int NIMG>
-__global__ __launch_bounds__(512, 1) void refl_train_fwd_x3_kernel(const ReflDesc rd, const f32x4* __restrict__ wx, const f32x4* __restrict__ wf,
+__global__ __launch_bounds__(512, RT_WAVES_EU(NIMG)) void refl_train_fwd_x3_kernel(const ReflDesc rd, const f32x4* __restrict__ wx, const f32x4* __restrict__ wf,
                                                                    const ReflFwdPtrs tp, const long P) {
   REFL_PROLOGUE();
   const int nE = rd.n_enc, ZT = rd.z_tiles;
@@ -413,7 +423,7 @@ __global__ __launch_bounds__(512, 1) void refl_train_fwd_x3_kernel(const ReflDes
 
 // ================================================================ backward ================================================================
 template <int NIMG>
-__global__ __launch_bounds__(512, 1) void refl_train_bwd_x3_kernel(const ReflDesc rd, const f32x4* __restrict__ wx, const f32x4* __restrict__ wf,
+__global__ __launch_bounds__(512, RT_WAVES_EU(NIMG)) void refl_train_bwd_x3_kernel(const ReflDesc rd, const f32x4* __restrict__ wx, const f32x4* __restrict__ wf,
                                                                    const ReflBwdPtrs tp, const long P, f32x4* __restrict__ scratch) {
   REFL_PROLOGUE();
   RT_STAMP_DECL
@@ -713,7 +723,7 @@ extern "C" int vqn_refl_train_fwd_x3(const int32_t* desc, const void* wbuf_piece
   auto kern = nimg == 1 ? refl_train_fwd_x3_kernel<1> : refl_train_fwd_x3_kernel<2>;
   VQN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long units = nimg == 1 ? n_tiles : (n_tiles + 1) / 2;
-  long grid = (long)vqn_num_cus();
+  long grid = (long)vqn_num_cus() * RT_WGS_PER_CU(nimg);
   if (grid > units) grid = units;
   const unsigned gy = (split_heads && nH > 1) ? (unsigned)nH : 1u;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid, gy), dim3(512), lds, (hipStream_t)stream, rd, reinterpret_cast<const f32x4*>(wbuf_pieces),
@@ -726,7 +736,7 @@ extern "C" int64_t vqn_refl_train_bwd_x3_scratch_bytes(const int32_t* desc) {
   if (!desc) return -1;
   ReflDesc rd;
   if (load_desc_r(desc, rd) != 0) return -1;
-  return (int64_t)vqn_num_cus() * RT_MAX_H * 2 * 4 * rd.z_tiles * 1024;
+  return (int64_t)vqn_num_cus() * RT_MAX_H * 2 * 4 * rd.z_tiles * 1024;      // (covers two one-image workgroups per CU as well)
 }
 
 extern "C" int vqn_refl_train_bwd_x3(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, int64_t P, const float* const* g_out,
@@ -775,7 +785,7 @@ extern "C" int vqn_refl_train_bwd_x3(const int32_t* desc, const void* wbuf_piece
   auto kern = nimg == 1 ? refl_train_bwd_x3_kernel<1> : refl_train_bwd_x3_kernel<2>;
   VQN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long units = nimg == 1 ? n_tiles : (n_tiles + 1) / 2;
-  long grid = (long)vqn_num_cus();
+  long grid = (long)vqn_num_cus() * RT_WGS_PER_CU(nimg);
   if (grid > units) grid = units;
   if ((int64_t)grid * gy * per_wg > scratch_bytes) grid = (long)(scratch_bytes / (per_wg * gy));
   VQN_CHECK_ARG(grid >= 1, "scratch too small (see vqn_refl_train_bwd_x3_scratch_bytes)");
