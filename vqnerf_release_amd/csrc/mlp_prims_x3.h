@@ -1,6 +1,7 @@
 // Exact-split variant of the fused small-MLP engine (gfx950): every f32 value x travels as THREE bf16 numbers
-//   p0 = trunc16(x),  p1 = trunc16(x - p0),  p2 = trunc16(x - p0 - p1)        =>  x = p0 + p1 + p2  EXACTLY
-// (8 + 8 + 8 significant bits, truncation: the high half of an f32 word IS its bf16; the two subtractions are exact in f32), and
+//   p0 = bf16(x),  p1 = bf16(x - p0),  p2 = bf16(x - p0 - p1)        =>  x = p0 + p1 + p2  EXACTLY
+// (8 + 8 + 8 significant bits; weights: truncation -- the high half of an f32 word IS its bf16 --, activations: round to nearest, see
+// split3x8; the two subtractions are exact in f32 either way), and
 // a product a*w keeps the six cross terms down to 2^-24 of |a||w|
 //     a w = a0 w0 + (a0 w1 + a1 w0) + (a0 w2 + a1 w1 + a2 w0)                 [dropped: a1 w2 + a2 w1 + a2 w2 <= 2^-23 |a w|]
 // i.e. what an f32 multiply rounds away, on v_mfma_f32_32x32x16_bf16 with f32 accumulation.  Six bf16 MFMAs (6 x 32 cycles)
@@ -33,18 +34,26 @@ __device__ __forceinline__ f32x16 mma_x3(const f32x4 a, const f32x4 b, const f32
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b8(a), as_b8(b), c, 0, 0, 0);
 }
 
-// 8 values (slot order) -> the three piece rows
+// 8 values (slot order) -> the three piece rows.  Round 4: the ACTIVATION pieces are cut with round-to-nearest-even on the conversion
+// instruction (v_cvt_pk_bf16_f32: two values per instruction; the residuals x - p0, x - p0 - p1 are still exact in f32 and the third
+// piece still takes all that is left: |x - p0| <= 2^-9 |x| leaves <= 16 bits, |.. - p1| <= 2^-17 |x| leaves <= 8), not by truncation:
+// nine instead of eleven vector instructions per pair of values, and -- the point -- residual pieces of BOTH signs, so that the three
+// cross terms an x3 product drops (a1 w2 + a2 w1 + a2 w2) no longer all carry the sign of a w (with truncated pieces the sdf network's
+// error against fp64 was almost pure bias: mean -5.9e-7 where its spread is 1e-7; tests/test_gpu_neus_x3.py prints both).
+// Weight packs keep their truncated pieces (host-side packers, tests/test_abi.py); either cut is an exact three-term representation.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split3x8(const float (&x)[8], f32x4& q0, f32x4& q1, f32x4& q2) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float e0 = x[2 * i], e1 = x[2 * i + 1];
-    const unsigned u0 = __float_as_uint(e0), u1 = __float_as_uint(e1);
-    q0[i] = __uint_as_float(__builtin_amdgcn_perm(u1, u0, 0x07060302u));
-    const float r0 = e0 - __uint_as_float(u0 & 0xffff0000u), r1 = e1 - __uint_as_float(u1 & 0xffff0000u);
-    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-    q1[i] = __uint_as_float(__builtin_amdgcn_perm(v1, v0, 0x07060302u));
-    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
-    q2[i] = __uint_as_float(__builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u));
+    const f32x2_t e = {x[2 * i], x[2 * i + 1]};
+    const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2_t));
+    q0[i] = __uint_as_float(u);
+    const f32x2_t r = e - (f32x2_t){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+    const unsigned v = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+    q1[i] = __uint_as_float(v);
+    const f32x2_t t = r - (f32x2_t){__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
+    q2[i] = __uint_as_float(__builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2_t)));
   }
 }
 

@@ -24,30 +24,29 @@ struct Pieces {
   u32x4 p0, p1, p2;          // bf16x8 each: elements j = 0..7 <-> points 8 kk + j of the step
 };
 
-// eight consecutive f32 -> three exact bf16x8 pieces (truncation: the high half of the word IS the bf16)
+// one pair of elements (slot i of the fragments) -- the unit in which the splits are dealt out between the MFMAs below.  Round 4: cut with
+// round-to-nearest on v_cvt_pk_bf16_f32 (nine instead of eleven vector instructions per pair; residual pieces of both signs, so the
+// dropped cross terms of a product do not all carry its sign -- see split3x8 in mlp_prims_x3.h); still x = p0 + p1 + p2 exactly.
+typedef __bf16 bf16x2_w __attribute__((ext_vector_type(2)));
+typedef float f32x2_w __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(const float e0, const float e1, unsigned& q0, unsigned& q1, unsigned& q2) {
+  const f32x2_w e = {e0, e1};
+  q0 = __builtin_bit_cast(unsigned, __builtin_convertvector(e, bf16x2_w));
+  const f32x2_w r = e - (f32x2_w){__uint_as_float(q0 << 16), __uint_as_float(q0 & 0xffff0000u)};
+  q1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_w));
+  const f32x2_w t = r - (f32x2_w){__uint_as_float(q1 << 16), __uint_as_float(q1 & 0xffff0000u)};
+  q2 = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2_w));
+}
+
+// eight consecutive f32 -> three exact bf16x8 pieces
 __device__ __forceinline__ void split3(const f32x4 lo4, const f32x4 hi4, Pieces& o) {
   const float x[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const unsigned u0 = __float_as_uint(x[2 * i]), u1 = __float_as_uint(x[2 * i + 1]);
-    o.p0[i] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-    const float r0 = x[2 * i] - __uint_as_float(u0 & 0xffff0000u), r1 = x[2 * i + 1] - __uint_as_float(u1 & 0xffff0000u);
-    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-    o.p1[i] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
-    o.p2[i] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    unsigned q0, q1, q2;
+    split_pair(x[2 * i], x[2 * i + 1], q0, q1, q2);
+    o.p0[i] = q0; o.p1[i] = q1; o.p2[i] = q2;
   }
-}
-
-// one pair of elements (slot i of the fragments) -- the unit in which the splits are dealt out between the MFMAs below
-__device__ __forceinline__ void split_pair(const float e0, const float e1, unsigned& q0, unsigned& q1, unsigned& q2) {
-  const unsigned u0 = __float_as_uint(e0), u1 = __float_as_uint(e1);
-  q0 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-  const float r0 = e0 - __uint_as_float(u0 & 0xffff0000u), r1 = e1 - __uint_as_float(u1 & 0xffff0000u);
-  const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-  q1 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-  const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
-  q2 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
 }
 
 __device__ __forceinline__ f32x16 mma(const u32x4 a, const u32x4 b, const f32x16 c) {
