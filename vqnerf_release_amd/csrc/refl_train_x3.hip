@@ -141,6 +141,15 @@ __device__ __forceinline__ void dact_mul(const int act, const float (&y)[16], fl
 // output tiles split the waves by image.  NIMG = 1 (small batches: fewer tile pairs than CUs): one image per workgroup, wave w owns
 // output tile w -- twice the workgroups, half the matrix time per layer.  gridDim.y > 1 (small batches again): one HEAD per workgroup
 // row, the encoder (forward) evaluated by each of them -- the reference batch of 2048 points is 64 tiles, a quarter of the chip.
+// (-DVQN_REFL_OCC2 A/B: the second workgroup of a CU starts half a layer late, so that its K loops fall under the first one's epilogues
+//  instead of beside its K loops -- partners that start together stay in lockstep)
+#if defined(VQN_REFL_OCC2) && defined(VQN_OCC2_DELAY)
+#define RT_OCC2_PHASE_DELAY()                                                                                \
+  if (NIMG == 1 && blockIdx.x >= gridDim.x / 2)                                                              \
+    for (int i_ = 0; i_ < VQN_OCC2_DELAY; ++i_) __builtin_amdgcn_s_sleep(127)
+#else
+#define RT_OCC2_PHASE_DELAY() (void)0
+#endif
 #define REFL_PROLOGUE()                                                                                      \
   extern __shared__ __attribute__((aligned(16))) f32x4 lds[];                                                \
   const int MT = rd.max_tiles;                                                                               \
@@ -156,7 +165,8 @@ __device__ __forceinline__ void dact_mul(const int act, const float (&y)[16], fl
   const int k_lo = gridDim.y > 1 ? (int)blockIdx.y : 0, k_hi = gridDim.y > 1 ? k_lo + 1 : rd.n_heads;       \
   auto blocks_of = [](int krows) { return (krows / 3 + 1) >> 1; };                                           \
   auto ptile_of = [&](long unit, int im) { return NIMG == 1 ? unit : 2 * unit + im; };                       \
-  (void)ldsi; (void)h; (void)p; (void)blocks_of; (void)part_i; (void)k_hi; (void)NWI;
+  (void)ldsi; (void)h; (void)p; (void)blocks_of; (void)part_i; (void)k_hi; (void)NWI;                        \
+  RT_OCC2_PHASE_DELAY();
 
 // sum of the NWI per-wave partial row dots of (point pp, output c)
 #define REFL_PART_SUM(pr, pp, nc, c)                                                                         \
