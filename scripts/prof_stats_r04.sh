@@ -19,5 +19,6 @@ for w in "${@:-decomp_train_256k decomp_train_graph2048}"; do
     geo_train) run geo_train python3 scripts/probe_train.py 2560 ;;
     decomp_k64) VQN_K=64 run decomp_k64 python3 scripts/probe_decomp_glue.py 3 ;;
     geo_render_x3) PROBE_B=80000 run geo_render_x3 python3 scripts/probe_neus_f16s.py x3 ;;
+    geo_render) run geo_render python3 bench.py --no-cpu-baseline --no-extras --no-traffic ;;     # the headline command's own kernels (5 + 2 steps)
   esac || exit 1
 done
