@@ -279,7 +279,9 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
     try:
         out['geo_render_x3'] = alt_mode_leg('x3', 'vqn_neus_fine_points_x3', 6.0, 2516.6,
                                             'exact-split mode (renderer.matrix_mode = "x3"): bf16x3 operands, 6 bf16 MFMAs per product, f32 '
-                                            'accumulate; passes every reference-golden test at the f32 tolerances; `value` is the f32-input-MFMA path')
+                                            'accumulate; passes every reference-golden test at the f32 tolerances; since round 4 (activation pieces cut with '
+                                            'round-to-nearest) its error against float64 is not above the f32 kernels\' (tests/test_gpu_neus_x3.py); '
+                                            '`value` is the f32-input-MFMA path')
     except Exception as e:                                      # noqa: BLE001
         out['geo_render_x3'] = {'error': repr(e)[:300]}
 

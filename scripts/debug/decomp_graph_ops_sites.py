@@ -33,6 +33,7 @@ for mod in (_rt, _nu, _vn, _vl, _um):
         c = getattr(mod, name)
         if isinstance(c, type) and issubclass(c, torch.autograd.Function) and c is not torch.autograd.Function and c.__module__ == mod.__name__:
             _wrap(c)
+torch.autograd.set_multithreading_enabled(False)      # backward on THIS thread: the dispatch mode sees the engine's own ops too
 n = 0
 while tr._captured is None and n < 8:
     if n >= tr.GRAPH_WARMUP:
