@@ -1030,12 +1030,35 @@ def main():
     out = out_box[0]
     assert torch.isfinite(out['color_fine']).all()
 
-    # every rank takes part in the data-parallel training legs (collectives); only rank 0 reports
-    dp = None
-    if world > 1 and not args.no_extras:
-        out_box[0] = None
-        dp = dp_train_leg(dev, rank, world, backend)
+    # every rank takes part in the data-parallel training legs (collectives); only rank 0 reports.  Those legs have run on two ranks
+    # sharing a card, never on a multi-GPU RCCL node: a watchdog makes sure the headline line is printed whatever they do -- if they have
+    # not returned after VQN_BENCH_DP_TIMEOUT seconds (default 420), rank 0 prints the line with the error under extra.dp_train and
+    # every rank leaves (a rank stuck in a collective cannot be interrupted any other way); an exception in them is reported the same way
+    def guarded_dp_legs(partial_line):
+        import threading
+        done = threading.Event()
+        limit = float(os.environ.get('VQN_BENCH_DP_TIMEOUT', '420'))
+
+        def watchdog():
+            if not done.wait(limit):
+                if rank == 0 and partial_line is not None:
+                    partial_line.setdefault('extra', {})['dp_train'] = {'error': f'the data-parallel training legs did not return within {limit:.0f} s '
+                                                                                 '(the render line above them is complete)'}
+                    print(json.dumps(partial_line), flush=True)
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            return dp_train_leg(dev, rank, world, backend)
+        except Exception as e:                                  # noqa: BLE001
+            return {'error': repr(e)[:400]}
+        finally:
+            done.set()
+
     if rank != 0:
+        if world > 1 and not args.no_extras:
+            out_box[0] = None
+            out = None
+            guarded_dp_legs(None)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -1103,11 +1126,20 @@ def main():
     extra = {}
     if world == 1 and not args.no_extras:
         # before the CPU legs: a spun-up host thread pool slows the launch-heavy training steps that follow it
-        extra = secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col)
+        # (a secondary leg that raises must not take the headline line with it)
+        try:
+            extra = secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col)
+        except Exception as e:                                  # noqa: BLE001
+            import traceback
+            extra = {'error': 'secondary_measurements raised: ' + repr(e)[:300], 'traceback': traceback.format_exc()[-1500:]}
         _log('dp_train legs')
-        extra['dp_train'] = dp_train_leg(dev, 0, 1, backend, steps=6, warmup=2)      # the same legs a multi-rank run reports
-    if dp is not None:
-        extra['dp_train'] = dp
+        try:
+            extra['dp_train'] = dp_train_leg(dev, 0, 1, backend, steps=6, warmup=2)      # the same legs a multi-rank run reports
+        except Exception as e:                                  # noqa: BLE001
+            extra['dp_train'] = {'error': repr(e)[:400]}
+    if world > 1 and not args.no_extras:
+        _log('dp_train legs (all ranks)')
+        extra['dp_train'] = guarded_dp_legs(result)
     if world == 1 and not args.no_cpu_baseline:
         _log('CPU baseline (oracle) legs')
         from oracle import geo as og                      # CPU-baseline leg only (test infrastructure)
@@ -1171,9 +1203,12 @@ def main():
         if not args.no_extras:
             _log('CPU baseline of the reflectance model')
             # the reference batch (2048 points) and a 65,536-point view share
-            result['cpu_baseline_decomp'] = decomp_cpu_leg(dev, cores, N=65536)
-            result['cpu_baseline_decomp']['at_2048_points'] = {k: v for k, v in decomp_cpu_leg(dev, cores, N=2048).items()
-                                                                if k in ('value', 'sample', 'gpu_points_per_s_same_sample', 'vq_idx_match_pct')}
+            try:
+                result['cpu_baseline_decomp'] = decomp_cpu_leg(dev, cores, N=65536)
+                result['cpu_baseline_decomp']['at_2048_points'] = {k: v for k, v in decomp_cpu_leg(dev, cores, N=2048).items()
+                                                                    if k in ('value', 'sample', 'gpu_points_per_s_same_sample', 'vq_idx_match_pct')}
+            except Exception as e:                              # noqa: BLE001
+                result['cpu_baseline_decomp'] = {'error': repr(e)[:400]}
     if extra:
         result['extra'] = extra
     print(json.dumps(result))

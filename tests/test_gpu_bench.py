@@ -21,8 +21,8 @@ def _free_port():
     return p
 
 
-def _run(extra_args, nproc=2):
-    env = dict(os.environ, VQN_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
+def _run(extra_args, nproc=2, **env_extra):
+    env = dict(os.environ, VQN_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1', **env_extra)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', str(nproc)] + extra_args
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
@@ -53,6 +53,14 @@ def test_two_rank_render_line_and_dp_training_legs():
     assert g['rays_per_s'] > 0 and d['points_per_s'] > 0
     dg = dp['decomp_graph']
     assert 'error' not in dg and dg['graph_segments'] == 3 and dg['all_reduce']['vq_stats']['calls_per_step'] == 1
+
+
+def test_two_rank_headline_survives_stuck_dp_legs():
+    """The data-parallel legs have never run on a multi-GPU RCCL node: if they do not return (here: a 1-second limit), rank 0 still prints
+    the complete render line, with the error under extra.dp_train, and every rank leaves with exit code 0."""
+    res = _run(['--steps', '2', '--warmup', '1', '--rays', '16000'], VQN_BENCH_DP_TIMEOUT='1')
+    assert res['n_gpus'] == 2 and res['value'] > 0 and 0.05 < res['roofline']['frac'] < 1.0
+    assert 'did not return within 1 s' in res['extra']['dp_train']['error']
 
 
 def test_two_rank_train_mode_times_the_dp_step():
