@@ -263,6 +263,10 @@ int vqn_neus_train_bwd_x3(const int32_t* desc, const void* wbuf_pieces, const fl
  * gather from a flat parameter vector fused with the exact three-way split x = p0 + p1 + p2 into bf16 pieces (truncation of the
  * word, twice on the exact remainders) -- a whole x3 weight pack in one launch. */
 int vqn_pack_x3_gather(const float* flat, const int32_t* gidx, int64_t n_steps, void* out, void* stream);
+/* ... and, in the same launch, the plain gather out_f32[i] = flat[fidx[i]], i < n_f32, of the thin f32 images the same kernels read
+ * (biases in accumulator order, row-dot images: `wbuf_f32` below); n_f32 = 0: the call above. */
+int vqn_pack_x3_gather2(const float* flat, const int32_t* gidx, int64_t n_steps, void* out, const int32_t* fidx, int64_t n_f32,
+                        float* out_f32, void* stream);
 
 /* Split-precision twins of vqn_neus_sdf_points / vqn_neus_fine_points ("fp16 MFMA path"): same arguments, same outputs,
  * every product taken as hi*hi + 2^-11 (hi*lo + lo*hi) over f16 hi/lo operand pairs on v_mfma_f32_32x32x16_f16 with f32

@@ -496,16 +496,26 @@ def neus_train_fwd(sdf_desc, wbuf_sdf, col_desc, wbuf_col, pts, dirs, saved, e_t
     _check(rc, entry)
 
 
-def pack_x3_gather(flat, gidx, n_steps):
-    """bf16 piece triples [n_steps, 3, 64, 8] (as an int16 tensor) of flat[gidx] -- gather + exact split in one launch."""
+def pack_x3_gather(flat, gidx, n_steps, fidx=None):
+    """bf16 piece triples [n_steps, 3, 64, 8] (as an int16 tensor) of flat[gidx] -- gather + exact split in one launch.  With `fidx`
+    (int32 or int64 index tensor): also flat[fidx], in the same launch -> (pieces, f32 images)."""
     _f32c(flat, 'flat')
     if gidx.dtype != torch.int32 or not gidx.is_contiguous() or gidx.numel() != n_steps * 512:
         raise VqnError('pack_x3_gather: gidx must be a contiguous int32 tensor of n_steps * 512 entries')
     out = torch.empty((n_steps, 3, 64, 8), dtype=torch.int16, device=flat.device)
+    if fidx is None:
+        with _clock('vqn_pack_x3_gather'):
+            rc = lib().vqn_pack_x3_gather(_ptr(flat), _ptr(gidx), ctypes.c_int64(n_steps), _ptr(out), _stream())
+        _check(rc, 'vqn_pack_x3_gather')
+        return out
+    if fidx.dtype != torch.int32 or not fidx.is_contiguous() or fidx.device != flat.device:
+        raise VqnError('pack_x3_gather: fidx must be a contiguous int32 tensor on the device of flat')
+    wf = torch.empty(fidx.shape, dtype=torch.float32, device=flat.device)
     with _clock('vqn_pack_x3_gather'):
-        rc = lib().vqn_pack_x3_gather(_ptr(flat), _ptr(gidx), ctypes.c_int64(n_steps), _ptr(out), _stream())
-    _check(rc, 'vqn_pack_x3_gather')
-    return out
+        rc = lib().vqn_pack_x3_gather2(_ptr(flat), _ptr(gidx), ctypes.c_int64(n_steps), _ptr(out), _ptr(fidx), ctypes.c_int64(fidx.numel()),
+                                       _ptr(wf), _stream())
+    _check(rc, 'vqn_pack_x3_gather2')
+    return out, wf
 
 
 def neus_train_bwd_x3(desc, wbuf_pieces, wbuf_f32, pts, g_rgb, rgb, g_n, g_sdf, saved, outs):

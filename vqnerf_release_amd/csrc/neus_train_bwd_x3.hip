@@ -389,8 +389,17 @@ int bwd_nacc() {
 }
 
 // out[t][q][lane][k] (bf16) = piece q of flat[gidx[t][lane][k]]: t over (tile, K step) of every matrix, 64 lanes x 8 slots per step
+// (blocks beyond the piece pack's: the plain f32 gather out_f[i] = flat[fidx[i]] of the thin images -- biases in accumulator order, row-dot
+//  images -- that every caller of this pack needs from the same flat vector: one launch for both)
 __global__ __launch_bounds__(256) void pack_x3_gather_kernel(const float* __restrict__ flat, const int32_t* __restrict__ gidx, const long n_steps,
-                                                             unsigned short* __restrict__ out) {
+                                                             unsigned short* __restrict__ out, const int32_t* __restrict__ fidx, const long n_f,
+                                                             float* __restrict__ out_f) {
+  const long pack_blocks = (n_steps + 3) / 4;
+  if ((long)blockIdx.x >= pack_blocks) {
+    const long i = ((long)blockIdx.x - pack_blocks) * 256 + threadIdx.x;
+    if (i < n_f) out_f[i] = flat[fidx[i]];
+    return;
+  }
   const long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (t >= n_steps) return;
@@ -417,14 +426,20 @@ __global__ __launch_bounds__(256) void pack_x3_gather_kernel(const float* __rest
 
 }  // namespace
 
-extern "C" int vqn_pack_x3_gather(const float* flat, const int32_t* gidx, int64_t n_steps, void* out, void* stream) {
-  VQN_CHECK_ARG(n_steps >= 0, "n_steps >= 0");
-  if (n_steps == 0) return VQN_OK;
+extern "C" int vqn_pack_x3_gather2(const float* flat, const int32_t* gidx, int64_t n_steps, void* out, const int32_t* fidx, int64_t n_f32,
+                                   float* out_f32, void* stream) {
   VQN_CHECK_ARG(flat && gidx && out, "null pointer");
-  hipLaunchKernelGGL(pack_x3_gather_kernel, dim3((unsigned)((n_steps + 3) / 4)), dim3(256), 0, (hipStream_t)stream, flat, gidx, (long)n_steps,
-                     reinterpret_cast<unsigned short*>(out));
+  VQN_CHECK_ARG(n_steps >= 1, "n_steps >= 1");
+  VQN_CHECK_ARG(n_f32 >= 0 && (n_f32 == 0 || (fidx && out_f32)), "fidx / out_f32 with n_f32 > 0");
+  const long blocks = (n_steps + 3) / 4 + (n_f32 + 255) / 256;
+  hipLaunchKernelGGL(pack_x3_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, flat, gidx, (long)n_steps,
+                     reinterpret_cast<unsigned short*>(out), fidx, (long)n_f32, out_f32);
   VQN_LAUNCH_CHECK();
   return VQN_OK;
+}
+
+extern "C" int vqn_pack_x3_gather(const float* flat, const int32_t* gidx, int64_t n_steps, void* out, void* stream) {
+  return vqn_pack_x3_gather2(flat, gidx, n_steps, out, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int64_t vqn_neus_train_bwd_x3_scratch_bytes(const int32_t* desc) {

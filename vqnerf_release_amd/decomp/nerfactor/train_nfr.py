@@ -145,7 +145,8 @@ class Trainer:
     def _step_body(self, batch, global_bs, thres, roll, sched, leaves):
         model = self.model
         self.optimizer.zero_grad(set_to_none=True)
-        self.bucket.attach()
+        by_value = not (leaves is None and (parallel.is_dist() or not self.bucket.flat.is_cuda))      # (the branch below that copies the gradients in)
+        self.bucket.attach(zero=not by_value)
         kw = {'thres': thres}
         if roll is not None:
             kw['roll'] = roll
@@ -159,7 +160,10 @@ class Trainer:
         else:
             # the gradients as VALUES, moved into the bucket by one multi-tensor copy: `backward()` accumulates into every
             # parameter's `.grad` view with a launch of its own (52 of them per step)
-            grads = torch.autograd.grad(weighted, leaves if leaves is not None else self.bucket.params, allow_unused=True)
+            if getattr(self, '_one', None) is None or self._one.device != weighted.device:
+                self._one = torch.ones((), dtype=weighted.dtype, device=weighted.device)        # the root adjoint, made once (not a fill per step)
+            grads = torch.autograd.grad(weighted, leaves if leaves is not None else self.bucket.params, grad_outputs=self._one,
+                                        allow_unused=True)
             with torch.no_grad():
                 # one multi-tensor copy for all gradients (a launch per parameter is ~40 of the captured step's launches)
                 have = [(v, g) for v, g in zip(self.bucket.views, grads) if g is not None]

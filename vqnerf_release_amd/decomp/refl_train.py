@@ -174,7 +174,7 @@ class ReflStackEngine:
         gidx = np.concatenate(chunks)
         assert gidx.size % 512 == 0 and gidx.max() < 2 ** 31
         dev = self.device
-        self._dev = (L, torch.from_numpy(gidx.astype(np.int32)).to(dev), gidx.size // 512, torch.from_numpy(np.concatenate(fch)).to(dev), d)
+        self._dev = (L, torch.from_numpy(gidx.astype(np.int32)).to(dev), gidx.size // 512, torch.from_numpy(np.concatenate(fch).astype(np.int32)).to(dev), d)
         return self._dev
 
     # ------------------------------------------------------------------ passes
@@ -187,8 +187,7 @@ class ReflStackEngine:
         N, dev = x.shape[0], x.device
         nt = (N + 31) // 32
         flat = L.flatten({n: p for n, p in zip(L.names, params)})
-        pieces = _C.pack_x3_gather(flat, gidx, n_steps)
-        wf = flat[fidx]
+        pieces, wf = _C.pack_x3_gather(flat, gidx, n_steps, fidx)        # (matrices as piece triples and the thin f32 images: one launch)
         S = {'pieces': pieces, 'wf': wf, 'N': N}
         saved = []
         if self.nE:
@@ -216,7 +215,7 @@ class ReflStackEngine:
         """(piece pack, f32 images) of the current weights: two launches + the flat copy; callers cache them per weights epoch."""
         L, gidx, n_steps, fidx, desc = self._static()
         flat = L.flatten({n: p.detach().float() for n, p in zip(L.names, params)})
-        return _C.pack_x3_gather(flat, gidx, n_steps), flat[fidx]
+        return _C.pack_x3_gather(flat, gidx, n_steps, fidx)
 
     @torch.no_grad()
     def infer(self, x, packs):

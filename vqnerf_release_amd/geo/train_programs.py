@@ -829,7 +829,7 @@ class NeusTrainEngine:
         gidx = np.concatenate(chunks)
         assert gidx.size % 512 == 0 and gidx.max() < 2 ** 31
         self._bwd_x3_dev[k] = (torch.from_numpy(gidx.astype(np.int32)).to(device), gidx.size // 512,
-                               torch.from_numpy(np.concatenate(fch)).to(device), desc)
+                               torch.from_numpy(np.concatenate(fch).astype(np.int32)).to(device), desc)
         return self._bwd_x3_dev[k]
 
     def run_fused_backward_x3(self, flat, T, P, g_rgb, g_n, g_sdf):
@@ -838,7 +838,8 @@ class NeusTrainEngine:
         saved = [T['U%d' % (l + 1)] for l in range(nL)] + [T['GH%d' % l] for l in range(nL)] + [T['C%d' % (l + 1)] for l in range(nC)]
         outs = [T['DC%d' % l] for l in range(nC + 1)] + [T['GOUTF'], T['ED']] + [T['UD%d' % (l + 1)] for l in range(nL)] + \
             [T['AB%d' % l] for l in range(nL)]
-        _C.neus_train_bwd_x3(desc, _C.pack_x3_gather(flat, gidx, n_steps), flat[fidx], T['X'], g_rgb, T['RGB'] if self.squeeze else None, g_n,
+        pieces, wf = _C.pack_x3_gather(flat, gidx, n_steps, fidx)
+        _C.neus_train_bwd_x3(desc, pieces, wf, T['X'], g_rgb, T['RGB'] if self.squeeze else None, g_n,
                              g_sdf, saved, outs)
 
     def _fused_backward_shape(self):

@@ -157,9 +157,12 @@ class FlatBucket:
             o += n
         self.extra = self.flat[self.n_grad:]
 
-    def attach(self):
-        """Make every p.grad a view into the bucket: backward then writes straight into it (no pack copy)."""
-        self.flat.zero_()
+    def attach(self, zero=True):
+        """Make every p.grad a view into the bucket: backward then writes straight into it (no pack copy).  `zero=False`: the caller
+        fills every view itself (gradients as values + one multi-tensor copy, zeros for parameters without one): the 11 MB fill of the
+        bucket is then one launch too many."""
+        if zero:
+            self.flat.zero_()
         for p, v in zip(self.params, self.views):
             p.grad = v
         self._reset_overlap()
