@@ -127,16 +127,18 @@ int vqn_vq_quantize_rows(const float* z, int64_t N, int D, const float* codebook
 /* Backward of that chain in one pass per row (round 4): g_xn = g_ste + (xnorm - quant) (g_loss 2 / (N D)) -- the straight-through
  * identity plus the commitment term's gradient (vq_layers.py:302, :327) -- then the l2-normalise backward of z at g_xn
  * (util/math.py:63-64).  g_ste may be NULL (zero), g_loss a device scalar.  = vqn_vq_ste_loss_bwd followed by
- * vqn_l2_normalize_rows_bwd, same roundings. */
-int vqn_vq_train_bwd(const float* z, const float* xnorm, const float* quant, const float* g_ste, const float* g_loss, int64_t N, int D,
-                     float eps, float* g_z, void* stream);
+ * vqn_l2_normalize_rows_bwd, same roundings.  loss_post: the forward's second loss factor (below), applied to g_loss first. */
+int vqn_vq_train_bwd(const float* z, const float* xnorm, const float* quant, const float* g_ste, const float* g_loss, float loss_post,
+                     int64_t N, int D, float eps, float* g_z, void* stream);
 
 /* vqn_vq_quantize_rows for the TRAINING path (round 4; vq_nfr.py:575-578 with is_training = True): the same single pass, and
  * xnorm [N, D] additionally receives the l2-normalised rows -- the x of the EMA statistics (vq_layers.py:304-309, vqn_vq_ema_stats)
- * and of the backward (vqn_vq_ste_loss_bwd, vqn_l2_normalize_rows_bwd).  Same indices / straight-through rows / loss / counts. */
+ * and of the backward (vqn_vq_ste_loss_bwd, vqn_l2_normalize_rows_bwd).  Same indices / straight-through rows / loss / counts.
+ * loss = (sum * loss_scale) * loss_post: the mean, then the commitment cost as its own rounded multiplication (vq_layers.py:327-330:
+ * `commitment_cost * mean(...)`); 1.0f leaves the mean. */
 int vqn_vq_quantize_rows_train(const float* z, int64_t N, int D, const float* codebook, int K, const float* sel_mask, float eps,
-                               float loss_scale, float* ws, int64_t* idx, float* ste, float* loss, float* counts, float* xnorm,
-                               void* stream);
+                               float loss_scale, float loss_post, float* ws, int64_t* idx, float* ste, float* loss, float* counts,
+                               float* xnorm, void* stream);
 
 /* ---- reflectance MLP stacks + shading (decomp/nerfvq_nfr3/nerfactor) ------------------------- */
 
@@ -166,7 +168,9 @@ int vqn_mlp_chain_fwd_f16s(const int32_t* desc, const float* wbuf, const float* 
  *   albedo_s, spec_s [N,3], rough_s [N]; gamma: device [2] = (bias, index) or NULL (data_type nerf);
  *   normal_out [N,3] or NULL; rgb_s [N,3]; rgb0_diff / rgb0_spec [N,3] or both NULL (vali mode,
  *   vq_nfr.py:605-610).  L in {256, 512, 1024}.  raw != 0: rgb_s receive the plain sums over lights
- *   (no gamma, no clip): the training path applies those in the host framework so that autograd sees them.
+ *   (no gamma, no clip): the training path applies those in the host framework so that autograd sees them; raw == 2: the plain sums
+ *   through x + (clip(x, 0, 1) - x) -- tfp's clip_by_value_preserve_gradient, whose gradient is the identity (so vqn_brdf_shade_bwd
+ *   is the reverse of raw = 1 and raw = 2 alike), as the training path of data_type 'nerf' applies it (no gamma curve there).
  *   probes [P,L,3] (or NULL): material set 0 is additionally re-lit by every probe in the same pass
  *   (vq_nfr.py:724-733, the per-probe Python loop of the reference) -> rgb0_probes [N,P,3]. */
 int vqn_brdf_shade_fwd(const float* xyz, const float* normal, const float* rayo, const float* lvis,

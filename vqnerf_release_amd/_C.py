@@ -301,7 +301,7 @@ def vq_ste_loss_bwd(x, quant, g_ste, g_loss):
     return gx
 
 
-def vq_train_bwd(z, xnorm, quant, g_ste, g_loss, eps=1e-6):
+def vq_train_bwd(z, xnorm, quant, g_ste, g_loss, eps=1e-6, loss_post=1.0):
     """Backward of the training quantiser in one pass (vqn_vq_train_bwd): straight-through + commitment adjoint, then the l2-normalise
     backward of z."""
     for t in (z, xnorm, quant, g_loss):
@@ -310,8 +310,8 @@ def vq_train_bwd(z, xnorm, quant, g_ste, g_loss, eps=1e-6):
         _f32c(g_ste, 'g_ste')
     gz = torch.empty_like(z)
     with _clock('vqn_vq_train_bwd'):
-        rc = lib().vqn_vq_train_bwd(_ptr(z), _ptr(xnorm), _ptr(quant), _ptr(g_ste), _ptr(g_loss), ctypes.c_int64(z.shape[0]), ctypes.c_int(z.shape[1]),
-                                    ctypes.c_float(eps), _ptr(gz), _stream())
+        rc = lib().vqn_vq_train_bwd(_ptr(z), _ptr(xnorm), _ptr(quant), _ptr(g_ste), _ptr(g_loss), ctypes.c_float(loss_post), ctypes.c_int64(z.shape[0]),
+                                    ctypes.c_int(z.shape[1]), ctypes.c_float(eps), _ptr(gz), _stream())
     _check(rc, 'vqn_vq_train_bwd')
     return gz
 
@@ -326,7 +326,7 @@ def l2_normalize_rows(x, eps=1e-6):
     return y
 
 
-def vq_quantize_rows(z, codebook, sel_mask=None, eps=1e-6, want_ste=True, want_xnorm=False):
+def vq_quantize_rows(z, codebook, sel_mask=None, eps=1e-6, want_ste=True, want_xnorm=False, loss_post=1.0):
     """Fused inference path: z [N,D] un-normalised, codebook [D,K] -> (idx int64 [N], ste [N,D] | None, mean((q - z^)^2) scalar
     tensor, counts [K]) in one pass over the rows (l2-normalise, nearest code, straight-through output, commitment term, usage)."""
     _f32c(z, 'z'); _f32c(codebook, 'codebook')
@@ -347,8 +347,8 @@ def vq_quantize_rows(z, codebook, sel_mask=None, eps=1e-6, want_ste=True, want_x
         xnorm = torch.empty((N, D), dtype=torch.float32, device=dev)
         with _clock('vqn_vq_quantize_rows_train'):
             rc = lib().vqn_vq_quantize_rows_train(_ptr(z), ctypes.c_int64(N), ctypes.c_int(D), _ptr(codebook), ctypes.c_int(K), _ptr(sel_mask),
-                                                  ctypes.c_float(eps), ctypes.c_float(1.0 / n if n else 0.0), _ptr(ws), _ptr(idx), _ptr(ste),
-                                                  _ptr(loss), _ptr(counts), _ptr(xnorm), _stream())
+                                                  ctypes.c_float(eps), ctypes.c_float(1.0 / n if n else 0.0), ctypes.c_float(loss_post), _ptr(ws), _ptr(idx),
+                                                  _ptr(ste), _ptr(loss), _ptr(counts), _ptr(xnorm), _stream())
         _check(rc, 'vqn_vq_quantize_rows_train')
         return idx, ste, loss, counts, xnorm
     with _clock('vqn_vq_quantize_rows'):
@@ -777,7 +777,7 @@ def brdf_shade_fwd(xyz, normal, rayo, lvis, lxyz, lareas, light, materials, gamm
         rc = lib().vqn_brdf_shade_fwd_rows(_ptr(rows), _ptr(xyz), _ptr(normal), _ptr(rayo), _ptr(lvis), _ptr(lxyz), _ptr(lareas),
                                            _ptr(light), ctypes.c_int64(N), ctypes.c_int(L), ctypes.c_int(len(materials)),
                                            *[_ptr(m) for m in mats], _ptr(gamma), _ptr(nout), _ptr(rgb[0]),
-                                           _ptr(rgb[1] if len(rgb) > 1 else None), _ptr(rd), _ptr(rs), ctypes.c_int(1 if raw else 0),
+                                           _ptr(rgb[1] if len(rgb) > 1 else None), _ptr(rd), _ptr(rs), ctypes.c_int(int(raw)),
                                            _ptr(probes), ctypes.c_int(n_probes), _ptr(rgb_probes), _stream())
     _check(rc, 'vqn_brdf_shade_fwd_rows')
     return dict(rgb=rgb, normal=nout, rgb_diff=rd, rgb_spec=rs, rgb_probes=rgb_probes)

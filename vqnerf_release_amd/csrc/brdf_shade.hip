@@ -80,7 +80,9 @@ struct ShadeArgs {
   float *normal_out, *rgb[2], *rgb_diff, *rgb_spec;
   long N;
   int n_sets;
-  int raw;                     // 1: write the plain sums over lights (no gamma, no [0,1] clip) -- the training path applies those in torch
+  int raw;                     // 1: write the plain sums over lights (no gamma, no [0,1] clip) -- the training path applies those in torch;
+                               // 2: the plain sums through x + (clip(x, 0, 1) - x), tfp's clip_by_value_preserve_gradient as the training path of
+                               //    data_type 'nerf' applies it (vq_nfr.py:735-745: no gamma there) -- the same roundings as vqn_clip_preserve
   const long long* rows;       // null, or [N]: point n takes its visibility row from row rows[n] of the FULL-view lvis tensor --
                                // the tf.boolean_mask gather of vq_nfr.py:558-559 (2 KB per point) without the copy
   const float* probes;         // [P][L][3] novel light probes (vq_nfr.py:724-733) or null
@@ -257,6 +259,8 @@ __global__ __launch_bounds__(PLDS ? (LQ == 4 ? 512 : 768) : 256) void brdf_shade
       if (!a.raw) {
         if (a.gamma) t = powf(t * gam_b, gam_i);
         t = clip01(t);
+      } else if (a.raw == 2) {
+        t = __fadd_rn(t, __fsub_rn(clip01(t), t));                   // clip_by_value_preserve_gradient's own arithmetic (vqn_clip_preserve)
       }
       // (one store per output array, each from a uniform base pointer)
       const int vi = lane >> 2;

@@ -313,11 +313,12 @@ __global__ __launch_bounds__(256) void ste_commit_bwd_kernel(const f32x4* __rest
 // l2-normalise backward of x at g_xn.  One wave per row, D <= 1024, D % 4 == 0; same roundings as the two-kernel sequence.
 __global__ __launch_bounds__(256) void vq_train_bwd_kernel(const float* __restrict__ x, const float* __restrict__ xn, const float* __restrict__ q,
                                                            const float* __restrict__ g_ste, const float* __restrict__ g_loss, float two_over_numel,
-                                                           long N, int D, float eps, float* __restrict__ gx) {
+                                                           float loss_post, long N, int D, float eps, float* __restrict__ gx) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= N) return;
-  const float t_c = __fmul_rn(g_loss[0], two_over_numel);
+  // (loss_post: the forward's second factor -- the commitment cost -- applied to the incoming adjoint as autograd's own multiplication would)
+  const float t_c = __fmul_rn(__fmul_rn(g_loss[0], loss_post), two_over_numel);
   const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * D);
   const f32x4* nr = reinterpret_cast<const f32x4*>(xn + row * D);
   const f32x4* qr = reinterpret_cast<const f32x4*>(q + row * D);
@@ -361,14 +362,14 @@ __global__ __launch_bounds__(256) void vq_train_bwd_kernel(const float* __restri
 
 }  // namespace
 
-extern "C" int vqn_vq_train_bwd(const float* z, const float* xnorm, const float* quant, const float* g_ste, const float* g_loss, int64_t N, int D,
-                                float eps, float* g_z, void* stream) {
+extern "C" int vqn_vq_train_bwd(const float* z, const float* xnorm, const float* quant, const float* g_ste, const float* g_loss, float loss_post,
+                                int64_t N, int D, float eps, float* g_z, void* stream) {
   VQN_CHECK_ARG(N >= 0 && D > 0, "N >= 0, D > 0");
   if (N == 0) return VQN_OK;
   VQN_CHECK_ARG(z && xnorm && quant && g_loss && g_z, "null pointer");
   VQN_CHECK_SHAPE(D % 4 == 0 && D <= 1024, "D a multiple of 4, at most 1024");
   hipLaunchKernelGGL(vq_train_bwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z, xnorm, quant, g_ste, g_loss,
-                     (float)(2.0 / ((double)N * D)), (long)N, D, eps, g_z);
+                     (float)(2.0 / ((double)N * D)), loss_post, (long)N, D, eps, g_z);
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }

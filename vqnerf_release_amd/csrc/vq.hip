@@ -881,12 +881,15 @@ __global__ __launch_bounds__(256) void vq_ste_loss_kernel(const f32x4* __restric
   if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 
-__global__ __launch_bounds__(64) void vq_ste_loss_final_kernel(const float* __restrict__ part, int n, float scale, float* __restrict__ loss) {
+// (`post`: a second factor applied AFTER the mean -- the commitment cost of the training quantiser, `commitment_cost * mean(...)` as the
+//  reference states it, vq_layers.py:327-330 -- rounded as its own multiplication; 1.0f is exact)
+__global__ __launch_bounds__(64) void vq_ste_loss_final_kernel(const float* __restrict__ part, int n, float scale, float* __restrict__ loss,
+                                                                float post = 1.0f) {
   float s = 0.f;                                         // lane l: part[l], part[l + 64], ... then a fixed xor tree
   for (int i = threadIdx.x; i < n; i += 64) s += part[i];
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m);
-  if (threadIdx.x == 0) *loss = s * scale;
+  if (threadIdx.x == 0) *loss = __fmul_rn(__fmul_rn(s, scale), post);
 }
 
 // counts only (dw == NULL): per-workgroup LDS histogram, then one float add of an integer per code and workgroup (sums of
@@ -1007,7 +1010,7 @@ __global__ __launch_bounds__(256) void vq_codebook_frags_kernel(const float* __r
 }  // namespace
 
 int vqn_internal_finish_loss(const float* part, int n, float scale, float* loss, hipStream_t s) {
-  hipLaunchKernelGGL(vq_ste_loss_final_kernel, dim3(1), dim3(64), 0, s, part, n, scale, loss);
+  hipLaunchKernelGGL(vq_ste_loss_final_kernel, dim3(1), dim3(64), 0, s, part, n, scale, loss, 1.0f);
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }
@@ -1063,7 +1066,8 @@ extern "C" int vqn_l2_normalize_rows(const float* x, int64_t N, int D, float eps
 }
 
 static int quantize_rows_impl(const float* z, int64_t N, int D, const float* codebook, int K, const float* sel_mask, float eps,
-                              float loss_scale, float* ws, int64_t* idx, float* ste, float* loss, float* counts, float* xnorm, void* stream) {
+                              float loss_scale, float* ws, int64_t* idx, float* ste, float* loss, float* counts, float* xnorm, void* stream,
+                              float loss_post = 1.0f) {
   VQN_CHECK_ARG(N >= 0 && D > 0 && K > 0, "N >= 0, D > 0, K > 0 required");
   VQN_CHECK_ARG(loss && counts && ws, "loss, counts and ws (VQN_QUANT_WS_FLOATS floats) must be non-null");
   hipStream_t s = (hipStream_t)stream;
@@ -1096,7 +1100,7 @@ static int quantize_rows_impl(const float* z, int64_t N, int D, const float* cod
     default: rc = launch_assign<8, true>(z, N, D, codebook, K, sel_mask, ws, idx_ll, ste, nullptr, fz, s); break;
   }
   if (rc != VQN_OK) return rc;
-  hipLaunchKernelGGL(vq_ste_loss_final_kernel, dim3(1), dim3(64), 0, s, ws + 1, (int)blocks, loss_scale, loss);
+  hipLaunchKernelGGL(vq_ste_loss_final_kernel, dim3(1), dim3(64), 0, s, ws + 1, (int)blocks, loss_scale, loss, loss_post);
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }
@@ -1109,10 +1113,10 @@ extern "C" int vqn_vq_quantize_rows(const float* z, int64_t N, int D, const floa
 // ... and the form the TRAINING path uses (round 4): the same pass also leaves the l2-normalised rows, which the EMA statistics
 // (vqn_vq_ema_stats) and the backward (vqn_vq_ste_loss_bwd, vqn_l2_normalize_rows_bwd) read.
 extern "C" int vqn_vq_quantize_rows_train(const float* z, int64_t N, int D, const float* codebook, int K, const float* sel_mask, float eps,
-                                          float loss_scale, float* ws, int64_t* idx, float* ste, float* loss, float* counts, float* xnorm,
-                                          void* stream) {
+                                          float loss_scale, float loss_post, float* ws, int64_t* idx, float* ste, float* loss, float* counts,
+                                          float* xnorm, void* stream) {
   VQN_CHECK_ARG(N == 0 || xnorm != nullptr, "xnorm must be non-null");
-  return quantize_rows_impl(z, N, D, codebook, K, sel_mask, eps, loss_scale, ws, idx, ste, loss, counts, xnorm, stream);
+  return quantize_rows_impl(z, N, D, codebook, K, sel_mask, eps, loss_scale, ws, idx, ste, loss, counts, xnorm, stream, loss_post);
 }
 
 extern "C" int64_t vqn_vq_ema_stats_ws_bytes(int64_t N, int D, int K) {
@@ -1216,7 +1220,7 @@ extern "C" int vqn_vq_ste_loss(const float* x, const float* quant, int64_t numel
   hipLaunchKernelGGL(vq_ste_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const f32x4*>(x),
                      reinterpret_cast<const f32x4*>(quant), n4, reinterpret_cast<f32x4*>(ste), ws);
   VQN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(vq_ste_loss_final_kernel, dim3(1), dim3(64), 0, s, ws, (int)blocks, scale, loss);
+  hipLaunchKernelGGL(vq_ste_loss_final_kernel, dim3(1), dim3(64), 0, s, ws, (int)blocks, scale, loss, 1.0f);
   VQN_LAUNCH_CHECK();
   return VQN_OK;
 }

@@ -109,12 +109,13 @@ class ShadeFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, geom, light, *mats):
-        xyz, normal, rayo, lvis, lxyz, lareas = geom
+        xyz, normal, rayo, lvis, lxyz, lareas = geom[:6]
+        clip = len(geom) > 6 and bool(geom[6])       # the sums through clip_by_value_preserve_gradient(0, 1) inside the kernel (identity gradient: backward unchanged)
         light = light.detach().float().reshape(-1, 3).contiguous()
         sets = [tuple(t.detach().float().contiguous() for t in mats[3 * i:3 * i + 3]) for i in range(len(mats) // 3)]
         sets = [(a, s.expand(-1, 3).contiguous(), r) for a, s, r in sets]
-        out = _C.brdf_shade_fwd(xyz, normal, rayo, lvis, lxyz, lareas, light, sets, want_normal=True, raw=True)
-        ctx.geom, ctx.light, ctx.sets = geom, light, sets
+        out = _C.brdf_shade_fwd(xyz, normal, rayo, lvis, lxyz, lareas, light, sets, want_normal=True, raw=2 if clip else 1)
+        ctx.geom, ctx.light, ctx.sets = geom[:6], light, sets
         ctx.spec_widths = [mats[3 * i + 1].shape[1] for i in range(len(sets))]
         ctx.mark_non_differentiable(out['normal'])
         return (out['normal'],) + tuple(out['rgb'])
@@ -631,16 +632,20 @@ class BrdfModel(ShapeModel):
         light = self.light if light is None else light
         lvis = dense_rows(lvis)
         c = lambda t: t.detach().float().contiguous()
+        # data_type 'nerf' has no gamma curve: the [0, 1] clip with identity gradient is applied by the kernel itself (raw = 2, the
+        # arithmetic of vqn_clip_preserve) -- it was a launch per material set
+        in_kernel_clip = self.data_type == 'nerf'
         geom = (c(xyz), c(normal), c(rayo), None if lvis is None else c(lvis), self.lxyz.reshape(-1, 3).contiguous(),
-                self.lareas.reshape(-1).contiguous())
+                self.lareas.reshape(-1).contiguous(), in_kernel_clip)
         flat = [t for m in materials for t in m]
         res = ShadeFunction.apply(geom, light.reshape(-1, 3), *flat)
         n_pred, sums = res[0], res[1:]
+        if in_kernel_clip:
+            return {'rgb': list(sums), 'normal': n_pred, 'rgb_diff': None, 'rgb_spec': None}
         rgb = []
         for sm in sums:
-            if self.data_type != 'nerf':
-                g = self.gamma
-                sm = (sm * g[0]) ** g[1]
+            g = self.gamma
+            sm = (sm * g[0]) ** g[1]
             rgb.append(mathutil.clip_preserve_gradient(sm, 0.0, 1.0))
         return {'rgb': rgb, 'normal': n_pred, 'rgb_diff': None, 'rgb_spec': None}
 

@@ -461,7 +461,8 @@ class Model(BrdfModel):
         z_vq = kwargs.pop('z') if w['smooth'] > 0 else None
         spec, rough = (kwargs.pop('spec'), kwargs.pop('rough')) if w['lambert'] > 0 else (None, None)
         terms = FusedTrainLoss.apply(rgb_pred, vq_rgb, rgb_gt, z_vq, spec, rough, self.data_type == 'nerf', w)
-        ld = {'rgb': terms[:, 0], 'vqrgb': terms[:, 1], 'vqloss': cfg('vq_loss_weight') * kwargs.pop('vqloss')}
+        wq = cfg('vq_loss_weight')                         # (1.0 in the reference's config: x * 1.0 is x exactly -- not worth two launches)
+        ld = {'rgb': terms[:, 0], 'vqrgb': terms[:, 1], 'vqloss': kwargs.pop('vqloss') if wq == 1.0 else wq * kwargs.pop('vqloss')}
         # the per-point total in the reference's own order, ONE launch (vqn_loss_total; seven framework launches before)
         if w['chr'] > 0:
             ld['chromaticity'] = terms[:, 2]

@@ -81,12 +81,14 @@ class _QuantiseTrain(torch.autograd.Function):
     difference)."""
 
     @staticmethod
-    def forward(ctx, z_raw, cb, sel, eps, aux):
+    def forward(ctx, z_raw, cb, sel, eps, aux, loss_post=1.0):
+        """loss_post: the commitment cost -- the returned loss is commitment_cost * mean(...), rounded as the framework's own
+        scalar multiplication would round it (that multiplication and its adjoint were two launches on one number)."""
         x = z_raw.detach().float().contiguous()
-        idx, ste, loss, counts, xnorm = _C.vq_quantize_rows(x, cb, sel_mask=sel, eps=eps, want_ste=True, want_xnorm=True)
+        idx, ste, loss, counts, xnorm = _C.vq_quantize_rows(x, cb, sel_mask=sel, eps=eps, want_ste=True, want_xnorm=True, loss_post=loss_post)
         aux.update(idx=idx, counts=counts, xnorm=xnorm)
         ctx.save_for_backward(x, xnorm, ste)
-        ctx.eps = float(eps)
+        ctx.eps, ctx.post = float(eps), float(loss_post)
         return ste, loss
 
     @staticmethod
@@ -95,9 +97,9 @@ class _QuantiseTrain(torch.autograd.Function):
         gs = None if g_ste is None else g_ste.float().contiguous()
         gl = torch.zeros((), dtype=torch.float32, device=x.device) if g_loss is None else g_loss.float().contiguous()
         if x.shape[1] <= 1024:
-            return _C.vq_train_bwd(x, xnorm, ste, gs, gl, ctx.eps), None, None, None, None         # (one pass: the two kernels below)
-        g_xn = _C.vq_ste_loss_bwd(xnorm, ste, gs, gl)
-        return _C.l2_normalize_rows_bwd(x, g_xn, ctx.eps), None, None, None, None
+            return _C.vq_train_bwd(x, xnorm, ste, gs, gl, ctx.eps, loss_post=ctx.post), None, None, None, None, None     # (one pass: the two kernels below)
+        g_xn = _C.vq_ste_loss_bwd(xnorm, ste, gs, gl if ctx.post == 1.0 else gl * ctx.post)
+        return _C.l2_normalize_rows_bwd(x, g_xn, ctx.eps), None, None, None, None, None
 
 
 class L2NormalizeRows(torch.autograd.Function):
@@ -258,7 +260,7 @@ class VectorQuantizerEMA(torch.nn.Module):
             thres_t = torch.as_tensor(thres, dtype=torch.float32, device=z_raw.device)
             sel = (roll.to(z_raw.device) >= thres_t).to(torch.float32).expand(1, K).reshape(K).contiguous()
         aux = {}
-        quantized, e_latent_loss = _QuantiseTrain.apply(z_raw.reshape(-1, D), cb, sel, float(eps), aux)
+        quantized, commitment = _QuantiseTrain.apply(z_raw.reshape(-1, D), cb, sel, float(eps), aux, float(self.commitment_cost))
         idx, x = aux['idx'], aux['xnorm']
         counts, dw = _C.vq_ema_stats(x, idx, K)
         local_counts = counts
@@ -281,7 +283,7 @@ class VectorQuantizerEMA(torch.nn.Module):
         def perplexity():
             avg = counts / max(idx.numel(), 1)
             return torch.exp(-torch.sum(avg * torch.log(avg + 1e-10)))
-        ret.update({'quantize': quantized.reshape(z_raw.shape), 'loss': self.commitment_cost * e_latent_loss,
+        ret.update({'quantize': quantized.reshape(z_raw.shape), 'loss': commitment,          # (= commitment_cost * e_latent_loss, from the kernel)
                     'encoding_indices': idx.reshape(z_raw.shape[:-1])})
         return LazyResult(ret, {'perplexity': perplexity, 'encodings': lambda: torch.nn.functional.one_hot(idx, K).to(torch.float32),
                                 'distances': lambda: _C.vq_assign(x, cb, sel_mask=sel, want_quant=False, want_dist=True)[2]})

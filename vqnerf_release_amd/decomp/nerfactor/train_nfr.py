@@ -157,6 +157,7 @@ class Trainer:
         weighted = compute_average_loss(per_example, global_bs)
         if leaves is None and (parallel.is_dist() or not self.bucket.flat.is_cuda):
             weighted.backward()                      # (data parallel: the bucket's post-accumulate hooks start its slices' all-reduces)
+            by_value = False
         else:
             # the gradients as VALUES, moved into the bucket by one multi-tensor copy: `backward()` accumulates into every
             # parameter's `.grad` view with a launch of its own (52 of them per step)
@@ -170,10 +171,12 @@ class Trainer:
                 for v, g in zip(self.bucket.views, grads):
                     if g is None:
                         v.zero_()
-                if have:
-                    parallel.multi_copy([v for v, _ in have], [g for _, g in have])
-        with torch.no_grad():
-            self.bucket.extra[0] = weighted
+                # (the loss rides along: the bucket's extra slot is one more destination of the same launch)
+                parallel.multi_copy([v for v, _ in have] + [self.bucket.extra[0:1]], [g for _, g in have] + [weighted.detach().reshape(1)])
+                by_value = True
+        if not by_value:
+            with torch.no_grad():
+                self.bucket.extra[0] = weighted
         extra = self.bucket.all_reduce()
         clipnorm, clipvalue = self.clip
         if clipnorm > 0:
