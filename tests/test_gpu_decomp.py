@@ -269,6 +269,25 @@ def test_shade_kernel_vs_oracle(setup, with_lvis):
     _assert_as_accurate_as_fp32_oracle(_np(got_g['rgb'][0]), g32['rgb'][0].numpy(), g64['rgb'][0].numpy(), 'gamma')
 
 
+def test_shade_clips_with_identity_gradient_inside_the_kernel(setup):
+    """raw = 2 (round 4: the training path of data_type 'nerf'): the plain sums through tfp's clip_by_value_preserve_gradient inside the
+    shading kernel == raw = 1 followed by vqn_clip_preserve, bit for bit (bright lights so that the clip bites)."""
+    od = setup['od']
+    N = 700
+    pts = od.make_points(N, seed=23)
+    rng = np.random.default_rng(24)
+    c = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32).cuda().contiguous()
+    mats = [(c(rng.uniform(0, 1, (N, 3))), c(rng.uniform(0, 1, (N, 3))), c(rng.uniform(0.02, 1, (N, 1)))) for _ in range(2)]
+    geo = (c(pts['xyz']), c(pts['normal']), c(pts['rayo']))
+    lights = (c(setup['lxyz'].reshape(-1, 3)), c(setup['lareas'].reshape(-1)), c(rng.uniform(0, 6, (512, 3))))
+    a = _C.brdf_shade_fwd(*geo, c(pts['lvis']), *lights, mats, raw=1)
+    b = _C.brdf_shade_fwd(*geo, c(pts['lvis']), *lights, mats, raw=2)
+    for s in range(2):
+        want = _C.clip_preserve(a['rgb'][s], 0.0, 1.0)
+        assert torch.equal(b['rgb'][s], want)
+        assert float((a['rgb'][s] > 1).float().mean()) > 0.01        # (the clip did something)
+
+
 def test_shade_reads_visibility_rows_in_place(setup):
     """vqn_brdf_shade_fwd_rows: the foreground gather of the visibility buffer (vq_nfr.py:558-559) folded into the kernel gives
     bit for bit what the gathered copy gives; the models use it on the inference path (LazyRows)."""

@@ -823,6 +823,40 @@ def test_hip_adam_is_torch_adam(amsgrad, tensor_lr, wd):
     ob.load_state_dict(oa.state_dict())                          # interchangeable checkpoints
 
 
+def test_pack_gather_leaves_the_f32_images_in_the_same_launch():
+    """vqn_pack_x3_gather2 (round 4): the piece pack of vqn_pack_x3_gather and, from the same flat vector, flat[fidx] -- one launch."""
+    from vqnerf_release_amd import _C
+    g = torch.Generator(device='cuda').manual_seed(3)
+    flat = torch.randn(50000, device='cuda', generator=g)
+    gidx = torch.randint(0, 50000, (37 * 512,), device='cuda', generator=g, dtype=torch.int32)
+    fidx = torch.randint(0, 50000, (1234,), device='cuda', generator=g, dtype=torch.int32)
+    want = _C.pack_x3_gather(flat, gidx, 37)
+    got, wf = _C.pack_x3_gather(flat, gidx, 37, fidx)
+    assert torch.equal(got, want) and torch.equal(wf, flat[fidx.long()])
+    with pytest.raises(_C.VqnError):
+        _C.pack_x3_gather(flat, gidx, 37, fidx.long())
+
+
+def test_commitment_cost_inside_the_quantiser_kernels_rounds_like_the_framework():
+    """loss_post of vqn_vq_quantize_rows_train / vqn_vq_train_bwd (round 4): (mean) * cost and g * cost as their own f32 multiplications --
+    what `commitment_cost * e_latent_loss` and its autograd did with two framework launches on one number."""
+    from vqnerf_release_amd import _C
+    g = torch.Generator(device='cuda').manual_seed(4)
+    N, D, K = 3001, 256, 15
+    z = torch.rand(N, D, device='cuda', generator=g)
+    cb = torch.nn.functional.normalize(torch.rand(D, K, device='cuda', generator=g), dim=0).contiguous()
+    cost = 0.1
+    idx1, ste1, loss1, cnt1, xn1 = _C.vq_quantize_rows(z, cb, want_ste=True, want_xnorm=True)
+    idx2, ste2, loss2, cnt2, xn2 = _C.vq_quantize_rows(z, cb, want_ste=True, want_xnorm=True, loss_post=cost)
+    assert torch.equal(idx1, idx2) and torch.equal(ste1, ste2) and torch.equal(xn1, xn2) and torch.equal(cnt1, cnt2)
+    assert torch.equal(loss2, cost * loss1)
+    gs = torch.randn(N, D, device='cuda', generator=g)
+    gl = torch.tensor(0.7, device='cuda')
+    a = _C.vq_train_bwd(z, xn1, ste1, gs, gl * cost)
+    b = _C.vq_train_bwd(z, xn1, ste1, gs, gl, loss_post=cost)
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('eps_mode,amsgrad', [('keras', True), ('keras', False), ('torch', True)])
 def test_hip_adam_against_the_oracle_statements(eps_mode, amsgrad):
     """vqn_adam_step against oracle/optim.py: Keras Adam(amsgrad) -- epsilon on the UN-debiased sqrt(vhat), the
