@@ -583,8 +583,20 @@ def test_training_backward_on_the_two_image_engine_matches_the_interpreted_progr
             eng.run_fused_backward(flat, Tb, P, g_rgb, g_n, g_sdf)
         assert rec.ran('vqn_tile_program:prog_sbwd') and rec.ran('vqn_neus_train_bwd')
     nt = (P + 31) // 32
+
+    def goutf_row0(T):
+        """round 4: the fused kernels leave d loss / d sdf / scale in row 0 of GOUTF (the interpreter: zeros), so that the contraction
+        GOUTF x u_L yields row 0 of the last layer's gradient by itself -- checked here, then taken out of the comparison"""
+        want = torch.zeros(nt * 32, device=dev)
+        want[:P] = g_sdf.reshape(-1) / eng.scale
+        got = T['GOUTF'][:nt, 0, 0, :].reshape(-1)
+        assert float((got - want).abs().max()) <= 1e-6 * max(float(want.abs().max()), 1e-6)
+        c0 = T['GOUTF'][:nt].clone()
+        c0[:, 0, 0, :] = 0.0
+        return c0
+
     for n in outs:
-        a, c = Ta[n][:nt], Tb[n][:nt]
+        a, c = Ta[n][:nt], (goutf_row0(Tb) if n == 'GOUTF' else Tb[n][:nt])
         assert torch.isfinite(c).all(), n
         wrote = ~torch.isnan(a)                  # (the interpreter leaves the feature rows past a one-row-quad tensor's eight unwritten)
         assert wrote.float().mean() > 0.2, n
@@ -603,7 +615,7 @@ def test_training_backward_on_the_two_image_engine_matches_the_interpreted_progr
             eng.run_fused_backward_x3(flat, Tx, P, g_rgb, g_n, g_sdf)
         assert rec.ran('vqn_neus_train_bwd_x3') and rec.ran('vqn_pack_x3_gather')
     for n in outs:
-        a, c = Ta[n][:nt], Tx[n][:nt]
+        a, c = Ta[n][:nt], (goutf_row0(Tx) if n == 'GOUTF' else Tx[n][:nt])
         assert torch.isfinite(c).all(), n
         wrote = ~torch.isnan(a)
         a, c = a[wrote], c[wrote]

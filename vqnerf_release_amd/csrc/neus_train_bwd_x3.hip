@@ -244,7 +244,8 @@ __global__ __launch_bounds__(512, 1) void neus_train_bwd_x3_kernel(const TrainBw
         const int im = (tid - 192) >> 5, t = tid & 31;
         if (2 * pair + im < n_tiles) {
           float* base = tp.GOUTF + (2 * pair + im) * (long)bd.outf_tiles * 1024;
-          base[t] = 0.f;
+          base[t] = sm->gs[im][t];                                        // row 0: d loss / d sdf / scale -- the contraction GOUTF x u_L then
+                                                                          // yields row 0 of the last layer's gradient (and its bias) by itself
           for (int f = 32 * bd.feat_tiles + 1; f < 32 * bd.outf_tiles; ++f) base[f * 32 + t] = 0.f;
         }
       }

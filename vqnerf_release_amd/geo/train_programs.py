@@ -958,16 +958,20 @@ class NeusTrainEngine:
             return out[:a_rows, :b_cols], rs_out[0, :a_rows]
         return out[:a_rows, :b_cols]
 
-    def weight_grads(self, T, g_sdf):
-        """dict of gradients w.r.t. the EFFECTIVE weights / biases, from the saved tensors."""
+    def weight_grads(self, T, g_sdf, goutf_row0_is_gs=False):
+        """dict of gradients w.r.t. the EFFECTIVE weights / biases, from the saved tensors.  goutf_row0_is_gs: the backward kernel left
+        d loss / d sdf / scale in row 0 of GOUTF (the fused kernels do, round 4), so the contraction GOUTF x u_L already holds row 0 of
+        the last layer's gradient and of its bias -- in torch that row was an elementwise product over u_L (84 M elements at the bench
+        batch) and a sum over it: 1 GB of traffic per step."""
         nL, nC, s2 = self.nL, self.nC, 1.0 / math.sqrt(2.0)
         dev = T['X'].device
         tsum = lambda t, n: t.sum((0, 3)).reshape(-1)[:n]        # sum over points of a TFMT tensor -> [features]
         dW, db, dWc, dbc = [None] * (nL + 1), [None] * (nL + 1), [None] * (nC + 1), [None] * (nC + 1)
         uL, udL = T['U%d' % nL], T['UD%d' % nL]
         nt = uL.shape[0]
-        gs = torch.zeros(nt * 32, dtype=torch.float32, device=dev)
-        gs[:g_sdf.numel()] = g_sdf.reshape(-1) / self.scale
+        if not goutf_row0_is_gs:
+            gs = torch.zeros(nt * 32, dtype=torch.float32, device=dev)
+            gs[:g_sdf.numel()] = g_sdf.reshape(-1) / self.scale
         if BATCHED_WGRAD[0]:
             new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
             batch = WgradBatch(self.n_split)
@@ -995,8 +999,11 @@ class NeusTrainEngine:
                 batch.contract(T['DC%d' % l], T['C%d' % l], self.cout[l], self.cin[l], dWc[l], self.cin[l], 1, bias_dst=dbc[l])
             batch.flush()
             # row 0 of the final layer = (g_sdf/scale) (x) u_L + u'_L ; its bias = sum of g_sdf / scale
-            dW[nL][0] = (uL * gs.view(nt, 1, 1, 32)).sum((0, 3)).reshape(-1)[:self.out[nL - 1]] + tsum(udL, self.out[nL - 1])
-            db[nL][0] = gs.sum()
+            if goutf_row0_is_gs:
+                dW[nL][0] += tsum(udL, self.out[nL - 1])
+            else:
+                dW[nL][0] = (uL * gs.view(nt, 1, 1, 32)).sum((0, 3)).reshape(-1)[:self.out[nL - 1]] + tsum(udL, self.out[nL - 1])
+                db[nL][0] = gs.sum()
             return dW, db, dWc, dbc
         ws = torch.empty(self.n_split * 256 * 256, dtype=torch.float32, device=dev)
         for l in range(nL):
@@ -1012,10 +1019,14 @@ class NeusTrainEngine:
             dW[l], db[l] = g, bsum
         # final layer: rows 1.. from the feature adjoints, row 0 = (g_sdf/scale) (x) u_L + u'_L
         gl, bl = self.wgrad(T['GOUTF'], T['U%d' % nL], self.F, self.out[nL - 1], ws, rowsum=True)
-        row0 = (uL * gs.view(nt, 1, 1, 32)).sum((0, 3)).reshape(-1)[:self.out[nL - 1]] + tsum(udL, self.out[nL - 1])
-        gl = torch.cat([row0[None], gl[1:]], 0)
-        bl = bl.clone()
-        bl[0] = gs.sum()
+        if goutf_row0_is_gs:
+            gl = gl.clone()
+            gl[0] += tsum(udL, self.out[nL - 1])
+        else:
+            row0 = (uL * gs.view(nt, 1, 1, 32)).sum((0, 3)).reshape(-1)[:self.out[nL - 1]] + tsum(udL, self.out[nL - 1])
+            gl = torch.cat([row0[None], gl[1:]], 0)
+            bl = bl.clone()
+            bl[0] = gs.sum()
         dW[nL], db[nL] = gl, bl
         # colour net
         d0 = T['DC0']
@@ -1072,6 +1083,6 @@ class NeusCoreFunction(torch.autograd.Function):
                 T['V'].copy_(T['GNCOL'] if g_n is None else g_n + T['GNCOL'])
                 T['GS'].copy_(gs)
                 e.run('prog_sbwd', ctx.descs, ctx.wbuf, T, P)
-            dW, db, dWc, dbc = e.weight_grads(T, gs)
+            dW, db, dWc, dbc = e.weight_grads(T, gs, goutf_row0_is_gs=bmode is not None)
         ctx.T = ctx.flat = None
         return (None, None, None) + tuple(dW) + tuple(db) + tuple(dWc) + tuple(dbc)
