@@ -34,6 +34,12 @@ class Log(TorchDispatchMode):
             numel = 0
             for a in list(args) + list((kwargs or {}).values()):
                 if torch.is_tensor(a): numel = max(numel, a.numel())
+            if numel >= 1000000 and 'add' in name:
+                try:
+                    node = torch._C._current_autograd_node()
+                except Exception:
+                    node = None
+                print('BIG ADD', [tuple(a.shape) for a in args if torch.is_tensor(a)], 'node:', None if node is None else node.name(), flush=True)
             sites[(site, name)] += 1
             big[(site, name)] = max(big.get((site, name), 0), numel)
         return func(*args, **(kwargs or {}))

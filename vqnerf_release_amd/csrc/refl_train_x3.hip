@@ -465,7 +465,7 @@ __global__ __launch_bounds__(512, RT_WAVES_EU(NIMG)) void refl_train_bwd_x3_kern
       const long ptile = ptile_of(unit, im);
       const long pt = (ptile << 5) + p;
       const bool valid = pt < P;
-      if (valid)
+      if (valid && blockIdx.y == 0)                // (one workgroup row per head: the incoming rows go into ONE of the slices that are summed later)
         for (int j = 0; j < tp.n_gz; ++j) {
           const float* row = tp.G_Z[j] + pt * (long)rd.z_feats + 32 * ot + 4 * h;
 #pragma unroll

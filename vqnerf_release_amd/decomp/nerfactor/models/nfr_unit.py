@@ -549,15 +549,21 @@ class BrdfModel(ShapeModel):
     def _pred_rough_at(self, z):
         return self._head('rough_out', z)
 
-    def _all_heads(self, z, suffix):
-        """(basecolor|albedo [N,3], ks|spec [N,1|3], rough [N,1]) of the `suffix` head family in one launch."""
+    def _all_heads(self, z, suffix, keep_input=False):
+        """(basecolor|albedo [N,3], ks|spec [N,1|3], rough [N,1]) of the `suffix` head family in one launch.  keep_input: a fourth value,
+        the rows `z` as a further consumer should read them (the same values; on the training kernels an output of the heads' node, so
+        that the consumer's adjoint is added inside the backward kernel -- ReflStackKeepFunction)."""
         names = [h + '_' + suffix for h in self.HEADS]
+        z_keep = z
         if self._fused(z):
             d, s, r = self._fused_heads(z, names)
         elif self._stack_engine(names, z, with_encoder=False) is not None:
-            from vqnerf_release_amd.decomp.refl_train import ReflStackFunction
+            from vqnerf_release_amd.decomp.refl_train import ReflStackFunction, ReflStackKeepFunction
             eng = self._stack_engine(names, z, with_encoder=False)
-            d, s, r = ReflStackFunction.apply(eng, z, *eng.params())
+            if keep_input and z.requires_grad and z.dtype == torch.float32 and z.is_contiguous():
+                z_keep, d, s, r = ReflStackKeepFunction.apply(eng, z, *eng.params())
+            else:
+                d, s, r = ReflStackFunction.apply(eng, z, *eng.params())
         elif self._train_hip(z):
             from vqnerf_release_amd.decomp.train_programs import HeadsFunction
             nets = [self.net[n] for n in names]
@@ -565,7 +571,8 @@ class BrdfModel(ShapeModel):
                                           *[l.bias for n in nets for l in n.layers])
         else:
             d, s, r = (self.net[n](z) for n in names)
-        return self._numerics(self._albedo_affine(d), 'Albedo'), self._numerics(s, 'Specular'), self._numerics(r, 'Roughness')
+        out = (self._numerics(self._albedo_affine(d), 'Albedo'), self._numerics(s, 'Specular'), self._numerics(r, 'Roughness'))
+        return out + (z_keep,) if keep_input else out
 
     @staticmethod
     def _normal_correct(normal, surf2c):

@@ -315,7 +315,11 @@ class Model(BrdfModel):
             if mode == 'train':                               # codebook is moved by the EMA, outside the optimiser (:582-583)
                 with torch.no_grad():
                     self._codebook.copy_(vq['update'])
-            vq_albedo, vq_spec, vq_rough = self._all_heads(z_vq, 'vq')
+            if mode == 'train':
+                # (the loss's smoothness term reads z_vq too: it takes the rows from the heads' node -- see _all_heads(keep_input))
+                vq_albedo, vq_spec, vq_rough, z_vq = self._all_heads(z_vq, 'vq', keep_input=True)
+            else:
+                vq_albedo, vq_spec, vq_rough = self._all_heads(z_vq, 'vq')
 
         spec, albedo = ks_split(ks, basecolor)
         sh = self._shade_or_render(xyz_m, normal_m, rayo, lvis_m, [(albedo, spec, rough), (vq_albedo, vq_spec, vq_rough)],

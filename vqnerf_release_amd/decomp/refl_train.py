@@ -249,7 +249,8 @@ class ReflStackEngine:
         return self.nH > 1 and nt * self.nH <= (3 * cus) // 2
 
     def backward(self, S, g_z, g_outs):
-        """g_z [N, Z] | None: adjoint of z from outside the heads (with an encoder); g_outs: adjoints of the head outputs (None: zeros).
+        """g_z [N, Z] | None: adjoint of z (with an encoder) / of the input rows (without: ReflStackKeepFunction) from outside the heads,
+        added inside the kernel; g_outs: adjoints of the head outputs (None: zeros).
         -> (d / d input rows | None, [dW, db, dW, db, ...] in params() order, Keras layout)."""
         L, gidx, n_steps, fidx, desc = self._static()
         N, dev = S['N'], S['wf'].device
@@ -282,14 +283,15 @@ class ReflStackEngine:
         if S['split'] and self.nH > 1:
             # one workgroup row per head -> one d / d z slice per head; with an encoder a second launch walks it from their sum
             part = torch.empty((self.nH, N, self.Z), dtype=torch.float32, device=dev)
-            _C.refl_train_bwd_x3(*args, [], saved, outs, part, run_heads=True, run_enc=False, split_heads=True, **d2kw)
+            _C.refl_train_bwd_x3(*args, [g_z] if (g_z is not None and not self.nE) else [], saved, outs, part, run_heads=True, run_enc=False,
+                                 split_heads=True, **d2kw)
             if self.nE:
                 _C.refl_train_bwd_x3(*args, [g_z] + [part[k] for k in range(self.nH)], saved, outs, None, run_heads=False, run_enc=True)
             else:
                 gz_rows = part.sum(0)
         else:
             gz_rows = None if self.nE else torch.empty((N, self.Z), dtype=torch.float32, device=dev)
-            _C.refl_train_bwd_x3(*args, [g_z] if self.nE else [], saved, outs, gz_rows, **d2kw)
+            _C.refl_train_bwd_x3(*args, [g_z] if g_z is not None else [], saved, outs, gz_rows, **d2kw)
         # ---- weight gradients: contractions over the points, straight into the Keras layout [in, out] ----
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         batch = WgradBatch(self.n_split, thin=True)          # (the heads' 1..3-output last layers: vqn_wgrad_thin_batched)
@@ -340,3 +342,26 @@ class ReflStackFunction(torch.autograd.Function):
             gz_rows, grads = eng.backward(ctx.S, g_z, list(g_outs))
         ctx.S = None
         return (None, gz_rows if not eng.nE else None) + tuple(grads)
+
+
+class ReflStackKeepFunction(torch.autograd.Function):
+    """Heads-only stack that also hands its INPUT rows on: (engine, x, *params) -> (x, head outputs ...).  A second consumer of the rows (the
+    smoothness term of the loss reads the quantised z the VQ heads read) then hangs off this node instead of off the rows' producer, its
+    adjoint arrives here, and the backward kernel adds it to d / d rows on the fly (`g_z_rows` of vqn_refl_train_bwd_x3) -- the autograd
+    engine's own accumulation was an [N, 256] framework addition per step (67 M elements at the 262,144-point batch)."""
+
+    @staticmethod
+    def forward(ctx, engine, x, *params):
+        assert not engine.nE
+        with torch.no_grad():
+            S, _, outs = engine.forward(x.detach().float().contiguous(), [p.detach().float() for p in params])
+        ctx.engine, ctx.S = engine, S
+        return (x,) + tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_keep, *g_outs):
+        eng = ctx.engine
+        with torch.no_grad():
+            gz_rows, grads = eng.backward(ctx.S, g_keep, list(g_outs))
+        ctx.S = None
+        return (None, gz_rows) + tuple(grads)
