@@ -49,7 +49,15 @@ __device__ __forceinline__ void pair_terms(const LossArgs& a, long i0, bool has_
   e = e > a.chr_thres ? e : 0.f;
   wexp = a.w_smooth * expf(-a.chr_alpha * e);
   float s = 0.f;
-  for (int d = lane; d < a.D; d += 64) s = fmaf(a.z[i0 * a.D + d], a.z[(i0 + 1) * a.D + d], s);
+  if (a.D == 256) {                      // (all eight loads in flight at once: with a run-time trip count the loop below waits for HBM four times in a row)
+    float za[4], zb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { za[q] = a.z[i0 * 256 + lane + 64 * q]; zb[q] = a.z[(i0 + 1) * 256 + lane + 64 * q]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s = fmaf(za[q], zb[q], s);       // the same order as the loop
+  } else {
+    for (int d = lane; d < a.D; d += 64) s = fmaf(a.z[i0 * a.D + d], a.z[(i0 + 1) * a.D + d], s);
+  }
   dot = wave_sum(s);
 }
 
@@ -104,6 +112,13 @@ __global__ __launch_bounds__(256) void decomp_loss_bwd_kernel(const LossArgs a, 
     if (g_z != nullptr) {
       // d (wexp (1 - <za, zb>)) / d za = -wexp zb, and the term sits in BOTH rows of the pair
       const float coef = has_b ? -wexp * (go[i0 * 5 + 3] + go[(i0 + 1) * 5 + 3]) : 0.f;
+      if (a.D == 256 && has_b) {
+        float za[4], zb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { za[q] = a.z[i0 * 256 + lane + 64 * q]; zb[q] = a.z[(i0 + 1) * 256 + lane + 64 * q]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { g_z[i0 * 256 + lane + 64 * q] = coef * zb[q]; g_z[(i0 + 1) * 256 + lane + 64 * q] = coef * za[q]; }
+      } else
       for (int d = lane; d < a.D; d += 64) {
         const float za = a.z[i0 * a.D + d], zb = has_b ? a.z[(i0 + 1) * a.D + d] : 0.f;
         g_z[i0 * a.D + d] = coef * zb;
