@@ -12,6 +12,11 @@ one flat-bucket RCCL all-reduce of the gradients per step); `value` is then trai
 multi-rank run also times that step and the reflectance (VQ) training step -- gradient bucket + codebook-statistics
 all-reduce -- after the timed render region and reports them under "extra.dp_train" (all-reduce time per step included).
 
+The stdout line is short (< 8 KB: numbers and identifiers only, `compact_line`); the full report -- notes, sample descriptions,
+timing windows, per-kernel tables -- is the sidecar gpurun_out/bench_detail.json (`detail` on the line names it; $VQN_BENCH_DETAIL).
+`python bench.py --gpus N` without WORLD_SIZE starts its N ranks itself as a child `python -m torch.distributed.run` (before any
+GPU call) and exits with that child's code; if the data-parallel legs hang, every rank exits 3 after rank 0 printed the render line.
+
 Extra objects in the JSON line:
   roofline     -- dominant kernel (vqn_neus_fine_points): algorithmic FLOPs per launch / its average
                   launch duration measured with HIP events on the launch stream, vs the dense f32 MFMA peak
@@ -646,6 +651,7 @@ def _max_over_ranks(x, dev, world, backend):
     return float(t.item())
 
 
+WATCHDOG_EXIT = 3          # exit status of every rank when the data-parallel legs hang (bench.py's watchdog)
 PRIME_LAUNCHES = 4600      # Round 3 primed the training legs past a one-off ~100 ms stall around a process's 4,100th clocked launch.  Its cause
                            # (round 4, scripts/debug/launch_stall.py): not launches -- 12,000 plain launches of either path show no stall --
                            # but live HIP EVENTS: the runtime extends its event pool with a stall of tens of ms (37 ms at the 2,400th live
@@ -951,6 +957,177 @@ def live_traffic(rays, timeout_s=170):
         '(DESIGN.md, round 3): the stream is not what bounds the kernel')
 
 
+# ---- the ONE stdout line (driver contract) and its sidecar ----------------------------------------------------------------------------
+# The line carries numbers and short identifiers only and stays under LINE_LIMIT bytes (round 4's 22 KB line was not captured by the
+# driver); every note, sample description, window list and per-kernel table goes to the sidecar file `bench_detail.json`.
+LINE_LIMIT = 8192
+_PROSE_KEYS = frozenset(('note', 'traffic_note', 'sample', 'what', 'frac_note', 'peak_note', 'arithmetic', 'traceback', 'calls', 'kernel',
+                         'flop_per_launch', 'macs_per_point'))
+_TABLE_KEYS = frozenset(('kernel_ms_per_step', 'kernel_ms_per_view', 'kernel_roofline', 'kernel_launches_per_call', 'windows_ms_per_step',
+                         'psnr_sample', 'wider', 'hbm', 'valu'))
+# constants of a leg that the sidecar (and bench.py itself) state: not repeated on the line's `extra`
+_EXTRA_CONST_KEYS = frozenset(('peak', 'unit', 'bound', 'flop_per_point', 'rows', 'D', 'points', 'batch_points', 'batch_rays', 'batch_rays_per_rank',
+                               'batch_points_per_rank', 'surface_points', 'secondary_rays', 'mflop_per_ray', 'mflop_per_secondary_ray',
+                               'issued_tflops', 'issued_f16_tflops', 'issued_bf16_tflops', 'frac_of_f32_mfma_peak_equiv'))
+# legs of `extra` in the order they are given up if the line is still too long (least important first)
+_DROP_ORDER = ('geo_train_wgrad_f32', 'decomp_render_f16s', 'geo_render_f16s', 'vq_ema_stats', 'vq_quantize_rows_k64', 'decomp_relight16',
+               'compute_vis', 'geo_render_s64', 'decomp_render_x3', 'geo_render_x3', 'decomp_render_k64', 'decomp_train_256k', 'decomp_render',
+               'vq_assign', 'vq_assign_k64', 'decomp_train', 'geo_train', 'decomp_train_graph', 'geo_train_graph', 'dp_train')
+
+
+def _sig(x, n=5):
+    """floats to n significant digits (the line is a report, not a checkpoint)"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float('inf'), float('-inf')):
+        return None
+    return float(f'{x:.{n}g}')
+
+
+def _compact(obj, depth=0, max_str=48, drop=frozenset()):
+    """numeric / boolean leaves and short identifier strings of a report dict; prose, tables and lists are left to the sidecar"""
+    if isinstance(obj, dict):
+        out = {}
+        for k, v in obj.items():
+            if k in _PROSE_KEYS or k in _TABLE_KEYS or k in drop:
+                continue
+            if k == 'error' and isinstance(v, str):
+                out[k] = v[:96]
+                continue
+            c = _compact(v, depth + 1, max_str, drop)
+            if c is not None and c != {}:
+                out[k] = c
+        return out
+    if isinstance(obj, (list, tuple)):
+        return None
+    if isinstance(obj, str):
+        return obj if len(obj) <= max_str else None
+    if isinstance(obj, (bool, int)) or obj is None:
+        return obj
+    if isinstance(obj, float):
+        return _sig(obj)
+    try:
+        return _sig(float(obj))
+    except Exception:                                           # noqa: BLE001
+        return None
+
+
+def _first_sentence(s, limit=160):
+    """a string cut at a word boundary to at most `limit` characters"""
+    s = ' '.join(str(s).split())
+    return s if len(s) <= limit else s[:limit].rsplit(' ', 1)[0]
+
+
+def compact_line(result, limit=LINE_LIMIT, detail_path=None):
+    """The stdout line of a full result dict: contract keys + `roofline` + `cpu_baseline` verbatim in meaning (numbers rounded to 5
+    significant digits, strings cut to identifiers), `extra` reduced to its numeric leaves; never longer than `limit` bytes -- legs of
+    `extra` are dropped (listed under `extra_dropped`) before anything of the headline is."""
+    line = {}
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data'):
+        if k in result:
+            v = result[k]
+            line[k] = _first_sentence(v, 120) if isinstance(v, str) else (_sig(v, 7) if isinstance(v, float) else v)
+    cfg = result.get('config', {})
+    line['config'] = {k: (_first_sentence(v, 200) if isinstance(v, str) else v) for k, v in cfg.items() if not isinstance(v, (dict, list))}
+    rf = result.get('roofline')
+    if rf is not None:
+        line['roofline'] = {k: (_first_sentence(rf[k], 64) if isinstance(rf[k], str) else _sig(rf[k], 6) if isinstance(rf[k], float) else rf[k])
+                            for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms', 'whole_step_frac',
+                                      'frac_of_bf16_mfma_peak_at_6_mfma_per_product') if k in rf}
+        line['roofline'].setdefault('traffic', None)
+    cb = result.get('cpu_baseline')
+    if cb is not None:
+        line['cpu_baseline'] = {k: (_first_sentence(cb[k], 120) if isinstance(cb[k], str) else _sig(cb[k], 6) if isinstance(cb[k], float) else cb[k])
+                                for k in ('value', 'unit', 'cores', 'kind', 'cpu_model', 'sample') if k in cb}
+    for k in ('psnr_vs_oracle_db', 'speedup_vs_cpu', 'psnr_f16s_vs_oracle_db', 'psnr_x3_vs_oracle_db'):
+        if k in result:
+            line[k] = _sig(result[k], 6)
+    for k in ('all_reduce', 'last_train_backend', 'error', 'exit_code'):
+        if k in result:
+            line[k] = _compact(result[k])
+    if 'kernel_ms_per_step' in result:
+        line['kernel_ms_per_step'] = {k: _sig(v, 4) for k, v in result['kernel_ms_per_step'].items()}
+    if 'cpu_baseline_decomp' in result:
+        line['cpu_baseline_decomp'] = _compact(result['cpu_baseline_decomp'])
+    if detail_path:
+        line['detail'] = detail_path
+    extra = _compact(result.get('extra', {}), drop=_EXTRA_CONST_KEYS) or {}
+    if extra:
+        line['extra'] = extra
+    dropped = []
+    # (unknown legs go first: the ranked ones are the ones somebody asked to see)
+    order = [k for k in extra if k not in _DROP_ORDER] + [k for k in _DROP_ORDER if k in extra]
+    while len(json.dumps(line, separators=(',', ':'))) > limit and order:
+        k = order.pop(0)
+        extra.pop(k, None)
+        dropped.append(k)
+        line['extra_dropped'] = dropped
+    if not extra:
+        line.pop('extra', None)
+    for k in ('cpu_baseline_decomp', 'kernel_ms_per_step', 'extra', 'extra_dropped'):
+        if len(json.dumps(line, separators=(',', ':'))) <= limit:
+            break
+        line.pop(k, None)
+    text = json.dumps(line, separators=(',', ':'))
+    assert len(text) <= limit, f'bench line is {len(text)} bytes (limit {limit})'
+    json.loads(text)
+    return text
+
+
+def detail_file():
+    """where the sidecar goes: $VQN_BENCH_DETAIL, else gpurun_out/bench_detail.json under the repo (gpurun brings that directory back)"""
+    p = os.environ.get('VQN_BENCH_DETAIL')
+    if p:
+        return p
+    d = os.path.join(ROOT, 'gpurun_out')
+    try:
+        os.makedirs(d, exist_ok=True)
+        return os.path.join(d, 'bench_detail.json')
+    except OSError:
+        return os.path.join('/tmp', 'bench_detail.json')
+
+
+def emit(result):
+    """sidecar first (full result: prose, windows, kernel tables), then the ONE short stdout line"""
+    path = detail_file()
+    rel = None
+    try:
+        with open(path, 'w') as f:
+            json.dump(result, f, indent=1, default=lambda o: repr(o)[:200])
+        rel = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except OSError as e:
+        _log(f'could not write the detail sidecar {path}: {e!r}')
+    print(compact_line(result, detail_path=rel), flush=True)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks OURSELVES, as a child
+    `python -m torch.distributed.run` of this very command (the reference splits its views the same way, one process per share:
+    gen_geo.py:141-146, trainvali.py:436-447).  Nothing in this process has touched the GPU at this point (and nothing will: it only
+    relays rank 0's line and exits with the child's code -- never an exec)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env['MASTER_ADDR'] = '127.0.0.1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    _log(f'--gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks as a child torch.distributed.run (port {port})')
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    for ln in child.stdout:                                      # rank 0's line (and anything else the ranks print) straight through
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    rc = child.wait()
+    if rc != 0:
+        _log(f'child torch.distributed.run exited with {rc}')
+    sys.exit(rc)
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -966,6 +1143,8 @@ def main():
     ap.add_argument('--no-traffic', action='store_true', help='do not measure roofline.traffic with child rocprofv3 --pmc passes')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(args)                                # (before any GPU call; exits with the child's code)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -1042,10 +1221,13 @@ def main():
         def watchdog():
             if not done.wait(limit):
                 if rank == 0 and partial_line is not None:
-                    partial_line.setdefault('extra', {})['dp_train'] = {'error': f'the data-parallel training legs did not return within {limit:.0f} s '
-                                                                                 '(the render line above them is complete)'}
-                    print(json.dumps(partial_line), flush=True)
-                os._exit(0)
+                    partial_line.setdefault('extra', {})['dp_train'] = {'error': f'the data-parallel training legs did not return within {limit:.0f} s',
+                                                                        'exit_code': WATCHDOG_EXIT}
+                    partial_line['exit_code'] = WATCHDOG_EXIT
+                    emit(partial_line)
+                # a rank stuck in a collective has touched the GPU and cannot be unwound: every rank leaves NON-ZERO (the launcher and
+                # the driver must see the hang), rank 0 after printing the complete render line
+                os._exit(WATCHDOG_EXIT)
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             return dp_train_leg(dev, rank, world, backend)
@@ -1211,7 +1393,7 @@ def main():
                 result['cpu_baseline_decomp'] = {'error': repr(e)[:400]}
     if extra:
         result['extra'] = extra
-    print(json.dumps(result))
+    emit(result)
     if world > 1:
         dist.destroy_process_group()
 
@@ -1272,7 +1454,7 @@ def main_train(args, dev, rank, world, backend):
     }
     if dec is not None:
         result['extra'] = {'decomp_train_dp': dec}
-    print(json.dumps(result))
+    emit(result)
     if world > 1:
         dist.destroy_process_group()
 

@@ -165,15 +165,17 @@ def vq_distances(x, C):
     return (x * x).sum(1, keepdim=True) - 2.0 * (x @ C) + (C * C).sum(0, keepdim=True)
 
 
-def vq_ema_call(x, C, ema_cs, ema_dw, is_training, thres=None, roll=None, commitment_cost=0.1, eps=1e-5):
-    """vq_layers.py:257-349.  `roll` is the explicit stand-in for tf.random.uniform((1,K)) (:287)."""
+def vq_ema_call(x, C, ema_cs, ema_dw, is_training, thres=None, roll=None, commitment_cost=0.1, eps=1e-5, idx=None):
+    """vq_layers.py:257-349.  `roll` is the explicit stand-in for tf.random.uniform((1,K)) (:287).  `idx` (tests only): nearest-code
+    indices to use instead of this function's own argmin -- a test whose rows hold a rounding-level tie between two codes hands over the
+    strict-order indices (checked bit for bit elsewhere) so that everything downstream of the argmin is still compared."""
     K = C.shape[1]
     dist = vq_distances(x, C)
     if thres is not None:
         mask_value = dist.max()
         sel = (roll >= thres).to(dist.dtype).reshape(1, K)
         dist = dist * sel + mask_value * (1.0 - sel)
-    idx = torch.argmax(-dist, 1)
+    idx = torch.argmax(-dist, 1) if idx is None else idx
     enc = torch.nn.functional.one_hot(idx, K).to(x.dtype)
     q = C.t()[idx]
     e_latent = ((q.detach() - x) ** 2).mean()
@@ -262,11 +264,13 @@ def render_integrate(brdf, l, n, lareas, light, lvis=None, gamma=None):
 
 def linear2srgb(x):
     x = x.clamp(0.0, 1.0)
-    return torch.where(x <= 0.0031308, x * 12.92, 1.055 * torch.pow(x, 1 / 2.4) - 0.055)
+    return torch.where(x <= 0.0031308, x * 12.92, 1.055 * torch.pow(x, 1 / 2.4) - (1.055 - 1))      # img.py:155-163
 
 
 def srgb2linear(x):
-    return torch.where(x <= 0.04045, x / 12.92, torch.pow((x + 0.055) / 1.055, 2.4))
+    # img.py:181 adds the coefficient BEFORE taking 1 off -- ((x + 1.055) - 1) / 1.055, each step rounded in the input's precision --
+    # not (x + 0.055): kept, since tests/golden/srgb.npz (outputs of the reference's numpy branch) pins this to the last place
+    return torch.where(x <= 0.04045, x / 12.92, torch.pow((x + 1.055 - 1) / 1.055, 2.4))
 
 
 def rgb2chromaticity(rgb):

@@ -19,6 +19,9 @@ from tests.gpu_util import launches
 from tests.test_oracle_geo import assert_render_matches
 
 pytestmark = pytest.mark.gpu
+
+# relative bound of the gradient goldens (largest |difference| over the tensor's largest |entry|); see profiles/r05_observed_errors.json
+GRAD_BOUND = 5e-3
 HITS_VARIANCE = 0.5
 
 
@@ -156,15 +159,17 @@ def test_hits_training_grads_vs_reference(hits, wgrad, engine):
     assert rec.ran('vqn_neus_train_bwd_x3') == (engine == 'x3') and rec.ran('vqn_tile_program:prog_sbwd') == (engine == 'prog')
     assert rec.ran('vqn_neus_train_fwd_x3') == (engine == 'x3') and rec.ran('vqn_tile_program:prog_fwd') == (engine == 'prog')
     np.testing.assert_allclose(loss.item(), float(g['bwd_loss']), rtol=2e-4)
-    worst = 0.0
+    worst, worst_at = 0.0, None
     for name, m in (('sdf', hits['sdf']), ('col', hits['col']), ('var', hits['var'])):
         for k, p in m.named_parameters():
             ref = g[f'bwd_{name}.{k}']
             scale = max(np.abs(ref).max(), 1e-6)
             err = np.abs(_np(p.grad) - ref).max() / scale
-            worst = max(worst, err)
-            assert err <= 5e-3, (name, k, err)
-    print(f'hits: worst relative gradient error vs the reference {worst:.2e}')
+            if err > worst:
+                worst, worst_at = err, f'{name}.{k}'
+            assert err <= GRAD_BOUND, (name, k, err)
+    from tests.gpu_util import record_observed
+    record_observed('hits_training_grads_vs_reference', f'{engine}/{wgrad}/{worst_at}', worst, GRAD_BOUND)
     for m in (hits['sdf'], hits['col'], hits['var']):
         m.zero_grad()
 

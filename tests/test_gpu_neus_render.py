@@ -12,6 +12,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+# relative bound of the gradient goldens (largest |difference| over the tensor's largest |entry|); see profiles/r05_observed_errors.json
+GRAD_BOUND = 5e-3
+
 CASES = [('full', 16), ('small', 64)]
 
 
@@ -177,12 +180,17 @@ def test_training_path_grads_vs_reference(case, wgrad, engine):
     assert ren.last_train_backend == 'hip' and (rec.ran('vqn_tile_program:prog_fwd') or rec.ran('vqn_neus_train_fwd')) and rec.ran('vqn_wgrad_partials')
     assert rec.ran('vqn_wgrad_partials_x3') == (wgrad == 'bf16x3')
     np.testing.assert_allclose(loss.item(), float(g['bwd_loss']), rtol=2e-4)
+    worst, worst_at = 0.0, None
     for name, m in (('sdf', case['sdf']), ('col', case['col']), ('var', case['var'])):
         for k, p in m.named_parameters():
             ref = g[f'bwd_{name}.{k}']
             scale = max(np.abs(ref).max(), 1e-6)
             err = np.abs(_np(p.grad) - ref).max() / scale
-            assert err <= 5e-3, (name, k, err)
+            if err > worst:
+                worst, worst_at = err, f'{name}.{k}'
+            assert err <= GRAD_BOUND, (name, k, err)
+    from tests.gpu_util import record_observed
+    record_observed('render_core_grads_vs_reference', f"{case['name']}/{engine}/{wgrad}/{worst_at}", worst, GRAD_BOUND)
     for m in (case['sdf'], case['col'], case['var']):
         m.zero_grad()
 

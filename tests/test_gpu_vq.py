@@ -3,6 +3,8 @@
 Bar: indices and distances BIT-EXACT against oracle/vq_strict.c (same fixed fmaf order), indices
 identical to the fp64 statement wherever the fp64 top-2 gap exceeds 1e-5; EMA sums within 1e-5
 relative of the correctly-rounded (double-accumulated) sums."""
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -157,13 +159,19 @@ def test_vector_quantizer_ema_module_matches_oracle_over_steps():
         thres = None if step == 0 else 0.2
         xin = torch.tensor(x).cuda().requires_grad_(True)
         out = vq(xin, C_dev, is_training=True, thres=thres, roll=roll)
-        ref = od.vq_ema_call(torch.tensor(x), C_ref, ecs, edw, True, thres=None if thres is None else torch.tensor(thres), roll=roll)
+        ecs0, edw0 = copy.deepcopy(ecs), copy.deepcopy(edw)
+        th = None if thres is None else torch.tensor(thres)
+        ref = od.vq_ema_call(torch.tensor(x), C_ref, ecs, edw, True, thres=th, roll=roll)
         same = out['encoding_indices'].cpu() == ref['encoding_indices']
         assert same.float().mean() > 0.999                           # numpy-BLAS order vs strict order: near ties only
-        if bool(same.all()):
-            np.testing.assert_allclose(out['update'].cpu().numpy(), ref['update'].numpy(), rtol=2e-4, atol=1e-6)
-            np.testing.assert_allclose(out['loss'].item(), ref['loss'].item(), rtol=1e-5)
-            np.testing.assert_allclose(out['perplexity'].item(), ref['perplexity'].item(), rtol=1e-5)
+        if not bool(same.all()):
+            # a rounding-level tie between two codes on some row: restate the oracle step on the strict-order indices (the device's, bit-
+            # checked against oracle/vq_strict.c above) from the saved EMA state, so that update / loss / perplexity are compared on EVERY run
+            ecs, edw = ecs0, edw0
+            ref = od.vq_ema_call(torch.tensor(x), C_ref, ecs, edw, True, thres=th, roll=roll, idx=out['encoding_indices'].cpu().reshape(-1))
+        np.testing.assert_allclose(out['update'].cpu().numpy(), ref['update'].numpy(), rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(out['loss'].item(), ref['loss'].item(), rtol=1e-5)
+        np.testing.assert_allclose(out['perplexity'].item(), ref['perplexity'].item(), rtol=1e-5)
         np.testing.assert_allclose(out['distances'].cpu().numpy(), ref['distances'].numpy(), atol=3e-6)
         # straight-through: d quantize / d inputs == identity ; commitment grad = 2 beta (x - q) / numel
         (out['quantize'].sum() + out['loss']).backward()

@@ -870,9 +870,11 @@ def refl_train_bwd_x3(desc, wbuf_pieces, wbuf_f32, P, g_out, head_out, g_z_rows,
     need = int(L.vqn_refl_train_bwd_x3_scratch_bytes(dp))
     if need <= 0:
         raise VqnError('vqn_refl_train_bwd_x3_scratch_bytes: invalid descriptor')
-    key = (str(dev), torch.cuda.current_stream().cuda_stream, 'refl_bwd')
+    # one buffer per (device, stream, size), never replaced: a captured training step (Trainer(graph=True)) holds this pointer for as long
+    # as its graph is replayed, so a later, larger request on the same stream must not free it
+    key = (str(dev), torch.cuda.current_stream().cuda_stream, 'refl_bwd', need)
     buf = _scratch.get(key)
-    if buf is None or buf.numel() < need:
+    if buf is None:
         buf = torch.empty((need,), dtype=torch.uint8, device=dev)
         _scratch[key] = buf
     arr = lambda ts: (ctypes.c_void_p * max(1, len(ts)))(*[t.data_ptr() for t in ts])

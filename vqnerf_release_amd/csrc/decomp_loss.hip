@@ -22,7 +22,8 @@ struct LossArgs {
 };
 
 __device__ __forceinline__ float srgb2linear(float x) {
-  return x <= 0.04045f ? x / 12.92f : powf((x + 0.055f) / 1.055f, 2.4f);
+  // (the reference's operation order, util/img.py:181: the coefficient is added before 1 is taken off, each step rounded to f32)
+  return x <= 0.04045f ? x / 12.92f : powf(((x + 1.055f) - 1.0f) / 1.055f, 2.4f);
 }
 
 __device__ __forceinline__ void chroma(const float v[3], float c[3], float& norm) {

@@ -457,7 +457,7 @@ class BrdfModel(ShapeModel):
         stack is outside what the kernels run (then the interpreted programs / torch statements take it)."""
         if not (self._train_hip(x) and not self._fused(x) and os.environ.get('VQN_REFL_TRAIN', self.REFL_TRAIN_DEFAULT) == 'x3'):
             return None
-        key = ('stack', with_encoder) + tuple(names)
+        key = ('stack', with_encoder, str(x.device)) + tuple(names)
         if key not in self._engines:
             from vqnerf_release_amd.decomp.refl_train import ReflStackEngine
             enc = [self.net['fine_enc'], self.net['bottleneck']] if with_encoder else None
@@ -468,13 +468,15 @@ class BrdfModel(ShapeModel):
         eng = self._engines[key]
         if eng is None or (not with_encoder and x.shape[1] != self.z_dim):
             return None
+        if with_encoder and x.requires_grad:     # ReflStackFunction has no adjoint for the points: the interpreted programs / torch take it
+            return None
         return eng if any(p.requires_grad for p in eng.params()) or x.requires_grad else None
 
     # ---- matrix_mode = 'x3' (round 4, opt-in like 'f16s'): inference on the exact-split stack kernel of the trainers
     # (csrc/refl_train_x3.hip with nothing kept for a backward) -- f32-level products (six bf16 MFMAs each), no operand-range caveat
     def _x3_infer(self, names, x, with_encoder):
         """(z rows | None, head outputs) on the exact-split engine, or None when the stack is outside its shape (then the f32 chain)."""
-        key = ('stack', with_encoder) + tuple(names)
+        key = ('stack', with_encoder, str(x.device)) + tuple(names)
         if key not in self._engines:
             from vqnerf_release_amd.decomp.refl_train import ReflStackEngine
             enc = [self.net['fine_enc'], self.net['bottleneck']] if with_encoder else None
@@ -484,6 +486,8 @@ class BrdfModel(ShapeModel):
             self._engines[key] = ReflStackEngine(enc, emb.n_freqs if with_encoder else 0, heads, self.z_dim, x.device) if ok else None
         eng = self._engines[key]
         if eng is None or (not with_encoder and x.shape[1] != self.z_dim):
+            return None
+        if with_encoder and x.requires_grad:     # ReflStackFunction has no adjoint for the points: the interpreted programs / torch take it
             return None
         cache = self._packs.setdefault(('x3',) + key, _PackCache())
         packs = cache.get(eng.params(), lambda: eng.build_packs(eng.params()))

@@ -56,6 +56,9 @@ class ReflStackEngine:
                 return False
             n, skips = 0, 0
             for ni, net in enumerate(enc_nets):
+                # a skip-concat AFTER a net's last layer would hand [y ; x] to the next net's first layer: not a shape the kernel runs
+                if net.skip_at is not None and any(int(si) >= len(net.widths) - 1 for si in net.skip_at):
+                    return False
                 for li, (w, a) in enumerate(zip(net.widths, net.act)):
                     if w > 256 or a not in ACTS:
                         return False

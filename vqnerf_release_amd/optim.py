@@ -35,6 +35,11 @@ class HipAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, maximize=maximize,
                          capturable=bool(capturable), fused=True if (capturable and on_dev) else None)
         self._ctor_flags = (bool(capturable), True if (capturable and on_dev) else None)
+        # the epsilon placement travels with the checkpoint (param_groups are part of state_dict): an optimiser built with the other mode
+        # must not silently train on a different update (31.6x effective epsilon at step 1)
+        self.defaults['eps_mode'] = eps_mode
+        for g in self.param_groups:
+            g['eps_mode'] = eps_mode
 
     # ------------------------------------------------------------------ checkpoints
     def load_state_dict(self, state_dict):
@@ -42,7 +47,13 @@ class HipAdam(torch.optim.Adam):
         capturable=False and host step counters.  Keep THIS optimiser's execution mode: lr value copied into the existing device
         scalar, capturable / fused as constructed, every state['step'] a float32 tensor on its parameter's device."""
         lr_before = [g['lr'] for g in self.param_groups]
+        saved_modes = {g.get('eps_mode', self.eps_mode) for g in state_dict.get('param_groups', [])}     # (absent: a plain torch.optim.Adam state)
+        if saved_modes - {self.eps_mode}:
+            raise ValueError(f"checkpoint was written by an Adam with eps_mode={sorted(saved_modes)}, this optimiser was built with "
+                             f"eps_mode='{self.eps_mode}': build it with the same mode (torch: eps inside the debiased root; keras: outside)")
         super().load_state_dict(state_dict)
+        for g in self.param_groups:
+            g['eps_mode'] = self.eps_mode
         capturable, fused = self._ctor_flags
         for g, lr0 in zip(self.param_groups, lr_before):
             g['capturable'], g['fused'] = capturable, fused
