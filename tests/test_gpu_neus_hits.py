@@ -20,8 +20,10 @@ from tests.test_oracle_geo import assert_render_matches
 
 pytestmark = pytest.mark.gpu
 
-# relative bound of the gradient goldens (largest |difference| over the tensor's largest |entry|); see profiles/r05_observed_errors.json
-GRAD_BOUND = 5e-3
+# relative bound of the gradient goldens (largest |difference| over the tensor's largest |entry|) = 2x the largest value observed over the
+# three engines and both contractions on this hit-heavy fixture (profiles/r05_observed_errors.json: 4.45e-4 under the f32-input kernels,
+# 4.11e-4 under x3); rounds 1-4 asserted 5e-3
+GRAD_BOUND = 9e-4
 HITS_VARIANCE = 0.5
 
 
@@ -123,7 +125,7 @@ def test_hits_render_variants_vs_reference(hits, variant, matrix_mode):
 @pytest.fixture(params=['f32', 'bf16x3'])
 def wgrad(request):
     """Both weight-gradient contractions against the reference's gradients: the f32 MFMA one (default) and the exact-split
-    bf16x3 one (opt-in, `train_programs.wgrad_mode('bf16x3')`) -- same 5e-3 bound (VERDICT r02 weak #3)."""
+    bf16x3 one (opt-in, `train_programs.wgrad_mode('bf16x3')`) -- same bound (VERDICT r02 weak #3)."""
     from vqnerf_release_amd.geo import train_programs as tp
     old = tp.wgrad_mode()
     tp.wgrad_mode(request.param)
@@ -134,7 +136,7 @@ def wgrad(request):
 @pytest.fixture(params=['x3', 'fused', 'prog'])
 def engine(request, monkeypatch):
     """The three forward / backward engines of the training step against the reference's gradients: the exact-split
-    kernels (default), the f32-input MFMA two-image kernels, the interpreted tile programs -- same 5e-3 bound."""
+    kernels (default), the f32-input MFMA two-image kernels, the interpreted tile programs -- same bound."""
     monkeypatch.setenv('VQN_TRAIN_FWD', request.param)
     monkeypatch.setenv('VQN_TRAIN_BWD', request.param)
     return request.param
@@ -142,7 +144,7 @@ def engine(request, monkeypatch):
 
 def test_hits_training_grads_vs_reference(hits, wgrad, engine):
     """Gradients of L1(colour) + 0.1 * eikonal wrt every parameter, HIP tile-program engine vs the REAL reference's autograd,
-    on rays that hit the surface: <= 5e-3 of each tensor's largest entry (the oracle itself holds 5e-3 against the same fixture)."""
+    on rays that hit the surface: <= GRAD_BOUND of each tensor's largest entry (the oracle itself holds 5e-3 against the same fixture)."""
     g, ren = hits['g'], hits['ren']
     r = hits['rays']
     for m in (hits['sdf'], hits['col'], hits['var']):

@@ -12,8 +12,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-# relative bound of the gradient goldens (largest |difference| over the tensor's largest |entry|); see profiles/r05_observed_errors.json
-GRAD_BOUND = 5e-3
+# relative bound of the gradient goldens (largest |difference| over the tensor's largest |entry|) = 2x the largest value observed over the
+# three engines and both contractions (profiles/r05_observed_errors.json: full-size nets 1.80e-4 under x3, 8.9e-5 under the f32-input
+# kernels; small nets 2.2e-6); rounds 1-4 asserted 5e-3
+GRAD_BOUNDS = {'full': 3.6e-4, 'small': 5e-6}
 
 CASES = [('full', 16), ('small', 64)]
 
@@ -147,7 +149,7 @@ def test_network_methods_hip_vs_autograd_path(case):
 @pytest.fixture(params=['f32', 'bf16x3'])
 def wgrad(request):
     """Both weight-gradient contractions against the reference's gradients: the f32 MFMA one (default) and the exact-split
-    bf16x3 one (opt-in, `train_programs.wgrad_mode('bf16x3')`) -- same 5e-3 bound (VERDICT r02 weak #3)."""
+    bf16x3 one (opt-in, `train_programs.wgrad_mode('bf16x3')`) -- same bound (VERDICT r02 weak #3)."""
     from vqnerf_release_amd.geo import train_programs as tp
     old = tp.wgrad_mode()
     tp.wgrad_mode(request.param)
@@ -158,7 +160,7 @@ def wgrad(request):
 @pytest.fixture(params=['x3', 'fused', 'prog'])
 def engine(request, monkeypatch):
     """The three forward / backward engines of the training step against the reference's gradients: the exact-split
-    kernels (default), the f32-input MFMA two-image kernels, the interpreted tile programs -- same 5e-3 bound."""
+    kernels (default), the f32-input MFMA two-image kernels, the interpreted tile programs -- same bound."""
     monkeypatch.setenv('VQN_TRAIN_FWD', request.param)
     monkeypatch.setenv('VQN_TRAIN_BWD', request.param)
     return request.param
@@ -166,7 +168,7 @@ def engine(request, monkeypatch):
 
 def test_training_path_grads_vs_reference(case, wgrad, engine):
     """Training path of the boundary class (tile-program engine + compositing backward kernel): grads of L1(colour) +
-    0.1 * eikonal wrt every parameter against the REAL reference's autograd, <= 5e-3 of each tensor's largest entry."""
+    0.1 * eikonal wrt every parameter against the REAL reference's autograd, <= GRAD_BOUNDS of each tensor's largest entry (2x the observed error)."""
     from tests.gpu_util import launches
     g, ren, B = case['g'], case['ren'], case['B']
     for m in (case['sdf'], case['col'], case['var']):
@@ -188,9 +190,9 @@ def test_training_path_grads_vs_reference(case, wgrad, engine):
             err = np.abs(_np(p.grad) - ref).max() / scale
             if err > worst:
                 worst, worst_at = err, f'{name}.{k}'
-            assert err <= GRAD_BOUND, (name, k, err)
+            assert err <= GRAD_BOUNDS[case['name']], (name, k, err)
     from tests.gpu_util import record_observed
-    record_observed('render_core_grads_vs_reference', f"{case['name']}/{engine}/{wgrad}/{worst_at}", worst, GRAD_BOUND)
+    record_observed('render_core_grads_vs_reference', f"{case['name']}/{engine}/{wgrad}/{worst_at}", worst, GRAD_BOUNDS[case['name']])
     for m in (case['sdf'], case['col'], case['var']):
         m.zero_grad()
 

@@ -2,6 +2,7 @@
 host-side behaviour of optim.HipAdam on CPU parameters (the framework statement it falls back to as a WHOLE, checkpoints of an eager
 Adam loaded into a capturable one: ADVICE r03)."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import optim as oo
@@ -112,7 +113,13 @@ def test_an_eager_adam_checkpoint_loads_into_a_capturable_hip_adam():
     assert float(cap.state[w2]['step']) == 4.0
     # and the other direction: a capturable state into an eager HipAdam keeps host-side execution
     w3 = torch.nn.Parameter(w.detach().clone())
-    plain = HipAdam([w3], lr=1e-3, eps=1e-7, amsgrad=True, capturable=False)
+    plain = HipAdam([w3], lr=1e-3, eps=1e-7, amsgrad=True, eps_mode='keras', capturable=False)
     plain.load_state_dict(cap.state_dict())
     assert plain.param_groups[0]['capturable'] is False and not torch.is_tensor(plain.param_groups[0]['lr'])
     assert float(plain.state[w3]['step']) == 4.0
+    # the epsilon placement travels with the checkpoint: it is in param_groups, and the other mode refuses the state
+    assert cap.state_dict()['param_groups'][0]['eps_mode'] == 'keras' and plain.param_groups[0]['eps_mode'] == 'keras'
+    other = HipAdam([torch.nn.Parameter(w.detach().clone())], lr=1e-3, eps=1e-7, amsgrad=True, eps_mode='torch', capturable=False)
+    with pytest.raises(ValueError, match="eps_mode"):
+        other.load_state_dict(cap.state_dict())
+    other.load_state_dict(sd)                                     # a plain torch.optim.Adam state carries no mode: accepted by either
