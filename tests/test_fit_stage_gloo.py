@@ -77,9 +77,13 @@ def _run(model_name, rank, world, outdir):
             return full
         lo, hi = rank * N_PER_RANK, (rank + 1) * N_PER_RANK                               # pairs stay together: N_PER_RANK is even
         return tuple(t[lo:hi] for t in full)
+    real = train_nfr.outer_sample
     train_nfr.outer_sample = sample
-    model, hist = train_nfr.fit_stage(cfg, outdir, _Views(n_all if world == 1 else N_PER_RANK),
-                                      None, model=model, device='cpu', log=lambda *_: None)
+    try:                                         # (restored: the single-process leg runs inside the test process, other tests follow it)
+        model, hist = train_nfr.fit_stage(cfg, outdir, _Views(n_all if world == 1 else N_PER_RANK),
+                                          None, model=model, device='cpu', log=lambda *_: None)
+    finally:
+        train_nfr.outer_sample = real
     return model, hist
 
 

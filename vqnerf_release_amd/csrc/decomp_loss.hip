@@ -454,6 +454,16 @@ __global__ __launch_bounds__(256) void codebook_prep_kernel(const float* __restr
 // (round 4: the codebook is staged in LDS first when it fits -- every thread walked its two columns through 256 dependent global
 //  loads, 65 us of the captured 2048-point step's 760; same fmaf chain over d, the same value bit for bit)
 constexpr int SIM_LDS_FLOATS = 12288;        // 48 KB: K <= 48 at D = 256
+// (round 5: 33 -> ~8 us at K = 15 -- as long as the encoder + heads forward of the captured 2048-point step.  Two things took the time:
+//  each pair's chain of D dependent fmaf waited for its two LDS operands one step at a time (now 16 steps' operands are read ahead
+//  of the chain -- the chain itself, and so every bit of the result, is unchanged), and thread 0 folded the 256 candidates serially
+//  from LDS (now a tree over the same total order -- smaller distance, then smaller pair index: associative, so the same pair bit for
+//  bit; a NaN distance still beats everything and makes out[0] NaN, but WHICH of several NaN pairs is reported is no longer the
+//  serial fold's last one -- the caller's numerics guard raises on the NaN loss either way).)
+__device__ __forceinline__ bool sim_later_wins(float da, int ia, float db, int ib) {     // candidate b (later in thread order) against a
+  return db < da || (db == da && ib < ia) || !(db == db);
+}
+
 __global__ __launch_bounds__(256) void sim_smooth_fwd_kernel(const float* __restrict__ cb, int D, int K, float w, float* __restrict__ out) {
   __shared__ float best[256];
   __shared__ int bi[256];
@@ -461,7 +471,14 @@ __global__ __launch_bounds__(256) void sim_smooth_fwd_kernel(const float* __rest
   const int t = threadIdx.x;
   const bool staged = D * K <= SIM_LDS_FLOATS;
   if (staged) {
-    for (int e = t; e < D * K; e += 256) cbs[e] = cb[e];
+    const int n = D * K;
+    if ((n & 3) == 0 && (((uintptr_t)cb) & 15) == 0) {
+      const float4* __restrict__ c4 = reinterpret_cast<const float4*>(cb);
+      float4* s4 = reinterpret_cast<float4*>(cbs);
+      for (int e = t; e < (n >> 2); e += 256) s4[e] = c4[e];
+    } else {
+      for (int e = t; e < n; e += 256) cbs[e] = cb[e];
+    }
     __syncthreads();
   }
   const float* __restrict__ src = staged ? cbs : cb;
@@ -472,7 +489,15 @@ __global__ __launch_bounds__(256) void sim_smooth_fwd_kernel(const float* __rest
     if (i >= j) continue;
     float s = 0.f;
     if (staged) {
-      for (int d = 0; d < D; ++d) { const float dl = cbs[d * K + i] - cbs[d * K + j]; s = fmaf(dl, dl, s); }
+      int d = 0;
+      for (; d + 16 <= D; d += 16) {
+        float a[16], b[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { a[u] = cbs[(d + u) * K + i]; b[u] = cbs[(d + u) * K + j]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const float dl = a[u] - b[u]; s = fmaf(dl, dl, s); }
+      }
+      for (; d < D; ++d) { const float dl = cbs[d * K + i] - cbs[d * K + j]; s = fmaf(dl, dl, s); }
     } else {
       for (int d = 0; d < D; ++d) { const float dl = src[(size_t)d * K + i] - src[(size_t)d * K + j]; s = fmaf(dl, dl, s); }
     }
@@ -481,9 +506,17 @@ __global__ __launch_bounds__(256) void sim_smooth_fwd_kernel(const float* __rest
   }
   best[t] = bd; bi[t] = bp;
   __syncthreads();
+  // (threads without a pair hold (inf, 0): the serial fold never took them either -- inf is not smaller, and on an all-inf tie pair 0 stays)
+  for (int half = 128; half > 0; half >>= 1) {
+    if (t < half) {
+      const float da = best[t], db = best[t + half];
+      const int ia = bi[t], ib = bi[t + half];
+      if (sim_later_wins(da, ia, db, ib)) { best[t] = db; bi[t] = ib; }
+    }
+    __syncthreads();
+  }
   if (t == 0) {
-    for (int k = 1; k < 256; ++k)
-      if (best[k] < bd || (best[k] == bd && bi[k] < bp) || !(best[k] == best[k])) { bd = best[k]; bp = bi[k]; }
+    bd = best[0]; bp = bi[0];
     out[0] = w * (-logf(bd));
     out[1] = bd;
     out[2] = (float)(bp / K);

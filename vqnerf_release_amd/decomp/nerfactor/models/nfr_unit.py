@@ -688,7 +688,9 @@ class Model(BrdfModel):
         self._validate_mode(mode)
         id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz, normal, lvis = self._unpack(batch)
         gt = {'rgb': rgb, 'normal': normal, 'alpha': alpha, 'xyz': xyz}
-        mask = fg_rows(alpha)
+        # (`assume_foreground`, set by a capturing Trainer: training batches of outer_sample hold foreground rows only -- no boolean gather,
+        #  no host sync; validation views do have background rows)
+        mask = None if (self.assume_foreground and mode == 'train') else fg_rows(alpha)
         n = alpha.shape[0]
         rayo, rgb_m, xyz_m, normal_m = take_rows(mask, rayo), take_rows(mask, rgb), take_rows(mask, xyz), take_rows(mask, normal)
         lvis_m = self.fg_lvis(lvis, mask, xyz_m)

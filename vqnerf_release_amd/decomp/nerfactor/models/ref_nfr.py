@@ -76,7 +76,7 @@ class Model(BrdfModel):
         self._validate_mode(mode)
         id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz, normal, ref = batch[:10]
         lvis = batch[10] if self.data_type == 'nerf' else None
-        mask = fg_rows(alpha)
+        mask = None if (self.assume_foreground and mode == 'train') else fg_rows(alpha)       # (see nfr_unit.Model.call)
         n = alpha.shape[0]
         rayo, rgb_m, xyz_m, normal_m, ref_m = take_rows(mask, rayo), take_rows(mask, rgb), take_rows(mask, xyz), take_rows(mask, normal), take_rows(mask, ref)
         lvis_m = self.fg_lvis(lvis, mask, xyz_m)

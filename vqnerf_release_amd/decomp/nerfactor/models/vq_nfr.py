@@ -176,7 +176,8 @@ class Model(BrdfModel):
         else:
             z_norm = l2_normalize_rows(z_enc) if on_kernels else mathutil.safe_l2_normalize(z_enc, axis=1)
             vq = self.vq_layer(z_norm, codebook, is_training=(mode == 'train'), thres=th, roll=roll)
-        return vq, vq['quantize'], vq['loss'], vq['encoding_indices'] + 1
+        # (the 1-based code map is an output of the inference modes only: in a training step the int64 addition was one launch nobody read)
+        return vq, vq['quantize'], vq['loss'], (None if mode == 'train' else vq['encoding_indices'] + 1)
 
     fuse_front = True          # inference, K <= 64, no code dropout: encoder -> heads -> VQ step -> VQ heads in ONE launch
 
@@ -300,7 +301,7 @@ class Model(BrdfModel):
         id_, hw, rayo, rayd, rgb, alpha, pred_alpha, xyz, normal, lvis = self._unpack(batch)
         # `assume_foreground`: the caller guarantees alpha > 0 on every row (outer_sample's batches are), so no boolean
         # gather / scatter -- and no host sync -- is needed
-        mask = None if self.assume_foreground else fg_rows(alpha)
+        mask = None if (self.assume_foreground and mode == 'train') else fg_rows(alpha)      # (validation views do have background rows)
         n = alpha.shape[0]
         rayo, rgb_m, xyz_m, normal_m = take_rows(mask, rayo, rgb, xyz, normal)
         lvis_m = self.fg_lvis(lvis, mask, xyz_m)

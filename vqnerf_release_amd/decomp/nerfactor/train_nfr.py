@@ -20,7 +20,9 @@ def make_optimizer(config, params, capturable=False):
     launch (csrc/adam.hip; torch's fused multi-tensor kernel takes 2 x 85 us for these ~1 M parameters, 16 workgroups each); CPU
     parameters (the gloo tests) take the framework statement of the same update."""
     from vqnerf_release_amd.optim import HipAdam
-    lr = config.getfloat('DEFAULT', 'lr')
+    # (the f32 value of the configured rate in BOTH execution modes: the captured step reads it from a device float, the eager one hands the
+    #  kernel a host double -- 5e-3 is not an f32 number, and the two runs would differ in the last place from the first update on)
+    lr = float(torch.tensor(config.getfloat('DEFAULT', 'lr'), dtype=torch.float32))
     params = list(params)
     if capturable:
         lr = torch.tensor(lr, dtype=torch.float32, device=params[0].device)
@@ -58,7 +60,7 @@ class Trainer:
         self.model, self.optimizer, self.clip, self.sched = model, optimizer, clip, sched
         self.bucket = None
         self.graph = bool(graph)
-        self._calls, self._captured, self._static_in, self._static_out = 0, None, None, None
+        self._calls, self._captured, self._static_in, self._static_out, self._captured_key = 0, None, None, None, ()
         if self.graph:
             # (data parallel: the captured step is cut at its two collectives -- VQ statistics, gradient bucket -- into three
             # graphs with the eager all-reduces between them: parallel.SegmentedCapture)
@@ -81,8 +83,15 @@ class Trainer:
         the number of ranks when each rank draws its own rays.  Returns (weighted_loss summed over ranks, to_vis, loss_dict)."""
         self._call_kwargs = call_kwargs
         if self.graph:
-            if roll is not None or call_kwargs:
-                raise ValueError('an explicit `roll` and per-call arguments are host-side: not available under graph=True')
+            if roll is not None:
+                raise ValueError('an explicit `roll` is host-side: not available under graph=True')
+            # per-call arguments (`pretrain`, `bias_weight` of the stage-1 / stage-3 models) are host-side constants of the recorded step:
+            # a call with other values than the captured step's drops that capture and records again (fit_stage: once, when the
+            # pretraining epochs end)
+            key = tuple(sorted((k, v if isinstance(v, (bool, int, float, str, type(None))) else id(v)) for k, v in call_kwargs.items()))
+            if self._captured is not None and key != self._captured_key:
+                self._captured, self._static_in, self._static_out = None, None, None
+            self._captured_key = key
             if thres is not None and not (torch.is_tensor(thres) and thres.is_cuda):
                 raise ValueError('under graph=True the code-dropout thresholds must be a device tensor (they are a graph input)')
             self._calls += 1
@@ -163,6 +172,9 @@ class Trainer:
             # parameter's `.grad` view with a launch of its own (52 of them per step)
             if getattr(self, '_one', None) is None or self._one.device != weighted.device:
                 self._one = torch.ones((), dtype=weighted.dtype, device=weighted.device)        # the root adjoint, made once (not a fill per step)
+            # (round 5, measured and NOT kept: the stacks' contractions forked to a side stream inside the captured step -- 0.538 -> 0.571 ms per
+            #  replay: a HIP graph's cross-stream edges cost more than the ~85 us of contractions they take off the critical path;
+            #  profiles/r05_refl_step.txt)
             grads = torch.autograd.grad(weighted, leaves if leaves is not None else self.bucket.params, grad_outputs=self._one,
                                         allow_unused=True)
             with torch.no_grad():
@@ -356,9 +368,25 @@ def _latest_checkpoint(ckptdir):
     return best
 
 
-def fit(config, outdir, dataset_train, dataset_vali=None, model=None, device='cuda', epochs=None, graph=False, seed=None,
+def graph_default(device, model=None):
+    """`graph=None` of fit() / fit_stage(): the captured step (bit-identical to the eager one, ~6x faster at the reference batch) whenever
+    it is eligible -- a GPU, the HIP training backend, and a single rank; data-parallel runs keep the explicit opt-in documented at
+    fit() (gloo rehearsals: on).  VQN_FIT_GRAPH=0 | 1 overrides."""
+    import os
+    force = os.environ.get('VQN_FIT_GRAPH')
+    if force in ('0', '1'):
+        return force == '1'
+    if torch.device(device).type != 'cuda' or not torch.cuda.is_available():
+        return False
+    if model is not None and getattr(model, 'train_backend', 'hip') != 'hip':
+        return False
+    return True
+
+
+def fit(config, outdir, dataset_train, dataset_vali=None, model=None, device='cuda', epochs=None, graph=None, seed=None,
         log=print):
     """Train the VQ stage for `epochs` (config `epochs`) passes over the training views; returns (model, history).
+    `graph`: None (default) = the captured step whenever it is eligible (`graph_default`), True / False force it.
 
     history: {'loss': [mean step loss per epoch], 'vali': [{'step', 'drop_losses', 'main_vq', 'vis_dirs'} ...]}."""
     import json, os
@@ -405,7 +433,7 @@ def fit(config, outdir, dataset_train, dataset_vali=None, model=None, device='cu
         model.set_codebook(np.zeros((num_embed, model.z_dim), np.float32))      # placeholder: the checkpoint below holds the values
     _ = model.light                                              # lazy variables exist before the optimiser is built
     model.register_trainable()
-    use_graph = bool(graph)                                       # (data parallel: the captured step is cut at its collectives)
+    use_graph = graph_default(device, model) if graph is None else bool(graph)      # (data parallel: the captured step is cut at its collectives)
     if use_graph and parallel.world_size() > 1 and parallel.backend() != 'gloo' and not config.getboolean('DEFAULT', 'dp_graph', fallback=False) \
             and os.environ.get('VQN_DP_GRAPH', '0') in ('', '0'):
         # the graph-segment replay of the DP step has been validated bit-identical to the eager one on two gloo ranks sharing a
@@ -505,7 +533,7 @@ def render_views(model, dataset, outroot, relight_olat=False, relight_probes=Fal
     return writer, n
 
 
-def fit_stage(config, outdir, dataset_train, dataset_vali=None, model=None, device='cuda', epochs=None, seed=None, log=print):
+def fit_stage(config, outdir, dataset_train, dataset_vali=None, model=None, device='cuda', epochs=None, seed=None, log=print, graph=None):
     """Epoch loop of the stage-1 (`nfr_unit`) and stage-3 (`ref_nfr`) models: the shape_unit branch of trainvali.py:201-318.
     One max-colour-difference pair sample and one step per training view and epoch; `pretrain=True` with `bias_weight` for
     the first `pretrain_epochs` epochs; checkpoints every `ckpt_period`; every `vali_period` the summed loss terms
@@ -526,7 +554,13 @@ def fit_stage(config, outdir, dataset_train, dataset_vali=None, model=None, devi
         model.build_nets(device=device, seed=seed).to(device)
     _ = model.light
     model.register_trainable()
-    opt, sched, clip = make_optimizer(config, model.trainable_variables)
+    # `graph`: the step captured once into a HIP graph and replayed (None = whenever eligible; under multi-rank RCCL the same explicit
+    # opt-in as fit())
+    use_graph = graph_default(device, model) if graph is None else bool(graph)
+    if use_graph and parallel.world_size() > 1 and parallel.backend() != 'gloo' and not config.getboolean('DEFAULT', 'dp_graph', fallback=False) \
+            and os.environ.get('VQN_DP_GRAPH', '0') in ('', '0'):
+        use_graph = False
+    opt, sched, clip = make_optimizer(config, model.trainable_variables, capturable=use_graph)
     ckptdir = os.path.join(outdir, 'checkpoints')
     latest, step = _latest_checkpoint(ckptdir), 0
     if latest is not None:
@@ -535,7 +569,7 @@ def fit_stage(config, outdir, dataset_train, dataset_vali=None, model=None, devi
         opt.load_state_dict(state['optimizer'])
         step = int(state['step'])
         log(f'Resumed from step {step}: {latest[1]}')
-    trainer = Trainer(model, opt, clip=clip, sched=sched)
+    trainer = Trainer(model, opt, clip=clip, sched=sched, graph=use_graph)
     epochs = config.getint('DEFAULT', 'epochs') if epochs is None else epochs
     pretrain_epochs = g('pretrain_epochs', int, 0)
     ckpt_period, vali_period = g('ckpt_period', int, 100), g('vali_period', int, 100)

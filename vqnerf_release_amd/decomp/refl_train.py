@@ -39,6 +39,12 @@ def _num_cus(device):
     return _CUS[k]
 
 
+def _tiles_per_block():
+    """point tiles per partial block of the contractions at small batches (VQN_WGRAD_TPB; 1 = one block per tile, rounds 1-4)"""
+    import os
+    return int(os.environ.get('VQN_WGRAD_TPB', '2'))
+
+
 class ReflStackEngine:
     n_split = 256
 
@@ -297,7 +303,7 @@ class ReflStackEngine:
             _C.refl_train_bwd_x3(*args, [g_z] if g_z is not None else [], saved, outs, gz_rows, **d2kw)
         # ---- weight gradients: contractions over the points, straight into the Keras layout [in, out] ----
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        batch = WgradBatch(self.n_split, thin=True)          # (the heads' 1..3-output last layers: vqn_wgrad_thin_batched)
+        batch = WgradBatch(self.n_split, thin=True, tiles_per_block=_tiles_per_block())          # (the heads' 1..3-output last layers: vqn_wgrad_thin_batched)
         grads = []
         for l, Ly in enumerate(self.layers):
             n_in, n_out = Ly['in_y'] + (self.E if Ly['skip'] else 0), Ly['out']
@@ -307,6 +313,11 @@ class ReflStackEngine:
             if Ly['skip']:
                 batch.contract(D[l], S['E'], n_out, self.E, G[Ly['in_y']:], 1, n_out)
             grads += [G, b]
+        self._queue_heads(batch, grads, S, D0, D1, D2, shared, roff, cs, new)
+        batch.flush()
+        return gz_rows, grads
+
+    def _queue_heads(self, batch, grads, S, D0, D1, D2, shared, roff, cs, new):
         z_targets = []
         for k, net in enumerate(self.heads):
             w0, w1, c = net.widths
@@ -322,8 +333,6 @@ class ReflStackEngine:
             grads += [g0, b0, g1, b1, g2, b2]
         if shared:
             batch.contract_thin_rows(D2[0], 0, sum(cs), S['ZT'], self.Z, z_targets)
-        batch.flush()
-        return gz_rows, grads
 
 
 class ReflStackFunction(torch.autograd.Function):

@@ -62,8 +62,12 @@ class WgradBatch:
     each result where it belongs -- a slice of a concatenated matrix, transposed, scaled, two contractions added -- in ONE launch
     (vqn_wgrad_finalize) instead of a reduce + transpose + cat + scale kernel sequence per weight."""
 
-    def __init__(self, n_split, thin=False):
+    def __init__(self, n_split, thin=False, tiles_per_block=1):
         self.n_split = n_split
+        # small batches: at least `tiles_per_block` point tiles per partial block.  The reference batch of the reflectance step is 64 point
+        # tiles; one block per tile made every workgroup of the partial kernels write a whole weight-sized block for two K steps of
+        # matrix work (200 MB of partials per step, as much again read by the finalize launch)
+        self.tiles_per_block = max(1, int(tiles_per_block))
         self.thin = thin          # contractions of at most 8 output rows on the vector-ALU stream kernel (vqn_wgrad_thin_batched)
         self.e, self.keep, self.p, self.nt, self.ws_floats, self.pt = [], [], [], None, 0, []
 
@@ -71,6 +75,7 @@ class WgradBatch:
         """queue one partial-block problem; -> (workspace offset, row-sum workspace offset | None) in floats"""
         if self.nt is None:
             self.nt = nt
+            self.n_split = max(1, min(self.n_split, nt // self.tiles_per_block))
         assert nt == self.nt, 'one WgradBatch = contractions over the same points'
         n_blocks = min(self.n_split, nt)
         ws, self.ws_floats = self.ws_floats, self.ws_floats + n_blocks * an * 32 * bn * 32
@@ -116,6 +121,7 @@ class WgradBatch:
         assert at == 1 and a_rows <= 8
         if self.nt is None:
             self.nt = nt
+            self.n_split = max(1, min(self.n_split, nt // self.tiles_per_block))
         assert nt == self.nt, 'one WgradBatch = contractions over the same points'
         n_blocks = min(self.n_split, nt)
         b_nt_all = (b_cols + 31) // 32
