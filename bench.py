@@ -531,6 +531,53 @@ def secondary_measurements(dev, sdf, col, var, ren, m_sdf, m_col):
                                          'replayed from one captured HIP graph; one 32-point image per workgroup and one workgroup row per head '
                                          '(64 point tiles x 3 heads on 256 CUs)'}
 
+    _log('leg: stage-3 (ref_nfr) training step')
+    # ---- stage 3 (ref_nfr): frozen stage-2 encoder + specular head on the inference kernels, rgb_enc + the two 512-wide heads on the exact-split
+    # training kernels with a second head input (round 5; the interpreted tile programs before: VQN_REFL_TRAIN=prog) ----
+    try:
+        ini3 = dict(DECOMP_INI)
+        ini3['model'] = 'ref_nfr'
+        m3 = get_model_class('ref_nfr')(config_from_dict(ini3))
+        m3.build_nets(device=dev, seed=0).to(dev)
+        m3.set_light(rng.uniform(0, 1, (16, 32, 3)).astype(np.float32))
+        for name in ('fine_enc', 'bottleneck', 'spec_out'):                # what load_stage2 does to the stage-2 parts
+            for prm in m3.net[name].parameters():
+                prm.requires_grad_(False)
+        m3.register_trainable()
+        _ = m3.light
+
+        def ref_points(n):
+            b = points(n)
+            return b[:9] + (torch.rand(n, 3, device=dev),) + b[9:]
+        res3 = {}
+        for label, env in (('x3', {}), ('prog', {'VQN_REFL_TRAIN': 'prog'})):
+            old_env = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                opt_s3, _, clip_s3 = train_nfr.make_optimizer(config_from_dict(ini3), m3.trainable_variables)
+                tr3 = train_nfr.Trainer(m3, opt_s3, clip=clip_s3)
+                for nb, reps in ((2048, 10), (262144, 3)):
+                    b3 = ref_points(nb)
+                    dt3, w3, _ = _time_windows(lambda: tr3.train_iter(b3, global_bs=nb // 2), reps, windows=3, warm=2)
+                    res3[f'{label}_{nb}'] = {'ms_per_step': dt3 * 1e3, 'points_per_s': nb / dt3, 'windows_ms_per_step': w3}
+                    del b3
+            finally:
+                for k, v in old_env.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+        rgb_enc_macs = 3 * 256 + 2 * 256 * 256
+        head3_macs = 2 * (512 * 256 + 256 * 128) + 640 * 3 + 640 * 1
+        res3['trained_macs_per_point'] = rgb_enc_macs + head3_macs
+        res3['speedup_262144_points'] = res3['prog_262144']['ms_per_step'] / res3['x3_262144']['ms_per_step']
+        res3['note'] = ('train_nfr.Trainer.train_iter of the stage-3 model at the reference batch (2048 points) and a 128x larger one, eager; x3 = '
+                        'the default (vqn_refl_train_fwd_x3_zx / _bwd_x3, frozen parts on vqn_mlp_chain_fwd), prog = the interpreted tile programs')
+        out['ref_nfr_train'] = res3
+        del m3
+    except Exception as e:                                          # noqa: BLE001
+        out['ref_nfr_train'] = {'error': repr(e)[:300]}
+
     _log('leg: standalone VQ nearest-code assignment + EMA statistics')
     # ---- standalone VQ nearest-code assignment + EMA statistics (HBM-bound) ----
     Nv, D, K = 1 << 20, 256, 15
@@ -972,7 +1019,7 @@ _EXTRA_CONST_KEYS = frozenset(('peak', 'unit', 'bound', 'flop_per_point', 'rows'
 # legs of `extra` in the order they are given up if the line is still too long (least important first)
 _DROP_ORDER = ('geo_train_wgrad_f32', 'decomp_render_f16s', 'geo_render_f16s', 'vq_ema_stats', 'vq_quantize_rows_k64', 'decomp_relight16',
                'compute_vis', 'geo_render_s64', 'decomp_render_x3', 'geo_render_x3', 'decomp_render_k64', 'decomp_train_256k', 'decomp_render',
-               'vq_assign', 'vq_assign_k64', 'decomp_train', 'geo_train', 'decomp_train_graph', 'geo_train_graph', 'dp_train')
+               'vq_assign', 'vq_assign_k64', 'ref_nfr_train', 'decomp_train', 'geo_train', 'decomp_train_graph', 'geo_train_graph', 'dp_train')
 
 
 def _sig(x, n=5):

@@ -577,6 +577,14 @@ int vqn_refl_train_desc_ints(void);
 int vqn_refl_train_fwd_x3(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, const float* pts, const float* z_rows,
                           int64_t P, float* const* saved, int n_saved, float* z_rows_out, float* const* head_out, int split_heads,
                           int save_tensors, void* stream);
+/* Stage 3 (ref_nfr.py:148-152,203-213: the diffuse / roughness heads read [z_xyz ; z_ref], 2 z_feats wide): descriptor field zx_tiles =
+ * z_tiles gives the heads a SECOND input of z_feats features -- zx_rows [P, z_feats], 16-byte aligned; with zx_tiles = 0 it must be NULL
+ * and the call is vqn_refl_train_fwd_x3.  The heads' first-layer pack then holds the K segments [z ; zx] (2 z_feats input rows), the last
+ * layer a second row-dot image at offW2zx[k].  zx_tiles_out (may be NULL): tile-format copy of zx for the weight-gradient contractions.
+ * No adjoint flows into zx (the backward entry is unchanged: d / d z of the z segment only). */
+int vqn_refl_train_fwd_x3_zx(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, const float* pts, const float* z_rows,
+                             const float* zx_rows, int64_t P, float* const* saved, int n_saved, float* z_rows_out, float* zx_tiles_out,
+                             float* const* head_out, int split_heads, int save_tensors, void* stream);
 int64_t vqn_refl_train_bwd_x3_scratch_bytes(const int32_t* desc);
 int vqn_refl_train_bwd_x3(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, int64_t P, const float* const* g_out,
                           const float* const* head_out, const float* const* g_z_rows, int n_gz, const float* const* saved, int n_saved,

@@ -570,6 +570,10 @@ def test_ref_nfr_training_grads_vs_oracle(setup, data_type):
         loss, ld = m.compute_loss(pred, gt, **dict(lk))
         loss.mean().backward()
     assert rec.ran('vqn_brdf_shade_bwd')
+    # round 5: rgb_enc + the two 512-wide heads on the dedicated exact-split kernels (second head input z_xyz), the frozen stage-2 parts on the
+    # inference chain kernels -- nothing of the step is left on the interpreted tile programs
+    assert rec.ran('vqn_refl_train_fwd_x3') and rec.ran('vqn_refl_train_bwd_x3') and not rec.ran('vqn_tile_program')
+    assert rec.ran('vqn_mlp_chain_fwd')
     pt = {k: ([(od.T(W).requires_grad_(True), od.T(b).requires_grad_(True)) for W, b in v] if isinstance(v, list) else od.T(v))
           for k, v in p.items()}
     gb, gi = torch.tensor([1.3], requires_grad=True), torch.tensor([0.8], requires_grad=True)

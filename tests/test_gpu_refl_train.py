@@ -105,6 +105,59 @@ def test_vq_heads_stack_against_torch_autograd(N, form):
         assert _rel(p.grad, w) < 1e-4, (tuple(p.shape), _rel(p.grad, w))
 
 
+@pytest.fixture(params=['auto', 'split', 'no-split'])
+def zx_form(request, monkeypatch):
+    """stage-3 stacks run one image per workgroup (two image regions); heads in one workgroup / one workgroup row per head"""
+    if request.param != 'auto':
+        monkeypatch.setenv('VQN_REFL_SPLIT', '1' if request.param == 'split' else '0')
+    return request.param
+
+
+@pytest.mark.parametrize('N', [1, 33, 600, 4113])
+def test_stage3_stack_against_torch_autograd(N, zx_form):
+    """Stage 3 (ref_nfr.py:137-152,203-213): rgb_enc (3 raw features -> 256 linear -> 256 relu -> 256 sigmoid) -> z_ref, then the diffuse (3
+    outputs) and roughness (1) heads over [z_xyz ; z_ref] (512 wide; z_xyz given, no adjoint) on the exact-split kernels with a SECOND head
+    input: outputs to 3e-6, every parameter gradient (incl. the z_xyz rows of the heads' first and last kernels) to 1e-4 of the tensor's
+    largest entry against torch autograd over networks/mlp.py, an adjoint flowing into z_ref from outside included."""
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    from vqnerf_release_amd.decomp.refl_train import ReflStackEngine, ReflStackZxFunction
+    m = get_model_class('ref_nfr')(make_config(model='ref_nfr'))
+    m.build_nets(device='cuda', seed=9).to('cuda')
+    g = torch.Generator(device='cuda').manual_seed(9)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.05 * torch.randn(p.shape, device='cuda', generator=g))
+    enc, heads = [m.net['rgb_enc']], [m.net['diff_out'], m.net['rough_out']]
+    assert ReflStackEngine.supports(enc, heads, m.z_dim, 3, zx=True)
+    eng = ReflStackEngine(enc, 0, heads, m.z_dim, 'cuda', zx=True)
+    ref = torch.rand(N, 3, device='cuda', generator=g)
+    z_xyz = torch.rand(N, 256, device='cuda', generator=g)
+    w_z = torch.randn(N, 256, device='cuda', generator=g)
+    w_o = [torch.randn(N, c, device='cuda', generator=g) for c in (3, 1)]
+
+    def loss_of(z, outs):
+        return (z * w_z).sum() + sum((o * w).sum() for o, w in zip(outs, w_o))
+    m.zero_grad(set_to_none=True)
+    z_t = m.net['rgb_enc'](ref)
+    zb = torch.cat([z_xyz, z_t], -1)
+    outs_t = [m.net['diff_out'](zb), m.net['rough_out'](zb)]
+    loss_of(z_t, outs_t).backward()
+    want = [p.grad.detach().clone() for p in eng.params()]
+    m.zero_grad(set_to_none=True)
+    with launches() as rec:
+        res = ReflStackZxFunction.apply(eng, ref, z_xyz, *eng.params())
+        loss_of(res[0], res[1:]).backward()
+    assert rec.counts['vqn_refl_train_fwd_x3'] == 1 and rec.ran('vqn_refl_train_bwd_x3') and not rec.ran('vqn_tile_program')
+    assert float((res[0] - z_t).abs().max()) < 3e-6
+    for a, b in zip(res[1:], outs_t):
+        assert a.shape == b.shape and float((a - b).abs().max()) < 3e-6
+    for p, w in zip(eng.params(), want):
+        assert p.grad is not None and p.grad.shape == w.shape and _rel(p.grad, w) < 1e-4, (tuple(p.shape), _rel(p.grad, w))
+    # the rows of the first kernel that face z_xyz are not a copy of the z_ref rows' gradient
+    g0 = m.net['diff_out'].layers[0].kernel.grad
+    assert g0.shape[0] == 512 and (N < 2 or not torch.allclose(g0[:256], g0[256:]))
+
+
 def test_saved_tensors_and_adjoints_are_the_interpreted_programs(form):
     """Layer outputs and per-point adjoints left for the contraction, against decomp/train_programs.py's interpreter on the f32-input
     MFMA (the engine of rounds 1-3): 2e-5 of each tensor's largest entry (the bound the geo x3 kernels hold against their interpreter),

@@ -838,19 +838,28 @@ def brdf_shade_bwd(xyz, normal, rayo, lvis, lxyz, lareas, light, materials, g_su
 
 
 # -------------------------------------------------------------------------------------- reflectance training passes (round 4)
-def refl_train_fwd_x3(desc, wbuf_pieces, wbuf_f32, pts, z_rows, P, saved, z_rows_out, head_out, split_heads=False, save=True):
+def refl_train_fwd_x3(desc, wbuf_pieces, wbuf_f32, pts, z_rows, P, saved, z_rows_out, head_out, split_heads=False, save=True, zx_rows=None,
+                      zx_tiles_out=None):
     """Forward of a reflectance stack (optional encoder + up to three heads) on the exact-split engine, keeping what the backward
-    needs (csrc/refl_train_x3.hip: vqn_refl_train_fwd_x3).  split_heads: one workgroup row per head (small batches)."""
+    needs (csrc/refl_train_x3.hip: vqn_refl_train_fwd_x3).  split_heads: one workgroup row per head (small batches).
+    zx_rows [P, z]: the heads' second input (descriptors with zx_tiles > 0: vqn_refl_train_fwd_x3_zx); zx_tiles_out: its tile-format copy."""
     _f32c(wbuf_f32, 'wbuf_f32')
-    for t in [t for t in saved if t is not None] + list(head_out) + [t for t in (pts, z_rows, z_rows_out) if t is not None]:
+    for t in [t for t in saved if t is not None] + list(head_out) + [t for t in (pts, z_rows, z_rows_out, zx_rows, zx_tiles_out) if t is not None]:
         _f32c(t, 'tensor')
     d, dp = _i32(desc)
     sp = (ctypes.c_void_p * len(saved))(*[0 if t is None else t.data_ptr() for t in saved])
     hp = (ctypes.c_void_p * max(1, len(head_out)))(*[t.data_ptr() for t in head_out])
     with _clock('vqn_refl_train_fwd_x3'):
-        rc = lib().vqn_refl_train_fwd_x3(dp, _ptr(wbuf_pieces), _ptr(wbuf_f32), _ptr(pts), _ptr(z_rows), ctypes.c_int64(P), sp,
-                                         ctypes.c_int(len(saved)), _ptr(z_rows_out), hp, ctypes.c_int(int(split_heads)), ctypes.c_int(int(save)),
-                                         _stream())
+        if zx_rows is None:
+            rc = lib().vqn_refl_train_fwd_x3(dp, _ptr(wbuf_pieces), _ptr(wbuf_f32), _ptr(pts), _ptr(z_rows), ctypes.c_int64(P), sp,
+                                             ctypes.c_int(len(saved)), _ptr(z_rows_out), hp, ctypes.c_int(int(split_heads)), ctypes.c_int(int(save)),
+                                             _stream())
+        else:
+            if zx_rows.shape[0] != P:
+                raise VqnError('refl_train_fwd_x3: zx_rows must have one row per point')
+            rc = lib().vqn_refl_train_fwd_x3_zx(dp, _ptr(wbuf_pieces), _ptr(wbuf_f32), _ptr(pts), _ptr(z_rows), _ptr(zx_rows), ctypes.c_int64(P), sp,
+                                                ctypes.c_int(len(saved)), _ptr(z_rows_out), _ptr(zx_tiles_out), hp, ctypes.c_int(int(split_heads)),
+                                                ctypes.c_int(int(save)), _stream())
     _check(rc, 'vqn_refl_train_fwd_x3')
 
 

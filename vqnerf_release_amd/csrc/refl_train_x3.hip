@@ -49,9 +49,15 @@ __device__ unsigned long long g_rt_stamps[8 * 16];      // [wave][phase]
 #define RT_STAMP_FLUSH
 #endif
 
+// Round 5 -- a SECOND z input for the heads (stage 3, ref_nfr.py:148-152,203-213: the diffuse / roughness heads read [z_xyz ; z_ref], 512
+// wide): `zx_tiles` = z_tiles switches it on.  The rows of the second input (z_xyz: the frozen stage-2 encoder's output, no adjoint
+// wanted) stand in a second image region X1 for the whole unit; a head's first layer is ONE GEMM over the two K segments [X0: z ; X1: zx]
+// (the pack holds the 2 Z input rows of the Dense kernel in that order), its last layer's row dots take a third share from X1.  The
+// backward kernel is unchanged: d / d z comes from the z rows of the kernels only, the weight gradients of the zx rows are two more
+// contractions against the tile-format copy of zx this kernel leaves.  One image per workgroup only (two regions = 108 KB of LDS).
 struct ReflDesc {
   int n_enc, skip, emb_rows, emb_feats, e_tiles, max_tiles, n_heads, z_tiles;
-  int z_feats, rsv[7];
+  int z_feats, zx_tiles, offW2zx[RT_MAX_H], rsv[3];
   int te[RT_MAX_L], act[RT_MAX_L], offW[RT_MAX_L], offBias[RT_MAX_L], offWb[RT_MAX_L];
   int t0[RT_MAX_H], t1[RT_MAX_H], c[RT_MAX_H], offW0[RT_MAX_H], offW1[RT_MAX_H], offB0[RT_MAX_H], offB1[RT_MAX_H], offW2y[RT_MAX_H],
       offW2z[RT_MAX_H], offB2[RT_MAX_H], offW1b[RT_MAX_H], offW0b[RT_MAX_H], offA2y[RT_MAX_H], offA2z[RT_MAX_H];
@@ -66,6 +72,7 @@ struct ReflFwdPtrs {
   float* ZROWS;                             // z as rows [N, z_feats] (with an encoder; may be NULL)
   float* H0[RT_MAX_H]; float* H1[RT_MAX_H]; float* OUT[RT_MAX_H];
   int save;                                 // 0: inference -- nothing is kept for a backward (only z's tile-format copy, which heads 2 and 3 re-read)
+  const float* ZX; float* ZXT;              // second head input (zx_tiles > 0): rows [N, z_feats] and their tile-format copy (may be NULL)
 };
 
 struct ReflBwdPtrs {
@@ -153,7 +160,8 @@ __device__ __forceinline__ void dact_mul(const int act, const float (&y)[16], fl
 #define REFL_PROLOGUE()                                                                                      \
   extern __shared__ __attribute__((aligned(16))) f32x4 lds[];                                                \
   const int MT = rd.max_tiles;                                                                               \
-  const int IMG = E_ROWS + 6 * MT, IS = IMG * 64;                                                            \
+  const int IMG = E_ROWS + 6 * MT + 6 * rd.zx_tiles, IS = IMG * 64;                                          \
+  const int X1 = E_ROWS + 6 * MT;                       /* rows of the second head input (zx_tiles > 0) */   \
   SmallsR* sm = reinterpret_cast<SmallsR*>(lds + (size_t)NIMG * IS);                                         \
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;                                \
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                 \
@@ -165,7 +173,7 @@ __device__ __forceinline__ void dact_mul(const int act, const float (&y)[16], fl
   const int k_lo = gridDim.y > 1 ? (int)blockIdx.y : 0, k_hi = gridDim.y > 1 ? k_lo + 1 : rd.n_heads;       \
   auto blocks_of = [](int krows) { return (krows / 3 + 1) >> 1; };                                           \
   auto ptile_of = [&](long unit, int im) { return NIMG == 1 ? unit : 2 * unit + im; };                       \
-  (void)ldsi; (void)h; (void)p; (void)blocks_of; (void)part_i; (void)k_hi; (void)NWI;                        \
+  (void)ldsi; (void)h; (void)p; (void)blocks_of; (void)part_i; (void)k_hi; (void)NWI; (void)X1;              \
   RT_OCC2_PHASE_DELAY();
 
 // sum of the NWI per-wave partial row dots of (point pp, output c)
@@ -266,11 +274,12 @@ __global__ __launch_bounds__(512, RT_WAVES_EU(NIMG)) void refl_train_fwd_x3_kern
     int n = 0;
     auto add = [&](int off, int krows, int tiles) { sm->tab[4 * n] = off; sm->tab[4 * n + 1] = blocks_of(krows); sm->tab[4 * n + 2] = tiles; sm->tab[4 * n + 3] = 0; ++n; };
     for (int l = 0; l < nE; ++l) add(rd.offW[l], l == 0 ? rd.emb_rows : 6 * rd.te[l - 1] + (l == rd.skip ? rd.emb_rows : 0), rd.te[l]);
-    for (int k = k_lo; k < k_hi; ++k) { add(rd.offW0[k], 6 * ZT, rd.t0[k]); add(rd.offW1[k], 6 * rd.t0[k], rd.t1[k]); }
+    for (int k = k_lo; k < k_hi; ++k) { add(rd.offW0[k], 6 * ZT + 6 * rd.zx_tiles, rd.t0[k]); add(rd.offW1[k], 6 * rd.t0[k], rd.t1[k]); }
     sm->n_calls = n;
   }
   __syncthreads();
   REFL_STREAM();
+  const int ZXT = rd.zx_tiles;
 
   for (long unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
     call = 0;
@@ -355,6 +364,29 @@ __global__ __launch_bounds__(512, RT_WAVES_EU(NIMG)) void refl_train_fwd_x3_kern
     }
 
     // ---------------- heads ----------------
+    if (ZXT > 0) {
+      // the second input's rows -> region X1 (piece triples) + their tile-format copy (the contraction's operand for the zx rows of
+      // the first / last Dense kernels); nothing writes X1 until the next unit
+      const long pt = (ptile_w << 5) + p;
+      const bool valid = pt < P;
+      const float* row = tp.ZX + (valid ? pt : P - 1) * (long)rd.z_feats;
+      for (int sl = w4; sl < 2 * ZXT; sl += NWI) {
+        float x[8];
+        const int f0 = 16 * sl + 4 * h;
+        const f32x4 a = (f0 < rd.z_feats) ? *reinterpret_cast<const f32x4*>(row + f0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 b = (f0 + 8 < rd.z_feats) ? *reinterpret_cast<const f32x4*>(row + f0 + 8) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
+        if (!valid) {
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) x[jj] = 0.f;
+        }
+        if (live_w && wr_shared && tp.ZXT != nullptr) tf_store_step(tp.ZXT, ptile_w, ZXT, sl, lane, x);
+        f32x4 q0, q1, q2;
+        split3x8(x, q0, q1, q2);
+        ldsi[(X1 + 3 * sl) * 64 + lane] = q0; ldsi[(X1 + 3 * sl + 1) * 64 + lane] = q1; ldsi[(X1 + 3 * sl + 2) * 64 + lane] = q2;
+      }
+      __syncthreads();
+    }
     // the z share of every head's last layer while z is in the buffer: part -> h2z[k][img][p * 3 + c]
     for (int k = k_lo; k < k_hi; ++k) {
       if (rd.c[k] == 1) rowdot_x3<1, NWI>(ldsi, X0, 6 * ZT, wf + rd.offW2z[k], part_i, w4, lane);
@@ -367,6 +399,17 @@ __global__ __launch_bounds__(512, RT_WAVES_EU(NIMG)) void refl_train_fwd_x3_kern
         sm->h2z[k][im][pp * 3 + c] = REFL_PART_SUM(pr, pp, nc, c);
       }
       __syncthreads();
+      if (ZXT > 0) {                                   // + the zx share (the rows of the last Dense kernel that face the second input)
+        if (rd.c[k] == 1) rowdot_x3<1, NWI>(ldsi, X1, 6 * ZXT, wf + rd.offW2zx[k], part_i, w4, lane);
+        else rowdot_x3<3, NWI>(ldsi, X1, 6 * ZXT, wf + rd.offW2zx[k], part_i, w4, lane);
+        __syncthreads();
+        if (tid < 32 * NIMG * nc) {
+          const int im = tid / (32 * nc), r = tid - 32 * nc * im, pp = r % 32, c = r / 32;
+          const float* pr = sm->part + im * (4 * 32 * 3);
+          sm->h2z[k][im][pp * 3 + c] += REFL_PART_SUM(pr, pp, nc, c);
+        }
+        __syncthreads();
+      }
     }
     for (int k = k_lo; k < k_hi; ++k) {
       if (k > k_lo) {                                    // z back into the buffer (the previous head ran over it)
@@ -386,7 +429,7 @@ __global__ __launch_bounds__(512, RT_WAVES_EU(NIMG)) void refl_train_fwd_x3_kern
         const int n_ot = rd.t0[k];
         const f32x4* bp = wf + rd.offB0[k];
         float* const t_y = tp.H0[k];
-        GC(rd.offW0[k], KSegs{X0, 6 * ZT, 0, 0}, n_ot,
+        GC(rd.offW0[k], KSegs{X0, 6 * ZT, X1, 6 * ZXT}, n_ot,
           [&](int ot, int, auto, f32x16& acc) __attribute__((always_inline)) { init_bias_f16s(bp, ot, lane, acc); },
           [&](int ot, int im, auto slc_, const f32x16& acc) __attribute__((always_inline)) {
             constexpr int sl_ = decltype(slc_)::value; (void)sl_;
@@ -666,7 +709,7 @@ __global__ __launch_bounds__(512, RT_WAVES_EU(NIMG)) void refl_train_bwd_x3_kern
   RT_STAMP_FLUSH
 }
 
-size_t lds_bytes_r(int MT, int nimg) { return (size_t)nimg * (E_ROWS + 6 * MT) * 1024 + sizeof(SmallsR); }
+size_t lds_bytes_r(int MT, int nimg, int zx_tiles = 0) { return (size_t)nimg * (E_ROWS + 6 * MT + 6 * zx_tiles) * 1024 + sizeof(SmallsR); }
 
 int load_desc_r(const int32_t* desc, ReflDesc& rd) {
   memcpy(&rd, desc, sizeof(ReflDesc));
@@ -683,12 +726,15 @@ int load_desc_r(const int32_t* desc, ReflDesc& rd) {
   }
   for (int k = 0; k < rd.n_heads; ++k)
     if (rd.t0[k] < 1 || rd.t0[k] > rd.max_tiles || rd.t1[k] < 1 || rd.t1[k] > rd.max_tiles || rd.c[k] < 1 || rd.c[k] > 3) return 8;
+  // a second head input: as wide as z, heads present, and one image (two regions) must fit the CU's LDS
+  if (rd.zx_tiles != 0 && (rd.zx_tiles != rd.z_tiles || rd.n_heads < 1 || lds_bytes_r(rd.max_tiles, 1, rd.zx_tiles) > 160 * 1024)) return 9;
   return 0;
 }
 
 // one image per workgroup when the two-image form would leave more than half of the CUs without a tile pair (VQN_REFL_NIMG = 1 | 2
 // forces a form: tests and A/B timings)
-int images_per_wg(long n_tiles) {
+int images_per_wg(long n_tiles, const ReflDesc& rd) {
+  if (rd.zx_tiles > 0) return 1;                                 // (two image regions per point tile: one image per workgroup)
   const char* e = getenv("VQN_REFL_NIMG");                       // (read per call: the tests switch it)
   if (e && (e[0] == '1' || e[0] == '2')) return e[0] - '0';
   return (n_tiles + 1) / 2 * 2 <= (long)vqn_num_cus() ? 1 : 2;
@@ -701,6 +747,13 @@ extern "C" int vqn_refl_train_desc_ints(void) { return RT_DESC_INTS; }
 extern "C" int vqn_refl_train_fwd_x3(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, const float* pts, const float* z_rows,
                                      int64_t P, float* const* saved, int n_saved, float* z_rows_out, float* const* head_out, int split_heads,
                                      int save_tensors, void* stream) {
+  return vqn_refl_train_fwd_x3_zx(desc, wbuf_pieces, wbuf_f32, pts, z_rows, nullptr, P, saved, n_saved, z_rows_out, nullptr, head_out, split_heads,
+                                  save_tensors, stream);
+}
+
+extern "C" int vqn_refl_train_fwd_x3_zx(const int32_t* desc, const void* wbuf_pieces, const float* wbuf_f32, const float* pts, const float* z_rows,
+                                        const float* zx_rows, int64_t P, float* const* saved, int n_saved, float* z_rows_out, float* zx_tiles_out,
+                                        float* const* head_out, int split_heads, int save_tensors, void* stream) {
   VQN_CHECK_ARG(desc && wbuf_pieces && wbuf_f32 && saved, "null pointer");
   VQN_CHECK_ARG(P >= 1, "P >= 1");
   ReflDesc rd;
@@ -713,9 +766,12 @@ extern "C" int vqn_refl_train_fwd_x3(const int32_t* desc, const void* wbuf_piece
   // (save_tensors = 0, inference: only z's tile-format tensor -- Y_{n_enc-1} / ZT -- is written and must be given)
   for (int i = 0; i < n_saved; ++i)
     VQN_CHECK_ARG(saved[i] != nullptr || (!save_tensors && i != (nE > 0 ? nE : 0)), "null saved tensor");
+  VQN_CHECK_ARG((rd.zx_tiles > 0) == (zx_rows != nullptr), "zx_rows exactly when the descriptor has a second head input");
+  VQN_CHECK_SHAPE(zx_rows == nullptr || ((uintptr_t)zx_rows & 15) == 0, "zx_rows must be 16-byte aligned");
   ReflFwdPtrs tp;
   memset(&tp, 0, sizeof(tp));
   tp.X = pts; tp.ZR = z_rows; tp.ZROWS = z_rows_out; tp.save = save_tensors != 0;
+  tp.ZX = zx_rows; tp.ZXT = zx_tiles_out;
   int s = 0;
   if (nE > 0) {
     tp.E = saved[s++];
@@ -728,8 +784,8 @@ extern "C" int vqn_refl_train_fwd_x3(const int32_t* desc, const void* wbuf_piece
     tp.OUT[k] = head_out[k];
   }
   const long n_tiles = (P + 31) / 32;
-  const int nimg = images_per_wg(n_tiles);
-  const size_t lds = lds_bytes_r(rd.max_tiles, nimg);
+  const int nimg = images_per_wg(n_tiles, rd);
+  const size_t lds = lds_bytes_r(rd.max_tiles, nimg, rd.zx_tiles);
   auto kern = nimg == 1 ? refl_train_fwd_x3_kernel<1> : refl_train_fwd_x3_kernel<2>;
   VQN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long units = nimg == 1 ? n_tiles : (n_tiles + 1) / 2;
@@ -788,10 +844,10 @@ extern "C" int vqn_refl_train_bwd_x3(const int32_t* desc, const void* wbuf_piece
     tp.D0[k] = outs[nE + 3 * k]; tp.D1[k] = outs[nE + 3 * k + 1]; tp.D2[k] = outs[nE + 3 * k + 2];
   }
   const long n_tiles = (P + 31) / 32;
-  const int nimg = images_per_wg(n_tiles);
+  const int nimg = images_per_wg(n_tiles, rd);
   const unsigned gy = split ? (unsigned)nH : 1u;
   const int64_t per_wg = (int64_t)nimg * 4 * rd.z_tiles * 1024;
-  const size_t lds = lds_bytes_r(rd.max_tiles, nimg);
+  const size_t lds = lds_bytes_r(rd.max_tiles, nimg, rd.zx_tiles);
   auto kern = nimg == 1 ? refl_train_bwd_x3_kernel<1> : refl_train_bwd_x3_kernel<2>;
   VQN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long units = nimg == 1 ? n_tiles : (n_tiles + 1) / 2;

@@ -61,6 +61,31 @@ class Model(BrdfModel):
             self._light.requires_grad_(False)
         return self._light                                        # used as loaded: no clip (ref_nfr.py:87, :424)
 
+    def _frozen_ctx(self, names, x):
+        """torch.no_grad() when none of the named nets' parameters (nor the input) wants a gradient, else a null context"""
+        import contextlib
+        if torch.is_grad_enabled() and not x.requires_grad and not any(p.requires_grad for n in names for p in self.net[n].parameters()):
+            return torch.no_grad()
+        return contextlib.nullcontext()
+
+    def _stage3_engine(self, ref, z_xyz):
+        """The exact-split training engine for rgb_enc -> z_ref -> {diff_out, rough_out}([z_xyz ; z_ref]) (decomp/refl_train.py, zx form), or None
+        when this is not a HIP training call, z_xyz wants an adjoint (the encoder is being trained: the interpreted programs take it), or the
+        nets are outside the kernels' shapes."""
+        import os
+        if not (self._train_hip(ref) and not self._fused(ref) and os.environ.get('VQN_REFL_TRAIN', self.REFL_TRAIN_DEFAULT) == 'x3'):
+            return None
+        if z_xyz.requires_grad or ref.requires_grad or z_xyz.shape[1] != self.z_dim:
+            return None
+        key = ('stage3', str(ref.device))
+        if key not in self._engines:
+            from vqnerf_release_amd.decomp.refl_train import ReflStackEngine
+            enc, heads = [self.net['rgb_enc']], [self.net['diff_out'], self.net['rough_out']]
+            ok = ReflStackEngine.supports(enc, heads, self.z_dim, 3, zx=True)
+            self._engines[key] = ReflStackEngine(enc, 0, heads, self.z_dim, ref.device, zx=True) if ok else None
+        eng = self._engines[key]
+        return eng if (eng is not None and any(p.requires_grad for p in eng.params())) else None
+
     def _pred_ref_at(self, ref):
         if self._fused(ref):
             if 'ref' not in self._plans:
@@ -80,11 +105,23 @@ class Model(BrdfModel):
         n = alpha.shape[0]
         rayo, rgb_m, xyz_m, normal_m, ref_m = take_rows(mask, rayo), take_rows(mask, rgb), take_rows(mask, xyz), take_rows(mask, normal), take_rows(mask, ref)
         lvis_m = self.fg_lvis(lvis, mask, xyz_m)
-        z_xyz = self._pred_bias_at(xyz_m)
-        ks = self._head('spec_out', z_xyz)
-        z_bias = torch.cat([z_xyz, self._pred_ref_at(ref_m)], -1)
-        basecolor = self._albedo_affine(self._head('diff_out', z_bias))
-        rough = self._head('rough_out', z_bias)
+        # the parts that come FROZEN from stage 2 (load_stage2: encoder, specular head) need no graph: in a training call they run on the
+        # inference kernels (one fused chain launch each), not on the training programs with everything kept for a backward
+        with self._frozen_ctx(['fine_enc', 'bottleneck'], xyz_m):
+            z_xyz = self._pred_bias_at(xyz_m)
+        with self._frozen_ctx(['spec_out'], z_xyz):
+            ks = self._head('spec_out', z_xyz)
+        eng = self._stage3_engine(ref_m, z_xyz) if mode == 'train' else None
+        if eng is not None:
+            # rgb_enc + the two 512-wide heads on the dedicated exact-split kernels (round 5; the interpreted tile programs before)
+            from vqnerf_release_amd.decomp.refl_train import ReflStackZxFunction
+            z_ref, d, r = ReflStackZxFunction.apply(eng, ref_m, z_xyz, *eng.params())
+            self._numerics(z_ref, 'Z_ref')
+            basecolor, rough = self._numerics(self._albedo_affine(d), 'Albedo'), self._numerics(r, 'Roughness')
+        else:
+            z_bias = torch.cat([z_xyz, self._pred_ref_at(ref_m)], -1)
+            basecolor = self._albedo_affine(self._head('diff_out', z_bias))
+            rough = self._head('rough_out', z_bias)
         spec, albedo = ks * basecolor, (1 - ks) * basecolor
         if (opt_scale is not None) and (mode == 'test'):
             albedo, spec = albedo * opt_scale, spec * opt_scale

@@ -10,7 +10,12 @@ over networks/mlp.py:24-50) under train_nfr.py:562-576, as TWO launches per stac
 adjoint; the contractions are the batched ones of geo/train_programs.py (WgradBatch).  Weights keep the Keras layout (kernel [in, out]).
 Packs: ONE gather + exact three-way split launch (vqn_pack_x3_gather) for all GEMM matrices of both directions and one gather of the
 thin f32 images, from the flat parameter vector; the index arrays and the descriptor do not depend on the weight values (cached).
-Stacks this engine does not cover (layers wider than 256: the stage-3 `ref_nfr` heads) keep decomp/train_programs.py's interpreter."""
+Round 5: the stage-3 stack (ref_nfr.py:137-152,203-213) -- rgb_enc (3 raw features -> 256 -> 256 -> 256) + the diffuse / roughness heads over
+[z_xyz ; z_ref] (512 wide) -- runs here too: `ReflStackEngine(enc_nets=[rgb_enc], n_freqs=0, heads=[diff_out, rough_out], zx=True)`.  z_xyz (the
+frozen stage-2 encoder's output) is the heads' SECOND input (`zx`): a second image region in the forward kernel, two K segments in the
+heads' first GEMM, a third row-dot share in their last layer; the backward kernel is the same (no adjoint flows into z_xyz), the weight
+gradients of the Dense kernels' z_xyz rows are two more contractions per head.  Stacks this engine does not cover keep
+decomp/train_programs.py's interpreter."""
 import ctypes
 
 import numpy as np
@@ -49,9 +54,12 @@ class ReflStackEngine:
     n_split = 256
 
     @staticmethod
-    def supports(enc_nets, heads, z_dim, emb_feats=0):
-        """the shapes csrc/refl_train_x3.hip runs: layers of at most 256 outputs, at most one skip-concat (of the encoding), standard heads"""
+    def supports(enc_nets, heads, z_dim, emb_feats=0, zx=False):
+        """the shapes csrc/refl_train_x3.hip runs: layers of at most 256 outputs, at most one skip-concat (of the encoding), standard heads;
+        zx: the heads read [zx ; z] (2 z_dim wide: their first kernel has 2 z_dim rows, their last w1 + 2 z_dim)"""
         if z_dim > 256 or z_dim % 4 or len(heads) > RT_MAX_H:
+            return False
+        if zx and (not heads or z_dim % 32):
             return False
         for net in heads:
             if not (len(net.widths) == 3 and net.skip_at == [1] and net.act == ['relu', 'relu', 'sigmoid'] and net.widths[0] <= 256
@@ -77,8 +85,9 @@ class ReflStackEngine:
                 return False
         return bool(enc_nets) or bool(heads)
 
-    def __init__(self, enc_nets, n_freqs, heads, z_dim, device):
+    def __init__(self, enc_nets, n_freqs, heads, z_dim, device, zx=False):
         self.device, self.Z, self.heads = device, z_dim, list(heads)
+        self.zx = bool(zx)                 # heads over [zx ; z]: a second input of z_dim features in FRONT of z (the order of ref_nfr's concat)
         self.enc_nets = list(enc_nets) if enc_nets else []
         self.E = 3 + 6 * n_freqs if self.enc_nets else 0
         self.layers, d_prev = [], self.E
@@ -88,7 +97,7 @@ class ReflStackEngine:
                 self.layers.append(dict(in_y=d_prev, out=w, act=ACTS[a], skip=skip_in))
                 d_prev = w
         self.nE, self.nH = len(self.layers), len(self.heads)
-        assert self.supports(self.enc_nets, self.heads, z_dim, self.E)
+        assert self.supports(self.enc_nets, self.heads, z_dim, self.E, zx=self.zx)
         self._dev = None
 
     # ------------------------------------------------------------------ parameters
@@ -106,8 +115,9 @@ class ReflStackEngine:
             shp += [('W%d' % l, (L['in_y'] + (self.E if L['skip'] else 0), L['out'])), ('b%d' % l, (L['out'],))]
         for k, net in enumerate(self.heads):
             w0, w1, c = net.widths
-            shp += [('H%d_W0' % k, (self.Z, w0)), ('H%d_b0' % k, (w0,)), ('H%d_W1' % k, (w0, w1)), ('H%d_b1' % k, (w1,)),
-                    ('H%d_W2' % k, (w1 + self.Z, c)), ('H%d_b2' % k, (c,))]
+            zin = self.Z * (2 if self.zx else 1)
+            shp += [('H%d_W0' % k, (zin, w0)), ('H%d_b0' % k, (w0,)), ('H%d_W1' % k, (w0, w1)), ('H%d_b1' % k, (w1,)),
+                    ('H%d_W2' % k, (w1 + zin, c)), ('H%d_b2' % k, (c,))]
         return FlatLayout(shp)
 
     def _static(self):
@@ -143,6 +153,7 @@ class ReflStackEngine:
                 skip = l
         mt = max([_tl(Ly['out']) for Ly in self.layers] + [_tl(self.Z)] + [_tl(w) for net in self.heads for w in net.widths[:2]])
         d[0:9] = [self.nE, skip, emb_rows, self.E, _tl(self.E) if self.nE else 0, mt, self.nH, _tl(self.Z), self.Z]
+        d[9] = _tl(self.Z) if self.zx else 0                  # zx_tiles
         o_te, o_act, o_w, o_b, o_wb = 16, 16 + RT_MAX_L, 16 + 2 * RT_MAX_L, 16 + 3 * RT_MAX_L, 16 + 4 * RT_MAX_L
         for l, Ly in enumerate(self.layers):
             n_in = Ly['in_y'] + (self.E if Ly['skip'] else 0)
@@ -164,12 +175,19 @@ class ReflStackEngine:
             w0, w1, c = net.widths
             nout = 1 if c == 1 else 3
             W0, W1, W2 = L['H%d_W0' % k], L['H%d_W1' % k], L['H%d_W2' % k]
+            pad = lambda m: np.concatenate([m, np.full((nout - c, m.shape[1]), L.zero, m.dtype)], 0) if nout > c else m
             d[H(0, k)], d[H(1, k)], d[H(2, k)] = _tl(w0), _tl(w1), c
-            d[H(3, k)] = add(W0.T, gx(w0, self.Z, [(zrows, _ident(self.Z))]))
+            if self.zx:
+                # kernel rows [zx (0 .. Z-1) ; z (Z .. 2Z-1)] (ref_nfr's concat order); the GEMM walks K segment X0 = z first, then X1 = zx
+                Z = self.Z
+                d[H(3, k)] = add(W0.T, gx(w0, 2 * Z, [(zrows, _ident(Z, base=Z)), (zrows, _ident(Z))]))
+                d[10 + k] = addf(pad(W2[w1:w1 + Z].T), packing.rowdot_index_x3(nout, zrows, Z))            # offW2zx
+                W0, W2 = W0[Z:], np.concatenate([W2[:w1], W2[w1 + Z:]], 0)       # from here on: the z part, as without a second input
+            else:
+                d[H(3, k)] = add(W0.T, gx(w0, self.Z, [(zrows, _ident(self.Z))]))
             d[H(4, k)] = add(W1.T, gx(w1, w0, [(6 * _tl(w0), _ident(w0))]))
             d[H(5, k)] = addf(L['H%d_b0' % k], packing.bias_index_f16s(w0))
             d[H(6, k)] = addf(L['H%d_b1' % k], packing.bias_index_f16s(w1))
-            pad = lambda m: np.concatenate([m, np.full((nout - c, m.shape[1]), L.zero, m.dtype)], 0) if nout > c else m
             d[H(7, k)] = addf(pad(W2[:w1].T), packing.rowdot_index_x3(nout, 6 * _tl(w1), w1))
             d[H(8, k)] = addf(pad(W2[w1:].T), packing.rowdot_index_x3(nout, zrows, self.Z))
             d[H(9, k)] = addf(L['H%d_b2' % k], np.where(np.arange(4) < c, np.arange(4), c))
@@ -190,8 +208,10 @@ class ReflStackEngine:
     def _tensor(self, nt, tiles, dev):
         return torch.empty((nt, tiles, 32, 32), dtype=torch.float32, device=dev)
 
-    def forward(self, x, params):
-        """x: xyz [N, 3] (with an encoder) | z rows [N, Z].  -> state dict (saved tensors, packs), z rows | None, head outputs."""
+    def forward(self, x, params, zx_rows=None):
+        """x: xyz [N, 3] (with an encoder) | z rows [N, Z]; zx_rows [N, Z]: the heads' second input (engines built with zx=True).
+        -> state dict (saved tensors, packs), z rows | None, head outputs."""
+        assert (zx_rows is not None) == self.zx, 'zx_rows exactly for an engine built with zx=True'
         L, gidx, n_steps, fidx, desc = self._static()
         N, dev = x.shape[0], x.device
         nt = (N + 31) // 32
@@ -216,7 +236,10 @@ class ReflStackEngine:
         outs = [torch.empty((N, net.widths[2]), dtype=torch.float32, device=dev) for net in self.heads]
         S['OUT'] = outs
         S['split'] = self._split_heads(nt)
-        _C.refl_train_fwd_x3(desc, pieces, wf, x if self.nE else None, None if self.nE else x, N, saved, zrows, outs, split_heads=S['split'])
+        if self.zx:
+            S['ZXT'] = self._tensor(nt, _tl(self.Z), dev)
+        _C.refl_train_fwd_x3(desc, pieces, wf, x if self.nE else None, None if self.nE else x, N, saved, zrows, outs, split_heads=S['split'],
+                             zx_rows=zx_rows, zx_tiles_out=S.get('ZXT'))
         return S, zrows, outs
 
     @torch.no_grad()
@@ -318,21 +341,30 @@ class ReflStackEngine:
         return gz_rows, grads
 
     def _queue_heads(self, batch, grads, S, D0, D1, D2, shared, roff, cs, new):
-        z_targets = []
+        z_targets, zx_targets = [], []
         for k, net in enumerate(self.heads):
             w0, w1, c = net.widths
-            g0, g1, g2, b0, b1, b2 = new(self.Z, w0), new(w0, w1), new(w1 + self.Z, c), new(w0), new(w1), new(c)
-            batch.contract(D0[k], S['ZT'], w0, self.Z, g0, 1, w0, bias_dst=b0)
+            Z, zo = self.Z, (self.Z if self.zx else 0)            # zo: rows of the kernels in front of the z rows (the zx rows)
+            g0, g1, g2, b0, b1, b2 = new(zo + Z, w0), new(w0, w1), new(w1 + zo + Z, c), new(w0), new(w1), new(c)
+            batch.contract(D0[k], S['ZT'], w0, Z, g0[zo:], 1, w0, bias_dst=b0)
+            if self.zx:
+                batch.contract(D0[k], S['ZXT'], w0, Z, g0, 1, w0)
             batch.contract(D1[k], S['H0'][k], w1, w0, g1, 1, w1, bias_dst=b1)
             if shared:
                 batch.contract_thin_rows(D2[k], roff[k], c, S['H1'][k], w1, [(0, c, g2, 1, c, b2)])
-                z_targets.append((roff[k], c, g2[w1:], 1, c, None))
+                z_targets.append((roff[k], c, g2[w1 + zo:], 1, c, None))
+                if self.zx:
+                    zx_targets.append((roff[k], c, g2[w1:], 1, c, None))
             else:
                 batch.contract(D2[k], S['H1'][k], c, w1, g2, 1, c, bias_dst=b2)
-                batch.contract(D2[k], S['ZT'], c, self.Z, g2[w1:], 1, c)
+                batch.contract(D2[k], S['ZT'], c, Z, g2[w1 + zo:], 1, c)
+                if self.zx:
+                    batch.contract(D2[k], S['ZXT'], c, Z, g2[w1:], 1, c)
             grads += [g0, b0, g1, b1, g2, b2]
         if shared:
             batch.contract_thin_rows(D2[0], 0, sum(cs), S['ZT'], self.Z, z_targets)
+            if self.zx:
+                batch.contract_thin_rows(D2[0], 0, sum(cs), S['ZXT'], self.Z, zx_targets)
 
 
 class ReflStackFunction(torch.autograd.Function):
@@ -354,6 +386,28 @@ class ReflStackFunction(torch.autograd.Function):
             gz_rows, grads = eng.backward(ctx.S, g_z, list(g_outs))
         ctx.S = None
         return (None, gz_rows if not eng.nE else None) + tuple(grads)
+
+
+class ReflStackZxFunction(torch.autograd.Function):
+    """Stage 3: (engine, x, zx, *engine.params()) -> (z rows, head outputs ...): encoder on x (the reference colours through rgb_enc) -> z, heads
+    over [zx ; z].  zx (z_xyz of the frozen stage-2 encoder) gets NO adjoint: callers pass rows that do not require one."""
+
+    @staticmethod
+    def forward(ctx, engine, x, zx, *params):
+        assert engine.zx and engine.nE and not zx.requires_grad
+        with torch.no_grad():
+            S, zrows, outs = engine.forward(x.detach().float().contiguous(), [p.detach().float() for p in params],
+                                            zx_rows=zx.detach().float().contiguous())
+        ctx.engine, ctx.S = engine, S
+        return (zrows,) + tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        eng = ctx.engine
+        with torch.no_grad():
+            _, grads = eng.backward(ctx.S, gs[0], list(gs[1:]))
+        ctx.S = None
+        return (None, None, None) + tuple(grads)
 
 
 class ReflStackKeepFunction(torch.autograd.Function):
