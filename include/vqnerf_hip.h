@@ -171,6 +171,7 @@ int vqn_mlp_chain_fwd_f16s(const int32_t* desc, const float* wbuf, const float* 
  *   (no gamma, no clip): the training path applies those in the host framework so that autograd sees them; raw == 2: the plain sums
  *   through x + (clip(x, 0, 1) - x) -- tfp's clip_by_value_preserve_gradient, whose gradient is the identity (so vqn_brdf_shade_bwd
  *   is the reverse of raw = 1 and raw = 2 alike), as the training path of data_type 'nerf' applies it (no gamma curve there).
+ *   raw must be 0, 1 or 2, and gamma must be NULL unless raw == 0 (-1 otherwise: a gamma that would be silently ignored).
  *   probes [P,L,3] (or NULL): material set 0 is additionally re-lit by every probe in the same pass
  *   (vq_nfr.py:724-733, the per-probe Python loop of the reference) -> rgb0_probes [N,P,3]. */
 int vqn_brdf_shade_fwd(const float* xyz, const float* normal, const float* rayo, const float* lvis,

@@ -266,3 +266,35 @@ def test_dtuset_matches_the_files(tmp_path):
     assert (ds2.H, ds2.W) == (20, 28)
     np.testing.assert_allclose(ds2.intrinsics_all[0, :2, :3].numpy(), 2 * K[:2, :3], atol=1e-3)
     assert ds.image_at(0, 2).shape == (H // 2, W // 2, 3)
+
+
+def test_ref_nfr_dataset_adds_the_reference_colour_column(tmp_path):
+    """Stage-3 loader (datasets/ref_nfr.py of the reference: :64-68, :258-273, :299-301): the shape_unit view + `ref` = rgb.png of the view's
+    geometry directory (normalised 8-bit), between `normal` and `lvis`; the pair sampler carries the column along."""
+    from PIL import Image
+    from vqnerf_release_amd.decomp.nerfactor.datasets import get_dataset_class
+    from vqnerf_release_amd.decomp.nerfactor import train_nfr
+    rng = np.random.default_rng(4)
+    H, W, L = 16, 20, 512
+    for vid in ('train_000', 'train_001'):
+        _write_decomp_view(str(tmp_path / 'data'), str(tmp_path / 'geo'), vid, H, W, L, rng, collapse=False)
+    cfg = _decomp_cfg(tmp_path, n_rays_per_step=16, model='ref_nfr')
+    ds = get_dataset_class('ref_nfr')(cfg, 'train', device='cpu')
+    base = get_dataset_class('shape_unit')(cfg, 'train', device='cpu')
+    v, b = ds.view(0), base.view(0)
+    assert len(v) == 11 and len(b) == 10
+    for i in range(2, 9):
+        assert torch.equal(v[i], b[i])
+    assert torch.equal(v[10], b[9])                                                  # lvis stays last
+    png = np.asarray(Image.open(tmp_path / 'geo' / 'train_000' / 'rgb.png')).astype(np.float32) / 255.0
+    np.testing.assert_allclose(v[9].numpy(), png.reshape(H * W, 3), rtol=0, atol=1e-7)
+    os.remove(tmp_path / 'geo' / 'train_001' / 'rgb.png')                            # a view without its stage-2 render is skipped
+    ds2 = get_dataset_class('ref_nfr')(cfg, 'train', device='cpu')
+    assert ds2.get_n_views() == 1 and len(ds2.incomplete_paths) == 1
+    batch = train_nfr.outer_sample(v, cfg, 'nerf', generator=torch.Generator().manual_seed(0), neighbour='max_diff')
+    assert len(batch) == 11 and batch[9].shape == (32, 3) and batch[10].shape == (32, L)
+    # `ref` rows are the gathered pixels' reference colours: find each sampled pixel through its (unique) ray direction
+    d_all = v[3]
+    for r in range(0, 32, 7):
+        j = int(torch.nonzero((d_all == batch[3][r]).all(1))[0, 0])
+        assert torch.equal(batch[9][r], v[9][j])

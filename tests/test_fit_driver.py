@@ -173,3 +173,44 @@ def test_fit_stage_trains_stage1_with_a_pretrain_epoch(tmp_path):
     meta = json.load(open(os.path.join(hist['vali_dirs'][0], 'metadata.json')))
     assert meta['id'] == 'val_000' and np.isfinite(meta['psnr'])
     assert json.load(open(tmp_path / 'run1' / 'vis_vali' / 'metas.json'))['psnr'] == [meta['psnr']]
+
+
+@pytest.mark.gpu
+def test_fit_stage_trains_stage3_on_the_dedicated_kernels(tmp_path):
+    """Stage 3 end to end: datasets/ref_nfr views from disk -> fit_stage (captured step by default) with the stage-2 parts frozen: the same
+    numbers as the eager loop bit for bit, rgb_enc and the 512-wide heads move, the frozen parts do not, and no launch of the step is an
+    interpreted tile program."""
+    from tests.gpu_util import launches
+    from tests.test_datasets import _write_decomp_view, _decomp_cfg
+    from vqnerf_release_amd.decomp.nerfactor import train_nfr
+    from vqnerf_release_amd.decomp.nerfactor.datasets import get_dataset_class
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    rng = np.random.default_rng(6)
+    for vid in ('train_000', 'train_001', 'val_000'):
+        _write_decomp_view(str(tmp_path / 'data'), str(tmp_path / 'geo'), vid, 24, 32, 512, rng, collapse=False)
+    cfg = _decomp_cfg(tmp_path, imh=24, n_rays_per_step=64, model='ref_nfr', epochs=3, ckpt_period=3, vali_period=3, vali_batches=1, random_seed=2)
+    Dataset = get_dataset_class('ref_nfr')
+    tr, va = Dataset(cfg, 'train', device='cuda'), Dataset(cfg, 'vali', device='cuda')
+
+    def stage3_model():
+        m = get_model_class('ref_nfr')(cfg)
+        m.build_nets(device='cuda', seed=2).to('cuda')
+        for name in ('fine_enc', 'bottleneck', 'spec_out'):                # load_stage2's freeze
+            for p in m.net[name].parameters():
+                p.requires_grad_(False)
+        return m
+    init = {k: v.detach().clone() for k, v in stage3_model().state_dict().items()}
+    with launches() as rec:
+        model, hist = train_nfr.fit_stage(cfg, str(tmp_path / 'run3'), tr, va, model=stage3_model(), log=lambda *_: None)
+    assert rec.ran('vqn_refl_train_fwd_x3') and rec.ran('vqn_refl_train_bwd_x3') and not rec.ran('vqn_tile_program')
+    model_e, hist_e = train_nfr.fit_stage(cfg, str(tmp_path / 'run3_eager'), tr, va, model=stage3_model(), graph=False, log=lambda *_: None)
+    assert len(hist['loss']) == 3 and all(np.isfinite(hist['loss'])) and hist['loss'] == hist_e['loss']
+    moved = 0
+    for (n1, a), (_, b) in zip(model.state_dict().items(), model_e.state_dict().items()):
+        assert torch.equal(a, b), n1
+        if n1.startswith('net.') and n1.split('.')[1] in ('fine_enc', 'bottleneck', 'spec_out'):
+            assert torch.equal(a, init[n1]), n1
+        elif n1.startswith('net.'):
+            moved += int(not torch.equal(a, init[n1]))
+    assert moved >= 10                                                      # rgb_enc (6 tensors) + two heads (12): they all train
+    assert len(hist['vali_dirs']) == 1 and 'pred_rgb.png' in os.listdir(hist['vali_dirs'][0])

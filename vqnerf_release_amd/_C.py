@@ -498,7 +498,7 @@ def neus_train_fwd(sdf_desc, wbuf_sdf, col_desc, wbuf_col, pts, dirs, saved, e_t
 
 def pack_x3_gather(flat, gidx, n_steps, fidx=None):
     """bf16 piece triples [n_steps, 3, 64, 8] (as an int16 tensor) of flat[gidx] -- gather + exact split in one launch.  With `fidx`
-    (int32 or int64 index tensor): also flat[fidx], in the same launch -> (pieces, f32 images)."""
+    (a contiguous int32 index tensor on flat's device): also flat[fidx], in the same launch -> (pieces, f32 images)."""
     _f32c(flat, 'flat')
     if gidx.dtype != torch.int32 or not gidx.is_contiguous() or gidx.numel() != n_steps * 512:
         raise VqnError('pack_x3_gather: gidx must be a contiguous int32 tensor of n_steps * 512 entries')

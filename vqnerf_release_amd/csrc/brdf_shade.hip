@@ -523,6 +523,8 @@ extern "C" int vqn_brdf_shade_fwd_rows(const int64_t* lvis_rows, const float* xy
   VQN_CHECK_ARG(albedo0 && spec0 && rough0 && rgb0, "material set 0 and rgb0 must be non-null");
   VQN_CHECK_ARG(n_sets == 1 || (albedo1 && spec1 && rough1 && rgb1), "material set 1 and rgb1 must be non-null");
   VQN_CHECK_ARG((rgb0_diff == nullptr) == (rgb0_spec == nullptr), "rgb0_diff and rgb0_spec go together");
+  VQN_CHECK_ARG(raw >= 0 && raw <= 2, "raw: 0 (gamma / clip as configured), 1 (no clip), 2 (no gamma, no clip)");
+  VQN_CHECK_ARG(raw == 0 || gamma == nullptr, "raw = 1 / 2 write the plain sums and ignore gamma: pass NULL");
   VQN_CHECK_SHAPE(L == 256 || L == 512 || L == 1024, "L must be 256, 512 or 1024 lights");
   VQN_CHECK_SHAPE(lvis == nullptr || ((uintptr_t)lvis & 15) == 0, "lvis must be 16-byte aligned");
   ShadeArgs a;

@@ -76,12 +76,21 @@ class Dataset:
                      'alpha': join(nerf_root, id_, 'alpha.png'), 'rgba': join(dirname(metadata_path), 'rgba.png')}
             if self.data_type == 'nerf':
                 paths['lvis'] = join(nerf_root, id_, 'lvis.npy')
+            paths.update(self._extra_paths(nerf_root, id_))
             if all(os.path.exists(p) for p in paths.values()):
                 metadata_paths.append(metadata_path)
                 self.meta2buf[metadata_path] = paths
             else:
                 self.incomplete_paths.append(metadata_path)       # skipped, as shape_unit.py:86-90
         return metadata_paths
+
+    def _extra_paths(self, nerf_root, id_):
+        """further per-view files a subclass needs (datasets/ref_nfr.py: the stage-2 render of the view)"""
+        return {}
+
+    def _extra_maps(self, paths, fit):
+        """[H,W,C] float32 maps a subclass puts between `normal` and `lvis` in the view tuple"""
+        return ()
 
     @staticmethod
     def _parse_id(metadata_path):
@@ -143,7 +152,7 @@ class Dataset:
         bg = np.ones_like(rgb) if white_bg else np.zeros_like(rgb)
         rgb = (rgb * alpha[..., None] + bg * (1.0 - alpha[..., None])).astype(np.float32)
         out = (id_, rayo, rayd, rgb, alpha.astype(np.float32), pred_alpha.astype(np.float32), xyz.astype(np.float32),
-               normal.astype(np.float32))
+               normal.astype(np.float32)) + tuple(self._extra_maps(paths, fit))
         if self.data_type == 'nerf':
             lvis = fit(np.load(paths['lvis']))
             out = out + (np.clip(lvis, 0, 1).astype(np.float32),)
