@@ -208,9 +208,9 @@ def test_fit_stage_trains_stage3_on_the_dedicated_kernels(tmp_path):
     moved = 0
     for (n1, a), (_, b) in zip(model.state_dict().items(), model_e.state_dict().items()):
         assert torch.equal(a, b), n1
-        if n1.startswith('net.') and n1.split('.')[1] in ('fine_enc', 'bottleneck', 'spec_out'):
+        if any(n1.startswith(f'net_{f}_') for f in ('fine_enc', 'bottleneck', 'spec_out')):
             assert torch.equal(a, init[n1]), n1
-        elif n1.startswith('net.'):
+        elif n1.startswith('net_'):
             moved += int(not torch.equal(a, init[n1]))
-    assert moved >= 10                                                      # rgb_enc (6 tensors) + two heads (12): they all train
+    assert moved == 18                                                      # rgb_enc (6 tensors) + two heads (12): they all train
     assert len(hist['vali_dirs']) == 1 and 'pred_rgb.png' in os.listdir(hist['vali_dirs'][0])

@@ -164,7 +164,11 @@ class _PackCache:
     def get(self, params, build):
         # besides the tensors' `_version`s the process-wide weights epoch: a fused / capturable Adam step and a replayed HIP graph
         # move the weights without bumping any version (vqnerf_release_amd/__init__.py)
-        key = (vqnerf_release_amd.weights_epoch(),) + tuple((id(p), p._version, str(p.device)) for p in params)
+        # (FROZEN parameters -- the stage-2 parts inside a stage-3 training step -- are moved by no optimiser and no graph replay: their packs
+        #  follow the tensors' versions only, and are NOT rebuilt after every step of the nets that do train; a rebuild reads small biases
+        #  back to the host, which a captured step cannot record)
+        epoch = vqnerf_release_amd.weights_epoch() if any(p.requires_grad for p in params) else -1
+        key = (epoch,) + tuple((id(p), p._version, str(p.device)) for p in params)
         if key != self.key:
             with torch.no_grad():
                 self.value = build()
