@@ -983,7 +983,7 @@ def live_traffic(rays, timeout_s=170):
     for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         d = tempfile.mkdtemp(prefix='vqn_pmc_', dir='/tmp')
         cmd = ['rocprofv3', '--kernel-trace', '--pmc', c, '--output-format', 'csv', '-d', d, '-o', 'c', '--', sys.executable,
-               os.path.abspath(__file__), '--no-cpu-baseline', '--no-extras', '--no-traffic', '--steps', '1', '--warmup', '0', '--rays', str(rays)]
+               os.path.abspath(__file__), '--no-cpu-baseline', '--no-extras', '--no-traffic', '--no-detail', '--steps', '1', '--warmup', '0', '--rays', str(rays)]
         try:
             subprocess.run(cmd, timeout=timeout_s, env={**os.environ, 'TMPDIR': '/tmp'}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                            check=True, cwd='/tmp')
@@ -1134,8 +1134,14 @@ def detail_file():
         return os.path.join('/tmp', 'bench_detail.json')
 
 
+NO_DETAIL = False           # --no-detail: a profiler / counter pass of this command must not overwrite the real run's sidecar
+
+
 def emit(result):
     """sidecar first (full result: prose, windows, kernel tables), then the ONE short stdout line"""
+    if NO_DETAIL:
+        print(compact_line(result), flush=True)
+        return
     path = detail_file()
     rel = None
     try:
@@ -1188,7 +1194,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary workloads (train steps, decomp, VQ)')
     ap.add_argument('--no-traffic', action='store_true', help='do not measure roofline.traffic with child rocprofv3 --pmc passes')
+    ap.add_argument('--no-detail', action='store_true', help='do not write the sidecar bench_detail.json (profiler / counter passes of this command)')
     args = ap.parse_args()
+    global NO_DETAIL
+    NO_DETAIL = bool(args.no_detail)
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         return self_launch(args)                                # (before any GPU call; exits with the child's code)

@@ -19,7 +19,7 @@ timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; rc=$?
 cat $OUT/bench.json; tail -3 $OUT/bench.err; echo "bench rc=$rc" | tee -a $OUT/status.txt
 [ $rc -ne 0 ] && exit $rc
 echo "== rocprofv3 kernel trace" | tee -a $OUT/status.txt
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python3 bench.py --no-cpu-baseline --no-extras > $OUT/rocprof.log 2>&1; rc=$?
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python3 bench.py --no-cpu-baseline --no-extras --no-detail > $OUT/rocprof.log 2>&1; rc=$?
 tail -3 $OUT/rocprof.log; echo "rocprof rc=$rc" | tee -a $OUT/status.txt
 find $OUT/prof -name '*kernel_stats*' | head; for f in $(find $OUT/prof -name '*kernel_stats.csv'); do head -12 $f; done
 # the raw trace is large: keep only the stats

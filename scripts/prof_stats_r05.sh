@@ -21,6 +21,6 @@ for w in "${@:-decomp_train_256k decomp_train_graph2048}"; do
     geo_render_x3) PROBE_B=80000 run geo_render_x3 python3 scripts/probe_neus_f16s.py x3 ;;
     ref_nfr_train_256k) run ref_nfr_train_256k python3 scripts/probe_decomp_train.py 262144 6 ref_nfr ;;
     decomp_train_graph2048_54) run decomp_train_graph2048_54 python3 scripts/probe_decomp_train.py 2048 54 graph ;;
-    geo_render) run geo_render python3 bench.py --no-cpu-baseline --no-extras --no-traffic ;;     # the headline command's own kernels (5 + 2 steps)
+    geo_render) run geo_render python3 bench.py --no-cpu-baseline --no-extras --no-traffic --no-detail ;;     # the headline command's own kernels (5 + 2 steps)
   esac || exit 1
 done

@@ -64,7 +64,10 @@ class Model(BrdfModel):
     def _frozen_ctx(self, names, x):
         """torch.no_grad() when none of the named nets' parameters (nor the input) wants a gradient, else a null context"""
         import contextlib
-        if torch.is_grad_enabled() and not x.requires_grad and not any(p.requires_grad for n in names for p in self.net[n].parameters()):
+        # (device tensors on the HIP backend only: the no-graph path IS the HIP inference kernels; CPU parameters -- the gloo tests -- and the
+        #  torch backend keep the framework statement)
+        if (torch.is_grad_enabled() and x.is_cuda and self.train_backend == 'hip' and not x.requires_grad
+                and not any(p.requires_grad for n in names for p in self.net[n].parameters())):
             return torch.no_grad()
         return contextlib.nullcontext()
 
