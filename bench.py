@@ -1171,9 +1171,10 @@ def self_launch(args):
            '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     _log(f'--gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks as a child torch.distributed.run (port {port})')
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
-    for ln in child.stdout:                                      # rank 0's line (and anything else the ranks print) straight through
-        sys.stdout.write(ln)
-        sys.stdout.flush()
+    for ln in child.stdout:                                      # rank 0's JSON line to stdout; anything else the ranks print (gloo's
+        out = sys.stdout if ln.lstrip().startswith('{') else sys.stderr      # connection notes, library banners) to stderr: ONE line on stdout
+        out.write(ln)
+        out.flush()
     rc = child.wait()
     if rc != 0:
         _log(f'child torch.distributed.run exited with {rc}')
