@@ -73,7 +73,12 @@ print('RESULT ' + json.dumps(out))
 
 
 def test_one_rank_rccl_group_carries_the_trainers_collectives(tmp_path):
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29531', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import socket
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, '-c', CHILD % {'root': ROOT}], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
