@@ -987,3 +987,60 @@ def test_training_forward_outputs_are_the_render_kernels(mode):
     # OUTF row 0 is the raw sdf output: sdf * scale
     outf0 = T['OUTF'].permute(0, 3, 1, 2).reshape(-1, T['OUTF'].shape[1] * 32)[:P, 0]
     assert float((outf0 / float(sdf.scale) - s_ref).abs().max()) <= 1e-6 * max(1.0, float(s_ref.abs().max()))
+
+
+@pytest.mark.parametrize('model_name,data_type', [('vq_nfr', 'nerf'), ('vq_nfr', 'dtu'), ('vq_nfr', 'hw'), ('nfr_unit', 'nerf'), ('nfr_unit', 'dtu'),
+                                                  ('ref_nfr', 'nerf'), ('ref_nfr', 'hw')])
+def test_captured_step_is_the_eager_step_for_every_stage_and_data_type(model_name, data_type):
+    """Round 5: `train_nfr.fit` / `fit_stage` replay the captured step BY DEFAULT, so every model they can be handed must record: the three
+    stages x the data types with (`nerf`) and without (`dtu`, `hw`: learnable display curve) light-visibility rows.  Eight steps of
+    Trainer(graph=True) (two eager warm-up steps, the capture, five replays) against eight eager steps from the same state: parameters bit
+    for bit."""
+    from oracle import decomp as od
+    from tests.decomp_util import make_config, make_batch
+    from vqnerf_release_amd.decomp.nerfactor import train_nfr
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    cfg = make_config(model=model_name, data_type=data_type, n_rays_per_step=128, lr=2e-3)
+    nerf = data_type == 'nerf'
+
+    def build():
+        m = get_model_class(model_name)(cfg)
+        m.build_nets(device='cuda', seed=4).to('cuda')
+        if model_name == 'vq_nfr':
+            cb = np.random.default_rng(0).uniform(0, 1, (15, 256)).astype(np.float32)
+            m.set_codebook(cb / np.linalg.norm(cb, axis=1, keepdims=True))
+        if model_name == 'ref_nfr':
+            for name in ('fine_enc', 'bottleneck', 'spec_out'):
+                for p in m.net[name].parameters():
+                    p.requires_grad_(False)
+            m.set_light(np.full((16, 32, 3), 0.5, np.float32))
+        _ = m.light
+        if not nerf:
+            _ = m.gamma
+        m.register_trainable()
+        return m
+    batches = []
+    for i in range(8):
+        pts = od.make_points(256, seed=70 + i, lvis=nerf)
+        b = make_batch(pts, 'cuda')
+        if model_name == 'ref_nfr':
+            ref = torch.tensor(np.random.default_rng(90 + i).uniform(0, 1, (256, 3)).astype(np.float32)).cuda()
+            b = b[:9] + (ref,) + b[9:]
+        batches.append(b)
+    finals = {}
+    for graph in (False, True):
+        m = build()
+        opt, _, clip = train_nfr.make_optimizer(cfg, m.trainable_variables, capturable=True)
+        tr = train_nfr.Trainer(m, opt, clip=clip, graph=graph)
+        for b in batches:
+            tr.train_iter(b, global_bs=128)
+        torch.cuda.synchronize()
+        assert (tr._captured is not None) == graph
+        finals[graph] = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    assert finals[True].keys() == finals[False].keys()
+    moved = 0
+    init = {k: v.detach().clone() for k, v in build().state_dict().items()}
+    for k in finals[True]:
+        assert torch.equal(finals[True][k], finals[False][k]), k
+        moved += int(k in init and not torch.equal(finals[True][k], init[k]))
+    assert moved >= 6

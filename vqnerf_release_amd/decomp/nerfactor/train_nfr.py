@@ -380,6 +380,8 @@ def graph_default(device, model=None):
         return False
     if model is not None and getattr(model, 'train_backend', 'hip') != 'hip':
         return False
+    if model is not None and getattr(model, 'check_numerics', False):
+        return False                                   # (debug mode: the numerics guards read a flag back per call -- not recordable)
     return True
 
 
