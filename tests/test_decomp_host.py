@@ -164,3 +164,31 @@ def test_check_numerics_guards_are_optional_debug_checks(setup):
         loud._pred_enc_at(xyz)
     with pytest.raises(InvalidArgumentError, match='^Albedo : '):
         loud._pred_diff_at(torch.full((4, 256), float('nan')))
+
+
+def test_stage3_stack_descriptor_is_accepted_by_the_library():
+    """CPU: the descriptor + gather indices `ReflStackEngine(zx=True)` lays out for the stage-3 stack (rgb_enc + the two 512-wide heads,
+    ref_nfr.py:137-152) -- shapes of the layout, the second-input fields, and the library's own validation of the descriptor
+    (vqn_refl_train_bwd_x3_scratch_bytes returns -1 for a descriptor load_desc_r rejects)."""
+    import ctypes
+    from vqnerf_release_amd import _C
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    from vqnerf_release_amd.decomp.refl_train import ReflStackEngine
+    m = get_model_class('ref_nfr')(make_config(model='ref_nfr'))
+    m.build_nets(device='cpu', seed=1)
+    enc, heads = [m.net['rgb_enc']], [m.net['diff_out'], m.net['rough_out']]
+    assert ReflStackEngine.supports(enc, heads, m.z_dim, 3, zx=True)
+    eng = ReflStackEngine(enc, 0, heads, m.z_dim, 'cpu', zx=True)
+    L, gidx, n_steps, fidx, d = eng._static()
+    shapes = dict(zip(L.names, [tuple(p.shape) for p in eng.params()]))
+    assert shapes['W0'] == (3, 256) and shapes['H0_W0'] == (512, 256) and shapes['H0_W2'] == (640, 3) and shapes['H1_W2'] == (640, 1)
+    assert d[0] == 3 and d[3] == 3 and d[6] == 2 and d[7] == 8 and d[8] == 256 and d[9] == 8          # n_enc, emb_feats, n_heads, z_tiles, z_feats, zx_tiles
+    assert d[10] > 0 and d[11] > d[10]                                                             # offW2zx of the two heads
+    assert gidx.numel() == n_steps * 512 and int(gidx.max()) <= L.zero
+    lib = _C.lib()
+    lib.vqn_refl_train_bwd_x3_scratch_bytes.restype = ctypes.c_int64
+    dd, dp = _C._i32(d)
+    assert lib.vqn_refl_train_bwd_x3_scratch_bytes(dp) > 0
+    bad = d.copy(); bad[9] = 4                                                                      # zx_tiles != z_tiles
+    dd2, dp2 = _C._i32(bad)
+    assert lib.vqn_refl_train_bwd_x3_scratch_bytes(dp2) == -1

@@ -238,9 +238,37 @@ def test_large_batch_linearity_and_zero_adjoints(monkeypatch):
         assert _rel(c, 2.0 * a - 0.5 * b) < 2e-5
 
 
+def test_stage3_large_batch_linearity_zero_adjoints_and_batch_independence():
+    """The stage-3 stack (second head input) at 40,001 points -- 1,251 point tiles, five passes of the persistent one-image workgroups:
+    backward linear in the incoming adjoints and exactly zero for zero adjoints; forward rows independent of the batch a point sits in."""
+    from vqnerf_release_amd.decomp.nerfactor.models import get_model_class
+    from vqnerf_release_amd.decomp.refl_train import ReflStackEngine
+    m = get_model_class('ref_nfr')(make_config(model='ref_nfr'))
+    m.build_nets(device='cuda', seed=21).to('cuda')
+    eng = ReflStackEngine([m.net['rgb_enc']], 0, [m.net['diff_out'], m.net['rough_out']], m.z_dim, 'cuda', zx=True)
+    N = 40001
+    g = torch.Generator(device='cuda').manual_seed(8)
+    ref, zx = torch.rand(N, 3, device='cuda', generator=g), torch.rand(N, 256, device='cuda', generator=g)
+    ps = [p.detach() for p in eng.params()]
+    mk = lambda: ([torch.randn(N, c, device='cuda', generator=g) for c in (3, 1)], torch.randn(N, 256, device='cuda', generator=g))
+    (go1, gz1), (go2, gz2) = mk(), mk()
+    with torch.no_grad():
+        S, zrows, outs = eng.forward(ref, ps, zx_rows=zx)
+        _, z_small, outs_small = eng.forward(ref[:4113].contiguous(), ps, zx_rows=zx[:4113].contiguous())
+        assert torch.equal(z_small, zrows[:4113]) and all(torch.equal(a, b[:4113]) for a, b in zip(outs_small, outs))
+        _, ga = eng.backward(S, gz1, go1)
+        _, gb = eng.backward(S, gz2, go2)
+        _, gc = eng.backward(S, 2.0 * gz1 - 0.5 * gz2, [2.0 * a - 0.5 * b for a, b in zip(go1, go2)])
+        _, g0 = eng.backward(S, torch.zeros_like(gz1), [torch.zeros_like(a) for a in go1])
+    assert len(ga) == 18
+    for a, b, c, z in zip(ga, gb, gc, g0):
+        assert float(z.abs().max()) == 0.0
+        assert _rel(c, 2.0 * a - 0.5 * b) < 2e-5
+
+
 def test_stacks_outside_the_kernels_shape_keep_the_interpreter():
-    """A 512-wide stage-3 head (ref_nfr) is outside the x3 engine's 256-feature image: `supports` says so and the model keeps the
-    interpreted programs for it."""
+    """Layers of more than 256 OUTPUTS are outside the x3 engine's 256-feature image (`supports` says so, the model keeps the interpreted
+    programs); a 512-wide head INPUT is the stage-3 form [zx ; z] (round 5: `zx=True`), anything else about the heads as before."""
     from vqnerf_release_amd.decomp.refl_train import ReflStackEngine
     from vqnerf_release_amd.decomp.nerfactor.networks import mlp
     wide = mlp.Network([512, 256, 3], act=['relu', 'relu', 'sigmoid'], skip_at=[1])
@@ -248,3 +276,4 @@ def test_stacks_outside_the_kernels_shape_keep_the_interpreter():
     ok = mlp.Network([256, 128, 3], act=['relu', 'relu', 'sigmoid'], skip_at=[1])
     assert ReflStackEngine.supports(None, [ok], 256)
     assert not ReflStackEngine.supports(None, [mlp.Network([256, 128, 3], act=['relu', 'relu', None], skip_at=[1])], 256)
+    assert ReflStackEngine.supports(None, [ok], 256, zx=True) and not ReflStackEngine.supports(None, [], 256, zx=True)

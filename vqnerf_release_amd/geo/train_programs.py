@@ -444,7 +444,7 @@ class NeusTrainEngine:
         self.cout = [c.dims[l + 1] for l in range(self.nC + 1)]
         self.cin = [c.dims[l] for l in range(self.nC + 1)]
         self.squeeze = bool(c.squeeze_out)
-        self.n_split = n_split
+        self.n_split = int(os.environ.get('VQN_GEO_WGRAD_SPLIT', n_split))      # partial blocks of the contractions over the point tiles
         self._rs_ws = None             # workspace of the fused bias-gradient partial sums
         self._fused_dev = {}           # per device: gather indices + descriptors of the fused forward's packs
         self._bwd_dev = {}             # per device: gather index + descriptor of the fused backward's pack
