@@ -777,3 +777,26 @@ def test_codebook_prep_and_code_separation_kernels_match_the_torch_statements():
         # (the term is -w log(d) with d near 1 for two codes: its error is absolute, ~ w ulp(d))
         assert float((cb - cb_ref).detach().abs().max()) <= 2e-7 and abs(float(sim.detach()) - float(sim_ref.detach())) <= 2e-6 * max(abs(float(sim_ref.detach())), w)
         assert float((xh.grad - xr.grad).abs().max()) <= 2e-5 * float(xr.grad.abs().max())
+
+
+def test_ref_nfr_with_a_trainable_encoder_keeps_the_interpreted_programs(setup):
+    """Stage 3 with NOTHING frozen (not the reference's schedule -- load_stage2 freezes the stage-2 parts -- but a legal model state): z_xyz
+    wants an adjoint, which the dedicated second-input kernel does not produce, so the step takes the interpreted programs for the
+    512-wide heads and every network, the encoder included, receives a gradient that agrees with the oracle under torch autograd."""
+    od, p, pt_, specs, m, _ = _ref_setup('nerf')
+    N = 150
+    pts, batch, keep, ob = _ref_batch(od, N, 'nerf', 35, 0)
+    with launches() as rec:
+        pred, gt, lk, _ = m.call(batch, mode='train')
+        loss, ld = m.compute_loss(pred, gt, **dict(lk))
+        loss.mean().backward()
+    assert rec.ran('vqn_tile_program')
+    pt = {k: ([(od.T(W).requires_grad_(True), od.T(b).requires_grad_(True)) for W, b in v] if isinstance(v, list) else od.T(v))
+          for k, v in p.items()}
+    want = od.ref_nfr_call(pt, specs, ob, setup['lxyz'], setup['lareas'], mode='train', data_type='nerf', gamma=None)
+    od.ref_nfr_loss(want, ob['rgb'], 'nerf').mean().backward()
+    for name in ('fine_enc', 'bottleneck', 'spec_out', 'rgb_enc', 'diff_out', 'rough_out'):
+        for layer, (W, b) in zip(m.net[name].layers, pt[name]):
+            for got, ref in ((layer.kernel.grad, W.grad), (layer.bias.grad, b.grad)):
+                ref = ref.numpy()
+                assert got is not None and np.abs(_np(got) - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-8) + 1e-9, name
