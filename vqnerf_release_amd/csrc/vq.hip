@@ -337,9 +337,12 @@ __global__ __launch_bounds__(512, 1) void vq_assign_split_kernel(const float* __
   for (int kt = 0; kt < KT; ++kt) c2r[kt] = c2[16 * kt + col];
   float wave_loss = 0.f;
 
-  // PRE (the index-only form): the rows of the NEXT group are requested as soon as this group's rows are converted to f16 pairs, so
-  // every wave keeps 16 KB in flight while it computes (two waves per SIMD cannot hide HBM latency otherwise); the rare groups
-  // that need the f32 rows again (exact passes, plain f32 path) re-read them (L2 / MALL hits).
+  // PRE (the index-only form): the rows of the NEXT group are in flight while this group computes (two waves per SIMD cannot hide HBM
+  // latency otherwise).  Round 5: into a SECOND register buffer, and this group's f32 rows stay where they are -- the f16 pairs are
+  // cut one 32-feature step at a time inside the MFMA loop (16 live registers instead of 64).  Rounds 2-4 prefetched into the rows' own
+  // registers once they were converted, so a group with an undecided row had to RE-READ its f32 rows for the exact passes, behind the
+  // prefetch on the in-order vector-memory counter: ~7 us per such group and wave against 0.85 us of exact matrix work
+  // (profiles/r05_engine_diag.txt #4) -- every group on encoder outputs, one in six on uniform rows.
   constexpr bool PRE = !FUSE;
   const long n_groups = (N + 15) >> 4;
   const long rg_step = (long)gridDim.x * 8;
@@ -366,14 +369,17 @@ __global__ __launch_bounds__(512, 1) void vq_assign_split_kernel(const float* __
     pp = pp + __shfl_xor(pp, 32);
     return pp;
   };
-  f32x4 av[16];
-  long rg = (long)blockIdx.x * 8 + wave;
-  if (PRE && rg < n_groups) load_rows(rg, av);
-  for (; rg < n_groups; rg += rg_step) {
+  // one group: `av` holds (PRE) or receives (FUSE) its rows; PRE: the next group's rows are requested into `an` first thing and stay in
+  // flight through everything below (the two buffers swap roles from group to group: the loop further down is unrolled by two)
+  auto one_group = [&](f32x4 (&av)[16], f32x4 (&an)[16], const long rg) __attribute__((always_inline)) {
     const long row0 = rg << 4;
     const bool rvalid = (row0 + col) < N;
     const bool ragged = (row0 + 16 > N) || D != 256;                // wave-uniform: only then are there registers to blank
-    if (!PRE) load_rows(rg, av);
+    if constexpr (PRE) {
+      if (rg + rg_step < n_groups) load_rows(rg + rg_step, an);
+    } else {
+      load_rows(rg, av);
+    }
     if (ragged) mask_rows(rg, av);
     float x2b;                                                      // an upper estimate of |x|^2 (the margin and the range checks only)
     if (FUSE) {
@@ -405,28 +411,26 @@ __global__ __launch_bounds__(512, 1) void vq_assign_split_kernel(const float* __
     //  group loop -- 256 VGPRs at KT = 4 -- and spills them to scratch)
     int lofs = lane;
     asm volatile("" : "+v"(lofs));
-    f16x8 hv[8], lv[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m)
-#pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
-        const float v = av[2 * m + (jj >> 2)][jj & 3];
-        const _Float16 h = (_Float16)v;
-        hv[m][jj] = h;
-        lv[m][jj] = (_Float16)fmaf((float)h, -2048.0f, v * 2048.0f);         // (v - hi) 2^11, exactly (one mixed-precision fma)
-      }
-    if (PRE && rg + rg_step < n_groups) load_rows(rg + rg_step, av);          // av now belongs to the next group
     f32x4 ahh[KT], axx[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) { ahh[kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; axx[kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
+      // the f16 pair of this 32-feature step, cut here (the f32 rows stay in av for the exact passes)
+      f16x8 hm, lm;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const float v = av[2 * m + (jj >> 2)][jj & 3];
+        const _Float16 h = (_Float16)v;
+        hm[jj] = h;
+        lm[jj] = (_Float16)fmaf((float)h, -2048.0f, v * 2048.0f);           // (v - hi) 2^11, exactly (one mixed-precision fma)
+      }
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         const f16x8 bh = Bh[(kt * 8 + m) * 64 + lofs], bl = Bl[(kt * 8 + m) * 64 + lofs];
-        ahh[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv[m], bh, ahh[kt], 0, 0, 0);
-        axx[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hv[m], bl, axx[kt], 0, 0, 0);
-        axx[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lv[m], bh, axx[kt], 0, 0, 0);
+        ahh[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hm, bh, ahh[kt], 0, 0, 0);
+        axx[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hm, bl, axx[kt], 0, 0, 0);
+        axx[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lm, bh, axx[kt], 0, 0, 0);
       }
     }
     // ---- 2. candidates: |c|^2 - 2 x.c (the row's |x|^2 is common to its codes) within the margin of the row's minimum.
@@ -467,12 +471,7 @@ __global__ __launch_bounds__(512, 1) void vq_assign_split_kernel(const float* __
 #pragma unroll
       for (int j = 0; j < 4; ++j) best_i[j] = rm_lo[j] ? __builtin_ctz(rm_lo[j]) : 32 + __builtin_ctz(rm_hi[j]);
     } else {
-      f32x4 aw[16];
-      if (PRE) { load_rows(rg, aw); mask_rows(rg, aw); }
-      else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) aw[i] = av[i];
-      }
+      const f32x4 (&aw)[16] = av;                                     // (the group's f32 rows: still in registers)
       const float p = strict_x2(aw);
       // this lane's row in the exact passes is row `col`: its mask sits in lane 16 (col >> 2) as entry col & 3
       unsigned long long my_mask = 0;
@@ -481,18 +480,39 @@ __global__ __launch_bounds__(512, 1) void vq_assign_split_kernel(const float* __
         const unsigned lo = __shfl(rm_lo[j], (col >> 2) * 16), hi = __shfl(rm_hi[j], (col >> 2) * 16);
         if ((col & 3) == j) my_mask = ((unsigned long long)hi << 32) | lo;
       }
-      int maxc = __popcll(my_mask);
+      // ---- 3. exact evaluation of the candidates of the UNDECIDED rows.  Rounds 2-4 ran one pass per candidate RANK -- column n of the B
+      // operand = the pass's candidate of row n, the result on the diagonal: 16 useful outputs of an instruction's 256, and as many
+      // passes as the group's worst row has candidates (3.1 on encoder rows, where 99.7 % of the groups hold an undecided row; groups
+      // with a row of more than four candidates took the plain path: 6.5 %).  Round 5: the columns are the UNION of the undecided rows'
+      // candidates -- a row with one candidate is decided and asks for nothing --: typically 5..15 codes for a whole group, i.e. ONE pass
+      // of 16 columns (two for up to 32 codes; beyond that the plain path), every (row, candidate) pair an output element.  An output
+      // element is the same k-ordered chain whichever column it stands in: bit-identical distances, compared as (distance, code).
+      const bool undecided = __popcll(my_mask) > 1;
+      unsigned u_lo = undecided ? (unsigned)my_mask : 0u, u_hi = undecided ? (unsigned)(my_mask >> 32) : 0u;
 #pragma unroll
-      for (int mm = 1; mm < 16; mm <<= 1) maxc = max(maxc, __shfl_xor(maxc, mm));
-      if (!any_bad && maxc <= 4) {
-        // ---- 3. exact evaluation of the candidates, one rank per pass: column n of the B operand is the pass's candidate of row n
-        float bd = INFINITY;
-        int bk = 0;
-        for (int ps = 0; ps < maxc; ++ps) {
-          unsigned long long mk = my_mask;
-          for (int i = 0; i < ps; ++i) mk &= mk - 1;
-          if (mk == 0ull) mk = my_mask;                              // fewer candidates than passes: the first one again
-          const int k = __builtin_ctzll(mk);
+      for (int mm = 1; mm < 16; mm <<= 1) { u_lo |= __shfl_xor(u_lo, mm); u_hi |= __shfl_xor(u_hi, mm); }
+      const unsigned long long uni = ((unsigned long long)u_hi << 32) | u_lo;       // (the same in every lane: all 16 rows folded)
+      const int n_uni = __popcll(uni);
+      if (!any_bad && n_uni <= 32) {
+        float bv[4];
+        int bi[4];
+        unsigned m_lo[4], m_hi[4];
+        float x2r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bv[j] = INFINITY; bi[j] = 0x7fffffff;
+          m_lo[j] = __shfl((unsigned)my_mask, 4 * q + j);                // row 4 q + j: its mask and |x|^2 live in lane col = 4 q + j
+          m_hi[j] = __shfl((unsigned)(my_mask >> 32), 4 * q + j);
+          x2r[j] = __shfl(p, 4 * q + j);
+        }
+        const int n_pass = (n_uni + 15) >> 4;
+        for (int ps = 0; ps < n_pass; ++ps) {
+          // this lane's column: the (16 ps + col)-th code of the union (none: column unused -- any code, never taken)
+          unsigned long long mk = uni;
+          const int want = 16 * ps + col;
+          for (int i = 0; i < want && mk != 0ull; ++i) mk &= mk - 1;
+          const bool has = mk != 0ull;
+          const int k = has ? __builtin_ctzll(mk) : __builtin_ctzll(uni);
           const f32x4* bp = Bf + ((size_t)(k >> 4) * D16) * 64 + 16 * q + (k & 15);
           f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -502,13 +522,29 @@ __global__ __launch_bounds__(512, 1) void vq_assign_split_kernel(const float* __
 #pragma unroll
               for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t][e], b[e], acc, 0, 0, 0);
             }
-          // the dot of row r with ITS candidate sits on the diagonal: lane (col = r, q = r >> 2), register r & 3
-          const float dot = (col & 3) == 0 ? acc[0] : ((col & 3) == 1 ? acc[1] : ((col & 3) == 2 ? acc[2] : acc[3]));
-          const float dv = (p - 2.0f * dot) + c2[k];
-          if (dv < bd) { bd = dv; bk = k; }                          // candidates come in increasing code order: ties keep the lowest
+          const float c2k = c2[k];
+          const unsigned kbit = 1u << (k & 31);
+          // register j of lane (col, q) = row 4 q + j against this lane's code
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool cand = has && (((k < 32 ? m_lo[j] : m_hi[j]) & kbit) != 0u);
+            const float dv = (x2r[j] - 2.0f * acc[j]) + c2k;
+            if (cand && (bi[j] == 0x7fffffff || dv < bv[j] || (dv == bv[j] && k < bi[j]))) { bv[j] = dv; bi[j] = k; }
+          }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) best_i[j] = __shfl(bk, 20 * q + j);     // row 4 q + j was decided in lane (col = 4 q + j, quarter q)
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int mm = 1; mm < 16; mm <<= 1) {
+            const float ov = __shfl_xor(bv[j], mm);
+            const int oi = __shfl_xor(bi[j], mm);
+            const bool take = (oi != 0x7fffffff) && (bi[j] == 0x7fffffff || ov < bv[j] || (ov == bv[j] && oi < bi[j]));
+            if (take) { bv[j] = ov; bi[j] = oi; }
+          }
+          // (a decided row -- one candidate -- took part in no column: its candidate is the answer)
+          const bool one = (__popc(m_lo[j]) + __popc(m_hi[j])) == 1;
+          best_i[j] = one ? (m_lo[j] ? __builtin_ctz(m_lo[j]) : 32 + __builtin_ctz(m_hi[j])) : bi[j];
+        }
       } else {
         // ---- plain f32 path for this group (vq_assign_kernel's arithmetic)
         f32x4 acc[KT];
@@ -586,6 +622,18 @@ __global__ __launch_bounds__(512, 1) void vq_assign_split_kernel(const float* __
         }
       }
     }
+  };
+  long rg = (long)blockIdx.x * 8 + wave;
+  if constexpr (PRE) {
+    f32x4 ra[16], rb[16];
+    if (rg < n_groups) load_rows(rg, ra);
+    for (; rg < n_groups; rg += 2 * rg_step) {
+      one_group(ra, rb, rg);
+      if (rg + rg_step < n_groups) one_group(rb, ra, rg + rg_step);
+    }
+  } else {
+    f32x4 ra[16];
+    for (; rg < n_groups; rg += rg_step) one_group(ra, ra, rg);
   }
   if (FUSE) {
     float* wsum = reinterpret_cast<float*>(hist + KT * 16);
