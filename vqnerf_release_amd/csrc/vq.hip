@@ -242,9 +242,10 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
 //      (operand split 2^-22 per factor, the dropped lo.lo term, two f32 summations of D <= 256 terms);
 //   2. every code whose approximate distance lies within a margin M of the row's minimum is a CANDIDATE, M = twice the largest
 //      possible |approximate - defined| distance error: no other code can be the argmin (or tie with it) in the defined arithmetic;
-//   3. a row with one candidate is decided; otherwise the candidates are evaluated EXACTLY, in the defined order (the f32 MFMA chain
-//      of vq_assign_kernel: one 16x16x4 pass per candidate rank, B operand column n = the candidate of row n, result on the diagonal),
-//      and compared as (distance, index) -- ties to the lowest index, as tf.argmax(-d).  More than 4 candidates in a row (or
+//   3. a row with one candidate is decided; the candidates of the other rows are evaluated EXACTLY, in the defined order (the f32 MFMA
+//      chain of vq_assign_kernel, 16x16x4 passes whose B columns are the UNION of the group's undecided rows' candidates: one pass for
+//      up to 16 codes, two for up to 32 -- round 5; rounds 2-4: one pass per candidate rank with the result on the diagonal), and
+//      compared as (distance, index) -- ties to the lowest index, as tf.argmax(-d).  More than 32 codes in a group's union (or
 //      non-finite inputs): the whole group takes the plain f32 path.
 // Bit-identical to vq_assign_kernel / oracle/vq_strict.c by construction; D <= 256, no code-dropout mask, no distance output
 // (those calls keep the f32 kernel).  One 512-thread workgroup per CU (codebook as f32 + f16 hi / lo fragments: 32 KB per 16 codes).
